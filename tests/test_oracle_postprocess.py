@@ -1,0 +1,61 @@
+"""CPU: numpy restatement of decode / corner sort / select against fixtures made
+by running the reference's dafne_outputs.py + sort_corners.py under stubs."""
+import numpy as np
+import pytest
+
+from oracle import postprocess as pp
+
+VARIANTS = ["d10", "d15", "hrsc", "ucas", "d10_topk", "d15_topk"]
+
+
+def test_sort_quadrilateral_golden(golden):
+    g = golden("sort_corners")
+    assert np.array_equal(pp.sort_quadrilateral(g["boxes"]), g["sorted"])
+    # SURVEY appendix B KATs observed on the reference
+    assert pp.sort_quadrilateral(np.array([[0, 0, 1, 0, 2, 0, 3, 0]], np.float32)).tolist() == [[0] * 8]
+    assert pp.sort_quadrilateral(np.array([[1, 1, 0, 0, 0, 1, 1, 0]], np.float32)).tolist() == \
+        [[0, 0, 0, 1, 1, 1, 1, 0]]
+
+
+def test_compute_locations():
+    loc = pp.compute_locations(2, 3, 8)
+    assert loc.tolist() == [[4, 4], [12, 4], [20, 4], [4, 12], [12, 12], [20, 12]]
+
+
+def _key(d):
+    return d["fpn_levels"] * (1 << 32) + d["locations"][:, 1].astype(np.int64) * (1 << 20) \
+        + d["locations"][:, 0].astype(np.int64) * 32 + d["pred_classes"]
+
+
+@pytest.mark.parametrize("name", VARIANTS)
+def test_predict_proposals_golden(golden, name):
+    g = golden("predict_proposals")
+    C, topk, post, twc, sortc = [int(v) for v in g[name + "_cfg"]]
+    thr, nms_thr = [float(v) for v in g[name + "_thr"]]
+    strides = [8, 16, 32, 64, 128]
+    for im in range(2):
+        levels = [(g["%s_logits%d" % (name, l)][im], g["%s_reg%d" % (name, l)][im],
+                   g["%s_ctr%d" % (name, l)][im]) for l in range(5)]
+        det = pp.predict_proposals(levels, strides, thresh=thr, topk=topk, nms_thresh=nms_thr,
+                                   post_topk=post, thresh_with_ctr=bool(twc), sort_corners=bool(sortc))
+        ref = {k: g["%s_im%d_%s" % (name, im, k)] for k in
+               ("pred_boxes", "pred_corners", "scores", "centerness", "pred_classes", "locations", "fpn_levels")}
+        # same detections, same (descending-score) order; keyed compare guards ties
+        assert det["scores"].shape == ref["scores"].shape
+        assert np.array_equal(_key(det), _key(ref))
+        assert np.allclose(det["scores"], ref["scores"], atol=1e-6)
+        assert np.allclose(det["pred_corners"], ref["pred_corners"], atol=1e-3)
+        assert np.allclose(det["pred_boxes"], ref["pred_boxes"], atol=1e-3)
+        assert np.allclose(det["centerness"], ref["centerness"], atol=1e-6)
+
+
+def test_detector_postprocess_drops_empty_and_scales():
+    det = {"pred_boxes": np.array([[10, 10, 20, 20], [-30, 5, -10, 9], [90, 90, 130, 130]], np.float32),
+           "pred_corners": np.tile(np.arange(8, dtype=np.float32), (3, 1)),
+           "scores": np.array([.9, .8, .7], np.float32), "centerness": np.ones(3, np.float32),
+           "pred_classes": np.zeros(3, np.int64), "locations": np.ones((3, 2), np.float32),
+           "fpn_levels": np.zeros(3, np.int64)}
+    out = pp.detector_postprocess(det, (100, 100), (200, 50), (100, 100))
+    assert out["scores"].tolist() == pytest.approx([.9, .7])
+    assert out["pred_boxes"].tolist() == [[5, 20, 10, 40], [45, 180, 50, 200]]
+    assert out["pred_corners"][0].tolist() == [0, 2, 1, 6, 2, 10, 3, 14]
