@@ -1,0 +1,160 @@
+"""Config surface of the engine: `get_cfg()` with the reference's key names.
+
+Drop-in for `dafne.config.get_cfg()` (dafne/config/config.py:4-13,
+dafne/config/defaults.py:8-151) for every key the inference path reads, plus
+the detectron2 keys it depends on (MODEL.RESNETS.*, MODEL.FPN.*, INPUT.*,
+MODEL.PIXEL_MEAN/STD, TEST.AUG.*).  YAML files with `_BASE_` inheritance and the
+reference's full dumps (configs/pre-trained/*.yaml) load as they are; unknown
+keys (e.g. GLOBAL.HACK) are accepted rather than rejected.
+"""
+import copy
+import os
+
+import yaml
+
+
+class CfgNode(dict):
+    """Attribute-style nested dict (the subset of yacs.CfgNode the path uses)."""
+
+    def __init__(self, init=None):
+        super().__init__()
+        for k, v in (init or {}).items():
+            self[k] = CfgNode(v) if isinstance(v, dict) and not isinstance(v, CfgNode) else v
+        object.__setattr__(self, "_frozen", False)
+
+    def __getattr__(self, k):
+        try:
+            return self[k]
+        except KeyError:
+            raise AttributeError(k)
+
+    def __setattr__(self, k, v):
+        if object.__getattribute__(self, "_frozen"):
+            raise AttributeError("Attempted to set %s on a frozen CfgNode" % k)
+        self[k] = v
+
+    def clone(self):
+        c = CfgNode(copy.deepcopy(dict(self)))
+        return c
+
+    def freeze(self):
+        object.__setattr__(self, "_frozen", True)
+        for v in self.values():
+            if isinstance(v, CfgNode):
+                v.freeze()
+
+    def defrost(self):
+        object.__setattr__(self, "_frozen", False)
+        for v in self.values():
+            if isinstance(v, CfgNode):
+                v.defrost()
+
+    def merge_from_dict(self, d):
+        for k, v in d.items():
+            if isinstance(v, dict) and isinstance(self.get(k), CfgNode):
+                self[k].merge_from_dict(v)
+            else:
+                self[k] = CfgNode(v) if isinstance(v, dict) else v
+
+    def merge_from_file(self, path):
+        self.merge_from_dict(_load_yaml_with_base(path))
+
+    def merge_from_list(self, opts):
+        assert len(opts) % 2 == 0, "override list must be KEY VALUE pairs"
+        for key, val in zip(opts[0::2], opts[1::2]):
+            node = self
+            parts = key.split(".")
+            for p in parts[:-1]:
+                if p not in node:
+                    node[p] = CfgNode()
+                node = node[p]
+            if isinstance(val, str):
+                try:
+                    val = yaml.safe_load(val)
+                except yaml.YAMLError:
+                    pass
+            node[parts[-1]] = val
+
+    def dump(self):
+        def plain(n):
+            return {k: plain(v) if isinstance(v, CfgNode) else v for k, v in n.items()}
+        return yaml.safe_dump(plain(self))
+
+
+def _load_yaml_with_base(path):
+    with open(path) as f:
+        d = yaml.safe_load(f) or {}
+    base = d.pop("_BASE_", None)
+    if base:
+        if not os.path.isabs(base):
+            base = os.path.join(os.path.dirname(path), base)
+        merged = CfgNode(_load_yaml_with_base(base))
+        merged.merge_from_dict(d)
+        return merged
+    return d
+
+
+def _defaults():
+    dafne = dict(
+        # head geometry
+        NUM_CLASSES=15, IN_FEATURES=["p3", "p4", "p5", "p6", "p7"], FPN_STRIDES=[8, 16, 32, 64, 128],
+        TOP_LEVELS=2, NUM_CLS_CONVS=4, NUM_BOX_CONVS=4, NUM_SHARE_CONVS=0, NORM="GN",
+        USE_SCALE=True, USE_RELU=True, USE_DEFORMABLE=False, PRIOR_PROB=0.01,
+        CORNER_PREDICTION="center-to-corner", CORNER_TOWER_ON_CENTER_TOWER=True,
+        MERGE_CORNER_CENTER_PRED=False, CENTERNESS="oriented", CENTERNESS_ALPHA=5,
+        CENTERNESS_USE_IN_SCORE=True, CTR_ON_REG=True, YIELD_PROPOSAL=False,
+        # inference post-process
+        INFERENCE_TH_TEST=0.05, INFERENCE_TH_TRAIN=0.05, NMS_TH=0.1,
+        PRE_NMS_TOPK_TEST=2000, PRE_NMS_TOPK_TRAIN=2000, POST_NMS_TOPK_TEST=1000,
+        POST_NMS_TOPK_TRAIN=1000, THRESH_WITH_CTR=False, SORT_CORNERS=True,
+        SORT_CORNERS_DATALOADER=True, ENABLE_FPN_STRIDE_NORM=True,
+        # training-only keys, kept so reference YAMLs merge cleanly
+        LOSS_SMOOTH_L1_BETA=1.0 / 9.0, ENABLE_LOSS_MODULATION=True, ENABLE_LOSS_LOG=True,
+        ENABLE_LEVEL_SIZE_FILTERING=True, ENABLE_IN_BOX_CHECK=True, LOSS_ALPHA=0.25, LOSS_GAMMA=2.0,
+        SIZES_OF_INTEREST=[64, 128, 256, 512], LOSS_LAMBDA_NORM=True,
+        LOSS_LAMBDA=dict(CORNERS=1.0, BOX=1.0, LTRB=1.0, CTR=1.0, CLS=1.0, CENTER=1.0),
+        CENTER_SAMPLE=True, CENTER_SAMPLE_ONLY=False, COMBINE_CENTER_SAMPLE=True, POS_RADIUS=2.0,
+        LOC_LOSS_TYPE="smoothl1",
+    )
+    model = dict(
+        META_ARCHITECTURE="OneStageDetector", DEVICE="cuda", WEIGHTS="",
+        PIXEL_MEAN=[103.53, 116.28, 123.675], PIXEL_STD=[1.0, 1.0, 1.0],
+        KEYPOINT_ON=False, LOAD_PROPOSALS=False, MASK_ON=False, MOBILENET=False,
+        BACKBONE=dict(NAME="build_dafne_resnet_fpn_backbone", FREEZE_AT=2, ANTI_ALIAS=False),
+        RESNETS=dict(DEPTH=50, NORM="FrozenBN", NUM_GROUPS=1, WIDTH_PER_GROUP=64,
+                     STRIDE_IN_1X1=True, RES5_DILATION=1, RES2_OUT_CHANNELS=256,
+                     STEM_OUT_CHANNELS=64, OUT_FEATURES=["res3", "res4", "res5"],
+                     DEFORM_INTERVAL=1, DEFORM_ON_PER_STAGE=[False] * 4, DEFORM_MODULATED=False,
+                     DEFORM_NUM_GROUPS=1),
+        FPN=dict(IN_FEATURES=["res3", "res4", "res5"], OUT_CHANNELS=256, NORM="", FUSE_TYPE="sum"),
+        PROPOSAL_GENERATOR=dict(NAME="DAFNe", MIN_SIZE=0),
+        TOP_MODULE=dict(NAME="", DIM=16),
+        DAFNE=dafne,
+    )
+    return dict(
+        VERSION=2, EXPERIMENT_NAME="dafne", OUTPUT_DIR="./output", SEED=-1,
+        MODEL=model,
+        INPUT=dict(FORMAT="BGR", MIN_SIZE_TEST=1024, MAX_SIZE_TEST=1024, MIN_SIZE_TRAIN=[1024],
+                   MAX_SIZE_TRAIN=1024, RESIZE_TYPE="shortest-edge"),
+        DATASETS=dict(TRAIN=[], TEST=[]),
+        DATALOADER=dict(NUM_WORKERS=4),
+        SOLVER=dict(IMS_PER_BATCH=8),
+        TEST=dict(DETECTIONS_PER_IMAGE=2000, IOU_TH=0.5, NUM_PRED_VIS=20, EXPECTED_RESULTS=[],
+                  AUG=dict(ENABLED=False, MIN_SIZES=[1024], MAX_SIZE=1200, FLIP=True,
+                           HFLIP=True, VFLIP=True, ROTATION_ANGLES=[])),
+        # engine-specific knobs (not in the reference)
+        ENGINE=dict(WEIGHT_DTYPE="bf16", ACT_DTYPE="bf16"),
+    )
+
+
+def get_cfg():
+    """A fresh default config (same call as dafne.config.get_cfg)."""
+    return CfgNode(_defaults())
+
+
+def load_cfg(path, opts=None):
+    cfg = get_cfg()
+    cfg.merge_from_file(path)
+    if opts:
+        cfg.merge_from_list(list(opts))
+    return cfg

@@ -1,0 +1,14 @@
+// ABI plumbing shared by every translation unit of libdafne_amd.so.
+#include "common.h"
+
+namespace dafne {
+char* err_buf() {
+    static thread_local char buf[512] = {0};
+    return buf;
+}
+}  // namespace dafne
+
+extern "C" {
+int dafne_abi_version(void) { return 100; }  // 0.1.0
+const char* dafne_last_error(void) { return dafne::err_buf(); }
+}

@@ -1,0 +1,700 @@
+// Rotated (polygon-IoU) NMS for gfx950.
+//
+// Replaces poly_nms.poly_gpu_nms (dafne/modeling/nms/nms.py:6,91 -> external CUDA
+// extension DOTA_devkit/poly_nms_gpu) plus the fp32 class-offset arithmetic of
+// batched_nms_poly (nms.py:74-90) and the kthvalue cap of select_over_all_levels
+// (dafne/modeling/dafne/dafne_outputs.py:907-925).
+//
+// Numerics: IoU is the fp64 triangle-fan clip of tools/prepare_dota/polyiou.cpp
+// (:10-133) applied to the float32 [M,9] rows, same operation order, compiled
+// with -ffp-contract=off, so decisions `iou > thresh` equal the CPU reference bit
+// for bit.  Everything else here is integer / ordering work.
+//
+// Pipeline (all images of a batch in one set of launches, counts read on device):
+//   nms_minmax   (select path only) per-image max/min -> fp32 span+1
+//   nms_prep     rank-by-counting sort (score desc, index desc on ties), gather
+//                rows into sorted order, hull boxes, |area|, max|coord|
+//   nms_mask     one wave per 64x64 tile of the upper triangle: hull pre-filter
+//                (wave ballot) -> dense list of candidate pairs -> 16 lanes per
+//                pair, one lane per triangle pair, fp64 clip -> 64-bit row words
+//   nms_reduce   one workgroup per image: block-serial greedy scan over the
+//                suppression matrix, ordered compaction of the kept rows, cap
+//
+// Wave64 throughout: one ballot == one 64-column tile row.
+#include "common.h"
+
+namespace {
+
+typedef unsigned long long u64;
+
+constexpr int kTile = 64;
+constexpr int kCapP = 10;   // clipped polygon capacity (reference: Point p[10])
+constexpr int kCapPP = 12;  // raw cut output capacity
+constexpr double kEps = 1E-8;
+
+struct P2 {
+    double x, y;
+};
+
+__device__ __forceinline__ int sgn(double d) { return (d > kEps) - (d < -kEps); }
+
+__device__ __forceinline__ bool same_pt(P2 a, P2 b) {
+    return sgn(a.x - b.x) == 0 && sgn(a.y - b.y) == 0;
+}
+
+// polyiou.cpp:22-24
+__device__ __forceinline__ double cross3(P2 o, P2 a, P2 b) {
+    return (a.x - o.x) * (b.y - o.y) - (b.x - o.x) * (a.y - o.y);
+}
+
+// Per-lane scratch lives in LDS, slot-major / lane-minor so that lanes touching
+// the same slot hit distinct banks: element s of lane l is at [s * 64 + l].
+struct Scratch {
+    P2* p;   // kCapP slots
+    P2* pp;  // kCapPP slots
+};
+
+// polyiou.cpp:25-32 over the scratch polygon (closing vertex by wrap-around)
+__device__ __forceinline__ double shoelace_s(const P2* p, int n) {
+    double res = 0;
+    if (n <= 0) return res / 2.0;
+    P2 first = p[0];
+    P2 cur = first;
+    for (int i = 0; i < n; i++) {
+        P2 nxt = (i + 1 < n) ? p[(i + 1) * kTile] : first;
+        res += cur.x * nxt.y - cur.y * nxt.x;
+        cur = nxt;
+    }
+    return res / 2.0;
+}
+
+// polyiou.cpp:62-75 (+ lineCross :33-43): keep the part of p left of a->b.
+__device__ void cut_left(Scratch s, int& n, P2 a, P2 b) {
+    int m = 0;
+    if (n > 0) {
+        P2 first = s.p[0];
+        double cfirst = cross3(a, b, first);
+        P2 cur = first;
+        double ci = cfirst;
+        for (int i = 0; i < n; i++) {
+            P2 nxt;
+            double cj;
+            if (i + 1 < n) {
+                nxt = s.p[(i + 1) * kTile];
+                cj = cross3(a, b, nxt);
+            } else {
+                nxt = first;
+                cj = cfirst;
+            }
+            int si = sgn(ci), sj = sgn(cj);
+            if (si > 0 && m < kCapPP) {
+                s.pp[m * kTile] = cur;
+                m++;
+            }
+            if (si != sj && m < kCapPP) {
+                // lineCross(a,b,cur,nxt): s1 = ci, s2 = cj; they cannot both be ~0 here
+                double den = cj - ci;
+                if (sgn(den) != 0) {
+                    P2 r;
+                    r.x = (cur.x * cj - nxt.x * ci) / den;
+                    r.y = (cur.y * cj - nxt.y * ci) / den;
+                    s.pp[m * kTile] = r;
+                }  // else: the slot keeps its stale value (see oracle/poly_oracle.c note 1)
+                m++;
+            }
+            cur = nxt;
+            ci = cj;
+        }
+    }
+    int nn = 0;
+    P2 prev = {0.0, 0.0};
+    for (int i = 0; i < m; i++) {
+        P2 v = s.pp[i * kTile];
+        if ((i == 0 || !same_pt(v, prev)) && nn < kCapP - 1) {
+            s.p[nn * kTile] = v;
+            nn++;
+        }
+        prev = v;
+    }
+    while (nn > 1 && same_pt(s.p[(nn - 1) * kTile], s.p[0])) nn--;
+    n = nn;
+}
+
+// polyiou.cpp:79-93: signed overlap of triangles (o,a,b) and (o,c,d).
+__device__ double tri_overlap(Scratch s, P2 a, P2 b, P2 c, P2 d) {
+    P2 o = {0.0, 0.0};
+    int s1 = sgn(cross3(o, a, b));
+    int s2 = sgn(cross3(o, c, d));
+    if (s1 == 0 || s2 == 0) return 0.0;
+    if (s1 == -1) { P2 t = a; a = b; b = t; }
+    if (s2 == -1) { P2 t = c; c = d; d = t; }
+#pragma unroll
+    for (int k = 0; k < kCapPP; k++) s.pp[k * kTile] = o;
+    s.p[0] = o;
+    s.p[1 * kTile] = a;
+    s.p[2 * kTile] = b;
+    int n = 3;
+    cut_left(s, n, o, c);
+    cut_left(s, n, c, d);
+    cut_left(s, n, d, o);
+    double res = fabs(shoelace_s(s.p, n));
+    if (s1 * s2 == -1) res = -res;
+    return res;
+}
+
+struct Quad {
+    P2 v[4];
+};
+
+__device__ __forceinline__ double quad_area(const Quad& q) {
+    double res = 0;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const P2& a = q.v[i];
+        const P2& b = q.v[(i + 1) & 3];
+        res += a.x * b.y - a.y * b.x;
+    }
+    return res / 2.0;
+}
+
+__device__ __forceinline__ void quad_orient(Quad& q) {  // polyiou.cpp:96-97
+    if (quad_area(q) < 0) {
+        P2 t = q.v[0]; q.v[0] = q.v[3]; q.v[3] = t;
+        t = q.v[1]; q.v[1] = q.v[2]; q.v[2] = t;
+    }
+}
+
+__device__ __forceinline__ P2 quad_vertex(const Quad& q, int i) {
+    // register-resident select (no dynamic indexing -> no scratch memory)
+    P2 r = q.v[0];
+    if (i == 1) r = q.v[1];
+    if (i == 2) r = q.v[2];
+    if (i == 3) r = q.v[3];
+    return r;
+}
+
+// IoU of (A,B) computed by a group of 16 consecutive lanes: lane `sub` clips
+// triangle pair (i=sub/4, j=sub%4); the 16 partial areas are then summed in the
+// reference's loop order (i outer, j inner) by every lane of the group.
+__device__ double iou_group16(Scratch s, Quad A, Quad B, int lane) {
+    quad_orient(A);
+    quad_orient(B);
+    const int sub = lane & 15;
+    const int i = sub >> 2, j = sub & 3;
+    double t = tri_overlap(s, quad_vertex(A, i), quad_vertex(A, (i + 1) & 3),
+                           quad_vertex(B, j), quad_vertex(B, (j + 1) & 3));
+    const int gbase = lane & ~15;
+    double inter = 0;
+#pragma unroll
+    for (int k = 0; k < 16; k++) inter += __shfl(t, gbase + k, 64);
+    double uni = fabs(quad_area(A)) + fabs(quad_area(B)) - inter;
+    if (uni == 0) return (inter + 1) / (uni + 1);
+    return inter / uni;
+}
+
+__device__ __forceinline__ Quad load_quad_f32(const float* p) {
+    Quad q;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        q.v[k].x = (double)p[2 * k];
+        q.v[k].y = (double)p[2 * k + 1];
+    }
+    return q;
+}
+
+// ------------------------------------------------------------ pairwise IoU API
+__global__ void __launch_bounds__(64) iou_pairs_kernel(const double* __restrict__ p,
+                                                       const double* __restrict__ q, long long n,
+                                                       double* __restrict__ out) {
+    __shared__ P2 lds_p[kCapP * kTile];
+    __shared__ P2 lds_pp[kCapPP * kTile];
+    const int lane = threadIdx.x;
+    Scratch s{lds_p + lane, lds_pp + lane};
+    long long pair = (long long)blockIdx.x * 4 + (lane >> 4);
+    bool live = pair < n;
+    long long idx = live ? pair : 0;
+    Quad A, B;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        A.v[k].x = p[idx * 8 + 2 * k];
+        A.v[k].y = p[idx * 8 + 2 * k + 1];
+        B.v[k].x = q[idx * 8 + 2 * k];
+        B.v[k].y = q[idx * 8 + 2 * k + 1];
+    }
+    double iou = iou_group16(s, A, B, lane);
+    if (live && (lane & 15) == 0) out[pair] = iou;
+}
+
+// -------------------------------------------------------------- NMS workspace
+struct NmsWs {
+    int* order;      // [N][Mp]    sorted position -> original row
+    float* sbox;     // [N][Mp][8] rows in sorted order
+    float* sscore;   // [N][Mp]
+    float4* hull;    // [N][Mp]    xmin, ymin, xmax, ymax
+    double* area;    // [N][Mp]    |shoelace|
+    u64* mask;       // [N][Mp][nblk]
+    u64* rowflag;    // [N][nblk]  bit r of word b: row 64b+r suppresses something
+    unsigned* meta;  // [N][4]     0: max|coord| (float bits) 1: span+1 (float bits)
+    float* dets9;    // [N][Mp][9] (select path only)
+    int Mp, nblk;
+};
+
+size_t carve(NmsWs& w, void* base, int N, int m_cap) {
+    int Mp = (m_cap + kTile - 1) / kTile * kTile;
+    if (Mp == 0) Mp = kTile;
+    int nblk = Mp / kTile;
+    dafne::WsCarver c(base);
+    size_t n = (size_t)N;
+    w.Mp = Mp;
+    w.nblk = nblk;
+    w.meta = c.take<unsigned>(n * 4);
+    w.rowflag = c.take<u64>(n * nblk);   // meta + rowflag are zeroed per call (contiguous)
+    w.order = c.take<int>(n * Mp);
+    w.sbox = c.take<float>(n * Mp * 8);
+    w.sscore = c.take<float>(n * Mp);
+    w.hull = c.take<float4>(n * Mp);
+    w.area = c.take<double>(n * Mp);
+    w.dets9 = c.take<float>(n * Mp * 9);
+    w.mask = c.take<u64>(n * Mp * nblk);
+    return dafne::align_up(c.off, 256);
+}
+
+__device__ __forceinline__ int img_count(const int* counts, int img, int m_cap) {
+    int m = counts ? counts[img] : m_cap;
+    return m < 0 ? 0 : (m > m_cap ? m_cap : m);
+}
+
+// --------------------------------------------------- class offsets (nms.py:74-90)
+__global__ void __launch_bounds__(1024) nms_minmax_kernel(const float* __restrict__ boxes,
+                                                          const int* __restrict__ counts, int m_cap,
+                                                          unsigned* __restrict__ meta) {
+    const int img = blockIdx.x;
+    const int M = img_count(counts, img, m_cap);
+    const float* b = boxes + (size_t)img * m_cap * 8;
+    float mx = -INFINITY, mn = INFINITY;
+    for (int i = threadIdx.x; i < M * 8; i += blockDim.x) {
+        float v = b[i];
+        mx = fmaxf(mx, v);
+        mn = fminf(mn, v);
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+        mn = fminf(mn, __shfl_xor(mn, o, 64));
+    }
+    __shared__ float smx[16], smn[16];
+    if ((threadIdx.x & 63) == 0) {
+        smx[threadIdx.x >> 6] = mx;
+        smn[threadIdx.x >> 6] = mn;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int k = 1; k < (int)(blockDim.x >> 6); k++) {
+            mx = fmaxf(mx, smx[k]);
+            mn = fminf(mn, smn[k]);
+        }
+        float span = mx - mn;          // fp32, like torch
+        float span1 = span + 1.0f;
+        meta[img * 4 + 1] = __float_as_uint(M > 0 ? span1 : 1.0f);
+    }
+}
+
+__global__ void __launch_bounds__(256) nms_offset_kernel(const float* __restrict__ boxes,
+                                                         const float* __restrict__ scores,
+                                                         const int* __restrict__ classes,
+                                                         const int* __restrict__ counts, int m_cap,
+                                                         int Mp, const unsigned* __restrict__ meta,
+                                                         float* __restrict__ dets9) {
+    const int img = blockIdx.y;
+    const int M = img_count(counts, img, m_cap);
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= M) return;
+    const float span1 = __uint_as_float(meta[img * 4 + 1]);
+    int c = classes[(size_t)img * m_cap + i];
+    if (c == 5) c = 4;                                       // nms.py:77-79
+    const float off = (float)c * span1;                      // nms.py:81
+    const float* b = boxes + ((size_t)img * m_cap + i) * 8;
+    float* d = dets9 + ((size_t)img * Mp + i) * 9;
+#pragma unroll
+    for (int k = 0; k < 8; k++) d[k] = b[k] + off;           // nms.py:83
+    d[8] = scores[(size_t)img * m_cap + i];
+}
+
+// ------------------------------------------------------------------ nms_prep
+__global__ void __launch_bounds__(256) nms_prep_kernel(const float* __restrict__ dets9, int row_cap,
+                                                       const int* __restrict__ counts, int m_cap,
+                                                       NmsWs w) {
+    const int img = blockIdx.y;
+    const int M = img_count(counts, img, m_cap);
+    if ((int)(blockIdx.x * blockDim.x) >= M) return;
+    const float* d = dets9 + (size_t)img * row_cap * 9;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool live = i < M;
+    const float si = live ? d[(size_t)i * 9 + 8] : 0.f;
+    __shared__ float ss[256];
+    int rank = 0;
+    for (int j0 = 0; j0 < M; j0 += 256) {
+        int j = j0 + threadIdx.x;
+        ss[threadIdx.x] = j < M ? d[(size_t)j * 9 + 8] : 0.f;
+        __syncthreads();
+        int lim = min(256, M - j0);
+        for (int jj = 0; jj < lim; jj++) {
+            float sj = ss[jj];
+            int jg = j0 + jj;
+            rank += (sj > si) || (sj == si && jg > i);   // argsort(kind="stable")[::-1]
+        }
+        __syncthreads();
+    }
+    float amax = 0.f;
+    if (live) {
+        const size_t base = (size_t)img * w.Mp + rank;
+        float v[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) v[k] = d[(size_t)i * 9 + k];
+        w.order[base] = i;
+        w.sscore[base] = si;
+        float4* sb = reinterpret_cast<float4*>(w.sbox + base * 8);
+        sb[0] = make_float4(v[0], v[1], v[2], v[3]);
+        sb[1] = make_float4(v[4], v[5], v[6], v[7]);
+        float xmin = fminf(fminf(v[0], v[2]), fminf(v[4], v[6]));
+        float xmax = fmaxf(fmaxf(v[0], v[2]), fmaxf(v[4], v[6]));
+        float ymin = fminf(fminf(v[1], v[3]), fminf(v[5], v[7]));
+        float ymax = fmaxf(fmaxf(v[1], v[3]), fmaxf(v[5], v[7]));
+        w.hull[base] = make_float4(xmin, ymin, xmax, ymax);
+        Quad q = load_quad_f32(v);
+        w.area[base] = fabs(quad_area(q));
+#pragma unroll
+        for (int k = 0; k < 8; k++) amax = fmaxf(amax, fabsf(v[k]));
+    }
+    for (int o = 32; o > 0; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o, 64));
+    if ((threadIdx.x & 63) == 0 && amax > 0.f) atomicMax(&w.meta[img * 4 + 0], __float_as_uint(amax));
+}
+
+// ------------------------------------------------------------------ nms_mask
+__device__ __forceinline__ int kth_set_bit(u64 m, int t) {
+    int pos = 0;
+#pragma unroll
+    for (int wbits = 32; wbits >= 1; wbits >>= 1) {
+        u64 low = m & ((1ull << wbits) - 1ull);
+        int c = __popcll(low);
+        if (t >= c) {
+            t -= c;
+            m >>= wbits;
+            pos += wbits;
+        } else {
+            m = low;
+        }
+    }
+    return pos;
+}
+
+__global__ void __launch_bounds__(64) nms_mask_kernel(const int* __restrict__ counts, int m_cap,
+                                                      double thresh, NmsWs w) {
+    const int img = blockIdx.y;
+    const int M = img_count(counts, img, m_cap);
+    // linear tile id -> (rb, cb), cb >= rb, row-major over the upper triangle
+    const int nb = w.nblk;
+    const long long t = blockIdx.x;
+    // row rb starts at rb*nb - rb*(rb-1)/2
+    int rb = (int)((2.0 * nb + 1.0 - sqrt((2.0 * nb + 1.0) * (2.0 * nb + 1.0) - 8.0 * (double)t)) * 0.5);
+    if (rb < 0) rb = 0;
+    if (rb >= nb) rb = nb - 1;
+    while (rb > 0 && (long long)rb * nb - (long long)rb * (rb - 1) / 2 > t) rb--;
+    while ((long long)(rb + 1) * nb - (long long)(rb + 1) * rb / 2 <= t) rb++;
+    const int cb = rb + (int)(t - ((long long)rb * nb - (long long)rb * (rb - 1) / 2));
+    if (rb * kTile >= M || cb * kTile >= M) return;
+
+    __shared__ P2 lds_p[kCapP * kTile];
+    __shared__ P2 lds_pp[kCapPP * kTile];
+    __shared__ float4 rhull[kTile];
+    __shared__ double rarea[kTile];
+    __shared__ u64 cand[kTile];
+    __shared__ int pre[kTile];
+    __shared__ u64 rowbits[kTile];
+
+    const int lane = threadIdx.x;
+    const size_t ibase = (size_t)img * w.Mp;
+    const int grow = rb * kTile + lane;
+    const int gcol = cb * kTile + lane;
+    const bool colv = gcol < M;
+    float4 ch = colv ? w.hull[ibase + gcol] : make_float4(0, 0, 0, 0);
+    double ca = colv ? w.area[ibase + gcol] : 0.0;
+    rhull[lane] = grow < M ? w.hull[ibase + grow] : make_float4(0, 0, 0, 0);
+    rarea[lane] = grow < M ? w.area[ibase + grow] : 0.0;
+    rowbits[lane] = 0ull;
+    __syncthreads();
+
+    // guard: see oracle/poly_oracle.c (orc_poly_nms_fast).  Separated hulls mean a
+    // true intersection of 0; the fp64 fan sum then differs from 0 by rounding only,
+    // which cannot reach thresh*union unless the union is itself negligible.
+    const float R = __uint_as_float(w.meta[img * 4 + 0]);
+    const bool prefilter = thresh >= 1e-6;
+    const double guard = 256.0 * (2e-13 * (double)R * (double)R + 1e-6) / (prefilter ? thresh : 1.0);
+
+    u64 mycand = 0ull;
+    const int rlim = min(kTile, M - rb * kTile);
+    for (int r = 0; r < rlim; r++) {
+        float4 h = rhull[r];
+        bool apart = ch.x > h.z || h.x > ch.z || ch.y > h.w || h.y > ch.w;
+        bool skip = prefilter && apart && (rarea[r] + ca) > guard;
+        bool c = colv && !skip && (rb != cb || lane > r);
+        u64 b = __ballot(c);
+        if (lane == r) mycand = b;
+    }
+    int cnt = __popcll(mycand);
+    int incl = cnt;
+    for (int o = 1; o < 64; o <<= 1) {
+        int v = __shfl_up(incl, o, 64);
+        if (lane >= o) incl += v;
+    }
+    const int total = __shfl(incl, 63, 64);
+    cand[lane] = mycand;
+    pre[lane] = incl - cnt;
+    __syncthreads();
+
+    if (total > 0) {
+        Scratch s{lds_p + lane, lds_pp + lane};
+        for (int base = 0; base < total; base += 4) {
+            int k = base + (lane >> 4);
+            bool live = k < total;
+            int kk = live ? k : total - 1;
+            // largest row with pre[row] <= kk (rows with cnt 0 share a prefix: the
+            // search lands on the last of them, whose successor owns the pair)
+            int lo = 0, hi = 63;
+            while (lo < hi) {
+                int mid = (lo + hi + 1) >> 1;
+                if (pre[mid] <= kk) lo = mid; else hi = mid - 1;
+            }
+            int row = lo;
+            int col = kth_set_bit(cand[row], kk - pre[row]);
+            Quad A = load_quad_f32(w.sbox + (ibase + rb * kTile + row) * 8);
+            Quad B = load_quad_f32(w.sbox + (ibase + cb * kTile + col) * 8);
+            double iou = iou_group16(s, A, B, lane);
+            if (live && (lane & 15) == 0 && iou > thresh) atomicOr(&rowbits[row], 1ull << col);
+        }
+    }
+    __syncthreads();
+    u64 word = rowbits[lane];
+    if (grow < M) {
+        w.mask[(ibase + grow) * nb + cb] = word;
+        if (word) atomicOr(&w.rowflag[(size_t)img * nb + rb], 1ull << lane);
+    }
+}
+
+// ---------------------------------------------------------------- nms_reduce
+__device__ __forceinline__ u64 readlane64(u64 v, int l) {
+    unsigned lo = __builtin_amdgcn_readlane((unsigned)v, l);
+    unsigned hi = __builtin_amdgcn_readlane((unsigned)(v >> 32), l);
+    return ((u64)hi << 32) | lo;
+}
+
+constexpr int kReduceThreads = 1024;
+constexpr int kMaxBlk = 1024;  // up to 65536 rows per image
+
+__global__ void __launch_bounds__(kReduceThreads) nms_reduce_kernel(
+    const int* __restrict__ counts, int m_cap, int post_topk, NmsWs w,
+    long long* __restrict__ keep, int* __restrict__ num_keep) {
+    const int img = blockIdx.x;
+    const int M = img_count(counts, img, m_cap);
+    const int nb = w.nblk;
+    const int nbu = (M + kTile - 1) / kTile;  // blocks in use
+    const size_t ibase = (size_t)img * w.Mp;
+    const u64* mask = w.mask + ibase * nb;
+    const u64* rowflag = w.rowflag + (size_t)img * nb;
+    long long* kout = keep + (size_t)img * m_cap;
+
+    __shared__ u64 remv[kMaxBlk];
+    __shared__ u64 kept[kMaxBlk];
+    __shared__ int kpre[kMaxBlk + 1];
+    __shared__ u64 kcur;
+    const int tid = threadIdx.x;
+    for (int k = tid; k < nb; k += kReduceThreads) {
+        remv[k] = 0ull;
+        kept[k] = 0ull;
+    }
+    __syncthreads();
+
+    for (int b = 0; b < nbu; b++) {
+        if (tid < 64) {
+            const int row = b * kTile + tid;
+            u64 d = row < M ? mask[(size_t)row * nb + b] : 0ull;
+            u64 rem = remv[b];
+            rem = ((u64)__builtin_amdgcn_readfirstlane((unsigned)(rem >> 32)) << 32) |
+                  __builtin_amdgcn_readfirstlane((unsigned)rem);   // wave-uniform -> SALU loop
+            const int valid = min(kTile, M - b * kTile);
+            if (valid < 64) rem |= ~0ull << valid;
+            u64 K = 0ull;
+#pragma unroll
+            for (int r = 0; r < 64; r++) {
+                u64 dr = readlane64(d, r);
+                if (!((rem >> r) & 1ull)) {
+                    K |= 1ull << r;
+                    rem |= dr;
+                }
+            }
+            if (tid == 0) {
+                kept[b] = K;
+                kcur = K & rowflag[b];
+            }
+        }
+        __syncthreads();
+        const u64 K2 = kcur;
+        if (K2) {
+            for (int wd = b + 1 + tid; wd < nbu; wd += kReduceThreads) {
+                u64 acc = 0ull;
+                u64 bits = K2;
+                while (bits) {
+                    int r = __ffsll((long long)bits) - 1;
+                    bits &= bits - 1;
+                    acc |= mask[(size_t)(b * kTile + r) * nb + wd];
+                }
+                remv[wd] |= acc;
+            }
+        }
+        __syncthreads();
+    }
+
+    // ordered compaction of the kept sorted positions
+    if (tid == 0) {
+        int run = 0;
+        for (int k = 0; k < nbu; k++) {
+            kpre[k] = run;
+            run += __popcll(kept[k]);
+        }
+        kpre[nbu] = run;
+    }
+    __syncthreads();
+    int total = nbu > 0 ? kpre[nbu] : 0;
+    // cap (dafne_outputs.py:916-923): keep every row whose score >= the post_topk-th
+    // best kept score; kept rows are in descending score order, so that is a prefix.
+    __shared__ int n_out;
+    if (tid == 0) n_out = total;
+    __syncthreads();
+    if (post_topk > 0 && total > post_topk) {
+        // find the sorted position of the post_topk-th kept row, then extend over ties
+        if (tid == 0) {
+            int blk = 0;
+            while (kpre[blk + 1] < post_topk) blk++;
+            int pos = blk * kTile + kth_set_bit(kept[blk], post_topk - 1 - kpre[blk]);
+            float thr = w.sscore[ibase + pos];
+            int n = post_topk;
+            // walk the following kept rows while they tie with thr
+            int p = pos + 1;
+            while (p < M) {
+                if ((kept[p >> 6] >> (p & 63)) & 1ull) {
+                    if (w.sscore[ibase + p] >= thr) n++; else break;
+                }
+                p++;
+            }
+            n_out = n;
+        }
+        __syncthreads();
+    }
+    const int nout = n_out;
+    for (int k = tid; k < nbu; k += kReduceThreads) {
+        u64 bits = kept[k];
+        int o = kpre[k];
+        while (bits && o < nout) {
+            int r = __ffsll((long long)bits) - 1;
+            bits &= bits - 1;
+            kout[o++] = (long long)w.order[ibase + k * kTile + r];
+        }
+    }
+    if (tid == 0) num_keep[img] = nout;
+}
+
+int run_nms(const float* d_dets9, int row_cap, const int* d_counts, int N, int m_cap, double thresh,
+            int post_topk, int64_t* d_keep, int32_t* d_num_keep, NmsWs& w, hipStream_t st,
+            bool meta_zeroed) {
+    if (!meta_zeroed) {
+        size_t zbytes = (size_t)((char*)(w.rowflag + (size_t)N * w.nblk) - (char*)w.meta);
+        DAFNE_HIP_TRY(hipMemsetAsync(w.meta, 0, zbytes, st));
+    }
+    dim3 gp((m_cap + 255) / 256, N);
+    hipLaunchKernelGGL(nms_prep_kernel, gp, dim3(256), 0, st, d_dets9, row_cap, d_counts, m_cap, w);
+    int rc = dafne::check_launch("nms_prep");
+    if (rc) return rc;
+    long long ntiles = (long long)w.nblk * (w.nblk + 1) / 2;
+    if (ntiles > 0x7fffffffLL) return dafne::fail(DAFNE_E_UNSUPPORTED, "too many NMS tiles");
+    hipLaunchKernelGGL(nms_mask_kernel, dim3((unsigned)ntiles, N), dim3(64), 0, st, d_counts, m_cap,
+                       thresh, w);
+    rc = dafne::check_launch("nms_mask");
+    if (rc) return rc;
+    hipLaunchKernelGGL(nms_reduce_kernel, dim3(N), dim3(kReduceThreads), 0, st, d_counts, m_cap,
+                       post_topk, w, reinterpret_cast<long long*>(d_keep), d_num_keep);
+    return dafne::check_launch("nms_reduce");
+}
+
+}  // namespace
+
+extern "C" {
+
+int dafne_poly_iou_pairs_hip(const double* d_p, const double* d_q, int64_t n, double* d_out,
+                             void* stream) {
+    if (n < 0 || (n > 0 && (!d_p || !d_q || !d_out))) return dafne::fail(DAFNE_E_INVALID, "iou_pairs: bad args");
+    if (n == 0) return DAFNE_OK;
+    long long blocks = (n + 3) / 4;
+    hipLaunchKernelGGL(iou_pairs_kernel, dim3((unsigned)blocks), dim3(64), 0, (hipStream_t)stream, d_p,
+                       d_q, (long long)n, d_out);
+    return dafne::check_launch("iou_pairs");
+}
+
+size_t dafne_poly_nms_workspace_bytes(int n_images, int m_cap) {
+    if (n_images <= 0 || m_cap < 0) return 0;
+    NmsWs w;
+    return carve(w, nullptr, n_images, m_cap);
+}
+
+int dafne_poly_nms_batched_hip(const float* d_dets9, const int32_t* d_counts, int n_images,
+                               int m_cap, double thresh, int post_topk, int64_t* d_keep,
+                               int32_t* d_num_keep, void* d_ws, size_t ws_bytes, void* stream) {
+    if (n_images <= 0 || m_cap < 0 || !d_num_keep) return dafne::fail(DAFNE_E_INVALID, "poly_nms: bad args");
+    hipStream_t st = (hipStream_t)stream;
+    if (m_cap == 0) {
+        DAFNE_HIP_TRY(hipMemsetAsync(d_num_keep, 0, sizeof(int32_t) * n_images, st));
+        return DAFNE_OK;
+    }
+    if (!d_dets9 || !d_keep || !d_ws) return dafne::fail(DAFNE_E_INVALID, "poly_nms: null pointer");
+    NmsWs w;
+    size_t need = carve(w, d_ws, n_images, m_cap);
+    if (ws_bytes < need) return dafne::fail(DAFNE_E_WORKSPACE, "poly_nms: workspace %zu < %zu", ws_bytes, need);
+    if (w.nblk > kMaxBlk) return dafne::fail(DAFNE_E_UNSUPPORTED, "poly_nms: m_cap %d > %d", m_cap, kMaxBlk * kTile);
+    return run_nms(d_dets9, m_cap, d_counts, n_images, m_cap, thresh, post_topk, d_keep, d_num_keep, w, st, false);
+}
+
+int dafne_poly_nms_hip(const float* d_dets9, int M, double thresh, int64_t* d_keep,
+                       int32_t* d_num_keep, void* d_ws, size_t ws_bytes, void* stream) {
+    return dafne_poly_nms_batched_hip(d_dets9, nullptr, 1, M, thresh, 0, d_keep, d_num_keep, d_ws,
+                                      ws_bytes, stream);
+}
+
+int dafne_select_over_all_levels_hip(const float* d_boxes8, const float* d_scores,
+                                     const int32_t* d_classes, const int32_t* d_counts,
+                                     int n_images, int m_cap, double nms_thresh, int post_topk,
+                                     int64_t* d_keep, int32_t* d_num_keep, void* d_ws,
+                                     size_t ws_bytes, void* stream) {
+    if (n_images <= 0 || m_cap < 0 || !d_num_keep) return dafne::fail(DAFNE_E_INVALID, "select: bad args");
+    hipStream_t st = (hipStream_t)stream;
+    if (m_cap == 0) {
+        DAFNE_HIP_TRY(hipMemsetAsync(d_num_keep, 0, sizeof(int32_t) * n_images, st));
+        return DAFNE_OK;
+    }
+    if (!d_boxes8 || !d_scores || !d_classes || !d_keep || !d_ws)
+        return dafne::fail(DAFNE_E_INVALID, "select: null pointer");
+    if (!(nms_thresh > 0)) return dafne::fail(DAFNE_E_UNSUPPORTED, "select: nms_thresh <= 0 bypasses NMS in the reference; handle on the caller side");
+    NmsWs w;
+    size_t need = carve(w, d_ws, n_images, m_cap);
+    if (ws_bytes < need) return dafne::fail(DAFNE_E_WORKSPACE, "select: workspace %zu < %zu", ws_bytes, need);
+    if (w.nblk > kMaxBlk) return dafne::fail(DAFNE_E_UNSUPPORTED, "select: m_cap %d > %d", m_cap, kMaxBlk * kTile);
+    size_t zbytes = (size_t)((char*)(w.rowflag + (size_t)n_images * w.nblk) - (char*)w.meta);
+    DAFNE_HIP_TRY(hipMemsetAsync(w.meta, 0, zbytes, st));
+    hipLaunchKernelGGL(nms_minmax_kernel, dim3(n_images), dim3(1024), 0, st, d_boxes8, d_counts, m_cap, w.meta);
+    int rc = dafne::check_launch("nms_minmax");
+    if (rc) return rc;
+    hipLaunchKernelGGL(nms_offset_kernel, dim3((m_cap + 255) / 256, n_images), dim3(256), 0, st, d_boxes8,
+                       d_scores, d_classes, d_counts, m_cap, w.Mp, w.meta, w.dets9);
+    rc = dafne::check_launch("nms_offset");
+    if (rc) return rc;
+    return run_nms(w.dets9, w.Mp, d_counts, n_images, m_cap, nms_thresh, post_topk, d_keep, d_num_keep, w, st, true);
+}
+
+}  // extern "C"

@@ -1,0 +1,182 @@
+/*
+ * dafne_amd.h -- C ABI of libdafne_amd.so, the MI355X (gfx950) replacement for the
+ * native pieces of braun-steven/DAFNe's inference path.
+ *
+ * Conventions (all entry points):
+ *   - plain C types only; every pointer named d_* is a DEVICE pointer owned by
+ *     the caller; `stream` is a hipStream_t passed as void* (NULL = default stream)
+ *   - the library never allocates device memory and never synchronises the
+ *     device: work is enqueued on `stream`; scratch comes from the caller through
+ *     (d_ws, ws_bytes), sized by the matching *_workspace_bytes() query
+ *   - return value: 0 = OK, non-zero = error (DAFNE_E_*); the message is
+ *     available from dafne_last_error() (thread-local); nothing throws across
+ *     the boundary
+ *   - re-entrant: no mutable global state; one call <-> one stream
+ *
+ * Reference interfaces replaced (paths relative to the reference repository):
+ *   poly_nms.poly_gpu_nms(dets[M,9] f32, thresh, device_id)   dafne/modeling/nms/nms.py:6,91
+ *       (external CUDA ext, DOTA_devkit poly_nms_gpu)         -> dafne_poly_nms_hip / _batched
+ *   batched_nms_poly's offset arithmetic                      dafne/modeling/nms/nms.py:74-90
+ *                                                             -> dafne_select_over_all_levels_hip
+ *   select_over_all_levels' kthvalue cap                      dafne/modeling/dafne/dafne_outputs.py:907-925
+ *                                                             -> dafne_select_over_all_levels_hip
+ *   polyiou.iou_poly (SWIG C++)                               tools/prepare_dota/polyiou.cpp:112
+ *                                                             -> dafne_poly_iou_pairs_hip
+ *   forward_for_single_feature_map (+ sort_quadrilateral)     dafne/modeling/dafne/dafne_outputs.py:792-905,
+ *                                                             dafne/utils/sort_corners.py:26-92
+ *                                                             -> dafne_decode_levels_hip
+ *   torch conv2d / GroupNorm / max_pool2d / interpolate       dafne/modeling/dafne/dafne.py:209-229,318-344,
+ *   (cuDNN through torch) in backbone and head                dafne/modeling/backbone/fpn.py:26-37
+ *                                                             -> dafne_conv2d_nhwc_bf16_hip and friends
+ */
+#ifndef DAFNE_AMD_H
+#define DAFNE_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DAFNE_OK 0
+#define DAFNE_E_INVALID 1   /* bad argument (null pointer, negative size, ...) */
+#define DAFNE_E_WORKSPACE 2 /* workspace too small */
+#define DAFNE_E_HIP 3       /* a HIP runtime call / kernel launch failed */
+#define DAFNE_E_UNSUPPORTED 4
+
+/* Library / ABI version: major*10000 + minor*100 + patch. */
+int dafne_abi_version(void);
+/* Thread-local message of the last failing call on this thread ("" if none). */
+const char* dafne_last_error(void);
+
+/* ---------------------------------------------------------------- polygon IoU */
+/*
+ * fp64 IoU of n quadrilateral pairs, bit-identical to the reference's
+ * polyiou.cpp arithmetic.  d_p, d_q: [n,8] float64 (x0,y0,..,x3,y3); d_out: [n].
+ */
+int dafne_poly_iou_pairs_hip(const double* d_p, const double* d_q, int64_t n,
+                             double* d_out, void* stream);
+
+/* --------------------------------------------------------------- rotated NMS */
+/*
+ * Greedy polygon NMS, the replacement for poly_nms.poly_gpu_nms (nms.py:91).
+ *   d_dets9   [M,9] float32, C-contiguous: 8 corner coordinates + score
+ *   thresh    a box is suppressed iff IoU(kept, box) > thresh (fp64 compare)
+ *   d_keep    [M] int64 out: indices into d_dets9 of the kept rows, in
+ *             descending-score order (equal scores: larger index first, i.e.
+ *             np.argsort(kind="stable")[::-1])
+ *   d_num_keep  [1] int32 out
+ * IoU: fp64 triangle-fan clip of polyiou.cpp on the float32 inputs.
+ */
+size_t dafne_poly_nms_workspace_bytes(int n_images, int m_cap);
+int dafne_poly_nms_hip(const float* d_dets9, int M, double thresh, int64_t* d_keep,
+                       int32_t* d_num_keep, void* d_ws, size_t ws_bytes, void* stream);
+/*
+ * Batched form: n_images independent problems in one set of launches.
+ *   d_dets9   [n_images, m_cap, 9]; d_counts [n_images] int32 DEVICE (rows used
+ *             per image, <= m_cap; read on the device, no host sync)
+ *   post_topk > 0: after NMS keep only rows whose score >= the post_topk-th
+ *             best kept score (dafne_outputs.py:916-923; ties may exceed it)
+ *   d_keep    [n_images, m_cap] int64; d_num_keep [n_images] int32
+ */
+int dafne_poly_nms_batched_hip(const float* d_dets9, const int32_t* d_counts, int n_images,
+                               int m_cap, double thresh, int post_topk, int64_t* d_keep,
+                               int32_t* d_num_keep, void* d_ws, size_t ws_bytes, void* stream);
+/*
+ * ml_nms + the post-NMS cap for a batch (nms.py:10-92, dafne_outputs.py:907-925):
+ * class 5 -> 4, offset = float(class) * (max(boxes) - min(boxes) + 1) in fp32 per
+ * image, NMS at nms_thresh, then the post_topk cap.
+ *   d_boxes8 [n_images, m_cap, 8] f32, d_scores [n_images, m_cap] f32,
+ *   d_classes [n_images, m_cap] int32, d_counts [n_images] int32 (device).
+ */
+int dafne_select_over_all_levels_hip(const float* d_boxes8, const float* d_scores,
+                                     const int32_t* d_classes, const int32_t* d_counts,
+                                     int n_images, int m_cap, double nms_thresh, int post_topk,
+                                     int64_t* d_keep, int32_t* d_num_keep, void* d_ws,
+                                     size_t ws_bytes, void* stream);
+
+/* ------------------------------------------------------ decode / top-k / sort */
+typedef struct dafne_level_desc {
+    const float* d_logits;  /* [N, H, W, C]  (NHWC == the reference's permuted view) */
+    const float* d_delta;   /* [N, H, W, 8]  corners_pred output                      */
+    const float* d_center;  /* [N, H, W, 2]  center_pred output                       */
+    const float* d_ctrness; /* [N, H, W]     ctrness logits                           */
+    int32_t H, W, stride;   /* feature size and FPN stride                            */
+    float scale;            /* the level's learnable Scale (dafne.py:405-411)         */
+} dafne_level_desc;
+
+typedef struct dafne_decode_params {
+    int32_t n_images, n_levels, n_classes;
+    int32_t pre_nms_topk;     /* PRE_NMS_TOPK_TEST per level            */
+    float pre_nms_thresh;     /* INFERENCE_TH_TEST, strict >            */
+    int32_t thresh_with_ctr;  /* THRESH_WITH_CTR                        */
+    int32_t sort_corners;     /* SORT_CORNERS                           */
+    int32_t m_cap;            /* rows per image in the outputs (>= n_levels*pre_nms_topk) */
+} dafne_decode_params;
+
+/*
+ * forward_for_single_feature_map for every level and image
+ * (dafne_outputs.py:771-772,792-905): sigmoid, sqrt(cls*ctr), threshold, per
+ * level top-k, corner decode ((center.repeat+delta)*scale*stride + location),
+ * optional canonical corner order, hull box.  Outputs are per image, levels
+ * concatenated in order, candidates within a level in (location, class) order:
+ *   d_corners [N, m_cap, 8], d_scores [N, m_cap], d_ctr [N, m_cap],
+ *   d_classes [N, m_cap] int32, d_locs [N, m_cap, 2], d_levels [N, m_cap] int32,
+ *   d_hbox [N, m_cap, 4], d_counts [N] int32.
+ */
+size_t dafne_decode_workspace_bytes(const dafne_decode_params* prm, const dafne_level_desc* levels);
+int dafne_decode_levels_hip(const dafne_decode_params* prm, const dafne_level_desc* levels,
+                            float* d_corners, float* d_scores, float* d_ctr, int32_t* d_classes,
+                            float* d_locs, int32_t* d_levels, float* d_hbox, int32_t* d_counts,
+                            void* d_ws, size_t ws_bytes, void* stream);
+/* sort_quadrilateral on [n,8] float32 (sort_corners.py:26-92). */
+int dafne_sort_quadrilateral_hip(const float* d_in, float* d_out, int64_t n, void* stream);
+/*
+ * Gather the kept rows and apply detector_postprocess + OneStageDetector._postprocess
+ * (one_stage_detector.py:79-98): hull boxes scaled by out/net-input size, clipped,
+ * empty ones dropped; corners and locations scaled by out/orig.  d_sizes:
+ * [N,6] float32 = (net_h, net_w, out_h, out_w, orig_h, orig_w) per image.
+ * Output rows [N, k_cap, 16] float32 = corners8, score, centerness, class, level,
+ * hbox4, loc2 (class/level stored as float); d_out_counts [N].
+ */
+int dafne_gather_detections_hip(const float* d_corners, const float* d_scores, const float* d_ctr,
+                                const int32_t* d_classes, const float* d_locs,
+                                const int32_t* d_levels, const float* d_hbox,
+                                const int64_t* d_keep, const int32_t* d_num_keep,
+                                const float* d_sizes, int do_postprocess, int n_images, int m_cap,
+                                int k_cap, float* d_out, int32_t* d_out_counts, void* stream);
+
+/* ------------------------------------------------------------- dense engine */
+/* Activations: NHWC bf16 with a zero halo of 1 pixel: [N, H+2, W+2, C].      */
+#define DAFNE_CONV_RELU 1u        /* ReLU in the epilogue                        */
+#define DAFNE_CONV_RESIDUAL 2u    /* += residual (same shape as out) before ReLU */
+#define DAFNE_CONV_UPSAMPLE_ADD 4u/* += nearest-2x upsample of `residual` (H/2)  */
+#define DAFNE_CONV_OUT_F32 8u     /* fp32 un-haloed NHWC output [N,H,W,Cout]     */
+#define DAFNE_CONV_GN_STATS 16u   /* emit per-(n,segment,group) sum / sumsq       */
+#define DAFNE_CONV_RELU_IN 32u    /* ReLU applied to the input while loading (P7) */
+
+typedef struct dafne_conv_seg {
+    const void* d_in;   /* bf16 [N, Hin+2, Win+2, Cin] (halo layout)               */
+    void* d_out;        /* bf16 [N, Hout+2, Wout+2, Cout] or fp32 [N,Hout,Wout,Cout] */
+    const void* d_res;  /* residual / coarser map for UPSAMPLE_ADD, or NULL        */
+    int32_t Hin, Win, Hout, Wout;
+} dafne_conv_seg;
+
+typedef struct dafne_conv_params {
+    int32_t n_images, n_segs;   /* segments share weights (FPN levels of the head) */
+    int32_t Cin, Cout, KH, KW, stride, pad;
+    uint32_t flags;
+    const void* d_weight;  /* bf16 [Cout_pad][KH*KW*Cin], k = (kh, kw, cin)         */
+    const float* d_bias;   /* [Cout] fp32 (FrozenBN folded) or NULL                 */
+    float* d_gn_partial;   /* GN_STATS: [tiles][Cout/8][2] fp32 partial sums        */
+} dafne_conv_params;
+
+int dafne_conv2d_nhwc_bf16_hip(const dafne_conv_params* prm, const dafne_conv_seg* segs, void* stream);
+/* number of M-tiles the conv above launches (rows of d_gn_partial) */
+int dafne_conv2d_num_tiles(const dafne_conv_params* prm, const dafne_conv_seg* segs);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DAFNE_AMD_H */

@@ -41,6 +41,11 @@
 
 #define ORC_EPS 1E-8
 #define ORC_MAXV 16
+/* capacities: the reference has Point p[10] (n <= 9 plus the closing vertex);
+ * a clipped triangle never gets near either bound, the clamps only keep
+ * garbage input from running off the arrays (same clamps in the HIP kernel) */
+#define ORC_CAP_P 10
+#define ORC_CAP_PP 12
 
 typedef struct { double x, y; } pt_t;
 
@@ -81,15 +86,15 @@ static void cut_left(pt_t *p, int *pn, pt_t a, pt_t b, pt_t *pp) {
     for (int i = 0; i < n; i++) {
         double ci = cross3(a, b, p[i]);
         double cj = cross3(a, b, p[i + 1]);
-        if (sgn_eps(ci) > 0) pp[m++] = p[i];
-        if (sgn_eps(ci) != sgn_eps(cj)) {
+        if (sgn_eps(ci) > 0 && m < ORC_CAP_PP) pp[m++] = p[i];
+        if (sgn_eps(ci) != sgn_eps(cj) && m < ORC_CAP_PP) {
             line_cross(ci, cj, p[i], p[i + 1], &pp[m]);
             m++;
         }
     }
     n = 0;
     for (int i = 0; i < m; i++)
-        if (!i || !pt_same(pp[i], pp[i - 1])) p[n++] = pp[i];
+        if ((!i || !pt_same(pp[i], pp[i - 1])) && n < ORC_CAP_P - 1) p[n++] = pp[i];
     while (n > 1 && pt_same(p[n - 1], p[0])) n--;
     *pn = n;
 }

@@ -1,0 +1,151 @@
+"""GPU parity: polygon IoU and rotated NMS through the C-ABI vs the CPU oracle
+(bit-exact: fp64 IoU values, kept indices)."""
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from oracle import postprocess as pp
+from conftest import rrects
+
+pytestmark = pytest.mark.gpu
+
+CASES = ["rand1", "rand2", "rand63", "rand64", "rand65", "rand300", "rand1000", "ties45",
+         "degenerate", "kat_resultmerge", "thr05_oneclass", "negcoords"]
+
+
+def dev():
+    return torch.device("cuda", 0)
+
+
+def test_iou_pairs_golden_bit_exact(golden):
+    from dafne_amd.modeling.nms import poly_iou_pairs
+    g = golden("iou_pairs")
+    got = poly_iou_pairs(torch.from_numpy(g["p"]).to(dev()), torch.from_numpy(g["q"]).to(dev())).cpu().numpy()
+    assert np.array_equal(got, g["iou"])
+
+
+def test_iou_pairs_random_bit_exact():
+    from dafne_amd.modeling.nms import poly_iou_pairs
+    rng = np.random.default_rng(77)
+    n = 100000
+    p = rrects(n, rng, extent=300.0).astype(np.float64)
+    q = rrects(n, rng, extent=300.0).astype(np.float64)
+    p[n // 2:] = rng.normal(0, 8, (n - n // 2, 8))      # arbitrary / self-intersecting quads
+    q[n // 2:] = rng.normal(0, 8, (n - n // 2, 8))
+    q[:1000] = p[:1000]                                   # identical
+    q[1000:2000] = p[1000:2000] + 1e-7                    # nearly identical
+    p[2000:3000] += 20000.0                               # class-offset magnitudes
+    q[2000:3000] += 20000.0
+    got = poly_iou_pairs(torch.from_numpy(p).to(dev()), torch.from_numpy(q).to(dev())).cpu().numpy()
+    exp = oracle.iou_poly_pairs(p, q)
+    assert np.array_equal(got, exp), int((got != exp).sum())
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_batched_nms_poly_golden(golden, name):
+    from dafne_amd.modeling.nms import batched_nms_poly
+    g = golden("nms_cases")
+    keep = batched_nms_poly(torch.from_numpy(g[name + "_boxes"]).to(dev()),
+                            torch.from_numpy(g[name + "_scores"]).to(dev()),
+                            torch.from_numpy(g[name + "_classes"]).to(dev()), float(g[name + "_thr"]))
+    assert keep.dtype == torch.int64
+    assert keep.cpu().tolist() == g[name + "_keep"].tolist()
+
+
+def test_poly_gpu_nms_matches_oracle_and_known_answer():
+    from dafne_amd.modeling.nms import poly_gpu_nms
+    d = np.array([[6.86e2, 2.976e3, 7.09e2, 2.976e3, 7.24e2, 2.976e3, 7.01e2, 2.976e3, 2.7137e-3],
+                  [6.86e2, 2.976e3, 7.09e2, 2.976e3, 7.24e2, 2.976e3, 7.01e2, 2.976e3, 2.7097e-3]], np.float32)
+    assert poly_gpu_nms(d, 0.1, 0) == [0]          # ResultMerge.py:54-63
+    assert poly_gpu_nms(np.zeros((0, 9), np.float32), 0.1, 0) == []
+    rng = np.random.default_rng(8)
+    for m, ext, thr in ((777, 200.0, 0.1), (2000, 1024.0, 0.1), (1500, 150.0, 0.3), (3000, 400.0, 0.1)):
+        b = rrects(m, rng, extent=ext)
+        s = rng.uniform(0.05, 1, m).astype(np.float32)
+        s[::5] = s[1::5][: len(s[::5])]                       # score ties
+        c = rng.integers(0, 16, m)
+        d9 = oracle.build_dets9(b, s, c)
+        assert poly_gpu_nms(d9, thr, 0) == oracle.poly_nms(d9, thr, fast=True)
+
+
+def test_tiny_and_degenerate_boxes_bypass_prefilter_correctly():
+    """Boxes with ~0 area: the union==0 branch makes disjoint zero-area boxes
+    suppress each other -- the hull pre-filter must not hide it."""
+    from dafne_amd.modeling.nms import poly_gpu_nms
+    rng = np.random.default_rng(9)
+    m = 300
+    b = rrects(m, rng, extent=100.0)
+    b[:100, 2:] = np.tile(b[:100, :2], (1, 3))              # points
+    b[100:150] = rrects(50, rng, extent=100.0, lo=1e-4, hi=1e-3, jitter=0.0)   # microscopic
+    s = rng.uniform(0.05, 1, m).astype(np.float32)
+    d9 = np.concatenate([b, s[:, None]], 1).astype(np.float32)
+    assert poly_gpu_nms(d9, 0.1, 0) == oracle.poly_nms(d9, 0.1)
+
+
+def test_batched_with_device_counts_and_cap():
+    from dafne_amd import _lib
+    L = _lib.load()
+    rng = np.random.default_rng(10)
+    N, cap = 3, 1200
+    counts = [1200, 0, 517]
+    boxes = np.zeros((N, cap, 8), np.float32)
+    scores = np.zeros((N, cap), np.float32)
+    classes = np.zeros((N, cap), np.int32)
+    for i, m in enumerate(counts):
+        boxes[i, :m] = rrects(m, rng, extent=600.0)
+        scores[i, :m] = rng.uniform(0.05, 1, m)
+        classes[i, :m] = rng.integers(0, 15, m)
+    d = dev()
+    tb, ts, tc = (torch.from_numpy(a).to(d) for a in (boxes, scores, classes))
+    tn = torch.tensor(counts, dtype=torch.int32, device=d)
+    keep = torch.full((N, cap), -1, dtype=torch.int64, device=d)
+    nk = torch.zeros(N, dtype=torch.int32, device=d)
+    nbytes = L.dafne_poly_nms_workspace_bytes(N, cap)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=d)
+    post = 400
+    _lib.check(L.dafne_select_over_all_levels_hip(_lib.ptr(tb), _lib.ptr(ts), _lib.ptr(tc), _lib.ptr(tn), N, cap,
+                                                  0.1, post, _lib.ptr(keep), _lib.ptr(nk), _lib.ptr(ws), nbytes,
+                                                  _lib.current_stream()))
+    torch.cuda.synchronize()
+    for i, m in enumerate(counts):
+        det = {"pred_corners": boxes[i, :m], "scores": scores[i, :m], "pred_classes": classes[i, :m].astype(np.int64)}
+        exp_keep = pp.batched_nms_poly(det["pred_corners"], det["scores"], det["pred_classes"], 0.1, fast=True)
+        if len(exp_keep) > post:
+            kth = np.sort(scores[i][exp_keep])[len(exp_keep) - post]
+            exp_keep = exp_keep[scores[i][exp_keep] >= kth]
+        n = int(nk[i])
+        assert keep[i, :n].cpu().tolist() == exp_keep.tolist()
+
+
+def test_full_size_properties():
+    """M = 10 000 (5 levels x PRE_NMS_TOPK) and 27 000 (TTA merge): idempotence and
+    mutual non-overlap of the kept set, checked with the oracle on a sample."""
+    from dafne_amd.modeling.nms import batched_nms_poly, poly_iou_pairs
+    rng = np.random.default_rng(1234)
+    for m in (10000, 27000):
+        b = rrects(m, rng, extent=1024.0)
+        s = rng.uniform(0.05, 1, m).astype(np.float32)
+        c = rng.integers(0, 16, m)
+        tb, ts, tc = torch.from_numpy(b).to(dev()), torch.from_numpy(s).to(dev()), torch.from_numpy(c).to(dev())
+        keep = batched_nms_poly(tb, ts, tc, 0.1)
+        k = keep.cpu().numpy()
+        assert len(np.unique(k)) == len(k) and np.all(np.diff(s[k]) <= 0)     # unique, sorted by score
+        again = batched_nms_poly(tb[keep], ts[keep], tc[keep], 0.1)           # idempotent
+        assert again.cpu().tolist() == list(range(len(k)))
+        # kept boxes of the same (merged) class never overlap above the threshold
+        cc = np.where(c == 5, 4, c)[k]
+        i = rng.integers(0, len(k), 200000)
+        j = rng.integers(0, len(k), 200000)
+        sel = (cc[i] == cc[j]) & (i != j)
+        iou = poly_iou_pairs(tb[keep][torch.from_numpy(i[sel]).to(dev())].double(),
+                             tb[keep][torch.from_numpy(j[sel]).to(dev())].double())
+        assert float(iou.max()) <= 0.1
+        # every suppressed box has a better-scoring kept box of its class with IoU > thr (oracle, sample)
+        sup = np.setdiff1d(np.arange(m), k)[:50]
+        d9 = oracle.build_dets9(b, s, c)
+        for t in sup:
+            cand = k[(np.where(c == 5, 4, c)[k] == (4 if c[t] == 5 else c[t]))]
+            cand = cand[(s[cand] > s[t]) | ((s[cand] == s[t]) & (cand > t))]
+            iou_t = oracle.iou_poly_pairs(np.repeat(d9[t:t + 1, :8], len(cand), 0), d9[cand, :8])
+            assert (iou_t > 0.1).any()
