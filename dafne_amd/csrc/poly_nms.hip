@@ -506,6 +506,7 @@ __global__ void __launch_bounds__(kReduceThreads) nms_reduce_kernel(
     __shared__ u64 kept[kMaxBlk];
     __shared__ int kpre[kMaxBlk + 1];
     __shared__ u64 kcur;
+    __shared__ u64 dsh[kTile];
     const int tid = threadIdx.x;
     for (int k = tid; k < nb; k += kReduceThreads) {
         remv[k] = 0ull;
@@ -516,25 +517,25 @@ __global__ void __launch_bounds__(kReduceThreads) nms_reduce_kernel(
     for (int b = 0; b < nbu; b++) {
         if (tid < 64) {
             const int row = b * kTile + tid;
-            u64 d = row < M ? mask[(size_t)row * nb + b] : 0ull;
+            dsh[tid] = row < M ? mask[(size_t)row * nb + b] : 0ull;
+        }
+        __syncthreads();
+        if (tid == 0) {
+            // greedy scan inside the block: 64 dependent bit tests on one lane; the
+            // 64 LDS reads are independent and issue up front
             u64 rem = remv[b];
-            rem = ((u64)__builtin_amdgcn_readfirstlane((unsigned)(rem >> 32)) << 32) |
-                  __builtin_amdgcn_readfirstlane((unsigned)rem);   // wave-uniform -> SALU loop
             const int valid = min(kTile, M - b * kTile);
             if (valid < 64) rem |= ~0ull << valid;
             u64 K = 0ull;
-#pragma unroll
+#pragma unroll 8
             for (int r = 0; r < 64; r++) {
-                u64 dr = readlane64(d, r);
-                if (!((rem >> r) & 1ull)) {
-                    K |= 1ull << r;
-                    rem |= dr;
-                }
+                const u64 dr = dsh[r];
+                const bool alive = !((rem >> r) & 1ull);
+                K |= alive ? (1ull << r) : 0ull;
+                rem |= alive ? dr : 0ull;
             }
-            if (tid == 0) {
-                kept[b] = K;
-                kcur = K & rowflag[b];
-            }
+            kept[b] = K;
+            kcur = K & rowflag[b];
         }
         __syncthreads();
         const u64 K2 = kcur;
