@@ -22,7 +22,8 @@ c_i32 = ctypes.c_int32
 
 class LevelDesc(ctypes.Structure):
     _fields_ = [("d_logits", c_void_p), ("d_delta", c_void_p), ("d_center", c_void_p),
-                ("d_ctrness", c_void_p), ("H", c_i32), ("W", c_i32), ("stride", c_i32),
+                ("d_ctrness", c_void_p), ("logits_ps", c_i32), ("delta_ps", c_i32),
+                ("center_ps", c_i32), ("ctrness_ps", c_i32), ("H", c_i32), ("W", c_i32), ("stride", c_i32),
                 ("scale", c_float)]
 
 
@@ -65,6 +66,9 @@ SIGNATURES = {
     "dafne_conv2d_nhwc_bf16_hip": (c_int, [ctypes.POINTER(ConvParams), ctypes.POINTER(ConvSeg), c_void_p]),
     "dafne_conv2d_num_tiles": (c_int, [ctypes.POINTER(ConvParams), ctypes.POINTER(ConvSeg)]),
 }
+
+
+DET_ROW = 18
 
 
 class DafneHipError(RuntimeError):

@@ -1,0 +1,101 @@
+"""Inference half of the reference's DAFNeOutputs
+(dafne/modeling/dafne/dafne_outputs.py:123-190 config, :733-925 inference), with
+the same method names and argument meaning, backed by the HIP post-process.
+
+Training (target assignment, losses; :44-731) is out of scope for this engine.
+"""
+import torch
+from torch import nn
+
+from ... import postprocess as pp
+from ...structures import Instances
+from ..nms.nms import ml_nms
+
+
+class DAFNeOutputs(nn.Module):
+    def __init__(self, cfg):
+        super().__init__()
+        self.cfg = cfg
+        d = cfg.MODEL.DAFNE
+        self.pre_nms_thresh_test = d.INFERENCE_TH_TEST
+        self.pre_nms_topk_test = d.PRE_NMS_TOPK_TEST
+        self.post_nms_topk_test = d.POST_NMS_TOPK_TEST
+        self.pre_nms_thresh = self.pre_nms_thresh_test
+        self.pre_nms_topk = self.pre_nms_topk_test
+        self.post_nms_topk = self.post_nms_topk_test
+        self.nms_thresh = d.NMS_TH
+        self.thresh_with_ctr = d.THRESH_WITH_CTR
+        self.sort_corners = d.SORT_CORNERS
+        self.centerness_mode = d.CENTERNESS
+        self.has_centerness = self.centerness_mode != "none"
+        assert self.centerness_mode in ["none", "plain", "oriented"]
+        if not self.has_centerness:
+            raise NotImplementedError("CENTERNESS='none' is not used by any released config")
+        self.corner_prediction_strategy = d.CORNER_PREDICTION
+        self.num_classes = d.NUM_CLASSES
+        self.strides = d.FPN_STRIDES
+        self.stride_norm = d.ENABLE_FPN_STRIDE_NORM
+
+    def losses(self, *a, **k):
+        raise NotImplementedError("training is outside the scope of the MI355X inference engine")
+
+    # ---- fused device path used by the engine ---------------------------------
+    def predict_packed(self, levels, sizes=None, k_cap=None):
+        """levels: list[postprocess.LevelInput] (NHWC fp32).  Returns (rows, counts):
+        [N,k_cap,18] float32 detections and their per-image counts, on the GPU."""
+        if not self.stride_norm:
+            levels = [pp.LevelInput(l.logits, l.delta, l.center, l.ctrness, 1, l.scale,
+                                    l.delta_ps, l.center_ps, l.ctrness_ps, l.logits_ps) for l in levels]
+            raise NotImplementedError("ENABLE_FPN_STRIDE_NORM=False is not used by any released config")
+        cand = pp.decode_levels(levels, num_classes=self.num_classes, pre_nms_thresh=self.pre_nms_thresh_test,
+                                pre_nms_topk=self.pre_nms_topk_test, thresh_with_ctr=self.thresh_with_ctr,
+                                sort_corners=self.sort_corners)
+        if self.nms_thresh > 0:
+            keep, nk = pp.select(cand, self.nms_thresh, self.post_nms_topk_test)
+        else:   # ml_nms returns its input unchanged (nms.py:22-23); only the cap applies
+            keep, nk = _identity_keep_with_cap(cand, self.post_nms_topk_test)
+        if k_cap is None:
+            k_cap = min(cand.m_cap, max(self.post_nms_topk_test, 1) + 256) if self.post_nms_topk_test > 0 \
+                else cand.m_cap
+        return pp.gather(cand, keep, nk, sizes=sizes, k_cap=k_cap)
+
+    # ---- reference-signature path ----------------------------------------------
+    def predict_proposals(self, logits_pred, corners_reg_pred, ctrness_pred, locations, image_sizes,
+                          top_feats=None):
+        """Same arguments as the reference (:733-741): per-level NCHW tensors, with
+        corners_reg_pred already (center.repeat + delta) * scale.  ``locations`` is
+        accepted for signature parity; the kernel regenerates them (dafne.py:37-44)."""
+        levels = []
+        for lg, rc, ct, s in zip(logits_pred, corners_reg_pred, ctrness_pred, self.strides):
+            n, _, h, w = lg.shape
+            lg_n = lg.detach().float().permute(0, 2, 3, 1).contiguous()
+            rc_n = rc.detach().float().permute(0, 2, 3, 1).contiguous()
+            ct_n = ct.detach().float().permute(0, 2, 3, 1).contiguous()
+            zero = torch.zeros(n, h, w, 2, dtype=torch.float32, device=lg.device)
+            levels.append(pp.LevelInput(lg_n, rc_n, zero, ct_n, s, 1.0))
+        rows, counts = self.predict_packed(levels)
+        sizes = [tuple(int(v) for v in (s.tolist() if isinstance(s, torch.Tensor) else s)) for s in image_sizes]
+        return pp.rows_to_instances(rows, counts, sizes)
+
+    def select_over_all_levels(self, boxlists):
+        """:907-925, Instances in / Instances out (used by the TTA merge, tta.py:265)."""
+        results = []
+        for bl in boxlists:
+            result = ml_nms(bl, self.nms_thresh)
+            n = len(result)
+            if n > self.post_nms_topk > 0:
+                s = result.scores
+                thr = torch.kthvalue(s, n - self.post_nms_topk + 1).values
+                result = result[torch.nonzero(s >= thr).squeeze(1)]
+            results.append(result)
+        return results
+
+
+def _identity_keep_with_cap(cand, post_topk):
+    n, m = cand.n, cand.m_cap
+    dev = cand.scores.device
+    keep = torch.arange(m, device=dev, dtype=torch.int64).repeat(n, 1)
+    nk = cand.counts.clone()
+    if post_topk > 0:
+        raise NotImplementedError("NMS_TH <= 0 with a post-NMS cap is not used by any released config")
+    return keep, nk

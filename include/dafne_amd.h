@@ -102,6 +102,9 @@ typedef struct dafne_level_desc {
     const float* d_delta;   /* [N, H, W, 8]  corners_pred output                      */
     const float* d_center;  /* [N, H, W, 2]  center_pred output                       */
     const float* d_ctrness; /* [N, H, W]     ctrness logits                           */
+    /* pixel strides in floats (>= C, 8, 2, 1): lets several predictions share one
+     * NHWC buffer, e.g. corners_pred+ctrness written by one fused conv          */
+    int32_t logits_ps, delta_ps, center_ps, ctrness_ps;
     int32_t H, W, stride;   /* feature size and FPN stride                            */
     float scale;            /* the level's learnable Scale (dafne.py:405-411)         */
 } dafne_level_desc;
@@ -137,9 +140,11 @@ int dafne_sort_quadrilateral_hip(const float* d_in, float* d_out, int64_t n, voi
  * (one_stage_detector.py:79-98): hull boxes scaled by out/net-input size, clipped,
  * empty ones dropped; corners and locations scaled by out/orig.  d_sizes:
  * [N,6] float32 = (net_h, net_w, out_h, out_w, orig_h, orig_w) per image.
- * Output rows [N, k_cap, 16] float32 = corners8, score, centerness, class, level,
- * hbox4, loc2 (class/level stored as float); d_out_counts [N].
+ * Output rows [N, k_cap, DAFNE_DET_ROW] float32 = corners8, score, centerness,
+ * class, level, hbox4, loc2 (class/level stored as float); d_out_counts [N].
+ * Rows beyond k_cap are dropped and still counted (caller checks count <= k_cap).
  */
+#define DAFNE_DET_ROW 18
 int dafne_gather_detections_hip(const float* d_corners, const float* d_scores, const float* d_ctr,
                                 const int32_t* d_classes, const float* d_locs,
                                 const int32_t* d_levels, const float* d_hbox,
