@@ -45,6 +45,10 @@ class ConvParams(ctypes.Structure):
                 ("d_gn_partial", c_void_p)]
 
 
+class GnSeg(ctypes.Structure):
+    _fields_ = [("d_x", c_void_p), ("H", c_i32), ("W", c_i32), ("tile0", c_i32), ("tiles_per_img", c_i32)]
+
+
 # name -> (restype, argtypes): every symbol include/dafne_amd.h declares
 SIGNATURES = {
     "dafne_abi_version": (c_int, []),
@@ -65,6 +69,14 @@ SIGNATURES = {
                                                              c_void_p]),
     "dafne_conv2d_nhwc_bf16_hip": (c_int, [ctypes.POINTER(ConvParams), ctypes.POINTER(ConvSeg), c_void_p]),
     "dafne_conv2d_num_tiles": (c_int, [ctypes.POINTER(ConvParams), ctypes.POINTER(ConvSeg)]),
+    "dafne_conv2d_cout_pad": (c_int, [c_int]),
+    "dafne_preprocess_image_hip": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p,
+                                           ctypes.POINTER(c_float), ctypes.POINTER(c_float), c_int, c_int,
+                                           c_void_p, c_void_p]),
+    "dafne_maxpool3x3s2_nhwc_bf16_hip": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    "dafne_groupnorm_relu_nhwc_bf16_hip": (c_int, [ctypes.POINTER(GnSeg), c_int, c_int, c_int, c_void_p, c_void_p,
+                                                   c_void_p, c_void_p, c_float, c_void_p]),
+    "dafne_relu_copy_bf16_hip": (c_int, [c_void_p, c_void_p, c_i64, c_void_p]),
 }
 
 

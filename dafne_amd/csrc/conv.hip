@@ -1,0 +1,389 @@
+// Implicit-GEMM convolution for gfx950: NHWC bf16 activations with a 1-pixel zero
+// halo, bf16 weights [Cout][KH*KW*Cin], fp32 accumulation on the matrix cores.
+//
+// Replaces every torch conv2d the reference's inference path issues through cuDNN:
+// detectron2 ResNet bottlenecks / FPN laterals and outputs (dafne/modeling/backbone/
+// fpn.py:58-91 [d2 ResNet/FPN recalled, SURVEY appendix B]), LastLevelP6P7
+// (fpn.py:16-37), and the DAFNeHead tower / prediction convs
+// (dafne/modeling/dafne/dafne.py:209-229,318-344).  Fused epilogues: folded-FrozenBN
+// bias, residual add, nearest-2x top-down add (FPN), ReLU, per-tile GroupNorm partial
+// sums, fp32 prediction outputs.
+//
+// GEMM view: D[cout][pixel] = sum_k W[cout][k] * X[pixel][k], k = (kh, kw, cin).
+// The halo makes every tap of a 3x3 a plain in-bounds 128-byte row segment, so the
+// pixel operand is staged exactly like the weight operand: `global_load_lds` 16-byte
+// pieces, 8 lanes per 64-channel row slab, XOR-swizzled on the SOURCE address
+// (LDS image stays lane-linear) so the MFMA fragment reads (`ds_read_b128`, rows =
+// lane&31) are bank-conflict free.  v_mfma_f32_32x32x16_bf16, weights as the A
+// operand: each lane ends up with 4 consecutive output channels of one pixel per
+// accumulator quad -> 8-byte NHWC stores.
+//
+// Pipeline: 2 LDS stages, one barrier per 64-deep K step; the next step's loads are
+// issued right after the barrier and land under the current step's 16 MFMAs/wave.
+#include "common.h"
+
+namespace {
+
+typedef __attribute__((ext_vector_type(8))) short bf16x8;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((address_space(1))) const void gvoid;
+typedef __attribute__((address_space(3))) void lvoid;
+
+constexpr int kMaxSegs = 5;
+constexpr int kBK = 64;           // K step (bf16 elements) = one 128-byte row slab
+constexpr int kRowBytes = kBK * 2;
+
+struct SegDev {
+    const char* in;
+    char* out;
+    const char* res;
+    int Hin, Win, Hout, Wout;
+    int tiles_per_img;   // ceil(Hout*Wout / BM)
+    int tile0;           // first M tile of this segment
+};
+
+struct ConvDev {
+    SegDev seg[kMaxSegs];
+    int n_segs, N;
+    int Cin, Cout, Cout_pad, KH, KW, stride, pad;
+    unsigned flags;
+    const char* w;
+    const float* bias;
+    float* gn_partial;
+    int ksteps;        // KH*KW*Cin/64 (stem: 4)
+    int kbytes;        // bytes per weight row
+    int mtiles, ntiles;
+    int stem;          // 7x7 s2 stem on the 4-channel padded image
+};
+
+__device__ __forceinline__ unsigned short f2bf(float f) {
+    unsigned u = __float_as_uint(f);
+    u += 0x7fffu + ((u >> 16) & 1u);   // round to nearest even (inputs are finite)
+    return (unsigned short)(u >> 16);
+}
+
+__device__ __forceinline__ float bf2f(unsigned short h) { return __uint_as_float((unsigned)h << 16); }
+
+// Bijective XCD-aware remap: consecutive logical tiles (which share the pixel
+// operand across N tiles and the halo rows across M tiles) land on one XCD's L2.
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+    const int xcd = bid & 7, idx = bid >> 3;
+    const int q = nwg >> 3, r = nwg & 7;
+    const int start = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return start + idx;
+}
+
+template <int WC, int WP, int TC, int TP>
+__global__ void __launch_bounds__(256) conv_igemm_kernel(ConvDev P) {
+    constexpr int BN = WC * TC * 32;       // output channels per block
+    constexpr int BM = WP * TP * 32;       // output pixels per block
+    constexpr int ROWS = BN + BM;
+    constexpr int NL = ROWS / 32;          // 1-KiB load instructions per wave per stage
+    constexpr int STAGE = ROWS * kRowBytes;
+    static_assert(WC * WP == 4, "4 waves");
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wc = wave / WP, wp = wave % WP;
+
+    const int bid = xcd_remap(blockIdx.x, P.mtiles * P.ntiles);
+    const int nt = bid % P.ntiles;
+    const int mt = bid / P.ntiles;
+    int si = 0;
+#pragma unroll
+    for (int k = 1; k < kMaxSegs; k++)
+        if (k < P.n_segs && mt >= P.seg[k].tile0) si = k;
+    const SegDev& S = P.seg[si];
+    const int img = (mt - S.tile0) / S.tiles_per_img;
+    const int m0 = ((mt - S.tile0) % S.tiles_per_img) * BM;
+    const int HW = S.Hout * S.Wout;
+    const int Wp = P.stem ? S.Win : S.Win + 2;   // input row pitch in pixels (stem: already padded)
+    const int Hp = P.stem ? S.Hin : S.Hin + 2;
+    const int cpx = P.stem ? 8 : P.Cin * 2;      // bytes per input pixel
+
+    // ---- per-lane source offsets of the rows this lane stages -----------------
+    unsigned gofs[NL];
+#pragma unroll
+    for (int j = 0; j < NL; j++) {
+        const int r = (j * 4 + wave) * 8 + (lane >> 3);
+        const int q = (lane & 7) ^ ((r >> 1) & 7);     // logical 16-byte chunk this lane fetches
+        if ((j * 4 + wave) * 8 < BN) {
+            gofs[j] = (unsigned)(nt * BN + r) * (unsigned)P.kbytes + (unsigned)q * 16u;
+        } else {
+            int pix = m0 + (r - BN);
+            pix = pix < HW ? pix : HW - 1;             // ragged last tile: stay in bounds
+            const int ho = pix / S.Wout, wo = pix - ho * S.Wout;
+            const unsigned row = (unsigned)(img * Hp + ho * P.stride + (P.stem ? 0 : 1 - P.pad));
+            const unsigned col = (unsigned)(wo * P.stride + (P.stem ? 0 : 1 - P.pad));
+            const unsigned lanepart = P.stem ? (unsigned)(q >> 2) * (unsigned)(Wp * 8) + (unsigned)(q & 3) * 16u
+                                             : (unsigned)q * 16u;
+            gofs[j] = (row * (unsigned)Wp + col) * (unsigned)cpx + lanepart;
+        }
+    }
+
+    // K-step bookkeeping (scalar): tap (kh,kw) and channel slab c0
+    int kh = 0, kw = 0, c0 = 0;
+    auto issue = [&](int stage, int step) {
+        const unsigned koffW = (unsigned)step * (unsigned)kRowBytes;
+        const unsigned koffX = P.stem ? (unsigned)(2 * step) * (unsigned)(Wp * 8)
+                                      : (unsigned)((kh * Wp + kw) * P.Cin + c0) * 2u;
+#pragma unroll
+        for (int j = 0; j < NL; j++) {
+            const bool isW = (j * 4 + wave) * 8 < BN;
+            const char* base = isW ? P.w : S.in;
+            const unsigned off = gofs[j] + (isW ? koffW : koffX);
+            char* dst = lds + stage * STAGE + (j * 4 + wave) * 8 * kRowBytes;
+            __builtin_amdgcn_global_load_lds((gvoid*)(base + off), (lvoid*)dst, 16, 0, 0);
+        }
+        c0 += kBK;
+        if (c0 >= P.Cin) {
+            c0 = 0;
+            if (++kw == P.KW) { kw = 0; ++kh; }
+        }
+    };
+
+    f32x16 acc[TC][TP];
+#pragma unroll
+    for (int a = 0; a < TC; a++)
+#pragma unroll
+        for (int b = 0; b < TP; b++)
+#pragma unroll
+            for (int k = 0; k < 16; k++) acc[a][b][k] = 0.f;
+
+    // fragment read offsets: row = lane&31 inside a 32-row tile, chunk (2ks + lane>>5) ^ f
+    const int frow = lane & 31;
+    const int fsw = (frow >> 1) & 7;
+    unsigned roff[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ks++) roff[ks] = (unsigned)frow * kRowBytes + (unsigned)(((2 * ks + (lane >> 5)) ^ fsw) * 16);
+    const int arow0 = wc * TC * 32;
+    const int brow0 = BN + wp * TP * 32;
+
+    issue(0, 0);
+    for (int step = 0; step < P.ksteps; step++) {
+        const int cur = step & 1;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (step + 1 < P.ksteps) issue(cur ^ 1, step + 1);
+        const char* sb = lds + cur * STAGE;
+#pragma unroll
+        for (int ks = 0; ks < 4; ks++) {
+            bf16x8 af[TC], bfr[TP];
+#pragma unroll
+            for (int a = 0; a < TC; a++) af[a] = *(const bf16x8*)(sb + (arow0 + a * 32) * kRowBytes + roff[ks]);
+#pragma unroll
+            for (int b = 0; b < TP; b++) bfr[b] = *(const bf16x8*)(sb + (brow0 + b * 32) * kRowBytes + roff[ks]);
+#pragma unroll
+            for (int a = 0; a < TC; a++)
+#pragma unroll
+                for (int b = 0; b < TP; b++)
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[a], bfr[b], acc[a][b], 0, 0, 0);
+        }
+    }
+
+    // ------------------------------------------------------------ epilogue
+    const bool relu = P.flags & DAFNE_CONV_RELU;
+    const bool has_res = P.flags & DAFNE_CONV_RESIDUAL;
+    const bool has_up = P.flags & DAFNE_CONV_UPSAMPLE_ADD;
+    const bool out_f32 = P.flags & DAFNE_CONV_OUT_F32;
+    const bool gn = P.flags & DAFNE_CONV_GN_STATS;
+    const int half = lane >> 5;
+    float gsum[TC][4], gsq[TC][4];
+#pragma unroll
+    for (int a = 0; a < TC; a++)
+#pragma unroll
+        for (int g = 0; g < 4; g++) gsum[a][g] = gsq[a][g] = 0.f;
+
+#pragma unroll
+    for (int b = 0; b < TP; b++) {
+        const int m = m0 + (wp * TP + b) * 32 + frow;
+        const bool valid = m < HW;
+        const int mm = valid ? m : HW - 1;
+        const int ho = mm / S.Wout, wo = mm - ho * S.Wout;
+        const size_t opix = ((size_t)(img * (S.Hout + 2) + ho + 1) * (S.Wout + 2) + wo + 1);
+        size_t rpix = opix;
+        if (has_up) rpix = ((size_t)(img * (S.Hout / 2 + 2) + ho / 2 + 1) * (S.Wout / 2 + 2) + wo / 2 + 1);
+#pragma unroll
+        for (int a = 0; a < TC; a++) {
+#pragma unroll
+            for (int g = 0; g < 4; g++) {
+                const int co = nt * BN + (wc * TC + a) * 32 + 8 * g + 4 * half;   // 4 consecutive channels
+                float v[4];
+#pragma unroll
+                for (int k = 0; k < 4; k++) v[k] = acc[a][b][4 * g + k];
+                if (P.bias) {
+                    const float4 bb = *(const float4*)(P.bias + co);
+                    v[0] += bb.x; v[1] += bb.y; v[2] += bb.z; v[3] += bb.w;
+                }
+                if (has_res || has_up) {
+                    const uint2 rr = *(const uint2*)(S.res + (rpix * P.Cout + co) * 2);
+                    v[0] += bf2f((unsigned short)(rr.x & 0xffff)); v[1] += bf2f((unsigned short)(rr.x >> 16));
+                    v[2] += bf2f((unsigned short)(rr.y & 0xffff)); v[3] += bf2f((unsigned short)(rr.y >> 16));
+                }
+                if (relu) {
+#pragma unroll
+                    for (int k = 0; k < 4; k++) v[k] = fmaxf(v[k], 0.f);
+                }
+                if (gn && valid) {
+#pragma unroll
+                    for (int k = 0; k < 4; k++) { gsum[a][g] += v[k]; gsq[a][g] += v[k] * v[k]; }
+                }
+                if (valid) {
+                    if (out_f32) {
+                        float* o = (float*)S.out + ((size_t)(img * S.Hout + ho) * S.Wout + wo) * P.Cout + co;
+#pragma unroll
+                        for (int k = 0; k < 4; k++) if (co + k < P.Cout) o[k] = v[k];
+                    } else {
+                        uint2 pk;
+                        pk.x = (unsigned)f2bf(v[0]) | ((unsigned)f2bf(v[1]) << 16);
+                        pk.y = (unsigned)f2bf(v[2]) | ((unsigned)f2bf(v[3]) << 16);
+                        *(uint2*)(S.out + (opix * P.Cout + co) * 2) = pk;
+                    }
+                }
+            }
+        }
+    }
+
+    if (gn) {
+        // deterministic: butterfly over the wave (32 pixels x 2 channel halves), then a
+        // fixed-order sum over the WP pixel-waves through LDS
+        __syncthreads();   // LDS stages are dead now
+        float* red = (float*)lds;   // [4 waves][TC*4][2]
+#pragma unroll
+        for (int a = 0; a < TC; a++)
+#pragma unroll
+            for (int g = 0; g < 4; g++) {
+                float s = gsum[a][g], q = gsq[a][g];
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) {
+                    s += __shfl_xor(s, o, 64);
+                    q += __shfl_xor(q, o, 64);
+                }
+                if (lane == 0) {
+                    red[(wave * TC * 4 + a * 4 + g) * 2 + 0] = s;
+                    red[(wave * TC * 4 + a * 4 + g) * 2 + 1] = q;
+                }
+            }
+        __syncthreads();
+        if (tid < BN / 8) {
+            const int wcc = tid / (TC * 4), ag = tid % (TC * 4);
+            float s = 0.f, q = 0.f;
+#pragma unroll
+            for (int p = 0; p < WP; p++) {
+                s += red[((wcc * WP + p) * TC * 4 + ag) * 2 + 0];
+                q += red[((wcc * WP + p) * TC * 4 + ag) * 2 + 1];
+            }
+            const int group = (nt * BN) / 8 + tid;
+            if (group < P.Cout / 8) {
+                float* o = P.gn_partial + ((size_t)mt * (P.Cout / 8) + group) * 2;
+                o[0] = s;
+                o[1] = q;
+            }
+        }
+    }
+}
+
+struct Cfg {
+    int bn, bm;
+};
+
+Cfg pick_cfg(int Cout) {
+    if (Cout >= 128) return {128, 128};
+    if (Cout > 32) return {64, 256};
+    return {32, 256};
+}
+
+int build(ConvDev& D, const dafne_conv_params* p, const dafne_conv_seg* segs) {
+    if (!p || !segs) return dafne::fail(DAFNE_E_INVALID, "conv: null params");
+    if (p->n_segs < 1 || p->n_segs > kMaxSegs || p->n_images < 1) return dafne::fail(DAFNE_E_INVALID, "conv: bad segment/image count");
+    const bool stem = p->Cin == 4 && p->KH == 7 && p->KW == 7 && p->stride == 2;
+    if (!stem) {
+        if (p->Cin % kBK) return dafne::fail(DAFNE_E_UNSUPPORTED, "conv: Cin %d not a multiple of 64", p->Cin);
+        if (!((p->KH == 1 && p->KW == 1 && p->pad == 0) || (p->KH == 3 && p->KW == 3 && p->pad == 1)))
+            return dafne::fail(DAFNE_E_UNSUPPORTED, "conv: only 1x1/p0 and 3x3/p1 (and the 7x7 stem)");
+        if (p->stride != 1 && p->stride != 2) return dafne::fail(DAFNE_E_UNSUPPORTED, "conv: stride %d", p->stride);
+    }
+    if (p->Cout < 1) return dafne::fail(DAFNE_E_INVALID, "conv: Cout");
+    Cfg c = pick_cfg(p->Cout);
+    D.Cout_pad = (p->Cout + c.bn - 1) / c.bn * c.bn;
+    if (!(p->flags & DAFNE_CONV_OUT_F32) && D.Cout_pad != p->Cout)
+        return dafne::fail(DAFNE_E_UNSUPPORTED, "conv: bf16 output needs Cout %% %d == 0", c.bn);
+    if ((p->flags & DAFNE_CONV_GN_STATS) && (!p->d_gn_partial || (p->Cout % 8))) return dafne::fail(DAFNE_E_INVALID, "conv: GN stats buffer");
+    if ((p->flags & (DAFNE_CONV_RESIDUAL | DAFNE_CONV_UPSAMPLE_ADD)) == (DAFNE_CONV_RESIDUAL | DAFNE_CONV_UPSAMPLE_ADD))
+        return dafne::fail(DAFNE_E_INVALID, "conv: residual and upsample-add are exclusive");
+    if (!p->d_weight) return dafne::fail(DAFNE_E_INVALID, "conv: null weight");
+    D.n_segs = p->n_segs; D.N = p->n_images;
+    D.Cin = p->Cin; D.Cout = p->Cout; D.KH = p->KH; D.KW = p->KW; D.stride = p->stride; D.pad = p->pad;
+    D.flags = p->flags; D.w = (const char*)p->d_weight; D.bias = p->d_bias; D.gn_partial = p->d_gn_partial;
+    D.stem = stem ? 1 : 0;
+    D.ksteps = stem ? 4 : p->KH * p->KW * p->Cin / kBK;
+    D.kbytes = D.ksteps * kRowBytes;
+    int t = 0;
+    for (int s = 0; s < p->n_segs; s++) {
+        const dafne_conv_seg& g = segs[s];
+        if (!g.d_in || !g.d_out || g.Hout < 1 || g.Wout < 1) return dafne::fail(DAFNE_E_INVALID, "conv: segment %d", s);
+        if ((p->flags & (DAFNE_CONV_RESIDUAL | DAFNE_CONV_UPSAMPLE_ADD)) && !g.d_res) return dafne::fail(DAFNE_E_INVALID, "conv: missing residual");
+        if ((p->flags & DAFNE_CONV_UPSAMPLE_ADD) && ((g.Hout | g.Wout) & 1)) return dafne::fail(DAFNE_E_UNSUPPORTED, "conv: upsample-add needs even output size");
+        // geometry check: every tap of every output pixel must fall inside the haloed input
+        if (!stem) {
+            if ((g.Hout - 1) * p->stride + p->KH - p->pad > g.Hin + 1 || (g.Wout - 1) * p->stride + p->KW - p->pad > g.Win + 1)
+                return dafne::fail(DAFNE_E_INVALID, "conv: segment %d output %dx%d reaches outside the input halo", s, g.Hout, g.Wout);
+        } else if ((g.Hout - 1) * 2 + 8 > g.Hin || (g.Wout - 1) * 2 + 8 > g.Win) {
+            return dafne::fail(DAFNE_E_INVALID, "conv: stem input must be padded to 2*Hout+6");
+        }
+        SegDev& o = D.seg[s];
+        o.in = (const char*)g.d_in; o.out = (char*)g.d_out; o.res = (const char*)g.d_res;
+        o.Hin = g.Hin; o.Win = g.Win; o.Hout = g.Hout; o.Wout = g.Wout;
+        o.tiles_per_img = (g.Hout * g.Wout + c.bm - 1) / c.bm;
+        o.tile0 = t;
+        t += o.tiles_per_img * p->n_images;
+    }
+    D.mtiles = t;
+    D.ntiles = D.Cout_pad / c.bn;
+    return DAFNE_OK;
+}
+
+template <int WC, int WP, int TC, int TP>
+int launch(const ConvDev& D, hipStream_t st) {
+    constexpr int ROWS = (WC * TC + WP * TP) * 32;
+    constexpr int smem = 2 * ROWS * kRowBytes;
+    static bool attr_done = false;   // idempotent attribute; a benign race sets it twice
+    if (!attr_done) {
+        DAFNE_HIP_TRY(hipFuncSetAttribute((const void*)conv_igemm_kernel<WC, WP, TC, TP>,
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+        attr_done = true;
+    }
+    hipLaunchKernelGGL((conv_igemm_kernel<WC, WP, TC, TP>), dim3(D.mtiles * D.ntiles), dim3(256), smem, st, D);
+    return dafne::check_launch("conv_igemm");
+}
+
+}  // namespace
+
+extern "C" {
+
+int dafne_conv2d_cout_pad(int Cout) {
+    if (Cout < 1) return 0;
+    Cfg c = pick_cfg(Cout);
+    return (Cout + c.bn - 1) / c.bn * c.bn;
+}
+
+int dafne_conv2d_num_tiles(const dafne_conv_params* prm, const dafne_conv_seg* segs) {
+    ConvDev D;
+    if (build(D, prm, segs)) return -1;
+    return D.mtiles;
+}
+
+int dafne_conv2d_nhwc_bf16_hip(const dafne_conv_params* prm, const dafne_conv_seg* segs, void* stream) {
+    ConvDev D;
+    int rc = build(D, prm, segs);
+    if (rc) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    Cfg c = pick_cfg(D.Cout);
+    if (c.bn == 128) return launch<2, 2, 2, 2>(D, st);
+    if (c.bn == 64) return launch<1, 4, 2, 2>(D, st);
+    return launch<1, 4, 1, 2>(D, st);
+}
+
+}  // extern "C"

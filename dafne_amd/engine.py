@@ -1,0 +1,355 @@
+"""Dense engine: weight packing, activation buffers and the launch plan that
+drives libdafne_amd.so's conv / pool / GroupNorm kernels.
+
+PyTorch is only the allocator and stream owner here: every arithmetic step is a
+HIP kernel behind include/dafne_amd.h.  Activations are NHWC bf16 with a 1-pixel
+zero halo ([N, H+2, W+2, C]); a plan (list of pre-built ctypes calls) is created
+once per input shape and replayed, optionally from a HIP graph.
+
+Graph semantics follow the reference: detectron2 ResNet/FPN,
+dafne/modeling/backbone/fpn.py:16-37,58-91 and dafne/modeling/dafne/dafne.py:
+350-494 (center-to-corner branch).
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+
+BF16 = torch.bfloat16
+STAGE_BLOCKS = {50: (3, 4, 6, 3), 101: (3, 4, 23, 3)}
+
+F_RELU, F_RES, F_UP, F_F32, F_GN = 1, 2, 4, 8, 16
+
+
+# ------------------------------------------------------------------ activations
+class Act:
+    """Haloed NHWC bf16 activation [N, H+2, W+2, C]; the halo is zero forever
+    because kernels only ever write the interior."""
+
+    __slots__ = ("t", "n", "h", "w", "c")
+
+    def __init__(self, n, h, w, c, device):
+        self.t = torch.zeros(n, h + 2, w + 2, c, dtype=BF16, device=device)
+        self.n, self.h, self.w, self.c = n, h, w, c
+
+    def nchw_float(self):
+        return self.t[:, 1:-1, 1:-1, :].permute(0, 3, 1, 2).float().contiguous()
+
+    @staticmethod
+    def from_nchw(x):
+        n, c, h, w = x.shape
+        a = Act(n, h, w, c, x.device)
+        a.t[:, 1:-1, 1:-1, :] = x.permute(0, 2, 3, 1).to(BF16)
+        return a
+
+
+class Pool:
+    """Shape-keyed buffer pool: same shape => same halo positions => reusable."""
+
+    def __init__(self, device):
+        self.device = device
+        self.free = {}
+        self.bytes = 0
+
+    def get(self, n, h, w, c):
+        lst = self.free.setdefault((n, h, w, c), [])
+        if lst:
+            return lst.pop()
+        self.bytes += n * (h + 2) * (w + 2) * c * 2
+        return Act(n, h, w, c, self.device)
+
+    def put(self, a):
+        self.free.setdefault((a.n, a.h, a.w, a.c), []).append(a)
+
+
+# --------------------------------------------------------------- weight packing
+def pack_conv(weight, bias, device):
+    """[Cout,Cin,KH,KW] fp32 (+bias) -> bf16 [Cout_pad, KH*KW*Cin] (k = kh,kw,cin),
+    fp32 bias [Cout_pad]."""
+    L = _lib.load()
+    cout, cin, kh, kw = weight.shape
+    cpad = L.dafne_conv2d_cout_pad(cout)
+    w = torch.zeros(cpad, kh * kw * cin, dtype=torch.float32)
+    w[:cout] = weight.detach().float().cpu().permute(0, 2, 3, 1).reshape(cout, -1)
+    b = torch.zeros(cpad, dtype=torch.float32)
+    if bias is not None:
+        b[:cout] = bias.detach().float().cpu()
+    return w.to(BF16).to(device).contiguous(), b.to(device).contiguous()
+
+
+def pack_stem(weight, bias, device):
+    """[64,3,7,7] -> bf16 [64, 256]: k = (kh 0..7, kw 0..7, c 0..3), zero where kh=7, kw=7 or c=3."""
+    cout = weight.shape[0]
+    w = torch.zeros(cout, 8, 8, 4, dtype=torch.float32)
+    w[:, :7, :7, :3] = weight.detach().float().cpu().permute(0, 2, 3, 1)
+    b = torch.zeros(cout, dtype=torch.float32)
+    if bias is not None:
+        b[:] = bias.detach().float().cpu()
+    return w.reshape(cout, 256).to(BF16).to(device).contiguous(), b.to(device).contiguous()
+
+
+def fold_frozen_bn(weight, bn_w, bn_b, bn_mean, bn_var, eps=1e-5):
+    s = bn_w * torch.rsqrt(bn_var + eps)
+    return weight * s[:, None, None, None], bn_b - bn_mean * s
+
+
+# --------------------------------------------------------------------- launches
+class ConvCall:
+    """One dafne_conv2d_nhwc_bf16_hip launch with its argument structs kept alive."""
+
+    def __init__(self, w, b, cin, cout, k, stride, pad, flags, segs, n_images, gn_partial=None):
+        L = _lib.load()
+        self.keep = (w, b, gn_partial, [s for s in segs])
+        self.prm = _lib.ConvParams(n_images, len(segs), cin, cout, k, k, stride, pad, flags,
+                                   w.data_ptr(), b.data_ptr() if b is not None else None,
+                                   gn_partial.data_ptr() if gn_partial is not None else None)
+        arr = (_lib.ConvSeg * len(segs))()
+        for i, (tin, tout, tres, hin, win, hout, wout) in enumerate(segs):
+            arr[i] = _lib.ConvSeg(tin.data_ptr(), tout.data_ptr(), tres.data_ptr() if tres is not None else None,
+                                  hin, win, hout, wout)
+        self.segs = arr
+        self.fn = L.dafne_conv2d_nhwc_bf16_hip
+        self.flops = 0
+        for (_, _, _, _, _, hout, wout) in segs:
+            kk = 49 * 3 if (cin == 4 and k == 7) else k * k * cin
+            self.flops += 2 * n_images * hout * wout * cout * kk
+
+    def num_tiles(self):
+        return _lib.load().dafne_conv2d_num_tiles(ctypes.byref(self.prm), self.segs)
+
+    def __call__(self, stream):
+        rc = self.fn(ctypes.byref(self.prm), self.segs, stream)
+        if rc:
+            _lib.check(rc, "dafne_conv2d_nhwc_bf16_hip")
+
+
+class FnCall:
+    def __init__(self, fn, args, keep, name):
+        self.fn, self.args, self.keep, self.name = fn, args, keep, name
+
+    def __call__(self, stream):
+        rc = self.fn(*self.args, stream)
+        if rc:
+            _lib.check(rc, self.name)
+
+
+def conv_out_hw(h, w, k, stride, pad):
+    return (h + 2 * pad - k) // stride + 1, (w + 2 * pad - k) // stride + 1
+
+
+# ------------------------------------------------------------------------- plan
+class DensePlan:
+    """Backbone + FPN + head for one (N, H, W): buffers + ordered launches."""
+
+    def __init__(self, weights, n, h, w, depth, num_classes, device, with_head=True):
+        assert h % 32 == 0 and w % 32 == 0
+        self.n, self.h, self.w = n, h, w
+        self.device = device
+        self.calls = []
+        self.flops = 0
+        L = _lib.load()
+        P = weights
+        pool = Pool(device)
+        self.pool = pool
+
+        def conv(key, tin, k, stride, pad, flags, res=None, out=None, cout=None):
+            wgt, bias = P[key]
+            cin = tin.c
+            cout = cout or wgt.shape[0]
+            ho, wo = conv_out_hw(tin.h, tin.w, k, stride, pad)
+            o = out or pool.get(n, ho, wo, cout)
+            c = ConvCall(wgt, bias, cin, cout, k, stride, pad, flags,
+                         [(tin.t, o.t, res.t if res is not None else None, tin.h, tin.w, ho, wo)], n)
+            self.calls.append(c)
+            self.flops += c.flops
+            return o
+
+        # stem: preprocess output [N, H+6, W+6, 4] -> conv7x7/s2 -> maxpool
+        self.stem_in = torch.zeros(n, h + 6, w + 6, 4, dtype=BF16, device=device)
+        wgt, bias = P["stem"]
+        stem_out = pool.get(n, h // 2, w // 2, 64)
+        c = ConvCall(wgt, bias, 4, 64, 7, 2, 3, F_RELU,
+                     [(self.stem_in, stem_out.t, None, h + 6, w + 6, h // 2, w // 2)], n)
+        self.calls.append(c)
+        self.flops += c.flops
+        x = pool.get(n, h // 4, w // 4, 64)
+        self.calls.append(FnCall(L.dafne_maxpool3x3s2_nhwc_bf16_hip,
+                                 (_lib.ptr(stem_out.t), _lib.ptr(x.t), n, h // 2, w // 2, 64),
+                                 (stem_out, x), "maxpool"))
+        pool.put(stem_out)
+
+        feats = {}
+        for si, nb in enumerate(STAGE_BLOCKS[depth]):
+            for b in range(nb):
+                p = "res%d.%d." % (si + 2, b)
+                stride = 2 if (b == 0 and si > 0) else 1
+                if b == 0:
+                    sc = conv(p + "shortcut", x, 1, stride, 0, 0)
+                else:
+                    sc = x
+                y1 = conv(p + "conv1", x, 1, stride, 0, F_RELU)       # STRIDE_IN_1X1
+                y2 = conv(p + "conv2", y1, 3, 1, 1, F_RELU)
+                pool.put(y1)
+                y3 = conv(p + "conv3", y2, 1, 1, 0, F_RELU | F_RES, res=sc)
+                pool.put(y2)
+                if b == 0:
+                    pool.put(sc)
+                if not any(x is f for k, f in feats.items() if k != "res2"):
+                    pool.put(x)          # res3/res4 outputs stay alive for the FPN laterals
+                x = y3
+            feats["res%d" % (si + 2)] = x
+        # FPN: laterals (+ top-down add fused) and 3x3 outputs
+        prev = None
+        outs = {}
+        for lvl in (5, 4, 3):
+            f = feats["res%d" % lvl]
+            lat = conv("fpn_lateral%d" % lvl, f, 1, 1, 0, F_UP if prev is not None else 0, res=prev)
+            outs["p%d" % lvl] = conv("fpn_output%d" % lvl, lat, 3, 1, 1, 0)
+            prev = lat
+        p6 = conv("p6", outs["p5"], 3, 2, 1, 0)
+        p6r = pool.get(n, p6.h, p6.w, p6.c)
+        self.calls.append(FnCall(L.dafne_relu_copy_bf16_hip, (_lib.ptr(p6.t), _lib.ptr(p6r.t), p6.t.numel()),
+                                 (p6, p6r), "relu_copy"))
+        p7 = conv("p7", p6r, 3, 2, 1, 0)
+        outs["p6"], outs["p7"] = p6, p7
+        self.features = [outs[k] for k in ("p3", "p4", "p5", "p6", "p7")]
+        self.head = HeadPlan(weights, self.features, num_classes, device, pool, self) if with_head else None
+
+    def run(self, stream=None):
+        stream = stream if stream is not None else _lib.current_stream()
+        for c in self.calls:
+            c(stream)
+
+
+class CallList:
+    """Bare launch list (what HeadPlan needs from its owner)."""
+
+    def __init__(self):
+        self.calls = []
+        self.flops = 0
+
+    def run(self, stream=None):
+        stream = stream if stream is not None else _lib.current_stream()
+        for c in self.calls:
+            c(stream)
+
+
+class HeadPlan:
+    """DAFNeHead over the 5 levels in single launches (weights are shared across
+    levels: dafne.py:350-494): 12 tower convs (+GroupNorm+ReLU) and 3 prediction
+    convs; outputs fp32 NHWC logits / [delta8|ctrness] / center."""
+
+    def __init__(self, P, feats, num_classes, device, pool, plan):
+        L = _lib.load()
+        n = feats[0].n
+        self.levels = feats
+        C = feats[0].c
+        self.num_classes = num_classes
+        calls = plan.calls
+
+        def seg_list(ins, outs, f32=False):
+            return [(i.t, (o if f32 else o.t), None, i.h, i.w, i.h, i.w) for i, o in zip(ins, outs)]
+
+        def tower(name, ins):
+            cur = ins
+            for i in range(4):
+                wgt, bias = P["%s.%d" % (name, 3 * i)]
+                gamma, beta = P["%s.%d.gn" % (name, 3 * i + 1)]
+                outs = [pool.get(n, f.h, f.w, C) for f in cur]
+                bm = 128                                  # M tile of the Cout>=128 kernel config
+                nt = sum((o.h * o.w + bm - 1) // bm for o in outs) * n
+                partial = torch.empty(nt, C // 8, 2, dtype=torch.float32, device=device)
+                c = ConvCall(wgt, bias, C, C, 3, 1, 1, F_GN, seg_list(cur, outs), n, gn_partial=partial)
+                calls.append(c)
+                plan.flops += c.flops
+                stats = torch.empty(len(outs), n, C // 8, 2, dtype=torch.float32, device=device)
+                gsegs = (_lib.GnSeg * len(outs))()
+                t0 = 0
+                for k, o in enumerate(outs):
+                    tpi = (o.h * o.w + bm - 1) // bm
+                    gsegs[k] = _lib.GnSeg(o.t.data_ptr(), o.h, o.w, t0, tpi)
+                    t0 += tpi * n
+                assert t0 == nt == c.num_tiles()
+                calls.append(FnCall(L.dafne_groupnorm_relu_nhwc_bf16_hip,
+                                    (gsegs, len(outs), n, C, _lib.ptr(partial), _lib.ptr(stats), _lib.ptr(gamma),
+                                     _lib.ptr(beta), ctypes.c_float(1e-5)), (outs, partial, stats, gamma, beta),
+                                    "groupnorm"))
+                if i > 0:
+                    for a in cur:
+                        pool.put(a)
+                cur = outs
+            return cur
+
+        cls_t = tower("cls_tower", feats)
+        ctr_t = tower("center_tower", feats)
+        cor_t = tower("corners_tower", ctr_t)
+
+        def pred(key, ins, cout):
+            wgt, bias = P[key]
+            outs = [torch.empty(n, f.h, f.w, cout, dtype=torch.float32, device=device) for f in ins]
+            c = ConvCall(wgt, bias, C, cout, 3, 1, 1, F_F32, seg_list(ins, outs, f32=True), n)
+            calls.append(c)
+            plan.flops += c.flops
+            return outs
+
+        self.logits = pred("cls_logits", cls_t, num_classes)
+        self.center = pred("center_pred", ctr_t, 2)
+        self.delta_ctr = pred("corners_ctrness", cor_t, 9)     # corners_pred (8) + ctrness (1) fused
+        self.scales = P["scales"]
+
+
+# ---------------------------------------------------------- weights from a state dict
+def pack_backbone_weights(sd, depth, device, prefix="backbone."):
+    """state dict with the reference checkpoint's names -> packed
+    backbone weights; FrozenBN folded into weight scale + bias."""
+    P = {}
+    bu = prefix + "bottom_up."
+
+    def cb(k):
+        return fold_frozen_bn(sd[k + ".weight"].float(), sd[k + ".norm.weight"].float(),
+                              sd[k + ".norm.bias"].float(), sd[k + ".norm.running_mean"].float(),
+                              sd[k + ".norm.running_var"].float())
+
+    w, b = cb(bu + "stem.conv1")
+    P["stem"] = pack_stem(w, b, device)
+    for si, nb in enumerate(STAGE_BLOCKS[depth]):
+        for blk in range(nb):
+            for cname in (("shortcut",) if blk == 0 else ()) + ("conv1", "conv2", "conv3"):
+                w, b = cb("%sres%d.%d.%s" % (bu, si + 2, blk, cname))
+                P["res%d.%d.%s" % (si + 2, blk, cname)] = pack_conv(w, b, device)
+    for lvl in (3, 4, 5):
+        for kind in ("lateral", "output"):
+            k = "%sfpn_%s%d" % (prefix, kind, lvl)
+            P["fpn_%s%d" % (kind, lvl)] = pack_conv(sd[k + ".weight"], sd[k + ".bias"], device)
+    for nme in ("p6", "p7"):
+        k = prefix + "top_block." + nme
+        P[nme] = pack_conv(sd[k + ".weight"], sd[k + ".bias"], device)
+    return P
+
+
+def pack_head_weights(sd, device, prefix="proposal_generator.dafne_head."):
+    """DAFNeHead parameters -> packed weights.  corners_pred and ctrness both read
+    the corners tower (dafne.py:403,467-468) and are fused into one 9-channel conv."""
+    P = {}
+    hp = prefix
+    for tower in ("cls_tower", "center_tower", "corners_tower"):
+        for i in range(4):
+            k = "%s%s.%d" % (hp, tower, 3 * i)
+            P["%s.%d" % (tower, 3 * i)] = pack_conv(sd[k + ".weight"], sd[k + ".bias"], device)
+            g = "%s%s.%d" % (hp, tower, 3 * i + 1)
+            P["%s.%d.gn" % (tower, 3 * i + 1)] = (sd[g + ".weight"].float().to(device).contiguous(),
+                                                  sd[g + ".bias"].float().to(device).contiguous())
+    P["cls_logits"] = pack_conv(sd[hp + "cls_logits.weight"], sd[hp + "cls_logits.bias"], device)
+    P["center_pred"] = pack_conv(sd[hp + "center_pred.weight"], sd[hp + "center_pred.bias"], device)
+    wcc = torch.cat([sd[hp + "corners_pred.weight"].float(), sd[hp + "ctrness.weight"].float()], 0)
+    bcc = torch.cat([sd[hp + "corners_pred.bias"].float(), sd[hp + "ctrness.bias"].float()], 0)
+    P["corners_ctrness"] = pack_conv(wcc, bcc, device)
+    P["scales"] = [float(sd["%sscales.%d.scale" % (hp, l)].reshape(-1)[0]) for l in range(5)]
+    return P
+
+
+def pack_model_weights(sd, depth, device):
+    P = pack_backbone_weights(sd, depth, device)
+    P.update(pack_head_weights(sd, device))
+    return P

@@ -153,33 +153,76 @@ int dafne_gather_detections_hip(const float* d_corners, const float* d_scores, c
                                 int k_cap, float* d_out, int32_t* d_out_counts, void* stream);
 
 /* ------------------------------------------------------------- dense engine */
-/* Activations: NHWC bf16 with a zero halo of 1 pixel: [N, H+2, W+2, C].      */
-#define DAFNE_CONV_RELU 1u        /* ReLU in the epilogue                        */
-#define DAFNE_CONV_RESIDUAL 2u    /* += residual (same shape as out) before ReLU */
-#define DAFNE_CONV_UPSAMPLE_ADD 4u/* += nearest-2x upsample of `residual` (H/2)  */
-#define DAFNE_CONV_OUT_F32 8u     /* fp32 un-haloed NHWC output [N,H,W,Cout]     */
-#define DAFNE_CONV_GN_STATS 16u   /* emit per-(n,segment,group) sum / sumsq       */
-#define DAFNE_CONV_RELU_IN 32u    /* ReLU applied to the input while loading (P7) */
+/*
+ * Activations: NHWC bf16 with a zero halo of 1 pixel: [N, H+2, W+2, C]; producers
+ * write the interior only, so the halo stays zero and a 3x3 tap never needs a
+ * bounds check.  Weights: bf16 [Cout_pad][KH*KW*Cin], k = (kh, kw, cin), rows
+ * beyond Cout zero; Cout_pad = dafne_conv2d_cout_pad(Cout).  Bias: fp32 [Cout_pad]
+ * (FrozenBN folded into weight scale + bias).
+ */
+#define DAFNE_CONV_RELU 1u         /* ReLU in the epilogue                              */
+#define DAFNE_CONV_RESIDUAL 2u     /* += d_res (same shape as the output) before ReLU   */
+#define DAFNE_CONV_UPSAMPLE_ADD 4u /* += nearest-2x upsample of d_res [N,H/2+2,W/2+2,C] */
+#define DAFNE_CONV_OUT_F32 8u      /* fp32 un-haloed NHWC output [N,Hout,Wout,Cout]     */
+#define DAFNE_CONV_GN_STATS 16u    /* emit per-(M tile, group of 8 ch) sum and sum-sq   */
 
 typedef struct dafne_conv_seg {
-    const void* d_in;   /* bf16 [N, Hin+2, Win+2, Cin] (halo layout)               */
-    void* d_out;        /* bf16 [N, Hout+2, Wout+2, Cout] or fp32 [N,Hout,Wout,Cout] */
-    const void* d_res;  /* residual / coarser map for UPSAMPLE_ADD, or NULL        */
+    const void* d_in;   /* bf16 [N, Hin+2, Win+2, Cin]; stem: [N, Hin, Win, 4] pre-padded */
+    void* d_out;        /* bf16 [N, Hout+2, Wout+2, Cout] or fp32 [N,Hout,Wout,Cout]      */
+    const void* d_res;  /* residual / coarser map for UPSAMPLE_ADD, or NULL               */
     int32_t Hin, Win, Hout, Wout;
 } dafne_conv_seg;
 
 typedef struct dafne_conv_params {
-    int32_t n_images, n_segs;   /* segments share weights (FPN levels of the head) */
+    int32_t n_images, n_segs;   /* segments share weights (the FPN levels of the head) */
     int32_t Cin, Cout, KH, KW, stride, pad;
     uint32_t flags;
-    const void* d_weight;  /* bf16 [Cout_pad][KH*KW*Cin], k = (kh, kw, cin)         */
-    const float* d_bias;   /* [Cout] fp32 (FrozenBN folded) or NULL                 */
-    float* d_gn_partial;   /* GN_STATS: [tiles][Cout/8][2] fp32 partial sums        */
+    const void* d_weight;
+    const float* d_bias;        /* or NULL */
+    float* d_gn_partial;        /* GN_STATS: [num_tiles][Cout/8][2] fp32 */
 } dafne_conv_params;
 
+/*
+ * 1x1 (pad 0) and 3x3 (pad 1) convolutions, stride 1 or 2, Cin % 64 == 0; plus the
+ * ResNet stem as (Cin=4, 7x7, stride 2) on the image layout that
+ * dafne_preprocess_image_hip writes (K = 7 rows x 8 cols x 4 ch, zero weights in
+ * the padding taps; weight rows are 256 bf16).
+ */
 int dafne_conv2d_nhwc_bf16_hip(const dafne_conv_params* prm, const dafne_conv_seg* segs, void* stream);
-/* number of M-tiles the conv above launches (rows of d_gn_partial) */
+int dafne_conv2d_cout_pad(int Cout);
+/* number of M tiles the call above launches (= rows of d_gn_partial), -1 on error */
 int dafne_conv2d_num_tiles(const dafne_conv_params* prm, const dafne_conv_seg* segs);
+
+/*
+ * OneStageDetector.preprocess_image (one_stage_detector.py:100-107) + ImageList
+ * padding: (x - mean)/std on uint8 BGR images [N,3,H,W] (layout_hwc=0) or [N,H,W,3]
+ * (=1), zero-padded to Hn x Wn (multiples of 32), written as bf16
+ * [N, Hn+6, Wn+6, 4] (3-pixel zero border for the 7x7 stem, 4th channel 0).
+ * d_valid_hw: optional int32 [N,2] true sizes (pixels beyond are padding).
+ * mean3/std3 are HOST pointers (3 floats each).
+ */
+int dafne_preprocess_image_hip(const uint8_t* d_img, int layout_hwc, int n_images, int H, int W,
+                               const int32_t* d_valid_hw, const float* mean3, const float* std3,
+                               int Hn, int Wn, void* d_out, void* stream);
+/* 3x3 stride-2 pad-1 max pool of a post-ReLU map: [N,Hin+2,Win+2,C] -> [N,Hin/2+2,Win/2+2,C] */
+int dafne_maxpool3x3s2_nhwc_bf16_hip(const void* d_in, void* d_out, int n_images, int Hin, int Win,
+                                     int C, void* stream);
+
+typedef struct dafne_gn_seg {
+    void* d_x;                      /* bf16 [N, H+2, W+2, C], normalised in place */
+    int32_t H, W;
+    int32_t tile0, tiles_per_img;   /* where this segment's tiles sit in d_partial */
+} dafne_gn_seg;
+/*
+ * GroupNorm(C/8 groups, eps) + ReLU (dafne.py:330-344) from the conv's tile
+ * partials: fixed-order reduction -> mean/rstd per (segment, image, group) in
+ * d_stats [n_segs][N][C/8][2], then y = relu((x-mean)*rstd*gamma+beta) in place.
+ */
+int dafne_groupnorm_relu_nhwc_bf16_hip(const dafne_gn_seg* segs, int n_segs, int n_images, int C,
+                                       const float* d_partial, float* d_stats, const float* d_gamma,
+                                       const float* d_beta, float eps, void* stream);
+/* out = relu(in) on n_elems bf16 values (n_elems % 8 == 0); halo zeros stay zero. */
+int dafne_relu_copy_bf16_hip(const void* d_in, void* d_out, int64_t n_elems, void* stream);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,189 @@
+"""GPU parity of the dense HIP kernels vs a plain PyTorch fp32 reference of the same
+op.  Inputs/weights are bf16-representable, so products are exact in fp32 and the
+only differences are fp32 summation order and the final bf16 rounding: tolerance
+2 bf16 ulps (2^-7 relative) on bf16 outputs, 2e-3 relative on fp32 outputs."""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+BF = torch.bfloat16
+
+
+def dev():
+    return torch.device("cuda", 0)
+
+
+def bfr(x):
+    return x.to(BF).float()
+
+
+def run_conv(x, w, b, k, stride, pad, flags=0, res=None, out_f32=False, gn=False):
+    """x: [N,C,H,W] float (bf16-representable) on CPU.  Returns engine output as NCHW float (CPU)."""
+    from dafne_amd import engine, _lib
+    d = dev()
+    n, cin, h, wd = x.shape
+    cout = w.shape[0]
+    a = engine.Act.from_nchw(x.to(d))
+    wp, bp = engine.pack_conv(w, b, d)
+    ho, wo = engine.conv_out_hw(h, wd, k, stride, pad)
+    if out_f32:
+        o = torch.full((n, ho, wo, cout), float("nan"), dtype=torch.float32, device=d)
+        ot = o
+        flags |= engine.F_F32
+    else:
+        oa = engine.Act(n, ho, wo, cout, d)
+        ot = oa.t
+    r = engine.Act.from_nchw(res.to(d)) if res is not None else None
+    partial = None
+    call = engine.ConvCall(wp, bp, cin, cout, k, stride, pad, flags,
+                           [(a.t, ot, r.t if r is not None else None, h, wd, ho, wo)], n)
+    if gn:
+        partial = torch.zeros(call.num_tiles() if not gn else 4096, cout // 8, 2, dtype=torch.float32, device=d)
+        call = engine.ConvCall(wp, bp, cin, cout, k, stride, pad, flags | engine.F_GN,
+                               [(a.t, ot, None, h, wd, ho, wo)], n, gn_partial=partial)
+    call(_lib.current_stream())
+    torch.cuda.synchronize()
+    if out_f32:
+        return o.permute(0, 3, 1, 2).cpu(), partial, call
+    # the halo must still be zero
+    assert float(oa.t[:, 0].abs().max()) == 0 and float(oa.t[:, -1].abs().max()) == 0
+    assert float(oa.t[:, :, 0].abs().max()) == 0 and float(oa.t[:, :, -1].abs().max()) == 0
+    return oa.nchw_float().cpu(), partial, call
+
+
+def close_bf16(got, ref, ulps=2):
+    tol = ulps * 2.0 ** -8 * ref.abs().clamp_min(2.0 ** -6) + 1e-3
+    bad = (got - ref).abs() > tol
+    assert not bad.any(), (int(bad.sum()), float((got - ref).abs().max()))
+
+
+CASES = [
+    # cin, cout, k, stride, pad, H, W, N
+    (64, 64, 1, 1, 0, 16, 16, 2),
+    (64, 256, 1, 1, 0, 12, 20, 1),      # ragged last tile (240 px)
+    (256, 128, 1, 2, 0, 16, 16, 2),     # stride-2 1x1 (STRIDE_IN_1X1)
+    (64, 64, 3, 1, 1, 16, 16, 1),
+    (128, 128, 3, 1, 1, 9, 13, 2),      # odd sizes, ragged
+    (256, 256, 3, 1, 1, 16, 16, 1),
+    (256, 256, 3, 2, 1, 16, 16, 1),     # P6/P7
+    (512, 2048, 1, 1, 0, 4, 4, 1),
+    (1024, 256, 1, 1, 0, 8, 8, 1),
+]
+
+
+@pytest.mark.parametrize("cin,cout,k,stride,pad,H,W,N", CASES)
+def test_conv_vs_torch(cin, cout, k, stride, pad, H, W, N):
+    g = torch.Generator().manual_seed(cin * 7 + cout + k)
+    x = bfr(torch.randn(N, cin, H, W, generator=g))
+    w = bfr(torch.randn(cout, cin, k, k, generator=g) / (cin * k * k) ** 0.5)
+    b = torch.randn(cout, generator=g) * 0.1
+    ref = bfr(F.conv2d(x, w, b, stride=stride, padding=pad))
+    got, _, _ = run_conv(x, w, b, k, stride, pad)
+    close_bf16(got, ref)
+
+
+def test_conv_relu_residual_and_upsample_add():
+    from dafne_amd import engine
+    g = torch.Generator().manual_seed(3)
+    x = bfr(torch.randn(2, 128, 8, 8, generator=g))
+    w = bfr(torch.randn(256, 128, 1, 1, generator=g) / 128 ** 0.5)
+    b = torch.randn(256, generator=g) * 0.1
+    res = bfr(torch.randn(2, 256, 8, 8, generator=g))
+    ref = bfr(F.relu(F.conv2d(x, w, b) + res))
+    got, _, _ = run_conv(x, w, b, 1, 1, 0, flags=engine.F_RELU | engine.F_RES, res=res)
+    close_bf16(got, ref)
+    coarse = bfr(torch.randn(2, 256, 4, 4, generator=g))
+    ref = bfr(F.conv2d(x, w, b) + F.interpolate(coarse, scale_factor=2, mode="nearest"))
+    got, _, _ = run_conv(x, w, b, 1, 1, 0, flags=engine.F_UP, res=coarse)
+    close_bf16(got, ref)
+
+
+@pytest.mark.parametrize("cout", [15, 9, 2, 1, 16])
+def test_prediction_conv_f32_output(cout):
+    g = torch.Generator().manual_seed(cout)
+    x = bfr(torch.randn(2, 256, 6, 10, generator=g))
+    w = bfr(torch.randn(cout, 256, 3, 3, generator=g) / 48.0)
+    b = torch.randn(cout, generator=g)
+    ref = F.conv2d(x, w, b, padding=1)
+    got, _, _ = run_conv(x, w, b, 3, 1, 1, out_f32=True)
+    assert torch.isfinite(got).all()
+    assert float((got - ref).abs().max()) < 2e-3 * float(ref.abs().max())
+
+
+def test_groupnorm_relu_pipeline():
+    """conv(+GN partial sums) -> finalize -> apply(+ReLU) vs torch group_norm on the
+    fp32 conv output (stats) applied to the bf16-rounded value (what the engine stores)."""
+    from dafne_amd import engine, _lib
+    L = _lib.load()
+    g = torch.Generator().manual_seed(5)
+    N, C, H, W = 2, 256, 10, 14
+    x = bfr(torch.randn(N, C, H, W, generator=g))
+    w = bfr(torch.randn(C, C, 3, 3, generator=g) / 48.0)
+    b = torch.randn(C, generator=g) * 0.1
+    gamma = torch.rand(C, generator=g) + 0.5
+    beta = torch.randn(C, generator=g) * 0.1
+    y = F.conv2d(x, w, b, padding=1)
+    grp = y.reshape(N, C // 8, -1)
+    mean = grp.mean(-1, keepdim=True)
+    var = (grp * grp).mean(-1, keepdim=True) - mean * mean
+    yn = ((bfr(y).reshape(N, C // 8, -1) - mean) * torch.rsqrt(var + 1e-5)).reshape(N, C, H, W)
+    ref = bfr(F.relu(yn * gamma[None, :, None, None] + beta[None, :, None, None]))
+    d = dev()
+    a = engine.Act.from_nchw(x.to(d))
+    wp, bp = engine.pack_conv(w, b, d)
+    oa = engine.Act(N, H, W, C, d)
+    tpi = (H * W + 127) // 128
+    partial = torch.zeros(tpi * N, C // 8, 2, dtype=torch.float32, device=d)
+    call = engine.ConvCall(wp, bp, C, C, 3, 1, 1, engine.F_GN, [(a.t, oa.t, None, H, W, H, W)], N, gn_partial=partial)
+    assert call.num_tiles() == tpi * N
+    call(_lib.current_stream())
+    stats = torch.zeros(1, N, C // 8, 2, dtype=torch.float32, device=d)
+    segs = (_lib.GnSeg * 1)(_lib.GnSeg(oa.t.data_ptr(), H, W, 0, tpi))
+    gd, bd = gamma.to(d), beta.to(d)
+    _lib.check(L.dafne_groupnorm_relu_nhwc_bf16_hip(segs, 1, N, C, _lib.ptr(partial), _lib.ptr(stats), _lib.ptr(gd),
+                                                    _lib.ptr(bd), ctypes.c_float(1e-5), _lib.current_stream()))
+    torch.cuda.synchronize()
+    assert torch.allclose(stats[0, :, :, 0].cpu(), mean.squeeze(-1), atol=1e-4)
+    close_bf16(oa.nchw_float().cpu(), ref, ulps=3)
+
+
+def test_stem_preprocess_maxpool():
+    from dafne_amd import engine, _lib
+    L = _lib.load()
+    g = torch.Generator().manual_seed(9)
+    N, H, W = 2, 64, 96
+    img = torch.randint(0, 256, (N, 3, H, W), generator=g, dtype=torch.uint8)
+    mean = [103.53, 116.28, 123.675]
+    std = [1.0, 1.0, 1.0]
+    w = bfr(torch.randn(64, 3, 7, 7, generator=g) / 200.0)
+    b = torch.randn(64, generator=g) * 0.1
+    xn = bfr((img.float() - torch.tensor(mean).view(1, 3, 1, 1)) / torch.tensor(std).view(1, 3, 1, 1))
+    ref = F.max_pool2d(bfr(F.relu(F.conv2d(xn, w, b, stride=2, padding=3))), 3, 2, 1)
+    d = dev()
+    stem_in = torch.zeros(N, H + 6, W + 6, 4, dtype=BF, device=d)
+    m3 = (ctypes.c_float * 3)(*mean)
+    s3 = (ctypes.c_float * 3)(*std)
+    imd = img.to(d)
+    _lib.check(L.dafne_preprocess_image_hip(_lib.ptr(imd), 0, N, H, W, None, m3, s3, H, W, _lib.ptr(stem_in),
+                                            _lib.current_stream()))
+    wp, bp = engine.pack_stem(w, b, d)
+    so = engine.Act(N, H // 2, W // 2, 64, d)
+    engine.ConvCall(wp, bp, 4, 64, 7, 2, 3, engine.F_RELU, [(stem_in, so.t, None, H + 6, W + 6, H // 2, W // 2)], N)(
+        _lib.current_stream())
+    po = engine.Act(N, H // 4, W // 4, 64, d)
+    _lib.check(L.dafne_maxpool3x3s2_nhwc_bf16_hip(_lib.ptr(so.t), _lib.ptr(po.t), N, H // 2, W // 2, 64,
+                                                  _lib.current_stream()))
+    torch.cuda.synchronize()
+    assert torch.equal(stem_in[:, 3:-3, 3:-3, :3].float().cpu(), xn.permute(0, 2, 3, 1))
+    close_bf16(po.nchw_float().cpu(), ref)
+    # HWC input layout gives the same stem input
+    stem2 = torch.zeros_like(stem_in)
+    imh = img.permute(0, 2, 3, 1).contiguous().to(d)
+    _lib.check(L.dafne_preprocess_image_hip(_lib.ptr(imh), 1, N, H, W, None, m3, s3, H, W, _lib.ptr(stem2),
+                                            _lib.current_stream()))
+    torch.cuda.synchronize()
+    assert torch.equal(stem2, stem_in)
