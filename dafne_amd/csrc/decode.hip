@@ -463,8 +463,10 @@ __global__ void __launch_bounds__(1024) gather_kernel(
         oh = sz[2]; ow = sz[3];
         sx = (float)((double)sz[3] / (double)sz[1]);   // python float division, then fp32 multiply
         sy = (float)((double)sz[2] / (double)sz[0]);
-        cxs = (float)((double)sz[3] / (double)sz[5]);
-        cys = (float)((double)sz[2] / (double)sz[4]);
+        if (do_post >= 2) {   // OneStageDetector._postprocess (skipped by the TTA path)
+            cxs = (float)((double)sz[3] / (double)sz[5]);
+            cys = (float)((double)sz[2] / (double)sz[4]);
+        }
     }
     __shared__ int wsum[16];
     __shared__ int s_base;

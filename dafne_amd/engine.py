@@ -199,6 +199,7 @@ class DensePlan:
                     pool.put(x)          # res3/res4 outputs stay alive for the FPN laterals
                 x = y3
             feats["res%d" % (si + 2)] = x
+        self.stage_feats = feats
         # FPN: laterals (+ top-down add fused) and 3x3 outputs
         prev = None
         outs = {}

@@ -40,7 +40,7 @@ class DAFNeOutputs(nn.Module):
         raise NotImplementedError("training is outside the scope of the MI355X inference engine")
 
     # ---- fused device path used by the engine ---------------------------------
-    def predict_packed(self, levels, sizes=None, k_cap=None):
+    def predict_packed(self, levels, sizes=None, k_cap=None, scale_corners=True):
         """levels: list[postprocess.LevelInput] (NHWC fp32).  Returns (rows, counts):
         [N,k_cap,18] float32 detections and their per-image counts, on the GPU."""
         if not self.stride_norm:
@@ -57,7 +57,7 @@ class DAFNeOutputs(nn.Module):
         if k_cap is None:
             k_cap = min(cand.m_cap, max(self.post_nms_topk_test, 1) + 256) if self.post_nms_topk_test > 0 \
                 else cand.m_cap
-        return pp.gather(cand, keep, nk, sizes=sizes, k_cap=k_cap)
+        return pp.gather(cand, keep, nk, sizes=sizes, k_cap=k_cap, scale_corners=scale_corners)
 
     # ---- reference-signature path ----------------------------------------------
     def predict_proposals(self, logits_pred, corners_reg_pred, ctrness_pred, locations, image_sizes,

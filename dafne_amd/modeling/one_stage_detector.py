@@ -1,0 +1,148 @@
+"""`OneStageDetector` meta-architecture on the MI355X engine.
+
+Same registry name and call contract as the reference
+(dafne/modeling/one_stage_detector.py:34-107 on top of detectron2's
+ProposalNetwork [recalled, SURVEY appendix B]): a list of {"image": uint8 CHW BGR,
+"height", "width"} in, a list of {"instances": Instances} out.
+
+forward() is one fused device pipeline -- uint8 image -> normalise/pad kernel ->
+ResNet-FPN -> head -> decode/top-k -> rotated NMS -> rescale/clip/gather -- with a
+single host sync at the very end (detection counts).
+"""
+import ctypes
+
+import torch
+from torch import nn
+
+from .. import _lib, engine
+from .. import postprocess as pp
+from ..registry import BACKBONE_REGISTRY, META_ARCH_REGISTRY, PROPOSAL_GENERATOR_REGISTRY
+from ..structures import ImageList
+from .dafne.dafne import head_levels
+
+
+@META_ARCH_REGISTRY.register()
+class OneStageDetector(nn.Module):
+    def __init__(self, cfg):
+        super().__init__()
+        self.cfg = cfg
+        self.backbone = BACKBONE_REGISTRY.get(cfg.MODEL.BACKBONE.NAME)(cfg, None)
+        self.proposal_generator = PROPOSAL_GENERATOR_REGISTRY.get(cfg.MODEL.PROPOSAL_GENERATOR.NAME)(
+            cfg, self.backbone.output_shape())
+        self.register_buffer("pixel_mean", torch.tensor(cfg.MODEL.PIXEL_MEAN, dtype=torch.float32).view(-1, 1, 1), False)
+        self.register_buffer("pixel_std", torch.tensor(cfg.MODEL.PIXEL_STD, dtype=torch.float32).view(-1, 1, 1), False)
+        self.top_module = None
+        if cfg.MODEL.TOP_MODULE.NAME:
+            raise NotImplementedError("MODEL.TOP_MODULE is not used by any released config")
+        self.depth = cfg.MODEL.RESNETS.DEPTH
+        self._packed = None
+        self._plans = {}
+        self._graphs = {}
+        self.eval()
+
+    @property
+    def device(self):
+        return self.pixel_mean.device
+
+    # ------------------------------------------------------------ engine state
+    def invalidate(self):
+        """Call after changing parameters: weights are re-packed lazily."""
+        self._packed = None
+        self._plans = {}
+        self._graphs = {}
+        self.backbone.invalidate()
+        self.proposal_generator.dafne_head.invalidate()
+
+    def load_state_dict(self, *a, **k):
+        r = super().load_state_dict(*a, **k)
+        self.invalidate()
+        return r
+
+    def _weights(self):
+        if self._packed is None:
+            self._packed = engine.pack_model_weights(self.state_dict(), self.depth, self.device)
+        return self._packed
+
+    def plan(self, n, h, w):
+        key = (n, h, w)
+        if key not in self._plans:
+            nc = self.proposal_generator.dafne_head.num_classes
+            self._plans[key] = engine.DensePlan(self._weights(), n, h, w, self.depth, nc, self.device)
+        return self._plans[key]
+
+    # ------------------------------------------------------------ fused path
+    def detect_packed(self, images_u8, valid_hw=None, out_hw=None, layout_hwc=False, do_postprocess=True,
+                      use_graph=False):
+        """images_u8: device uint8 [N,3,H,W] (or [N,H,W,3] with layout_hwc) BGR.
+        valid_hw: optional per-image (h, w) true sizes; out_hw: optional per-image
+        requested output (height, width).  Returns (rows [N,k_cap,18], counts [N])
+        on the device, no host synchronisation."""
+        if not images_u8.is_cuda or images_u8.dtype != torch.uint8:
+            raise RuntimeError("detect_packed needs a uint8 CUDA tensor (the MI355X engine has no CPU path)")
+        L = _lib.load()
+        if layout_hwc:
+            n, h, w, _ = images_u8.shape
+        else:
+            n, _, h, w = images_u8.shape
+        hn, wn = (h + 31) // 32 * 32, (w + 31) // 32 * 32
+        with torch.cuda.device(images_u8.device):
+            plan = self.plan(n, hn, wn)
+            vt = None
+            if valid_hw is not None:
+                vt = torch.tensor(valid_hw, dtype=torch.int32).reshape(n, 2).to(self.device, non_blocking=True)
+            mean = (ctypes.c_float * 3)(*[float(v) for v in self.cfg.MODEL.PIXEL_MEAN])
+            std = (ctypes.c_float * 3)(*[float(v) for v in self.cfg.MODEL.PIXEL_STD])
+            images_u8 = images_u8.contiguous()
+            sizes = None
+            if valid_hw is None:
+                valid_hw = [(h, w)] * n
+            if out_hw is None:
+                out_hw = valid_hw
+            sizes = [(vh, vw, oh, ow, vh, vw) for (vh, vw), (oh, ow) in zip(valid_hw, out_hw)]
+            outs = self.proposal_generator.dafne_outputs
+            strides = self.proposal_generator.fpn_strides
+
+            def body():
+                _lib.check(L.dafne_preprocess_image_hip(_lib.ptr(images_u8), int(layout_hwc), n, h, w, _lib.ptr(vt),
+                                                        mean, std, hn, wn, _lib.ptr(plan.stem_in),
+                                                        _lib.current_stream()), "dafne_preprocess_image_hip")
+                plan.run()
+                return outs.predict_packed(head_levels(plan.head, strides), sizes=sizes,
+                                           scale_corners=do_postprocess)
+
+            return body()
+
+    def forward(self, batched_inputs, do_postprocess=True):
+        if self.training:
+            raise NotImplementedError("training is outside the scope of the MI355X inference engine")
+        dev = self.device
+        imgs = [x["image"] for x in batched_inputs]
+        n = len(imgs)
+        hs = [int(i.shape[1]) for i in imgs]
+        ws = [int(i.shape[2]) for i in imgs]
+        H, W = max(hs), max(ws)
+        if all(i.dtype == torch.uint8 for i in imgs):
+            if n == 1:
+                batch = imgs[0].to(dev, non_blocking=True).unsqueeze(0)
+            else:
+                batch = torch.zeros(n, 3, H, W, dtype=torch.uint8, device=dev)
+                for k, im in enumerate(imgs):
+                    batch[k, :, : hs[k], : ws[k]] = im.to(dev, non_blocking=True)
+        else:
+            raise NotImplementedError("the engine takes uint8 images, as the reference's data loader yields them")
+        valid = list(zip(hs, ws))
+        out_hw = [(int(x.get("height", hs[k])), int(x.get("width", ws[k]))) for k, x in enumerate(batched_inputs)]
+        rows, counts = self.detect_packed(batch, valid_hw=valid, out_hw=out_hw, do_postprocess=do_postprocess)
+        insts = pp.rows_to_instances(rows, counts, out_hw)
+        return [{"instances": r} for r in insts]
+
+    def inference(self, batched_inputs, detected_instances=None, do_postprocess=True):
+        assert not self.training
+        return self.forward(batched_inputs, do_postprocess)
+
+    def preprocess_image(self, batched_inputs):
+        """Normalize, pad and batch the input images (one_stage_detector.py:100-107);
+        kept for API parity -- forward() fuses this into the stem's load kernel."""
+        images = [x["image"].to(self.device) for x in batched_inputs]
+        images = [(x.float() - self.pixel_mean) / self.pixel_std for x in images]
+        return ImageList.from_tensors(images, self.backbone.size_divisibility)

@@ -93,7 +93,7 @@ def select(cand, nms_thresh, post_topk):
     return keep, nk
 
 
-def gather(cand, keep, num_keep, sizes=None, k_cap=None):
+def gather(cand, keep, num_keep, sizes=None, k_cap=None, scale_corners=True):
     """Kept rows -> [N, k_cap, DET_ROW] float32 (+ detector_postprocess when
     ``sizes`` [N,6] = (net_h, net_w, out_h, out_w, orig_h, orig_w) is given)."""
     L = _lib.load()
@@ -108,7 +108,7 @@ def gather(cand, keep, num_keep, sizes=None, k_cap=None):
         _lib.check(L.dafne_gather_detections_hip(
             _lib.ptr(cand.corners), _lib.ptr(cand.scores), _lib.ptr(cand.ctr), _lib.ptr(cand.classes),
             _lib.ptr(cand.locs), _lib.ptr(cand.levels), _lib.ptr(cand.hbox), _lib.ptr(keep),
-            _lib.ptr(num_keep), _lib.ptr(sizes), int(sizes is not None), n, m, k_cap, _lib.ptr(out),
+            _lib.ptr(num_keep), _lib.ptr(sizes), (2 if scale_corners else 1) if sizes is not None else 0, n, m, k_cap, _lib.ptr(out),
             _lib.ptr(cnt), _lib.current_stream()), "dafne_gather_detections_hip")
     return out, cnt
 

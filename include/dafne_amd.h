@@ -140,6 +140,8 @@ int dafne_sort_quadrilateral_hip(const float* d_in, float* d_out, int64_t n, voi
  * (one_stage_detector.py:79-98): hull boxes scaled by out/net-input size, clipped,
  * empty ones dropped; corners and locations scaled by out/orig.  d_sizes:
  * [N,6] float32 = (net_h, net_w, out_h, out_w, orig_h, orig_w) per image.
+ * do_postprocess: 0 = plain gather; 1 = d2 detector_postprocess only (hull boxes;
+ * what forward(do_postprocess=False) still does); 2 = also rescale corners/locations.
  * Output rows [N, k_cap, DAFNE_DET_ROW] float32 = corners8, score, centerness,
  * class, level, hbox4, loc2 (class/level stored as float); d_out_counts [N].
  * Rows beyond k_cap are dropped and still counted (caller checks count <= k_cap).
