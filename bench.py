@@ -1,0 +1,297 @@
+#!/usr/bin/env python3
+"""bench.py -- images/sec of the DAFNe inference hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W          (N=1)
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+One step = one pass of the whole path over one batch of synthetic 1024x1024 BGR
+uint8 tiles that already sit in HBM: normalise/pad -> ResNet-FPN -> DAFNe head ->
+decode/top-k -> rotated NMS -> rescale/gather, and for N>1 the final detection
+gather to rank 0 over RCCL.  Weak scaling: every rank runs the same per-GPU batch
+(images are independent; weights replicated); value = images of all ranks / the
+slowest rank's time.
+
+Workload (config.workload): BASELINE.json's metric names R101-FPN on 1024x1024
+DOTA tiles at 1/2/4/8 GPUs, i.e. the per-GPU shard of configs[2] (batch 8 per GPU,
+DOTA-1.0 head: 15 classes, THRESH_WITH_CTR, SORT_CORNERS).  configs[1] (R50-FPN,
+batch 8, one GPU) is measured in the same run at N=1 and reported under
+"configs1_r50_b8".  Random-init weights (seeded), synthetic images.
+
+Extra objects on the JSON line:
+  roofline      dominant kernel = conv_igemm_kernel<2,2,2,2> (all Cout>=128 convs):
+                algorithmic FLOPs of those launches / their HIP-event time, vs the
+                dense bf16 MFMA peak (2.5 PFLOP/s)
+  cpu_baseline  the torch fp32 oracle (oracle/model.py + oracle/postprocess.py, a
+                port) timed on the host cores on a bounded sample, rank 0, N=1 only
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_BF16_TFLOPS = 2500.0     # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
+GFLOP_PER_IMG = {50: 505.97, 101: 661.13}   # SURVEY 8(d), 1024^2, C=15
+
+
+def seeded_state_dict(model, seed):
+    """Random-init weights of the architecture: He-normal convs, FrozenBN scale
+    U(0.5,1.5) / shift N(0,0.1), head towers N(0, 0.03), class prior -4.595
+    (dafne.py:269-285).  He init (instead of the reference's N(0,0.01) towers /
+    pretrained trunk) keeps activations O(1) through the trunk so the bench does
+    not time an all-zero network (zeros clock higher: guide rule 25)."""
+    g = torch.Generator().manual_seed(seed)
+    sd = {}
+    for k, v in model.state_dict().items():
+        leaf = k.split(".")[-1]
+        if v.dim() == 4:
+            fan_in = v.shape[1] * v.shape[2] * v.shape[3]
+            std = (2.0 / fan_in) ** 0.5
+            if "_tower" in k:
+                std = (2.0 / fan_in) ** 0.5
+            if any(t in k for t in ("cls_logits", "ctrness", "corners_pred", "center_pred")):
+                std = 0.01
+            sd[k] = torch.randn(v.shape, generator=g) * std
+        elif leaf == "running_var":
+            sd[k] = torch.rand(v.shape, generator=g) + 0.5
+        elif leaf == "running_mean":
+            sd[k] = torch.randn(v.shape, generator=g) * 0.1
+        elif leaf == "scale":
+            sd[k] = torch.ones(v.shape)
+        elif leaf == "weight":
+            sd[k] = torch.rand(v.shape, generator=g) + 0.5
+        elif leaf == "bias":
+            sd[k] = torch.randn(v.shape, generator=g) * 0.1
+            if "cls_logits" in k:
+                sd[k] = torch.full(v.shape, -4.59512)
+        else:
+            sd[k] = v.clone()
+    return sd
+
+
+def build_model(depth, device, seed=0):
+    import dafne_amd.modeling  # noqa: F401
+    from dafne_amd.config import load_cfg
+    from dafne_amd.registry import build_model as bm
+    cfg = load_cfg(os.path.join(ROOT, "configs", "dota-1.0_r%d.yaml" % depth))
+    m = bm(cfg)
+    sd = seeded_state_dict(m, seed)
+    m.load_state_dict(sd)
+    m.to(device)
+    m.invalidate()
+    return cfg, m, sd
+
+
+def time_steps(step_fn, steps, warmup, distributed):
+    for _ in range(warmup):
+        step_fn()
+    if distributed:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step_fn()
+    if distributed:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if distributed:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    return dt
+
+
+def conv_kernel_profile(model, batch, reps=3):
+    """Per-launch HIP-event timing of every conv launch of one step (events on the
+    stream the kernels are launched on = torch's current stream)."""
+    from dafne_amd import engine, _lib
+    n, _, h, w = batch.shape
+    plan = model.plan(n, h, w)
+    model.detect_packed(batch)          # fills stem_in etc.
+    torch.cuda.synchronize()
+    stream = _lib.current_stream()
+    stats = {}
+    for _ in range(reps):
+        evs = []
+        for c in plan.calls:
+            if isinstance(c, engine.ConvCall):
+                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                a.record()
+                c(stream)
+                b.record()
+                evs.append((c, a, b))
+            else:
+                c(stream)
+        torch.cuda.synchronize()
+        for c, a, b in evs:
+            cout = c.prm.Cout
+            cfgname = "conv_igemm<2,2,2,2>" if cout >= 128 else ("conv_igemm<1,4,2,2>" if cout > 32 else "conv_igemm<1,4,1,2>")
+            s = stats.setdefault(cfgname, {"ms": 0.0, "flops": 0.0, "launches": 0})
+            s["ms"] += a.elapsed_time(b)
+            s["flops"] += c.flops
+            s["launches"] += 1
+    for s in stats.values():
+        s["ms"] /= reps
+        s["flops"] /= reps
+        s["launches"] //= reps
+        s["tflops"] = s["flops"] / (s["ms"] * 1e-3) / 1e12 if s["ms"] > 0 else 0.0
+        s["avg_launch_us"] = 1e3 * s["ms"] / max(s["launches"], 1)
+    return stats
+
+
+def nms_ms_per_image(device, m=10000, n_images=8, reps=5):
+    """Rotated-NMS ms/img (A10+A11 only) on the synthetic candidate set of SURVEY
+    8(d): M = 5 x PRE_NMS_TOPK rotated rectangles per image, seed 1234."""
+    from dafne_amd import _lib
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from conftest import rrects
+    L = _lib.load()
+    rng = np.random.default_rng(1234)
+    b = np.stack([rrects(m, rng, extent=1024.0) for _ in range(n_images)])
+    s = rng.uniform(0.05, 1, (n_images, m)).astype(np.float32)
+    c = rng.integers(0, 15, (n_images, m)).astype(np.int32)
+    tb, ts, tc = (torch.from_numpy(a).to(device) for a in (b, s, c))
+    tn = torch.full((n_images,), m, dtype=torch.int32, device=device)
+    keep = torch.empty((n_images, m), dtype=torch.int64, device=device)
+    nk = torch.zeros(n_images, dtype=torch.int32, device=device)
+    nbytes = L.dafne_poly_nms_workspace_bytes(n_images, m)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=device)
+
+    def run():
+        _lib.check(L.dafne_select_over_all_levels_hip(_lib.ptr(tb), _lib.ptr(ts), _lib.ptr(tc), _lib.ptr(tn), n_images,
+                                                      m, 0.1, 1000, _lib.ptr(keep), _lib.ptr(nk), _lib.ptr(ws), nbytes,
+                                                      _lib.current_stream()))
+    run()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        run()
+    torch.cuda.synchronize()
+    return 1e3 * (time.perf_counter() - t0) / reps / n_images
+
+
+def cpu_baseline(cfg, sd, depth, budget_s=25.0):
+    """Oracle (port) on the host cores: full path for single 1024^2 images until
+    ~budget_s of CPU work is spent (at least one image)."""
+    from oracle import model as om
+    from oracle import postprocess as opp
+    d = cfg.MODEL.DAFNE
+    P = {k: v.float() for k, v in sd.items()}
+    g = torch.Generator().manual_seed(0)
+    cores = torch.get_num_threads()
+    n_done, t_total = 0, 0.0
+    while n_done < 1 or (t_total < budget_s and n_done < 8):
+        img = torch.randint(0, 256, (3, 1024, 1024), generator=g, dtype=torch.uint8)
+        t0 = time.perf_counter()
+        with torch.no_grad():
+            x, sizes = om.preprocess([img], cfg.MODEL.PIXEL_MEAN, cfg.MODEL.PIXEL_STD)
+            f = om.backbone_forward(P, x, depth)
+            lg, rg, ce, ct = om.head_forward(P, [f[k] for k in ("p3", "p4", "p5", "p6", "p7")])
+        levels = [(lg[l][0].numpy(), rg[l][0].numpy(), ct[l][0].numpy()) for l in range(5)]
+        det = opp.predict_proposals(levels, d.FPN_STRIDES, thresh=d.INFERENCE_TH_TEST, topk=d.PRE_NMS_TOPK_TEST,
+                                    nms_thresh=d.NMS_TH, post_topk=d.POST_NMS_TOPK_TEST,
+                                    thresh_with_ctr=d.THRESH_WITH_CTR, sort_corners=d.SORT_CORNERS, fast=True)
+        opp.detector_postprocess(det, (1024, 1024), (1024, 1024), (1024, 1024))
+        t_total += time.perf_counter() - t0
+        n_done += 1
+    return {"value": n_done / t_total, "unit": "images/sec", "cores": cores, "kind": "port",
+            "sample": "%d x 1024x1024 image(s), R%d-FPN fp32 torch-CPU + C/numpy post-process, batch 1, %.1f s"
+                      % (n_done, depth, t_total)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=8, help="images per GPU per step")
+    ap.add_argument("--depth", type=int, default=101, choices=[50, 101])
+    ap.add_argument("--size", type=int, default=1024)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip roofline profile pass, R50 and NMS side metrics")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    distributed = world > 1
+    if distributed:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if distributed:
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+    assert args.gpus == world, "--gpus must equal the launched world size"
+
+    from dafne_amd.evaluation.gather import gather_detections
+    cfg, model, sd = build_model(args.depth, device, seed=0)
+    g = torch.Generator().manual_seed(rank)
+    batch = torch.randint(0, 256, (args.batch, 3, args.size, args.size), generator=g, dtype=torch.uint8).to(device)
+
+    def step():
+        rows, counts = model.detect_packed(batch)
+        if distributed:
+            gather_detections(rows, counts, dst=0)
+        return rows, counts
+
+    dt = time_steps(step, args.steps, args.warmup, distributed)
+    n_imgs = args.batch * world * args.steps
+    value = n_imgs / dt
+    rows, counts = step()
+    torch.cuda.synchronize()
+
+    out = {
+        "metric": "images/sec on 1024x1024 DOTA tiles, R%d-FPN" % args.depth,
+        "value": value, "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+        "config": {"workload": "DOTA-1.0 %dx%d R%d-FPN bf16, batch %d per GPU (per-GPU shard of configs[2]; "
+                               "the model BASELINE.json's metric names), uint8 tiles resident in HBM -> detections"
+                               % (args.size, args.size, args.depth, args.batch),
+                   "per_gpu_batch": args.batch, "global_batch": args.batch * world, "classes": 15,
+                   "parallelism": "dp%d (independent images, RCCL gather of detections)" % world,
+                   "detections_per_image_mean": float(counts.float().mean().item())},
+    }
+    if rank == 0 and not args.no_extras:
+        prof = conv_kernel_profile(model, batch)
+        dom = prof.get("conv_igemm<2,2,2,2>")
+        if dom:
+            out["roofline"] = {"bound": "mfma", "achieved": dom["tflops"], "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                               "frac": dom["tflops"] / PEAK_BF16_TFLOPS, "traffic": None,
+                               "kernel": "conv_igemm_kernel<2,2,2,2>", "launches_per_step": dom["launches"],
+                               "avg_launch_us": dom["avg_launch_us"],
+                               "algorithmic_gflop_per_step": dom["flops"] / 1e9}
+        out["kernels"] = {k: {"tflops": v["tflops"], "ms_per_step": v["ms"], "launches": v["launches"]}
+                          for k, v in prof.items()}
+        tot_flops = sum(v["flops"] for v in prof.values())
+        out["model_tflops_end_to_end"] = tot_flops / (dt / args.steps) / 1e12
+        out["mfma_frac_end_to_end"] = out["model_tflops_end_to_end"] / PEAK_BF16_TFLOPS
+        out["rotated_nms_ms_per_img"] = nms_ms_per_image(device)
+        if world == 1 and args.depth == 101:
+            cfg50, m50, _ = build_model(50, device, seed=0)
+            dt50 = time_steps(lambda: m50.detect_packed(batch), max(args.steps // 2, 3), 2, False)
+            out["configs1_r50_b8"] = {"images_per_sec": args.batch * max(args.steps // 2, 3) / dt50,
+                                      "workload": "DOTA-1.0 1024x1024 R50-FPN bf16, batch 8, 1 GPU"}
+            del m50
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(cfg, sd, args.depth)
+    if rank == 0:
+        print(json.dumps(out))
+    if distributed:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
