@@ -74,13 +74,20 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
 }
 
 template <int WC, int WP, int TC, int TP>
-__global__ void __launch_bounds__(256) conv_igemm_kernel(ConvDev P) {
+__global__ void __launch_bounds__(WC * WP * 64) conv_igemm_kernel(ConvDev P) {
+    constexpr int NW = WC * WP;            // waves per block
+    constexpr int NT = NW * 64;
     constexpr int BN = WC * TC * 32;       // output channels per block
     constexpr int BM = WP * TP * 32;       // output pixels per block
     constexpr int ROWS = BN + BM;
-    constexpr int NL = ROWS / 32;          // 1-KiB load instructions per wave per stage
+    constexpr int NL = ROWS / (8 * NW);    // 1-KiB load instructions per wave per stage
     constexpr int STAGE = ROWS * kRowBytes;
-    static_assert(WC * WP == 4, "4 waves");
+    // epilogue staging: fp32 [BM][EN] (+16 B row pad), EN channels per pass
+    constexpr int EN = BN > 128 ? 128 : BN;
+    constexpr int EPASS = BN / EN;
+    constexpr int ROWF = EN * 4 + 16;
+    constexpr int CH = EN / 8;             // 16-byte bf16 output chunks per pixel row
+    static_assert(ROWS % (8 * NW) == 0 && NT % CH == 0 && BM % (NT / CH) == 0, "tile shape");
     extern __shared__ __attribute__((aligned(16))) char lds[];
 
     const int tid = threadIdx.x;
@@ -107,9 +114,9 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(ConvDev P) {
     unsigned gofs[NL];
 #pragma unroll
     for (int j = 0; j < NL; j++) {
-        const int r = (j * 4 + wave) * 8 + (lane >> 3);
+        const int r = (j * NW + wave) * 8 + (lane >> 3);
         const int q = (lane & 7) ^ ((r >> 1) & 7);     // logical 16-byte chunk this lane fetches
-        if ((j * 4 + wave) * 8 < BN) {
+        if ((j * NW + wave) * 8 < BN) {
             gofs[j] = (unsigned)(nt * BN + r) * (unsigned)P.kbytes + (unsigned)q * 16u;
         } else {
             int pix = m0 + (r - BN);
@@ -131,10 +138,10 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(ConvDev P) {
                                       : (unsigned)((kh * Wp + kw) * P.Cin + c0) * 2u;
 #pragma unroll
         for (int j = 0; j < NL; j++) {
-            const bool isW = (j * 4 + wave) * 8 < BN;
+            const bool isW = (j * NW + wave) * 8 < BN;
             const char* base = isW ? P.w : S.in;
             const unsigned off = gofs[j] + (isW ? koffW : koffX);
-            char* dst = lds + stage * STAGE + (j * 4 + wave) * 8 * kRowBytes;
+            char* dst = lds + stage * STAGE + (j * NW + wave) * 8 * kRowBytes;
             __builtin_amdgcn_global_load_lds((gvoid*)(base + off), (lvoid*)dst, 16, 0, 0);
         }
         c0 += kBK;
@@ -184,102 +191,120 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(ConvDev P) {
     }
 
     // ------------------------------------------------------------ epilogue
+    // Accumulators go through LDS as fp32 [pixel][channel] so that global traffic is
+    // coalesced: every lane then owns 8 consecutive channels (16 B bf16) of one pixel,
+    // 16-lane groups cover 256 contiguous bytes; residual reads are coalesced the same
+    // way, and 8 channels == one GroupNorm group.
     const bool relu = P.flags & DAFNE_CONV_RELU;
     const bool has_res = P.flags & DAFNE_CONV_RESIDUAL;
     const bool has_up = P.flags & DAFNE_CONV_UPSAMPLE_ADD;
     const bool out_f32 = P.flags & DAFNE_CONV_OUT_F32;
     const bool gn = P.flags & DAFNE_CONV_GN_STATS;
     const int half = lane >> 5;
-    float gsum[TC][4], gsq[TC][4];
-#pragma unroll
-    for (int a = 0; a < TC; a++)
-#pragma unroll
-        for (int g = 0; g < 4; g++) gsum[a][g] = gsq[a][g] = 0.f;
+    const int col = tid % CH;
+    char* stg = lds;
+    float* red = (float*)(lds + BM * ROWF);   // [NW][CH][2]
 
 #pragma unroll
-    for (int b = 0; b < TP; b++) {
-        const int m = m0 + (wp * TP + b) * 32 + frow;
-        const bool valid = m < HW;
-        const int mm = valid ? m : HW - 1;
-        const int ho = mm / S.Wout, wo = mm - ho * S.Wout;
-        const size_t opix = ((size_t)(img * (S.Hout + 2) + ho + 1) * (S.Wout + 2) + wo + 1);
-        size_t rpix = opix;
-        if (has_up) rpix = ((size_t)(img * (S.Hout / 2 + 2) + ho / 2 + 1) * (S.Wout / 2 + 2) + wo / 2 + 1);
+    for (int ep = 0; ep < EPASS; ep++) {
+        __syncthreads();   // previous readers of this LDS region are done
+        // waves whose channel range falls into this pass deposit their accumulators
+        const int cw0 = wc * TC * 32 - ep * EN;          // wave's first channel relative to the pass
+        if (cw0 >= 0 && cw0 < EN) {
 #pragma unroll
-        for (int a = 0; a < TC; a++) {
+            for (int b = 0; b < TP; b++) {
+                const int px = (wp * TP + b) * 32 + frow;
 #pragma unroll
-            for (int g = 0; g < 4; g++) {
-                const int co = nt * BN + (wc * TC + a) * 32 + 8 * g + 4 * half;   // 4 consecutive channels
-                float v[4];
+                for (int a = 0; a < TC; a++)
 #pragma unroll
-                for (int k = 0; k < 4; k++) v[k] = acc[a][b][4 * g + k];
-                if (P.bias) {
-                    const float4 bb = *(const float4*)(P.bias + co);
-                    v[0] += bb.x; v[1] += bb.y; v[2] += bb.z; v[3] += bb.w;
-                }
-                if (has_res || has_up) {
-                    const uint2 rr = *(const uint2*)(S.res + (rpix * P.Cout + co) * 2);
-                    v[0] += bf2f((unsigned short)(rr.x & 0xffff)); v[1] += bf2f((unsigned short)(rr.x >> 16));
-                    v[2] += bf2f((unsigned short)(rr.y & 0xffff)); v[3] += bf2f((unsigned short)(rr.y >> 16));
-                }
-                if (relu) {
-#pragma unroll
-                    for (int k = 0; k < 4; k++) v[k] = fmaxf(v[k], 0.f);
-                }
-                if (gn && valid) {
-#pragma unroll
-                    for (int k = 0; k < 4; k++) { gsum[a][g] += v[k]; gsq[a][g] += v[k] * v[k]; }
-                }
-                if (valid) {
-                    if (out_f32) {
-                        float* o = (float*)S.out + ((size_t)(img * S.Hout + ho) * S.Wout + wo) * P.Cout + co;
-#pragma unroll
-                        for (int k = 0; k < 4; k++) if (co + k < P.Cout) o[k] = v[k];
-                    } else {
-                        uint2 pk;
-                        pk.x = (unsigned)f2bf(v[0]) | ((unsigned)f2bf(v[1]) << 16);
-                        pk.y = (unsigned)f2bf(v[2]) | ((unsigned)f2bf(v[3]) << 16);
-                        *(uint2*)(S.out + (opix * P.Cout + co) * 2) = pk;
+                    for (int g = 0; g < 4; g++) {
+                        const int co = cw0 + a * 32 + 8 * g + 4 * half;
+                        float4 v = make_float4(acc[a][b][4 * g], acc[a][b][4 * g + 1], acc[a][b][4 * g + 2],
+                                               acc[a][b][4 * g + 3]);
+                        *(float4*)(stg + px * ROWF + co * 4) = v;
                     }
-                }
             }
         }
-    }
-
-    if (gn) {
-        // deterministic: butterfly over the wave (32 pixels x 2 channel halves), then a
-        // fixed-order sum over the WP pixel-waves through LDS
-        __syncthreads();   // LDS stages are dead now
-        float* red = (float*)lds;   // [4 waves][TC*4][2]
-#pragma unroll
-        for (int a = 0; a < TC; a++)
-#pragma unroll
-            for (int g = 0; g < 4; g++) {
-                float s = gsum[a][g], q = gsq[a][g];
-#pragma unroll
-                for (int o = 32; o > 0; o >>= 1) {
-                    s += __shfl_xor(s, o, 64);
-                    q += __shfl_xor(q, o, 64);
-                }
-                if (lane == 0) {
-                    red[(wave * TC * 4 + a * 4 + g) * 2 + 0] = s;
-                    red[(wave * TC * 4 + a * 4 + g) * 2 + 1] = q;
-                }
-            }
         __syncthreads();
-        if (tid < BN / 8) {
-            const int wcc = tid / (TC * 4), ag = tid % (TC * 4);
-            float s = 0.f, q = 0.f;
+        const int cobase = nt * BN + ep * EN + col * 8;   // first of this lane's 8 channels
+        float bia[8];
 #pragma unroll
-            for (int p = 0; p < WP; p++) {
-                s += red[((wcc * WP + p) * TC * 4 + ag) * 2 + 0];
-                q += red[((wcc * WP + p) * TC * 4 + ag) * 2 + 1];
+        for (int k = 0; k < 8; k++) bia[k] = 0.f;
+        if (P.bias) {
+            const float4 b0 = *(const float4*)(P.bias + cobase), b1 = *(const float4*)(P.bias + cobase + 4);
+            bia[0] = b0.x; bia[1] = b0.y; bia[2] = b0.z; bia[3] = b0.w;
+            bia[4] = b1.x; bia[5] = b1.y; bia[6] = b1.z; bia[7] = b1.w;
+        }
+        float gs = 0.f, gq = 0.f;
+#pragma unroll 2
+        for (int p = tid / CH; p < BM; p += NT / CH) {
+            const int m = m0 + p;
+            if (m >= HW) continue;
+            const int ho = m / S.Wout, wo = m - ho * S.Wout;
+            const float4 x0 = *(const float4*)(stg + p * ROWF + col * 32);
+            const float4 x1 = *(const float4*)(stg + p * ROWF + col * 32 + 16);
+            float v[8] = {x0.x + bia[0], x0.y + bia[1], x0.z + bia[2], x0.w + bia[3],
+                          x1.x + bia[4], x1.y + bia[5], x1.z + bia[6], x1.w + bia[7]};
+            if (has_res || has_up) {
+                const size_t rpix = has_up
+                    ? ((size_t)(img * (S.Hout / 2 + 2) + ho / 2 + 1) * (S.Wout / 2 + 2) + wo / 2 + 1)
+                    : ((size_t)(img * (S.Hout + 2) + ho + 1) * (S.Wout + 2) + wo + 1);
+                const uint4 rr = *(const uint4*)(S.res + (rpix * P.Cout + cobase) * 2);
+                const unsigned u[4] = {rr.x, rr.y, rr.z, rr.w};
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    v[2 * k] += bf2f((unsigned short)(u[k] & 0xffff));
+                    v[2 * k + 1] += bf2f((unsigned short)(u[k] >> 16));
+                }
             }
-            const int group = (nt * BN) / 8 + tid;
-            if (group < P.Cout / 8) {
-                float* o = P.gn_partial + ((size_t)mt * (P.Cout / 8) + group) * 2;
-                o[0] = s;
-                o[1] = q;
+            if (relu) {
+#pragma unroll
+                for (int k = 0; k < 8; k++) v[k] = fmaxf(v[k], 0.f);
+            }
+            if (gn) {
+#pragma unroll
+                for (int k = 0; k < 8; k++) { gs += v[k]; gq += v[k] * v[k]; }
+            }
+            if (out_f32) {
+                float* o = (float*)S.out + ((size_t)(img * S.Hout + ho) * S.Wout + wo) * P.Cout + cobase;
+#pragma unroll
+                for (int k = 0; k < 8; k++) if (cobase + k < P.Cout) o[k] = v[k];
+            } else {
+                const size_t opix = ((size_t)(img * (S.Hout + 2) + ho + 1) * (S.Wout + 2) + wo + 1);
+                uint4 pk;
+                pk.x = (unsigned)f2bf(v[0]) | ((unsigned)f2bf(v[1]) << 16);
+                pk.y = (unsigned)f2bf(v[2]) | ((unsigned)f2bf(v[3]) << 16);
+                pk.z = (unsigned)f2bf(v[4]) | ((unsigned)f2bf(v[5]) << 16);
+                pk.w = (unsigned)f2bf(v[6]) | ((unsigned)f2bf(v[7]) << 16);
+                *(uint4*)(S.out + (opix * P.Cout + cobase) * 2) = pk;
+            }
+        }
+        if (gn) {
+            // deterministic: butterfly over the lanes that share a channel group, then a
+            // fixed-order sum over the waves through LDS
+#pragma unroll
+            for (int o = 32; o >= CH; o >>= 1) {
+                gs += __shfl_xor(gs, o, 64);
+                gq += __shfl_xor(gq, o, 64);
+            }
+            if (lane < CH) {
+                red[(wave * CH + lane) * 2 + 0] = gs;
+                red[(wave * CH + lane) * 2 + 1] = gq;
+            }
+            __syncthreads();
+            if (tid < CH) {
+                float s = 0.f, q = 0.f;
+#pragma unroll
+                for (int w2 = 0; w2 < NW; w2++) {
+                    s += red[(w2 * CH + tid) * 2 + 0];
+                    q += red[(w2 * CH + tid) * 2 + 1];
+                }
+                const int group = (nt * BN + ep * EN) / 8 + tid;
+                if (group < P.Cout / 8) {
+                    float* o = P.gn_partial + ((size_t)mt * (P.Cout / 8) + group) * 2;
+                    o[0] = s;
+                    o[1] = q;
+                }
             }
         }
     }
@@ -348,14 +373,18 @@ int build(ConvDev& D, const dafne_conv_params* p, const dafne_conv_seg* segs) {
 template <int WC, int WP, int TC, int TP>
 int launch(const ConvDev& D, hipStream_t st) {
     constexpr int ROWS = (WC * TC + WP * TP) * 32;
-    constexpr int smem = 2 * ROWS * kRowBytes;
+    constexpr int BN = WC * TC * 32, BM = WP * TP * 32, NW = WC * WP;
+    constexpr int EN = BN > 128 ? 128 : BN;
+    constexpr int stage2 = 2 * ROWS * kRowBytes;
+    constexpr int epi = BM * (EN * 4 + 16) + NW * (EN / 8) * 2 * 4;
+    constexpr int smem = stage2 > epi ? stage2 : epi;
     static bool attr_done = false;   // idempotent attribute; a benign race sets it twice
     if (!attr_done) {
         DAFNE_HIP_TRY(hipFuncSetAttribute((const void*)conv_igemm_kernel<WC, WP, TC, TP>,
                                           hipFuncAttributeMaxDynamicSharedMemorySize, smem));
         attr_done = true;
     }
-    hipLaunchKernelGGL((conv_igemm_kernel<WC, WP, TC, TP>), dim3(D.mtiles * D.ntiles), dim3(256), smem, st, D);
+    hipLaunchKernelGGL((conv_igemm_kernel<WC, WP, TC, TP>), dim3(D.mtiles * D.ntiles), dim3(WC * WP * 64), smem, st, D);
     return dafne::check_launch("conv_igemm");
 }
 

@@ -103,35 +103,64 @@ struct GnDev {
     float eps;
 };
 
-// one thread per (segment, image, group): fixed-order sum of the conv's tile partials
+// one 256-thread block per (segment, image): thread = (tile slice 0..7, group 0..31+);
+// every slice sums its tiles in order, then the 8 slices are added in order: the
+// result does not depend on launch geometry or timing.
 __global__ void __launch_bounds__(256) gn_finalize_kernel(GnDev P) {
     const int G = P.C / 8;
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= P.n_segs * P.N * G) return;
-    const int g = i % G, n = (i / G) % P.N, s = i / (G * P.N);
+    const int n = blockIdx.x % P.N, s = blockIdx.x / P.N;
     const GnSeg& S = P.seg[s];
-    float sum = 0.f, sq = 0.f;
+    __shared__ float part[8][64][2];
     const int t0 = S.tile0 + n * S.tiles_per_img;
-    for (int t = 0; t < S.tiles_per_img; t++) {
-        const float* p = P.partial + ((size_t)(t0 + t) * G + g) * 2;
-        sum += p[0];
-        sq += p[1];
+    for (int g0 = 0; g0 < G; g0 += 32) {
+        const int g = g0 + (threadIdx.x & 31), sl = threadIdx.x >> 5;
+        float sum = 0.f, sq = 0.f;
+        if (g < G) {
+            for (int t = sl; t < S.tiles_per_img; t += 8) {
+                const float2 p = *(const float2*)(P.partial + ((size_t)(t0 + t) * G + g) * 2);
+                sum += p.x;
+                sq += p.y;
+            }
+        }
+        part[sl][threadIdx.x & 31][0] = sum;
+        part[sl][threadIdx.x & 31][1] = sq;
+        __syncthreads();
+        if (threadIdx.x < 32 && g < G) {
+            float a = 0.f, b = 0.f;
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                a += part[k][threadIdx.x][0];
+                b += part[k][threadIdx.x][1];
+            }
+            const float cnt = (float)(S.H * S.W * 8);
+            const float mean = a / cnt;
+            float var = b / cnt - mean * mean;
+            var = var > 0.f ? var : 0.f;
+            float* o = P.stats + (((size_t)s * P.N + n) * G + g) * 2;
+            o[0] = mean;
+            o[1] = rsqrtf(var + P.eps);
+        }
+        __syncthreads();
     }
-    const float cnt = (float)(S.H * S.W * 8);
-    const float mean = sum / cnt;
-    float var = sq / cnt - mean * mean;
-    var = var > 0.f ? var : 0.f;
-    P.stats[(size_t)i * 2 + 0] = mean;
-    P.stats[(size_t)i * 2 + 1] = rsqrtf(var + P.eps);
 }
 
-// y = relu((x - mean) * rstd * gamma + beta), in place; a 16-byte lane == one group of 8 channels
-__global__ void __launch_bounds__(256) gn_apply_kernel(GnDev P, int seg_idx, long long total) {
-    const GnSeg& S = P.seg[seg_idx];
+struct GnApplyDev {
+    long long seg_start[6];   // first flat element (16-byte lane) of each segment
+};
+
+// y = relu((x - mean) * rstd * gamma + beta), in place; a 16-byte lane == one group of
+// 8 channels; all segments in one launch.
+__global__ void __launch_bounds__(256) gn_apply_kernel(GnDev P, GnApplyDev A, long long total) {
     const int G = P.C / 8;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
-        const int g = (int)(i % G);
-        long long t = i / G;
+        int seg_idx = 0;
+#pragma unroll
+        for (int k = 1; k < 5; k++)
+            if (k < P.n_segs && i >= A.seg_start[k]) seg_idx = k;
+        const GnSeg& S = P.seg[seg_idx];
+        const long long j = i - A.seg_start[seg_idx];
+        const int g = (int)(j % G);
+        long long t = j / G;
         const int w = (int)(t % S.W);
         t /= S.W;
         const int h = (int)(t % S.H);
@@ -223,16 +252,17 @@ int dafne_groupnorm_relu_nhwc_bf16_hip(const dafne_gn_seg* segs, int n_segs, int
         D.seg[s].tile0 = segs[s].tile0; D.seg[s].tiles_per_img = segs[s].tiles_per_img;
     }
     hipStream_t st = (hipStream_t)stream;
-    const int nstat = n_segs * n_images * (C / 8);
-    hipLaunchKernelGGL(gn_finalize_kernel, dim3((nstat + 255) / 256), dim3(256), 0, st, D);
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3(n_segs * n_images), dim3(256), 0, st, D);
     int rc = dafne::check_launch("gn_finalize");
     if (rc) return rc;
-    for (int s = 0; s < n_segs; s++) {
-        const long long total = (long long)n_images * segs[s].H * segs[s].W * (C / 8);
-        hipLaunchKernelGGL(gn_apply_kernel, dim3(grid_for(total)), dim3(256), 0, st, D, s, total);
-        if ((rc = dafne::check_launch("gn_apply"))) return rc;
+    GnApplyDev A;
+    long long total = 0;
+    for (int s = 0; s < 6; s++) {
+        A.seg_start[s] = total;
+        if (s < n_segs) total += (long long)n_images * segs[s].H * segs[s].W * (C / 8);
     }
-    return DAFNE_OK;
+    hipLaunchKernelGGL(gn_apply_kernel, dim3(grid_for(total)), dim3(256), 0, st, D, A, total);
+    return dafne::check_launch("gn_apply");
 }
 
 int dafne_relu_copy_bf16_hip(const void* d_in, void* d_out, int64_t n_elems, void* stream) {

@@ -452,6 +452,7 @@ __global__ void __launch_bounds__(64) nms_mask_kernel(const int* __restrict__ co
     __syncthreads();
 
     if (total > 0) {
+        if (lane == 0) atomicAdd(&w.meta[img * 4 + 2], (unsigned)total);   // statistics: clipped pairs
         Scratch s{lds_p + lane, lds_pp + lane};
         for (int base = 0; base < total; base += 4) {
             int k = base + (lane >> 4);
