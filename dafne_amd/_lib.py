@@ -70,6 +70,7 @@ SIGNATURES = {
     "dafne_conv2d_nhwc_bf16_hip": (c_int, [ctypes.POINTER(ConvParams), ctypes.POINTER(ConvSeg), c_void_p]),
     "dafne_conv2d_num_tiles": (c_int, [ctypes.POINTER(ConvParams), ctypes.POINTER(ConvSeg)]),
     "dafne_conv2d_cout_pad": (c_int, [c_int]),
+    "dafne_conv2d_tile_pixels": (c_int, [ctypes.POINTER(ConvParams), ctypes.POINTER(ConvSeg)]),
     "dafne_preprocess_image_hip": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p,
                                            ctypes.POINTER(c_float), ctypes.POINTER(c_float), c_int, c_int,
                                            c_void_p, c_void_p]),

@@ -21,6 +21,7 @@
 // Pipeline: 2 LDS stages, one barrier per 64-deep K step; the next step's loads are
 // issued right after the barrier and land under the current step's 16 MFMAs/wave.
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -53,6 +54,7 @@ struct ConvDev {
     int ksteps;        // KH*KW*Cin/64 (stem: 4)
     int kbytes;        // bytes per weight row
     int mtiles, ntiles;
+    int bn, bm;        // chosen tile
     int stem;          // 7x7 s2 stem on the 4-channel padded image
 };
 
@@ -314,7 +316,12 @@ struct Cfg {
     int bn, bm;
 };
 
-Cfg pick_cfg(int Cout) {
+// Tile choice: 256x256 (8 waves, 1 block/CU) halves the L2->LDS operand traffic per
+// FLOP, but only pays when the launch still has >= 2 blocks per CU; otherwise the
+// 128x128 (4 waves, 2 blocks/CU) tile keeps the 256 CUs busy.
+Cfg pick_cfg(int Cout, long long blocks256 = 0) {
+    static const bool big = getenv("DAFNE_CONV_NO256") == nullptr;
+    if (big && Cout % 256 == 0 && blocks256 >= 512) return {256, 256};
     if (Cout >= 128) return {128, 128};
     if (Cout > 32) return {64, 256};
     return {32, 256};
@@ -331,7 +338,12 @@ int build(ConvDev& D, const dafne_conv_params* p, const dafne_conv_seg* segs) {
         if (p->stride != 1 && p->stride != 2) return dafne::fail(DAFNE_E_UNSUPPORTED, "conv: stride %d", p->stride);
     }
     if (p->Cout < 1) return dafne::fail(DAFNE_E_INVALID, "conv: Cout");
-    Cfg c = pick_cfg(p->Cout);
+    long long b256 = 0;
+    for (int s = 0; s < p->n_segs; s++)
+        b256 += (long long)((segs[s].Hout * segs[s].Wout + 255) / 256) * p->n_images * (p->Cout / 256);
+    Cfg c = pick_cfg(p->Cout, b256);
+    D.bn = c.bn;
+    D.bm = c.bm;
     D.Cout_pad = (p->Cout + c.bn - 1) / c.bn * c.bn;
     if (!(p->flags & DAFNE_CONV_OUT_F32) && D.Cout_pad != p->Cout)
         return dafne::fail(DAFNE_E_UNSUPPORTED, "conv: bf16 output needs Cout %% %d == 0", c.bn);
@@ -398,6 +410,12 @@ int dafne_conv2d_cout_pad(int Cout) {
     return (Cout + c.bn - 1) / c.bn * c.bn;
 }
 
+int dafne_conv2d_tile_pixels(const dafne_conv_params* prm, const dafne_conv_seg* segs) {
+    ConvDev D;
+    if (build(D, prm, segs)) return -1;
+    return D.bm;
+}
+
 int dafne_conv2d_num_tiles(const dafne_conv_params* prm, const dafne_conv_seg* segs) {
     ConvDev D;
     if (build(D, prm, segs)) return -1;
@@ -409,9 +427,9 @@ int dafne_conv2d_nhwc_bf16_hip(const dafne_conv_params* prm, const dafne_conv_se
     int rc = build(D, prm, segs);
     if (rc) return rc;
     hipStream_t st = (hipStream_t)stream;
-    Cfg c = pick_cfg(D.Cout);
-    if (c.bn == 128) return launch<2, 2, 2, 2>(D, st);
-    if (c.bn == 64) return launch<1, 4, 2, 2>(D, st);
+    if (D.bn == 256) return launch<4, 2, 2, 4>(D, st);
+    if (D.bn == 128) return launch<2, 2, 2, 2>(D, st);
+    if (D.bn == 64) return launch<1, 4, 2, 2>(D, st);
     return launch<1, 4, 1, 2>(D, st);
 }
 

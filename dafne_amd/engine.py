@@ -118,6 +118,9 @@ class ConvCall:
     def num_tiles(self):
         return _lib.load().dafne_conv2d_num_tiles(ctypes.byref(self.prm), self.segs)
 
+    def tile_pixels(self):
+        return _lib.load().dafne_conv2d_tile_pixels(ctypes.byref(self.prm), self.segs)
+
     def __call__(self, stream):
         rc = self.fn(ctypes.byref(self.prm), self.segs, stream)
         if rc:
@@ -258,8 +261,9 @@ class HeadPlan:
                 wgt, bias = P["%s.%d" % (name, 3 * i)]
                 gamma, beta = P["%s.%d.gn" % (name, 3 * i + 1)]
                 outs = [pool.get(n, f.h, f.w, C) for f in cur]
-                bm = 128                                  # M tile of the Cout>=128 kernel config
-                nt = sum((o.h * o.w + bm - 1) // bm for o in outs) * n
+                # M-tile count comes from the library (the kernel config picks the tile size)
+                probe = ConvCall(wgt, bias, C, C, 3, 1, 1, 0, seg_list(cur, outs), n)
+                nt = probe.num_tiles()
                 partial = torch.empty(nt, C // 8, 2, dtype=torch.float32, device=device)
                 c = ConvCall(wgt, bias, C, C, 3, 1, 1, F_GN, seg_list(cur, outs), n, gn_partial=partial)
                 calls.append(c)
@@ -267,6 +271,7 @@ class HeadPlan:
                 stats = torch.empty(len(outs), n, C // 8, 2, dtype=torch.float32, device=device)
                 gsegs = (_lib.GnSeg * len(outs))()
                 t0 = 0
+                bm = probe.tile_pixels()
                 for k, o in enumerate(outs):
                     tpi = (o.h * o.w + bm - 1) // bm
                     gsegs[k] = _lib.GnSeg(o.t.data_ptr(), o.h, o.w, t0, tpi)

@@ -192,6 +192,8 @@ typedef struct dafne_conv_params {
  */
 int dafne_conv2d_nhwc_bf16_hip(const dafne_conv_params* prm, const dafne_conv_seg* segs, void* stream);
 int dafne_conv2d_cout_pad(int Cout);
+/* output pixels per M tile the call would use (geometry of d_gn_partial rows), -1 on error */
+int dafne_conv2d_tile_pixels(const dafne_conv_params* prm, const dafne_conv_seg* segs);
 /* number of M tiles the call above launches (= rows of d_gn_partial), -1 on error */
 int dafne_conv2d_num_tiles(const dafne_conv_params* prm, const dafne_conv_seg* segs);
 

@@ -72,6 +72,8 @@ CASES = [
     (256, 256, 3, 2, 1, 16, 16, 1),     # P6/P7
     (512, 2048, 1, 1, 0, 4, 4, 1),
     (1024, 256, 1, 1, 0, 8, 8, 1),
+    (64, 256, 1, 1, 0, 256, 256, 2),    # >= 512 blocks of 256x256: the 8-wave tile
+    (64, 512, 3, 1, 1, 120, 150, 2),    # 8-wave tile, ragged, two N tiles
 ]
 
 
@@ -136,7 +138,8 @@ def test_groupnorm_relu_pipeline():
     a = engine.Act.from_nchw(x.to(d))
     wp, bp = engine.pack_conv(w, b, d)
     oa = engine.Act(N, H, W, C, d)
-    tpi = (H * W + 127) // 128
+    bm = engine.ConvCall(wp, bp, C, C, 3, 1, 1, 0, [(a.t, oa.t, None, H, W, H, W)], N).tile_pixels()
+    tpi = (H * W + bm - 1) // bm
     partial = torch.zeros(tpi * N, C // 8, 2, dtype=torch.float32, device=d)
     call = engine.ConvCall(wp, bp, C, C, 3, 1, 1, engine.F_GN, [(a.t, oa.t, None, H, W, H, W)], N, gn_partial=partial)
     assert call.num_tiles() == tpi * N
@@ -149,6 +152,36 @@ def test_groupnorm_relu_pipeline():
     torch.cuda.synchronize()
     assert torch.allclose(stats[0, :, :, 0].cpu(), mean.squeeze(-1), atol=1e-4)
     close_bf16(oa.nchw_float().cpu(), ref, ulps=3)
+
+
+def test_big_tile_groupnorm_stats_and_residual():
+    """256x256 tile path: GN partial sums (reduced on the host here) and residual+ReLU."""
+    from dafne_amd import engine, _lib
+    g = torch.Generator().manual_seed(6)
+    N, C, H, W = 2, 256, 256, 256
+    x = bfr(torch.randn(N, 64, H, W, generator=g))
+    w = bfr(torch.randn(C, 64, 1, 1, generator=g) / 8.0)
+    b = torch.randn(C, generator=g) * 0.1
+    y = F.conv2d(x, w, b)
+    d = dev()
+    a = engine.Act.from_nchw(x.to(d))
+    wp, bp = engine.pack_conv(w, b, d)
+    oa = engine.Act(N, H, W, C, d)
+    probe = engine.ConvCall(wp, bp, 64, C, 1, 1, 0, 0, [(a.t, oa.t, None, H, W, H, W)], N)
+    assert probe.tile_pixels() == 256
+    nt = probe.num_tiles()
+    partial = torch.zeros(nt, C // 8, 2, dtype=torch.float32, device=d)
+    engine.ConvCall(wp, bp, 64, C, 1, 1, 0, engine.F_GN, [(a.t, oa.t, None, H, W, H, W)], N, gn_partial=partial)(
+        _lib.current_stream())
+    torch.cuda.synchronize()
+    close_bf16(oa.nchw_float().cpu(), bfr(y))
+    ps = partial.cpu().reshape(N, nt // N, C // 8, 2).sum(1)
+    grp = y.reshape(N, C // 8, -1)
+    assert torch.allclose(ps[..., 0], grp.sum(-1), rtol=1e-4, atol=1e-1)
+    assert torch.allclose(ps[..., 1], (grp * grp).sum(-1), rtol=1e-4, atol=1e-1)
+    res = bfr(torch.randn(N, C, H, W, generator=g))
+    got, _, _ = run_conv(x, w, b, 1, 1, 0, flags=engine.F_RELU | engine.F_RES, res=res)
+    close_bf16(got, bfr(F.relu(y + res)))
 
 
 def test_stem_preprocess_maxpool():
