@@ -22,6 +22,7 @@
 //
 // Wave64 throughout: one ballot == one 64-column tile row.
 #include "common.h"
+#include <algorithm>
 
 namespace {
 
@@ -30,6 +31,7 @@ typedef unsigned long long u64;
 constexpr int kTile = 64;
 constexpr int kCapP = 10;   // clipped polygon capacity (reference: Point p[10])
 constexpr int kCapPP = 12;  // raw cut output capacity
+constexpr int kPairCap = 1024;   // candidate pairs listed per 64-row block (more: clipped in place)
 constexpr double kEps = 1E-8;
 
 struct P2 {
@@ -69,7 +71,7 @@ __device__ __forceinline__ double shoelace_s(const P2* p, int n) {
 }
 
 // polyiou.cpp:62-75 (+ lineCross :33-43): keep the part of p left of a->b.
-__device__ void cut_left(Scratch s, int& n, P2 a, P2 b) {
+__device__ __forceinline__ void cut_left(Scratch s, int& n, P2 a, P2 b) {
     int m = 0;
     if (n > 0) {
         P2 first = s.p[0];
@@ -121,7 +123,7 @@ __device__ void cut_left(Scratch s, int& n, P2 a, P2 b) {
 }
 
 // polyiou.cpp:79-93: signed overlap of triangles (o,a,b) and (o,c,d).
-__device__ double tri_overlap(Scratch s, P2 a, P2 b, P2 c, P2 d) {
+__device__ __forceinline__ double tri_overlap(Scratch s, P2 a, P2 b, P2 c, P2 d) {
     P2 o = {0.0, 0.0};
     int s1 = sgn(cross3(o, a, b));
     int s2 = sgn(cross3(o, c, d));
@@ -176,7 +178,7 @@ __device__ __forceinline__ P2 quad_vertex(const Quad& q, int i) {
 // IoU of (A,B) computed by a group of 16 consecutive lanes: lane `sub` clips
 // triangle pair (i=sub/4, j=sub%4); the 16 partial areas are then summed in the
 // reference's loop order (i outer, j inner) by every lane of the group.
-__device__ double iou_group16(Scratch s, Quad A, Quad B, int lane) {
+__device__ __forceinline__ double iou_group16(Scratch s, Quad A, Quad B, int lane) {
     quad_orient(A);
     quad_orient(B);
     const int sub = lane & 15;
@@ -232,11 +234,15 @@ struct NmsWs {
     float* sscore;   // [N][Mp]
     float4* hull;    // [N][Mp]    xmin, ymin, xmax, ymax
     double* area;    // [N][Mp]    |shoelace|
-    u64* mask;       // [N][Mp][nblk]
+    u64* mask;       // [N][ntiles][64]  tile-major
     u64* rowflag;    // [N][nblk]  bit r of word b: row 64b+r suppresses something
     unsigned* meta;  // [N][4]     0: max|coord| (float bits) 1: span+1 (float bits)
     float* dets9;    // [N][Mp][9] (select path only)
-    int Mp, nblk;
+    unsigned* pair_cnt;        // [N][nblk]  pairs appended per row block (may exceed pair_cap)
+    u64* pairs;                // [N][nblk][pair_cap]  (row | col << 32), sorted positions
+    unsigned char* tile_flag;  // [N][ntiles]  tile did not fit the pair list
+    int Mp, nblk, pair_cap;    // pair_cap: per row block
+    size_t mask_words;         // per image
 };
 
 size_t carve(NmsWs& w, void* base, int N, int m_cap) {
@@ -247,16 +253,27 @@ size_t carve(NmsWs& w, void* base, int N, int m_cap) {
     size_t n = (size_t)N;
     w.Mp = Mp;
     w.nblk = nblk;
+    const size_t ntiles = (size_t)nblk * (nblk + 1) / 2;
+    w.pair_cap = kPairCap;
     w.meta = c.take<unsigned>(n * 4);
-    w.rowflag = c.take<u64>(n * nblk);   // meta + rowflag are zeroed per call (contiguous)
+    w.pair_cnt = c.take<unsigned>(n * nblk);
+    w.rowflag = c.take<u64>(n * nblk);
+    w.tile_flag = c.take<unsigned char>(n * ntiles);   // meta .. tile_flag are zeroed per call (contiguous)
+    w.pairs = c.take<u64>(n * nblk * (size_t)w.pair_cap);
     w.order = c.take<int>(n * Mp);
     w.sbox = c.take<float>(n * Mp * 8);
     w.sscore = c.take<float>(n * Mp);
     w.hull = c.take<float4>(n * Mp);
     w.area = c.take<double>(n * Mp);
     w.dets9 = c.take<float>(n * Mp * 9);
-    w.mask = c.take<u64>(n * Mp * nblk);
+    w.mask_words = ntiles * kTile;
+    w.mask = c.take<u64>(n * w.mask_words);
     return dafne::align_up(c.off, 256);
+}
+
+size_t zero_bytes(const NmsWs& w, int N) {
+    const size_t ntiles = (size_t)w.nblk * (w.nblk + 1) / 2;
+    return (size_t)((char*)(w.tile_flag + (size_t)N * ntiles) - (char*)w.meta);
 }
 
 __device__ __forceinline__ int img_count(const int* counts, int img, int m_cap) {
@@ -330,18 +347,24 @@ __global__ void __launch_bounds__(256) nms_prep_kernel(const float* __restrict__
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     const bool live = i < M;
     const float si = live ? d[(size_t)i * 9 + 8] : 0.f;
-    __shared__ float ss[256];
+    __shared__ __attribute__((aligned(16))) float ss[256];
     int rank = 0;
     for (int j0 = 0; j0 < M; j0 += 256) {
         int j = j0 + threadIdx.x;
-        ss[threadIdx.x] = j < M ? d[(size_t)j * 9 + 8] : 0.f;
+        ss[threadIdx.x] = j < M ? d[(size_t)j * 9 + 8] : -INFINITY;
         __syncthreads();
-        int lim = min(256, M - j0);
-        for (int jj = 0; jj < lim; jj++) {
-            float sj = ss[jj];
-            int jg = j0 + jj;
-            rank += (sj > si) || (sj == si && jg > i);   // argsort(kind="stable")[::-1]
+        const int lim = min(256, M - j0);
+        const float4* ss4 = reinterpret_cast<const float4*>(ss);
+#pragma unroll 4
+        for (int j4 = 0; j4 < 64; j4++) {                 // entries beyond lim hold -inf: never counted
+            const float4 v = ss4[j4];
+            const int jg = j0 + 4 * j4;
+            rank += (v.x > si) || (v.x == si && jg > i);  // argsort(kind="stable")[::-1]
+            rank += (v.y > si) || (v.y == si && jg + 1 > i);
+            rank += (v.z > si) || (v.z == si && jg + 2 > i);
+            rank += (v.w > si) || (v.w == si && jg + 3 > i);
         }
+        (void)lim;
         __syncthreads();
     }
     float amax = 0.f;
@@ -387,97 +410,196 @@ __device__ __forceinline__ int kth_set_bit(u64 m, int t) {
     return pos;
 }
 
-__global__ void __launch_bounds__(64) nms_mask_kernel(const int* __restrict__ counts, int m_cap,
-                                                      double thresh, NmsWs w) {
-    const int img = blockIdx.y;
-    const int M = img_count(counts, img, m_cap);
-    // linear tile id -> (rb, cb), cb >= rb, row-major over the upper triangle
-    const int nb = w.nblk;
-    const long long t = blockIdx.x;
+// The suppression matrix is stored tile-major: the 64 row words of tile (rb, cb) are
+// contiguous (512 B), tiles in row-major order over the upper triangle.
+__device__ __forceinline__ size_t tile_id(int rb, int cb, int nb) {
+    return (size_t)rb * nb - (size_t)rb * (rb - 1) / 2 + (size_t)(cb - rb);
+}
+
+// tile id -> (rb, cb), cb >= rb, row-major over the upper triangle of nb x nb blocks
+__device__ __forceinline__ void tile_rc(long long t, int nb, int& rb, int& cb) {
     // row rb starts at rb*nb - rb*(rb-1)/2
-    int rb = (int)((2.0 * nb + 1.0 - sqrt((2.0 * nb + 1.0) * (2.0 * nb + 1.0) - 8.0 * (double)t)) * 0.5);
-    if (rb < 0) rb = 0;
-    if (rb >= nb) rb = nb - 1;
-    while (rb > 0 && (long long)rb * nb - (long long)rb * (rb - 1) / 2 > t) rb--;
-    while ((long long)(rb + 1) * nb - (long long)(rb + 1) * rb / 2 <= t) rb++;
-    const int cb = rb + (int)(t - ((long long)rb * nb - (long long)rb * (rb - 1) / 2));
-    if (rb * kTile >= M || cb * kTile >= M) return;
+    int r = (int)((2.0 * nb + 1.0 - sqrt((2.0 * nb + 1.0) * (2.0 * nb + 1.0) - 8.0 * (double)t)) * 0.5);
+    if (r < 0) r = 0;
+    if (r >= nb) r = nb - 1;
+    while (r > 0 && (long long)r * nb - (long long)r * (r - 1) / 2 > t) r--;
+    while ((long long)(r + 1) * nb - (long long)(r + 1) * r / 2 <= t) r++;
+    rb = r;
+    cb = r + (int)(t - ((long long)r * nb - (long long)r * (r - 1) / 2));
+}
 
-    __shared__ P2 lds_p[kCapP * kTile];
-    __shared__ P2 lds_pp[kCapPP * kTile];
-    __shared__ float4 rhull[kTile];
-    __shared__ double rarea[kTile];
-    __shared__ u64 cand[kTile];
-    __shared__ int pre[kTile];
-    __shared__ u64 rowbits[kTile];
-
-    const int lane = threadIdx.x;
+// Hull pre-filter of one 64x64 tile by one wave.  Lane r ends up with the 64-bit set
+// of columns row r must be clipped against.  Guard: see oracle/poly_oracle.c
+// (orc_poly_nms_fast): separated hulls mean a true intersection of 0; the fp64 fan
+// sum then differs from 0 by rounding only, which cannot reach thresh*union unless
+// the union is itself negligible.
+__device__ __forceinline__ u64 tile_candidates(const NmsWs& w, int img, int M, int rb, int cb, double thresh,
+                                               float4* rhull) {
+    const int lane = threadIdx.x & 63;
     const size_t ibase = (size_t)img * w.Mp;
     const int grow = rb * kTile + lane;
     const int gcol = cb * kTile + lane;
     const bool colv = gcol < M;
-    float4 ch = colv ? w.hull[ibase + gcol] : make_float4(0, 0, 0, 0);
-    double ca = colv ? w.area[ibase + gcol] : 0.0;
-    rhull[lane] = grow < M ? w.hull[ibase + grow] : make_float4(0, 0, 0, 0);
-    rarea[lane] = grow < M ? w.area[ibase + grow] : 0.0;
-    rowbits[lane] = 0ull;
-    __syncthreads();
-
-    // guard: see oracle/poly_oracle.c (orc_poly_nms_fast).  Separated hulls mean a
-    // true intersection of 0; the fp64 fan sum then differs from 0 by rounding only,
-    // which cannot reach thresh*union unless the union is itself negligible.
+    const float4 ch = colv ? w.hull[ibase + gcol] : make_float4(0, 0, 0, 0);
     const float R = __uint_as_float(w.meta[img * 4 + 0]);
     const bool prefilter = thresh >= 1e-6;
     const double guard = 256.0 * (2e-13 * (double)R * (double)R + 1e-6) / (prefilter ? thresh : 1.0);
-
+    // area_r + area_c > guard is implied by either area alone exceeding it (areas >= 0);
+    // testing the two flags keeps fp64 out of the 64-step loop (never skips more than
+    // the exact test would)
+    const bool bigc = colv && w.area[ibase + gcol] > guard;
+    const u64 rowbig = __ballot(grow < M && w.area[ibase + grow] > guard);
+    // row hulls: one coalesced load per lane, then LDS broadcast reads (whole float4,
+    // branch-free tests, so the unrolled loop keeps 8 reads in flight)
+    rhull[lane] = grow < M ? w.hull[ibase + grow] : make_float4(0, 0, 0, 0);
+    __builtin_amdgcn_wave_barrier();
     u64 mycand = 0ull;
     const int rlim = min(kTile, M - rb * kTile);
+    const bool offdiag = rb != cb;
+#pragma unroll 8
     for (int r = 0; r < rlim; r++) {
-        float4 h = rhull[r];
-        bool apart = ch.x > h.z || h.x > ch.z || ch.y > h.w || h.y > ch.w;
-        bool skip = prefilter && apart && (rarea[r] + ca) > guard;
-        bool c = colv && !skip && (rb != cb || lane > r);
-        u64 b = __ballot(c);
+        const float4 h = rhull[r];
+        const bool apart = (ch.x > h.z) | (h.x > ch.z) | (ch.y > h.w) | (h.y > ch.w);
+        const bool skip = prefilter & apart & (bigc | (bool)((rowbig >> r) & 1ull));
+        const bool c = colv & !skip & (offdiag | (lane > r));
+        const u64 b = __ballot(c);
         if (lane == r) mycand = b;
     }
-    int cnt = __popcll(mycand);
+    return mycand;
+}
+
+// ------------------------------------------------------------------ nms_scan
+// One wave per tile: zero the tile's mask words, run the hull pre-filter and append
+// the surviving (row, col) pairs to the image's pair list.  A tile whose pairs do not
+// fit the list is flagged and clipped later in place (nms_iou, second phase).
+__global__ void __launch_bounds__(256) nms_scan_kernel(const int* __restrict__ counts, int m_cap,
+                                                       double thresh, NmsWs w, long long ntiles) {
+    __shared__ float4 rhull_s[4][kTile];
+    const int img = blockIdx.y;
+    const int M = img_count(counts, img, m_cap);
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const long long t = (long long)blockIdx.x * 4 + wv;     // wave-uniform by construction
+    if (t >= ntiles) return;
+    int rb, cb;
+    tile_rc(t, w.nblk, rb, cb);
+    if (rb * kTile >= M || cb * kTile >= M) return;
+    const size_t ibase = (size_t)img * w.Mp;
+    const int grow = rb * kTile + lane;
+    w.mask[(size_t)img * w.mask_words + (size_t)t * kTile + lane] = 0ull;
+    const u64 mycand = tile_candidates(w, img, M, rb, cb, thresh, rhull_s[wv]);
+    const int cnt = __popcll(mycand);
     int incl = cnt;
     for (int o = 1; o < 64; o <<= 1) {
-        int v = __shfl_up(incl, o, 64);
+        const int v = __shfl_up(incl, o, 64);
         if (lane >= o) incl += v;
     }
     const int total = __shfl(incl, 63, 64);
-    cand[lane] = mycand;
-    pre[lane] = incl - cnt;
-    __syncthreads();
+    if (total == 0) return;
+    unsigned base = 0;
+    // one list per (image, row block): the counters of different row blocks sit on
+    // different addresses, so the appends do not serialise on one L2 atomic unit
+    const size_t lbase = ((size_t)img * w.nblk + rb) * w.pair_cap;
+    if (lane == 0) base = atomicAdd(&w.pair_cnt[(size_t)img * w.nblk + rb], (unsigned)total);
+    base = __shfl(base, 0, 64);
+    if (base + (unsigned)total > (unsigned)w.pair_cap) {
+        // the part of the reservation that lies inside the list gets skip markers
+        for (unsigned i = (unsigned)lane; i < (unsigned)total && base + i < (unsigned)w.pair_cap; i += 64)
+            w.pairs[lbase + base + i] = ~0ull;
+        if (lane == 0) {
+            w.tile_flag[(size_t)img * ntiles + t] = 1;
+            w.meta[img * 4 + 3] = 1u;               // some tile overflowed
+        }
+        return;
+    }
+    u64* list = w.pairs + lbase + base + (incl - cnt);
+    u64 bits = mycand;
+    const u64 rowpart = (u64)(unsigned)grow;
+    int k = 0;
+    while (bits) {
+        const int c = __ffsll((long long)bits) - 1;
+        bits &= bits - 1;
+        list[k++] = rowpart | ((u64)(unsigned)(cb * kTile + c) << 32);
+    }
+}
 
-    if (total > 0) {
-        if (lane == 0) atomicAdd(&w.meta[img * 4 + 2], (unsigned)total);   // statistics: clipped pairs
-        Scratch s{lds_p + lane, lds_pp + lane};
-        for (int base = 0; base < total; base += 4) {
-            int k = base + (lane >> 4);
-            bool live = k < total;
-            int kk = live ? k : total - 1;
-            // largest row with pre[row] <= kk (rows with cnt 0 share a prefix: the
-            // search lands on the last of them, whose successor owns the pair)
-            int lo = 0, hi = 63;
-            while (lo < hi) {
-                int mid = (lo + hi + 1) >> 1;
-                if (pre[mid] <= kk) lo = mid; else hi = mid - 1;
-            }
-            int row = lo;
-            int col = kth_set_bit(cand[row], kk - pre[row]);
-            Quad A = load_quad_f32(w.sbox + (ibase + rb * kTile + row) * 8);
-            Quad B = load_quad_f32(w.sbox + (ibase + cb * kTile + col) * 8);
-            double iou = iou_group16(s, A, B, lane);
-            if (live && (lane & 15) == 0 && iou > thresh) atomicOr(&rowbits[row], 1ull << col);
+// ------------------------------------------------------------------- nms_iou
+// Persistent waves over the pair list: 16 lanes clip one pair, 4 pairs per wave step.
+__global__ void __launch_bounds__(64) nms_iou_kernel(const int* __restrict__ counts, int m_cap, double thresh,
+                                                     NmsWs w, long long ntiles) {
+    // one wave per block: the per-lane clip scratch (22.5 KB per wave) is what limits
+    // residency, so small blocks let ~6 waves share a CU and hide each other's LDS latency
+    __shared__ P2 lds_p[1][kCapP * kTile];
+    __shared__ P2 lds_pp[1][kCapPP * kTile];
+    __shared__ float4 rhull_s[1][kTile];
+    __shared__ u64 cand_s[1][kTile];
+    __shared__ int pre_s[1][kTile];
+    const int img = blockIdx.y;
+    const int M = img_count(counts, img, m_cap);
+    if (M == 0) return;
+    const int wv = 0, lane = threadIdx.x & 63;
+    const int nb = w.nblk;
+    const size_t ibase = (size_t)img * w.Mp;
+    Scratch s{lds_p[wv] + lane, lds_pp[wv] + lane};
+    const int gw = blockIdx.x, nw = gridDim.x;                   // wave id / waves per image
+    const int nbu = (M + kTile - 1) / kTile;
+    const int chunks = w.pair_cap / 4;                           // 4 pairs per wave step
+    for (long long item = gw; item < (long long)nbu * chunks; item += nw) {
+        const int lrb = (int)(item / chunks);
+        const unsigned p0 = (unsigned)(item % chunks) * 4u;
+        const unsigned n_pairs = min(w.pair_cnt[(size_t)img * nb + lrb], (unsigned)w.pair_cap);
+        if (p0 >= n_pairs) continue;
+        const u64* list = w.pairs + ((size_t)img * nb + lrb) * w.pair_cap;
+        const unsigned k = p0 + (unsigned)(lane >> 4);
+        u64 en = list[k < n_pairs ? k : n_pairs - 1];
+        const bool live = k < n_pairs && en != ~0ull;
+        if (en == ~0ull) en = 0ull;                      // skip marker: clip row 0 with itself, discard
+        const int r = (int)(unsigned)en, c = (int)(en >> 32);
+        Quad A = load_quad_f32(w.sbox + (ibase + r) * 8);
+        Quad B = load_quad_f32(w.sbox + (ibase + c) * 8);
+        const double iou = iou_group16(s, A, B, lane);
+        if (live && (lane & 15) == 0 && iou > thresh) {
+            atomicOr(&w.mask[(size_t)img * w.mask_words + tile_id(r >> 6, c >> 6, nb) * kTile + (r & 63)], 1ull << (c & 63));
+            atomicOr(&w.rowflag[(size_t)img * nb + (r >> 6)], 1ull << (r & 63));
         }
     }
-    __syncthreads();
-    u64 word = rowbits[lane];
-    if (grow < M) {
-        w.mask[(ibase + grow) * nb + cb] = word;
-        if (word) atomicOr(&w.rowflag[(size_t)img * nb + rb], 1ull << lane);
+    if (w.meta[img * 4 + 3] == 0u) return;
+    // overflow phase: tiles whose pairs did not fit the list are clipped in place
+    for (long long t = gw; t < ntiles; t += nw) {
+        if (!w.tile_flag[(size_t)img * ntiles + t]) continue;
+        int rb, cb;
+        tile_rc(t, nb, rb, cb);
+        const u64 mycand = tile_candidates(w, img, M, rb, cb, thresh, rhull_s[wv]);
+        const int cnt = __popcll(mycand);
+        int incl = cnt;
+        for (int o = 1; o < 64; o <<= 1) {
+            const int v = __shfl_up(incl, o, 64);
+            if (lane >= o) incl += v;
+        }
+        const int total = __shfl(incl, 63, 64);
+        cand_s[wv][lane] = mycand;
+        pre_s[wv][lane] = incl - cnt;
+        __builtin_amdgcn_wave_barrier();
+        for (int base = 0; base < total; base += 4) {
+            const int k = base + (lane >> 4);
+            const bool live = k < total;
+            const int kk = live ? k : total - 1;
+            int lo = 0, hi = 63;       // largest row with pre[row] <= kk
+            while (lo < hi) {
+                const int mid = (lo + hi + 1) >> 1;
+                if (pre_s[wv][mid] <= kk) lo = mid; else hi = mid - 1;
+            }
+            const int row = lo;
+            const int col = kth_set_bit(cand_s[wv][row], kk - pre_s[wv][row]);
+            const int r = rb * kTile + row, c = cb * kTile + col;
+            Quad A = load_quad_f32(w.sbox + (ibase + r) * 8);
+            Quad B = load_quad_f32(w.sbox + (ibase + c) * 8);
+            const double iou = iou_group16(s, A, B, lane);
+            if (live && (lane & 15) == 0 && iou > thresh) {
+                atomicOr(&w.mask[(size_t)img * w.mask_words + (size_t)t * kTile + row], 1ull << col);
+                atomicOr(&w.rowflag[(size_t)img * nb + rb], 1ull << row);
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
     }
 }
 
@@ -499,7 +621,7 @@ __global__ void __launch_bounds__(kReduceThreads) nms_reduce_kernel(
     const int nb = w.nblk;
     const int nbu = (M + kTile - 1) / kTile;  // blocks in use
     const size_t ibase = (size_t)img * w.Mp;
-    const u64* mask = w.mask + ibase * nb;
+    const u64* mask = w.mask + (size_t)img * w.mask_words;
     const u64* rowflag = w.rowflag + (size_t)img * nb;
     long long* kout = keep + (size_t)img * m_cap;
 
@@ -507,7 +629,7 @@ __global__ void __launch_bounds__(kReduceThreads) nms_reduce_kernel(
     __shared__ u64 kept[kMaxBlk];
     __shared__ int kpre[kMaxBlk + 1];
     __shared__ u64 kcur;
-    __shared__ u64 dsh[kTile];
+    __shared__ u64 dsh[2][kTile];
     const int tid = threadIdx.x;
     for (int k = tid; k < nb; k += kReduceThreads) {
         remv[k] = 0ull;
@@ -515,29 +637,39 @@ __global__ void __launch_bounds__(kReduceThreads) nms_reduce_kernel(
     }
     __syncthreads();
 
+    // diag words of block 0; later blocks are prefetched one iteration ahead by wave 1
+    if (tid < 64) {
+        const int row = tid;
+        dsh[0][tid] = row < M ? mask[tile_id(0, 0, nb) * kTile + tid] : 0ull;
+    }
+    __syncthreads();
     for (int b = 0; b < nbu; b++) {
+        u64 dnext = 0ull;
+        if (tid >= 64 && tid < 128 && b + 1 < nbu) {
+            const int row = (b + 1) * kTile + (tid - 64);
+            dnext = row < M ? mask[tile_id(b + 1, b + 1, nb) * kTile + (tid - 64)] : 0ull;   // lands under the scan below
+        }
         if (tid < 64) {
-            const int row = b * kTile + tid;
-            dsh[tid] = row < M ? mask[(size_t)row * nb + b] : 0ull;
-        }
-        __syncthreads();
-        if (tid == 0) {
-            // greedy scan inside the block: 64 dependent bit tests on one lane; the
-            // 64 LDS reads are independent and issue up front
-            u64 rem = remv[b];
-            const int valid = min(kTile, M - b * kTile);
-            if (valid < 64) rem |= ~0ull << valid;
-            u64 K = 0ull;
-#pragma unroll 8
-            for (int r = 0; r < 64; r++) {
-                const u64 dr = dsh[r];
-                const bool alive = !((rem >> r) & 1ull);
-                K |= alive ? (1ull << r) : 0ull;
-                rem |= alive ? dr : 0ull;
+            // greedy scan inside the block.  rem only grows and row r's bit can only be set
+            // by rows < r (upper-triangular words), so kept = ~rem_final; only rows whose
+            // diag word is non-zero can change rem -> one lane walks just those, in order.
+            const u64 nz = __ballot(dsh[b & 1][tid] != 0ull);
+            if (tid == 0) {
+                u64 rem = remv[b];
+                const int valid = min(kTile, M - b * kTile);
+                if (valid < 64) rem |= ~0ull << valid;
+                u64 bits = nz;
+                while (bits) {
+                    const int r = __ffsll((long long)bits) - 1;
+                    bits &= bits - 1;
+                    if (!((rem >> r) & 1ull)) rem |= dsh[b & 1][r];
+                }
+                const u64 K = ~rem;
+                kept[b] = K;
+                kcur = K & rowflag[b];
             }
-            kept[b] = K;
-            kcur = K & rowflag[b];
         }
+        if (tid >= 64 && tid < 128) dsh[(b + 1) & 1][tid - 64] = dnext;
         __syncthreads();
         const u64 K2 = kcur;
         if (K2) {
@@ -547,7 +679,7 @@ __global__ void __launch_bounds__(kReduceThreads) nms_reduce_kernel(
                 while (bits) {
                     int r = __ffsll((long long)bits) - 1;
                     bits &= bits - 1;
-                    acc |= mask[(size_t)(b * kTile + r) * nb + wd];
+                    acc |= mask[tile_id(b, wd, nb) * kTile + r];
                 }
                 remv[wd] |= acc;
             }
@@ -608,8 +740,7 @@ int run_nms(const float* d_dets9, int row_cap, const int* d_counts, int N, int m
             int post_topk, int64_t* d_keep, int32_t* d_num_keep, NmsWs& w, hipStream_t st,
             bool meta_zeroed) {
     if (!meta_zeroed) {
-        size_t zbytes = (size_t)((char*)(w.rowflag + (size_t)N * w.nblk) - (char*)w.meta);
-        DAFNE_HIP_TRY(hipMemsetAsync(w.meta, 0, zbytes, st));
+        DAFNE_HIP_TRY(hipMemsetAsync(w.meta, 0, zero_bytes(w, N), st));
     }
     dim3 gp((m_cap + 255) / 256, N);
     hipLaunchKernelGGL(nms_prep_kernel, gp, dim3(256), 0, st, d_dets9, row_cap, d_counts, m_cap, w);
@@ -617,9 +748,13 @@ int run_nms(const float* d_dets9, int row_cap, const int* d_counts, int N, int m
     if (rc) return rc;
     long long ntiles = (long long)w.nblk * (w.nblk + 1) / 2;
     if (ntiles > 0x7fffffffLL) return dafne::fail(DAFNE_E_UNSUPPORTED, "too many NMS tiles");
-    hipLaunchKernelGGL(nms_mask_kernel, dim3((unsigned)ntiles, N), dim3(64), 0, st, d_counts, m_cap,
-                       thresh, w);
-    rc = dafne::check_launch("nms_mask");
+    hipLaunchKernelGGL(nms_scan_kernel, dim3((unsigned)((ntiles + 3) / 4), N), dim3(256), 0, st, d_counts, m_cap,
+                       thresh, w, ntiles);
+    rc = dafne::check_launch("nms_scan");
+    if (rc) return rc;
+    const int iou_blocks = 256 * 6 / (N < 6 ? N : 6) + 1;      // ~6 resident waves per CU in total
+    hipLaunchKernelGGL(nms_iou_kernel, dim3(iou_blocks, N), dim3(64), 0, st, d_counts, m_cap, thresh, w, ntiles);
+    rc = dafne::check_launch("nms_iou");
     if (rc) return rc;
     hipLaunchKernelGGL(nms_reduce_kernel, dim3(N), dim3(kReduceThreads), 0, st, d_counts, m_cap,
                        post_topk, w, reinterpret_cast<long long*>(d_keep), d_num_keep);
@@ -687,8 +822,7 @@ int dafne_select_over_all_levels_hip(const float* d_boxes8, const float* d_score
     size_t need = carve(w, d_ws, n_images, m_cap);
     if (ws_bytes < need) return dafne::fail(DAFNE_E_WORKSPACE, "select: workspace %zu < %zu", ws_bytes, need);
     if (w.nblk > kMaxBlk) return dafne::fail(DAFNE_E_UNSUPPORTED, "select: m_cap %d > %d", m_cap, kMaxBlk * kTile);
-    size_t zbytes = (size_t)((char*)(w.rowflag + (size_t)n_images * w.nblk) - (char*)w.meta);
-    DAFNE_HIP_TRY(hipMemsetAsync(w.meta, 0, zbytes, st));
+    DAFNE_HIP_TRY(hipMemsetAsync(w.meta, 0, zero_bytes(w, n_images), st));
     hipLaunchKernelGGL(nms_minmax_kernel, dim3(n_images), dim3(1024), 0, st, d_boxes8, d_counts, m_cap, w.meta);
     int rc = dafne::check_launch("nms_minmax");
     if (rc) return rc;
