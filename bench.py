@@ -18,9 +18,11 @@ batch 8, one GPU) is measured in the same run at N=1 and reported under
 "configs1_r50_b8".  Random-init weights (seeded), synthetic images.
 
 Extra objects on the JSON line:
-  roofline      dominant kernel = conv_igemm_kernel<2,2,2,2> (all Cout>=128 convs):
-                algorithmic FLOPs of those launches / their HIP-event time, vs the
-                dense bf16 MFMA peak (2.5 PFLOP/s)
+  roofline      dominant kernel = the conv_igemm_kernel<...> instantiation with the
+                most time per step (128x128 tile <2,2,2,2> or 256x256 tile <4,2,2,4>):
+                algorithmic FLOPs of its launches / their HIP-event time, vs the
+                dense bf16 MFMA peak (2.5 PFLOP/s); every instantiation is listed
+                under "kernels"
   cpu_baseline  the torch fp32 oracle (oracle/model.py + oracle/postprocess.py, a
                 port) timed on the host cores on a bounded sample, rank 0, N=1 only
 """
@@ -133,7 +135,12 @@ def conv_kernel_profile(model, batch, reps=3):
         torch.cuda.synchronize()
         for c, a, b in evs:
             cout = c.prm.Cout
-            cfgname = "conv_igemm<2,2,2,2>" if cout >= 128 else ("conv_igemm<1,4,2,2>" if cout > 32 else "conv_igemm<1,4,1,2>")
+            if cout <= 32:
+                cfgname = "conv_igemm<1,4,1,2>"
+            elif cout <= 64:
+                cfgname = "conv_igemm<1,4,2,2>"
+            else:
+                cfgname = "conv_igemm<2,2,2,2>" if c.tile_pixels() == 128 else "conv_igemm<4,2,2,4>"
             s = stats.setdefault(cfgname, {"ms": 0.0, "flops": 0.0, "launches": 0})
             s["ms"] += a.elapsed_time(b)
             s["flops"] += c.flops
@@ -265,11 +272,12 @@ def main():
     }
     if rank == 0 and not args.no_extras:
         prof = conv_kernel_profile(model, batch)
-        dom = prof.get("conv_igemm<2,2,2,2>")
+        domname = max(prof, key=lambda k: prof[k]["ms"])
+        dom = prof.get(domname)
         if dom:
             out["roofline"] = {"bound": "mfma", "achieved": dom["tflops"], "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                                "frac": dom["tflops"] / PEAK_BF16_TFLOPS, "traffic": None,
-                               "kernel": "conv_igemm_kernel<2,2,2,2>", "launches_per_step": dom["launches"],
+                               "kernel": domname.replace("conv_igemm", "conv_igemm_kernel"), "launches_per_step": dom["launches"],
                                "avg_launch_us": dom["avg_launch_us"],
                                "algorithmic_gflop_per_step": dom["flops"] / 1e9}
         out["kernels"] = {k: {"tflops": v["tflops"], "ms_per_step": v["ms"], "launches": v["launches"]}

@@ -238,8 +238,25 @@ __global__ void __launch_bounds__(WC * WP * 64) conv_igemm_kernel(ConvDev P) {
             bia[4] = b1.x; bia[5] = b1.y; bia[6] = b1.z; bia[7] = b1.w;
         }
         float gs = 0.f, gq = 0.f;
-#pragma unroll 2
-        for (int p = tid / CH; p < BM; p += NT / CH) {
+        constexpr int PPT = BM / (NT / CH);     // pixels per thread per pass
+        // residual / top-down rows first: all PPT 16-byte loads in flight together
+        uint4 rr[PPT];
+        if (has_res || has_up) {
+#pragma unroll
+            for (int i = 0; i < PPT; i++) {
+                const int p = tid / CH + i * (NT / CH);
+                int m = m0 + p;
+                m = m < HW ? m : HW - 1;
+                const int ho = m / S.Wout, wo = m - ho * S.Wout;
+                const size_t rpix = has_up
+                    ? ((size_t)(img * (S.Hout / 2 + 2) + ho / 2 + 1) * (S.Wout / 2 + 2) + wo / 2 + 1)
+                    : ((size_t)(img * (S.Hout + 2) + ho + 1) * (S.Wout + 2) + wo + 1);
+                rr[i] = *(const uint4*)(S.res + (rpix * P.Cout + cobase) * 2);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < PPT; i++) {
+            const int p = tid / CH + i * (NT / CH);
             const int m = m0 + p;
             if (m >= HW) continue;
             const int ho = m / S.Wout, wo = m - ho * S.Wout;
@@ -248,11 +265,7 @@ __global__ void __launch_bounds__(WC * WP * 64) conv_igemm_kernel(ConvDev P) {
             float v[8] = {x0.x + bia[0], x0.y + bia[1], x0.z + bia[2], x0.w + bia[3],
                           x1.x + bia[4], x1.y + bia[5], x1.z + bia[6], x1.w + bia[7]};
             if (has_res || has_up) {
-                const size_t rpix = has_up
-                    ? ((size_t)(img * (S.Hout / 2 + 2) + ho / 2 + 1) * (S.Wout / 2 + 2) + wo / 2 + 1)
-                    : ((size_t)(img * (S.Hout + 2) + ho + 1) * (S.Wout + 2) + wo + 1);
-                const uint4 rr = *(const uint4*)(S.res + (rpix * P.Cout + cobase) * 2);
-                const unsigned u[4] = {rr.x, rr.y, rr.z, rr.w};
+                const unsigned u[4] = {rr[i].x, rr[i].y, rr[i].z, rr[i].w};
 #pragma unroll
                 for (int k = 0; k < 4; k++) {
                     v[2 * k] += bf2f((unsigned short)(u[k] & 0xffff));
