@@ -1,0 +1,206 @@
+"""Test-time augmentation for the MI355X engine: same class names and call
+contract as the reference's dafne/modeling/tta.py (`DotaDatasetMapperTTA` :29-135,
+`OneStageRCNNWithTTA` :138-268).
+
+For every TEST.AUG.MIN_SIZES entry the image is resized (shortest edge, capped by
+MAX_SIZE) and additionally flipped horizontally / vertically; the detector runs on
+chunks of 3 views with do_postprocess=False; corners are mapped back through the
+inverse transforms (un-flip, then un-resize; float64 like detectron2's
+apply_coords on the numpy copy, :244-259) and all views are merged by ONE rotated
+NMS + cap (`select_over_all_levels`, :264-268) -- up to 27 x 1000 quads, on the GPU.
+
+The pixel resampling itself (detectron2 uses PIL bilinear on uint8 [recalled]) is
+done with torch bilinear interpolation here; it is SURVEY 8(f) row 4 ("next") and
+not part of the pinned path.  Rotation TTA (ROTATION_ANGLES) is empty in every
+released config and not built.
+"""
+import copy
+from itertools import count
+
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+from ..structures import Instances
+from .one_stage_detector import OneStageDetector
+
+__all__ = ["DotaDatasetMapperTTA", "OneStageRCNNWithTTA"]
+
+
+class ResizeT:
+    def __init__(self, h, w, new_h, new_w):
+        self.h, self.w, self.new_h, self.new_w = h, w, new_h, new_w
+
+    def apply_image(self, img):            # uint8 CHW
+        if (self.h, self.w) == (self.new_h, self.new_w):
+            return img
+        x = F.interpolate(img[None].float(), size=(self.new_h, self.new_w), mode="bilinear", align_corners=False)
+        return x[0].round().clamp(0, 255).to(torch.uint8)
+
+    def apply_coords(self, c):             # [n,2] float64
+        c = c.clone()
+        c[:, 0] = c[:, 0] * (self.new_w * 1.0 / self.w)
+        c[:, 1] = c[:, 1] * (self.new_h * 1.0 / self.h)
+        return c
+
+    def inverse(self):
+        return ResizeT(self.new_h, self.new_w, self.h, self.w)
+
+
+class HFlipT:
+    def __init__(self, width):
+        self.width = width
+
+    def apply_image(self, img):
+        return torch.flip(img, dims=[2])
+
+    def apply_coords(self, c):
+        c = c.clone()
+        c[:, 0] = self.width - c[:, 0]
+        return c
+
+    def inverse(self):
+        return self
+
+
+class VFlipT:
+    def __init__(self, height):
+        self.height = height
+
+    def apply_image(self, img):
+        return torch.flip(img, dims=[1])
+
+    def apply_coords(self, c):
+        c = c.clone()
+        c[:, 1] = self.height - c[:, 1]
+        return c
+
+    def inverse(self):
+        return self
+
+
+class TransformList:
+    def __init__(self, tfms):
+        self.tfms = list(tfms)
+
+    def __add__(self, other):
+        return TransformList(self.tfms + (other.tfms if isinstance(other, TransformList) else list(other)))
+
+    def apply_coords(self, c):
+        for t in self.tfms:
+            c = t.apply_coords(c)
+        return c
+
+    def inverse(self):
+        return TransformList([t.inverse() for t in reversed(self.tfms)])
+
+
+def shortest_edge_size(h, w, size, max_size):
+    """detectron2 ResizeShortestEdge.get_output_shape [recalled]."""
+    scale = size * 1.0 / min(h, w)
+    if h < w:
+        newh, neww = size, scale * w
+    else:
+        newh, neww = scale * h, size
+    if max(newh, neww) > max_size:
+        scale = max_size * 1.0 / max(newh, neww)
+        newh, neww = newh * scale, neww * scale
+    return int(newh + 0.5), int(neww + 0.5)
+
+
+class DotaDatasetMapperTTA:
+    def __init__(self, cfg):
+        self.min_sizes = cfg.TEST.AUG.MIN_SIZES
+        self.max_size = cfg.TEST.AUG.MAX_SIZE
+        self.resize_type = cfg.INPUT.RESIZE_TYPE
+        self.vflip = cfg.TEST.AUG.VFLIP
+        self.hflip = cfg.TEST.AUG.HFLIP
+        self.rotation_angles = cfg.TEST.AUG.ROTATION_ANGLES
+        self.image_format = cfg.INPUT.FORMAT
+        if len(self.rotation_angles):
+            raise NotImplementedError("rotation TTA is not used by any released config")
+        if self.resize_type != "shortest-edge":
+            raise NotImplementedError("INPUT.RESIZE_TYPE='both' is not used by any released config")
+
+    def __call__(self, dataset_dict):
+        image = dataset_dict["image"]
+        h, w = int(image.shape[1]), int(image.shape[2])
+        orig = (int(dataset_dict["height"]), int(dataset_dict["width"]))
+        pre = TransformList([ResizeT(orig[0], orig[1], h, w)] if (h, w) != orig else [])
+        ret = []
+        for s in self.min_sizes:
+            nh, nw = shortest_edge_size(h, w, s, self.max_size)
+            rs = ResizeT(h, w, nh, nw)
+            cands = [[rs]]
+            if self.hflip:
+                cands.append([rs, HFlipT(nw)])
+            if self.vflip:
+                cands.append([rs, VFlipT(nh)])
+            base = rs.apply_image(image)
+            for tf in cands:
+                im = base
+                for t in tf[1:]:
+                    im = t.apply_image(im)
+                dic = {k: v for k, v in dataset_dict.items() if k != "image"}
+                dic = copy.deepcopy(dic)
+                dic["transforms"] = pre + TransformList(tf)
+                dic["image"] = im.contiguous()
+                ret.append(dic)
+        return ret
+
+
+class OneStageRCNNWithTTA(nn.Module):
+    def __init__(self, cfg, model, tta_mapper=None, batch_size=3):
+        super().__init__()
+        assert isinstance(model, OneStageDetector), \
+            "TTA is only supported on OneStageDetector. Got a model of type {}".format(type(model))
+        self.cfg = cfg.clone() if hasattr(cfg, "clone") else cfg
+        self.model = model
+        self.tta_mapper = tta_mapper if tta_mapper is not None else DotaDatasetMapperTTA(cfg)
+        self.batch_size = batch_size
+
+    def _batch_inference(self, batched_inputs, detected_instances=None):
+        outputs, inputs = [], []
+        for idx, inp in zip(count(), batched_inputs):
+            inputs.append(inp)
+            if len(inputs) == self.batch_size or idx == len(batched_inputs) - 1:
+                outputs.extend(self.model.inference(inputs, None, do_postprocess=False))
+                inputs = []
+        return outputs
+
+    def __call__(self, batched_inputs):
+        def _fill(d):
+            ret = copy.copy(d)
+            if "height" not in ret and "width" not in ret:
+                ret["height"], ret["width"] = int(ret["image"].shape[1]), int(ret["image"].shape[2])
+            return ret
+        return [self._inference_one_image(_fill(x)) for x in batched_inputs]
+
+    def _inference_one_image(self, input):
+        augmented_inputs, tfms = self._get_augmented_inputs(input)
+        instances = self._get_augmented_corners(augmented_inputs, tfms)
+        return {"instances": self._merge_detections(instances)}
+
+    def _get_augmented_inputs(self, input):
+        augmented_inputs = self.tta_mapper(input)
+        tfms = [x.pop("transforms") for x in augmented_inputs]
+        return augmented_inputs, tfms
+
+    def _get_augmented_corners(self, augmented_inputs, tfms):
+        outputs = self._batch_inference(augmented_inputs)
+        lst = []
+        for output, tfm in zip(outputs, tfms):
+            inst = output["instances"]
+            pc = inst.pred_corners
+            n = pc.shape[0]
+            orig = tfm.inverse().apply_coords(pc.reshape(-1, 2).to(torch.float64)).reshape(n, 8).to(pc.dtype)
+            r = Instances(inst.image_size)
+            r.scores = inst.scores
+            r.centerness = inst.centerness
+            r.pred_corners = orig
+            r.pred_classes = inst.pred_classes
+            lst.append(r)
+        return Instances.cat(lst)
+
+    def _merge_detections(self, instances):
+        return self.model.proposal_generator.dafne_outputs.select_over_all_levels([instances])[0]

@@ -101,12 +101,30 @@ def test_end_to_end_detections_vs_oracle_postprocess(cfgname):
         exp = opp.detector_postprocess(det, hw, (inputs[i]["height"], inputs[i]["width"]), hw)
         assert len(inst) == exp["scores"].shape[0] and len(inst) > 0
         assert inst.image_size == (inputs[i]["height"], inputs[i]["width"])
-        assert np.array_equal(inst.pred_classes.cpu().numpy(), exp["pred_classes"])
-        assert np.array_equal(inst.fpn_levels.cpu().numpy(), exp["fpn_levels"])
-        assert np.abs(inst.scores.cpu().numpy() - exp["scores"]).max() < 1e-6
-        assert np.abs(inst.pred_corners.cpu().numpy() - exp["pred_corners"]).max() < 1e-3
-        assert np.abs(inst.pred_boxes.tensor.cpu().numpy() - exp["pred_boxes"]).max() < 1e-3
-        assert np.abs(inst.locations.cpu().numpy() - exp["locations"]).max() < 1e-3
+        # The oracle's sigmoid/sqrt (numpy) and the kernel's (expf/sqrtf) differ by an
+        # ulp now and then, which may swap two detections whose scores are 1 ulp apart:
+        # match detections by their (level, location, class) key, then compare values.
+        gs = inst.scores.cpu().numpy()
+        assert np.all(np.diff(gs) <= 0)                                  # descending score
+        sx = inputs[i]["width"] / hw[1]
+        sy = inputs[i]["height"] / hw[0]
+
+        def keys(levels_, locs_, classes_):
+            x = np.rint(locs_[:, 0] / sx).astype(np.int64)
+            y = np.rint(locs_[:, 1] / sy).astype(np.int64)
+            return levels_.astype(np.int64) * (1 << 40) + y * (1 << 24) + x * 64 + classes_.astype(np.int64)
+        gk = keys(inst.fpn_levels.cpu().numpy(), inst.locations.cpu().numpy(), inst.pred_classes.cpu().numpy())
+        ek = keys(exp["fpn_levels"], exp["locations"], exp["pred_classes"])
+        assert len(np.unique(gk)) == len(gk)
+        assert np.array_equal(np.sort(gk), np.sort(ek)), "different detection sets"
+        go, eo = np.argsort(gk), np.argsort(ek)
+        assert np.abs(gs[go] - exp["scores"][eo]).max() < 1e-6
+        assert np.abs(inst.pred_corners.cpu().numpy()[go] - exp["pred_corners"][eo]).max() < 1e-3
+        assert np.abs(inst.pred_boxes.tensor.cpu().numpy()[go] - exp["pred_boxes"][eo]).max() < 1e-3
+        assert np.abs(inst.locations.cpu().numpy()[go] - exp["locations"][eo]).max() < 1e-3
+        # positions may differ only where scores are (nearly) tied
+        moved = np.nonzero(gk != ek)[0]
+        assert all(abs(gs[j] - exp["scores"][j]) < 1e-6 for j in moved)
 
 
 def test_batch_invariance_and_determinism():
@@ -121,3 +139,34 @@ def test_batch_invariance_and_determinism():
         assert torch.equal(x["instances"].pred_corners, y["instances"].pred_corners)       # run-to-run identical
         assert torch.equal(x["instances"].scores, y["instances"].scores)
         assert torch.equal(x["instances"].pred_corners, z["instances"].pred_corners)       # batch-size independent
+
+
+def test_tta_merge_vs_oracle():
+    """OneStageRCNNWithTTA: per-view detections come from the engine; the inverse
+    transforms + merged NMS + cap are checked against the numpy/C oracle."""
+    from dafne_amd.modeling.tta import DotaDatasetMapperTTA, OneStageRCNNWithTTA
+    cfg, m, P = build("dota-1.5_r101.yaml", seed=9)
+    cfg.TEST.AUG.MIN_SIZES = [96, 128, 160]
+    cfg.TEST.AUG.MAX_SIZE = 192
+    g = torch.Generator().manual_seed(4)
+    img = torch.randint(0, 256, (3, 128, 160), generator=g, dtype=torch.uint8)
+    tta = OneStageRCNNWithTTA(cfg, m)
+    inp = {"image": img, "height": 128, "width": 160}
+    out = tta([inp])[0]["instances"]
+    # expected: run the views one by one, invert with the oracle, merge with the oracle
+    views = DotaDatasetMapperTTA(cfg)(dict(inp))
+    assert len(views) == 9
+    dets = []
+    for k, v in enumerate(views):
+        r = m.inference([{kk: vv for kk, vv in v.items() if kk != "transforms"}], None, do_postprocess=False)[0]["instances"]
+        nh, nw = v["image"].shape[1:]
+        hf, vf = (k % 3 == 1), (k % 3 == 2)
+        c = opp.tta_invert_corners(r.pred_corners.cpu().numpy(), (160 / nw, 128 / nh), hf, vf, (nh, nw))
+        dets.append({"pred_corners": c, "scores": r.scores.cpu().numpy(), "centerness": r.centerness.cpu().numpy(),
+                     "pred_classes": r.pred_classes.cpu().numpy()})
+    d = cfg.MODEL.DAFNE
+    exp = opp.select_over_all_levels(opp.cat(dets), d.NMS_TH, d.POST_NMS_TOPK_TEST, fast=True)
+    assert len(out) == exp["scores"].shape[0] and len(out) > 0
+    assert np.array_equal(out.pred_classes.cpu().numpy(), exp["pred_classes"])
+    assert np.abs(out.scores.cpu().numpy() - exp["scores"]).max() == 0
+    assert np.abs(out.pred_corners.cpu().numpy() - exp["pred_corners"]).max() < 1e-3

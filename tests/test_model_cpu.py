@@ -53,3 +53,29 @@ def test_cpu_input_fails_loudly():
         m.backbone(torch.zeros(1, 3, 64, 64))
     with pytest.raises(Exception):
         m([{"image": torch.zeros(3, 64, 64, dtype=torch.uint8), "height": 64, "width": 64}])
+
+
+def test_tta_mapper_geometry_and_inverse_transforms():
+    """CPU: view list, sizes and inverse coordinate maps of the TTA mapper
+    (tta.py:48-135, 244-262) -- no kernels involved."""
+    import numpy as np
+    from dafne_amd.modeling.tta import DotaDatasetMapperTTA, shortest_edge_size
+    from oracle import postprocess as opp
+    cfg = _cfg("dota-1.0_r101.yaml")
+    assert shortest_edge_size(1024, 1024, 450, 1200) == (450, 450)
+    assert shortest_edge_size(600, 1000, 800, 1200) == (720, 1200)      # capped by MAX_SIZE
+    mapper = DotaDatasetMapperTTA(cfg)
+    img = torch.randint(0, 256, (3, 96, 128), dtype=torch.uint8)
+    views = mapper({"image": img, "height": 96, "width": 128, "image_id": 7})
+    assert len(views) == 27                                               # 9 sizes x {none, hflip, vflip}
+    v_plain, v_h, v_v = views[0], views[1], views[2]
+    assert v_plain["image"].shape == v_h["image"].shape == v_v["image"].shape
+    assert torch.equal(v_h["image"], torch.flip(v_plain["image"], dims=[2]))
+    assert torch.equal(v_v["image"], torch.flip(v_plain["image"], dims=[1]))
+    nh, nw = v_plain["image"].shape[1:]
+    rng = np.random.default_rng(0)
+    c = rng.uniform(0, 400, (5, 8)).astype(np.float32)
+    for v, hf, vf in ((v_plain, False, False), (v_h, True, False), (v_v, False, True)):
+        got = v["transforms"].inverse().apply_coords(torch.from_numpy(c).reshape(-1, 2).double()).reshape(5, 8).float()
+        exp = opp.tta_invert_corners(c, (128 / nw, 96 / nh), hf, vf, (nh, nw))
+        assert np.array_equal(got.numpy(), exp)
