@@ -247,9 +247,12 @@ def main():
     batch = torch.randint(0, 256, (args.batch, 3, args.size, args.size), generator=g, dtype=torch.uint8).to(device)
 
     def step():
-        rows, counts = model.detect_packed(batch)
+        # NMS + gather (+ the RCCL detection gather) ride a side stream and overlap the next
+        # step's convolutions; every step still runs the whole path on its own batch.
+        rows, counts = model.detect_packed(batch, pipelined=True)
         if distributed:
-            gather_detections(rows, counts, dst=0)
+            with torch.cuda.stream(model.side_stream):
+                gather_detections(rows, counts, dst=0)
         return rows, counts
 
     dt = time_steps(step, args.steps, args.warmup, distributed)
@@ -288,7 +291,7 @@ def main():
         out["rotated_nms_ms_per_img"] = nms_ms_per_image(device)
         if world == 1 and args.depth == 101:
             cfg50, m50, _ = build_model(50, device, seed=0)
-            dt50 = time_steps(lambda: m50.detect_packed(batch), max(args.steps // 2, 3), 2, False)
+            dt50 = time_steps(lambda: m50.detect_packed(batch, pipelined=True), max(args.steps // 2, 3), 2, False)
             out["configs1_r50_b8"] = {"images_per_sec": args.batch * max(args.steps // 2, 3) / dt50,
                                       "workload": "DOTA-1.0 1024x1024 R50-FPN bf16, batch 8, 1 GPU"}
             del m50

@@ -134,7 +134,9 @@ __global__ void __launch_bounds__(WC * WP * 64) conv_igemm_kernel(ConvDev P) {
 
     // K-step bookkeeping (scalar): tap (kh,kw) and channel slab c0
     int kh = 0, kw = 0, c0 = 0;
+    const bool dbg_noload = P.flags & 0x40000000u;     // experiment: skip operand loads (garbage math)
     auto issue = [&](int stage, int step) {
+        if (dbg_noload && step > 0) return;
         const unsigned koffW = (unsigned)step * (unsigned)kRowBytes;
         const unsigned koffX = P.stem ? (unsigned)(2 * step) * (unsigned)(Wp * 8)
                                       : (unsigned)((kh * Wp + kw) * P.Cin + c0) * 2u;
@@ -170,6 +172,78 @@ __global__ void __launch_bounds__(WC * WP * 64) conv_igemm_kernel(ConvDev P) {
     const int arow0 = wc * TC * 32;
     const int brow0 = BN + wp * TP * 32;
 
+    if constexpr (NW == 8) {
+        // ---- staggered two-group schedule (8 waves = 2 per SIMD) -----------------------
+        // A K step is 4 phases: L0 (fragment reads, first half of K), M0 (16 MFMAs), L1, M1.
+        // Waves 4-7 run one phase behind waves 0-3, so on every SIMD one wave is in an MFMA
+        // phase while its partner is reading LDS / issuing the next loads: the matrix pipe
+        // never waits for a fragment read.  Raw s_barrier between phases (no vmcnt drain);
+        // the loads of step s+1 are issued ~4 phases before they are read and drained by a
+        // vmcnt(0) placed just before the barrier that precedes their first reader.
+        const int grp = wave >> 2;
+        const int K = P.ksteps;
+        bf16x8 af[2][TC], bfr[2][TP];
+        auto read_half = [&](int stage, int h) {
+            const char* sb = lds + stage * STAGE;
+#pragma unroll
+            for (int k2 = 0; k2 < 2; k2++) {
+#pragma unroll
+                for (int a = 0; a < TC; a++) af[k2][a] = *(const bf16x8*)(sb + (arow0 + a * 32) * kRowBytes + roff[2 * h + k2]);
+#pragma unroll
+                for (int b = 0; b < TP; b++) bfr[k2][b] = *(const bf16x8*)(sb + (brow0 + b * 32) * kRowBytes + roff[2 * h + k2]);
+            }
+        };
+        auto mma_half = [&]() {
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int k2 = 0; k2 < 2; k2++)
+#pragma unroll
+                for (int a = 0; a < TC; a++)
+#pragma unroll
+                    for (int b = 0; b < TP; b++)
+                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[k2][a], bfr[k2][b], acc[a][b], 0, 0, 0);
+            __builtin_amdgcn_s_setprio(0);
+        };
+        auto phase_end = [&]() {
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        issue(0, 0);
+        if (grp == 1 && K > 1) issue(1, 1);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (group 1: also its share of step 1)
+        phase_end();
+        if (grp == 0) {
+            for (int j = 0; j < K; j++) {
+                const int cur = j & 1;
+                if (j + 1 < K) issue(cur ^ 1, j + 1);          // L0
+                read_half(cur, 0);
+                phase_end();
+                mma_half();                                    // M0
+                phase_end();
+                read_half(cur, 1);                             // L1
+                phase_end();
+                mma_half();                                    // M1
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                phase_end();
+            }
+        } else {
+            phase_end();                                       // one phase behind group 0
+            for (int j = 0; j < K; j++) {
+                const int cur = j & 1;
+                read_half(cur, 0);                             // L0
+                phase_end();
+                mma_half();                                    // M0
+                phase_end();
+                read_half(cur, 1);                             // L1
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                phase_end();
+                if (j + 2 < K) issue(cur, j + 2);              // M1 (stage `cur` is free now)
+                mma_half();
+                if (j + 1 < K) phase_end();
+            }
+        }
+    } else {
     issue(0, 0);
     for (int step = 0; step < P.ksteps; step++) {
         const int cur = step & 1;
@@ -190,6 +264,7 @@ __global__ void __launch_bounds__(WC * WP * 64) conv_igemm_kernel(ConvDev P) {
                 for (int b = 0; b < TP; b++)
                     acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[a], bfr[b], acc[a][b], 0, 0, 0);
         }
+    }
     }
 
     // ------------------------------------------------------------ epilogue

@@ -47,9 +47,15 @@ class DAFNeOutputs(nn.Module):
             levels = [pp.LevelInput(l.logits, l.delta, l.center, l.ctrness, 1, l.scale,
                                     l.delta_ps, l.center_ps, l.ctrness_ps, l.logits_ps) for l in levels]
             raise NotImplementedError("ENABLE_FPN_STRIDE_NORM=False is not used by any released config")
-        cand = pp.decode_levels(levels, num_classes=self.num_classes, pre_nms_thresh=self.pre_nms_thresh_test,
+        cand = self.decode_packed(levels)
+        return self.select_packed(cand, sizes=sizes, k_cap=k_cap, scale_corners=scale_corners)
+
+    def decode_packed(self, levels, out=None):
+        return pp.decode_levels(levels, num_classes=self.num_classes, pre_nms_thresh=self.pre_nms_thresh_test,
                                 pre_nms_topk=self.pre_nms_topk_test, thresh_with_ctr=self.thresh_with_ctr,
-                                sort_corners=self.sort_corners)
+                                sort_corners=self.sort_corners, out=out)
+
+    def select_packed(self, cand, sizes=None, k_cap=None, scale_corners=True):
         if self.nms_thresh > 0:
             keep, nk = pp.select(cand, self.nms_thresh, self.post_nms_topk_test)
         else:   # ml_nms returns its input unchanged (nms.py:22-23); only the cap applies

@@ -38,6 +38,7 @@ class OneStageDetector(nn.Module):
         self._packed = None
         self._plans = {}
         self._graphs = {}
+        self.side_stream = None
         self.eval()
 
     @property
@@ -72,11 +73,16 @@ class OneStageDetector(nn.Module):
 
     # ------------------------------------------------------------ fused path
     def detect_packed(self, images_u8, valid_hw=None, out_hw=None, layout_hwc=False, do_postprocess=True,
-                      use_graph=False):
+                      pipelined=False):
         """images_u8: device uint8 [N,3,H,W] (or [N,H,W,3] with layout_hwc) BGR.
         valid_hw: optional per-image (h, w) true sizes; out_hw: optional per-image
         requested output (height, width).  Returns (rows [N,k_cap,18], counts [N])
-        on the device, no host synchronisation."""
+        on the device, no host synchronisation.
+
+        pipelined=True: rotated NMS + gather (latency-bound, few CUs) run on a side HIP
+        stream so that they overlap the next call's convolutions; candidates are double
+        buffered.  The returned tensors are then produced on `self.side_stream`: wait on
+        it (or torch.cuda.synchronize()) before reading them."""
         if not images_u8.is_cuda or images_u8.dtype != torch.uint8:
             raise RuntimeError("detect_packed needs a uint8 CUDA tensor (the MI355X engine has no CPU path)")
         L = _lib.load()
@@ -102,15 +108,34 @@ class OneStageDetector(nn.Module):
             outs = self.proposal_generator.dafne_outputs
             strides = self.proposal_generator.fpn_strides
 
-            def body():
-                _lib.check(L.dafne_preprocess_image_hip(_lib.ptr(images_u8), int(layout_hwc), n, h, w, _lib.ptr(vt),
-                                                        mean, std, hn, wn, _lib.ptr(plan.stem_in),
-                                                        _lib.current_stream()), "dafne_preprocess_image_hip")
-                plan.run()
+            _lib.check(L.dafne_preprocess_image_hip(_lib.ptr(images_u8), int(layout_hwc), n, h, w, _lib.ptr(vt),
+                                                    mean, std, hn, wn, _lib.ptr(plan.stem_in),
+                                                    _lib.current_stream()), "dafne_preprocess_image_hip")
+            plan.run()
+            if not pipelined:
                 return outs.predict_packed(head_levels(plan.head, strides), sizes=sizes,
                                            scale_corners=do_postprocess)
-
-            return body()
+            # ---- two-stream pipeline: [preprocess, convs, decode] | [NMS, gather]
+            main = torch.cuda.current_stream()
+            if self.side_stream is None:
+                self.side_stream = torch.cuda.Stream(device=images_u8.device)
+                self._pipe = {}
+            st = self._pipe.setdefault((n, hn, wn), {"i": 0, "cand": [None, None], "done": [None, None]})
+            slot = st["i"] & 1
+            st["i"] += 1
+            if st["done"][slot] is not None:
+                main.wait_event(st["done"][slot])        # the side stream is done with this buffer
+            cand = outs.decode_packed(head_levels(plan.head, strides), out=st["cand"][slot])
+            st["cand"][slot] = cand
+            ready = torch.cuda.Event()
+            ready.record(main)
+            with torch.cuda.stream(self.side_stream):
+                self.side_stream.wait_event(ready)
+                res = outs.select_packed(cand, sizes=sizes, scale_corners=do_postprocess)
+                done = torch.cuda.Event()
+                done.record(self.side_stream)
+            st["done"][slot] = done
+            return res
 
     def forward(self, batched_inputs, do_postprocess=True):
         if self.training:

@@ -32,3 +32,5 @@ bench(64, 256, 1, 1, 256, 256, res=True, label="res2 conv3")
 bench(256, 64, 1, 1, 256, 256, label="res2 conv1")
 bench(256, 256, 3, 1, 128, 128, label="head-like p3")
 bench(256, 256, 3, 1, 256, 256, N=2, label="big 3x3")
+bench(256, 256, 3, 1, 256, 256, N=2, flags=0x40000000, label="big 3x3 NOLOAD")
+bench(256, 256, 3, 1, 64, 64, flags=0x40000000, label="res4 conv2 NOLOAD (128 tile)")

@@ -170,3 +170,19 @@ def test_tta_merge_vs_oracle():
     assert np.array_equal(out.pred_classes.cpu().numpy(), exp["pred_classes"])
     assert np.abs(out.scores.cpu().numpy() - exp["scores"]).max() == 0
     assert np.abs(out.pred_corners.cpu().numpy() - exp["pred_corners"]).max() < 1e-3
+
+
+def test_pipelined_side_stream_equals_serial():
+    cfg, m, P = build("dota-1.0_r50.yaml", seed=13)
+    g = torch.Generator().manual_seed(6)
+    batches = [torch.randint(0, 256, (2, 3, 128, 160), generator=g, dtype=torch.uint8).to(dev()) for _ in range(4)]
+    serial = [m.detect_packed(b) for b in batches]
+    torch.cuda.synchronize()
+    serial = [(r.clone(), c.clone()) for r, c in serial]
+    piped = [m.detect_packed(b, pipelined=True) for b in batches]      # no sync in between
+    torch.cuda.synchronize()
+    for (r0, c0), (r1, c1) in zip(serial, piped):
+        assert torch.equal(c0, c1)
+        for i in range(2):
+            k = int(c0[i])
+            assert torch.equal(r0[i, :k], r1[i, :k])
