@@ -1,5 +1,5 @@
 // Implicit-GEMM convolution for gfx950: NHWC bf16 activations with a 1-pixel zero
-// halo, bf16 weights [Cout][KH*KW*Cin], fp32 accumulation on the matrix cores.
+// halo, bf16 weights [Cout][Cin/64][KH][KW][64], fp32 accumulation on the matrix cores.
 //
 // Replaces every torch conv2d the reference's inference path issues through cuDNN:
 // detectron2 ResNet bottlenecks / FPN laterals and outputs (dafne/modeling/backbone/
@@ -9,7 +9,7 @@
 // bias, residual add, nearest-2x top-down add (FPN), ReLU, per-tile GroupNorm partial
 // sums, fp32 prediction outputs.
 //
-// GEMM view: D[cout][pixel] = sum_k W[cout][k] * X[pixel][k], k = (kh, kw, cin).
+// GEMM view: D[cout][pixel] = sum_k W[cout][k] * X[pixel][k], k = (cin/64, kh, kw, cin%64).
 // The halo makes every tap of a 3x3 a plain in-bounds 128-byte row segment, so the
 // pixel operand is staged exactly like the weight operand: `global_load_lds` 16-byte
 // pieces, 8 lanes per 64-channel row slab, XOR-swizzled on the SOURCE address
@@ -134,9 +134,7 @@ __global__ void __launch_bounds__(WC * WP * 64) conv_igemm_kernel(ConvDev P) {
 
     // K-step bookkeeping (scalar): tap (kh,kw) and channel slab c0
     int kh = 0, kw = 0, c0 = 0;
-    const bool dbg_noload = P.flags & 0x40000000u;     // experiment: skip operand loads (garbage math)
     auto issue = [&](int stage, int step) {
-        if (dbg_noload && step > 0) return;
         const unsigned koffW = (unsigned)step * (unsigned)kRowBytes;
         const unsigned koffX = P.stem ? (unsigned)(2 * step) * (unsigned)(Wp * 8)
                                       : (unsigned)((kh * Wp + kw) * P.Cin + c0) * 2u;
@@ -148,10 +146,11 @@ __global__ void __launch_bounds__(WC * WP * 64) conv_igemm_kernel(ConvDev P) {
             char* dst = lds + stage * STAGE + (j * NW + wave) * 8 * kRowBytes;
             __builtin_amdgcn_global_load_lds((gvoid*)(base + off), (lvoid*)dst, 16, 0, 0);
         }
-        c0 += kBK;
-        if (c0 >= P.Cin) {
-            c0 = 0;
-            if (++kw == P.KW) { kw = 0; ++kh; }
+        // K order = (64-channel slab, kh, kw): the 9 taps of one slab touch the same input
+        // rows back to back, so 8 of the 9 re-reads hit L2/L1 instead of MALL/HBM
+        if (++kw == P.KW) {
+            kw = 0;
+            if (++kh == P.KH) { kh = 0; c0 += kBK; }
         }
     };
 
@@ -173,24 +172,74 @@ __global__ void __launch_bounds__(WC * WP * 64) conv_igemm_kernel(ConvDev P) {
     const int brow0 = BN + wp * TP * 32;
 
     if constexpr (NW == 8) {
-        // ---- staggered two-group schedule (8 waves = 2 per SIMD) -----------------------
-        // A K step is 4 phases: L0 (fragment reads, first half of K), M0 (16 MFMAs), L1, M1.
-        // Waves 4-7 run one phase behind waves 0-3, so on every SIMD one wave is in an MFMA
-        // phase while its partner is reading LDS / issuing the next loads: the matrix pipe
-        // never waits for a fragment read.  Raw s_barrier between phases (no vmcnt drain);
-        // the loads of step s+1 are issued ~4 phases before they are read and drained by a
-        // vmcnt(0) placed just before the barrier that precedes their first reader.
+        // ---- streaming two-group schedule (8 waves = 2 per SIMD) -----------------------
+        // A K step (64 channels of one tap) is 4 phases: L0 (fragment reads of K-half 0),
+        // M0 (16 MFMAs), L1, M1.  Waves 4-7 run one phase behind waves 0-3, so on every
+        // SIMD one wave is in an MFMA phase while its partner reads LDS.
+        // Operand staging is a continuous stream of HALF-K pieces (16 rows x 64 B per
+        // global_load_lds): every wave issues 2 pieces per phase -- uniform load on the
+        // vector-memory path instead of a burst -- into the half-stage that became free
+        // two phases earlier; a piece is first read >= 4 phases after it was issued.
+        // Waits are counted (vmcnt(8): the 8 youngest pieces stay in flight across the
+        // raw s_barrier), never a drain, except in the last ~1.5 steps.
+        //   piece m (per wave):  step = m/8, K-half = (m/4)&1, instruction i = m&3
+        //   prologue issues m = 0..11; global phase t issues m = 12+2t, 13+2t
         const int grp = wave >> 2;
         const int K = P.ksteps;
+        constexpr int HSTAGE = ROWS * 64;          // bytes of one K-half of a stage
+        // half-K staging map: lane -> (row = 16*inst + lane/4, chunk = lane&3), 64-byte rows,
+        // physical chunk = logical ^ ((row>>2)&3)  (conflict-free ds_read_b128, 64 B pitch)
+        unsigned hofs[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const int r = (i * NW + wave) * 16 + (lane >> 2);
+            const int q = (lane & 3) ^ ((r >> 2) & 3);
+            if ((i * NW + wave) * 16 < BN) {
+                hofs[i] = (unsigned)(nt * BN + r) * (unsigned)P.kbytes + (unsigned)q * 16u;
+            } else {
+                int pix = m0 + (r - BN);
+                pix = pix < HW ? pix : HW - 1;
+                const int ho = pix / S.Wout, wo = pix - ho * S.Wout;
+                const unsigned row = (unsigned)(img * Hp + ho * P.stride + 1 - P.pad);
+                const unsigned colp = (unsigned)(wo * P.stride + 1 - P.pad);
+                hofs[i] = (row * (unsigned)Wp + colp) * (unsigned)cpx + (unsigned)q * 16u;
+            }
+        }
+        // running tap offsets of the two steps pieces are currently issued for
+        int tkh = 0, tkw = 0, tc0 = 0, tstep = 0;     // (kh,kw,c0) of step `tstep`
+        unsigned offX[2];                             // pixel-side K offset of step s at offX[s&1]
+        offX[0] = 0u;
+        offX[1] = 0u;
+        auto advance_to = [&](int sidx) {             // make offX[sidx&1] valid for step sidx
+            while (tstep < sidx) {
+                if (++tkw == P.KW) { tkw = 0; if (++tkh == P.KH) { tkh = 0; tc0 += kBK; } }
+                ++tstep;
+            }
+            offX[sidx & 1] = (unsigned)((tkh * Wp + tkw) * P.Cin + tc0) * 2u;
+        };
+        auto piece = [&](int sidx, int h, int i) {    // i is a compile-time constant at every call site
+            if (sidx >= K) return;
+            const bool isW = (i * NW + wave) * 16 < BN;
+            const char* base = isW ? P.w : S.in;
+            const unsigned koff = isW ? (unsigned)sidx * (unsigned)kRowBytes : offX[sidx & 1];
+            const unsigned off = hofs[i] + koff + (unsigned)h * 64u;
+            char* dst = lds + (sidx & 1) * STAGE + h * HSTAGE + (i * NW + wave) * 16 * 64;
+            __builtin_amdgcn_global_load_lds((gvoid*)(base + off), (lvoid*)dst, 16, 0, 0);
+        };
+        // fragment offsets for 64-byte rows
+        const int fsw4 = (frow >> 2) & 3;
+        unsigned hroff[2];
+#pragma unroll
+        for (int k2 = 0; k2 < 2; k2++) hroff[k2] = (unsigned)frow * 64u + (unsigned)(((2 * k2 + (lane >> 5)) ^ fsw4) * 16);
         bf16x8 af[2][TC], bfr[2][TP];
         auto read_half = [&](int stage, int h) {
-            const char* sb = lds + stage * STAGE;
+            const char* sb = lds + stage * STAGE + h * HSTAGE;
 #pragma unroll
             for (int k2 = 0; k2 < 2; k2++) {
 #pragma unroll
-                for (int a = 0; a < TC; a++) af[k2][a] = *(const bf16x8*)(sb + (arow0 + a * 32) * kRowBytes + roff[2 * h + k2]);
+                for (int a = 0; a < TC; a++) af[k2][a] = *(const bf16x8*)(sb + (arow0 + a * 32) * 64 + hroff[k2]);
 #pragma unroll
-                for (int b = 0; b < TP; b++) bfr[k2][b] = *(const bf16x8*)(sb + (brow0 + b * 32) * kRowBytes + roff[2 * h + k2]);
+                for (int b = 0; b < TP; b++) bfr[k2][b] = *(const bf16x8*)(sb + (brow0 + b * 32) * 64 + hroff[k2]);
             }
         };
         auto mma_half = [&]() {
@@ -204,43 +253,62 @@ __global__ void __launch_bounds__(WC * WP * 64) conv_igemm_kernel(ConvDev P) {
                         acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[k2][a], bfr[k2][b], acc[a][b], 0, 0, 0);
             __builtin_amdgcn_s_setprio(0);
         };
-        auto phase_end = [&]() {
+        auto phase_end = [&](bool odd, int t) {       // t = global phase index
+            if (odd) {
+                if (14 + 2 * t <= 8 * K) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
             __builtin_amdgcn_sched_barrier(0);
             __builtin_amdgcn_s_barrier();
             __builtin_amdgcn_sched_barrier(0);
         };
-        issue(0, 0);
-        if (grp == 1 && K > 1) issue(1, 1);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (group 1: also its share of step 1)
-        phase_end();
+        // prologue: (step 0, both halves), (step 1, half 0)
+        advance_to(0);
+#pragma unroll
+        for (int i = 0; i < 4; i++) piece(0, 0, i);
+#pragma unroll
+        for (int i = 0; i < 4; i++) piece(0, 1, i);
+        advance_to(1);
+#pragma unroll
+        for (int i = 0; i < 4; i++) piece(1, 0, i);
+        if (K > 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        phase_end(false, -1);
         if (grp == 0) {
             for (int j = 0; j < K; j++) {
                 const int cur = j & 1;
-                if (j + 1 < K) issue(cur ^ 1, j + 1);          // L0
+                piece(j + 1, 1, 0); piece(j + 1, 1, 1);        // t = 4j    : L0
                 read_half(cur, 0);
-                phase_end();
-                mma_half();                                    // M0
-                phase_end();
-                read_half(cur, 1);                             // L1
-                phase_end();
-                mma_half();                                    // M1
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                phase_end();
+                phase_end(false, 4 * j);
+                piece(j + 1, 1, 2); piece(j + 1, 1, 3);        // t = 4j+1  : M0
+                mma_half();
+                phase_end(true, 4 * j + 1);
+                advance_to(j + 2);
+                piece(j + 2, 0, 0); piece(j + 2, 0, 1);        // t = 4j+2  : L1
+                read_half(cur, 1);
+                phase_end(false, 4 * j + 2);
+                piece(j + 2, 0, 2); piece(j + 2, 0, 3);        // t = 4j+3  : M1
+                mma_half();
+                phase_end(true, 4 * j + 3);
             }
         } else {
-            phase_end();                                       // one phase behind group 0
+            piece(1, 1, 0); piece(1, 1, 1);                    // t = 0 (this group idles one phase)
+            phase_end(false, 0);
             for (int j = 0; j < K; j++) {
                 const int cur = j & 1;
-                read_half(cur, 0);                             // L0
-                phase_end();
-                mma_half();                                    // M0
-                phase_end();
-                read_half(cur, 1);                             // L1
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                phase_end();
-                if (j + 2 < K) issue(cur, j + 2);              // M1 (stage `cur` is free now)
+                piece(j + 1, 1, 2); piece(j + 1, 1, 3);        // t = 4j+1  : L0
+                read_half(cur, 0);
+                phase_end(true, 4 * j + 1);
+                advance_to(j + 2);
+                piece(j + 2, 0, 0); piece(j + 2, 0, 1);        // t = 4j+2  : M0
                 mma_half();
-                if (j + 1 < K) phase_end();
+                phase_end(false, 4 * j + 2);
+                piece(j + 2, 0, 2); piece(j + 2, 0, 3);        // t = 4j+3  : L1
+                read_half(cur, 1);
+                phase_end(true, 4 * j + 3);
+                piece(j + 2, 1, 0); piece(j + 2, 1, 1);        // t = 4j+4  : M1
+                mma_half();
+                if (j + 1 < K) phase_end(false, 4 * j + 4);
             }
         }
     } else {

@@ -65,13 +65,14 @@ class Pool:
 
 # --------------------------------------------------------------- weight packing
 def pack_conv(weight, bias, device):
-    """[Cout,Cin,KH,KW] fp32 (+bias) -> bf16 [Cout_pad, KH*KW*Cin] (k = kh,kw,cin),
-    fp32 bias [Cout_pad]."""
+    """[Cout,Cin,KH,KW] fp32 (+bias) -> bf16 [Cout_pad, Cin/64, KH, KW, 64] flattened
+    (k = 64-channel slab, kh, kw, channel in slab: the kernel walks the taps of one
+    slab back to back for L2 locality), fp32 bias [Cout_pad]."""
     L = _lib.load()
     cout, cin, kh, kw = weight.shape
     cpad = L.dafne_conv2d_cout_pad(cout)
     w = torch.zeros(cpad, kh * kw * cin, dtype=torch.float32)
-    w[:cout] = weight.detach().float().cpu().permute(0, 2, 3, 1).reshape(cout, -1)
+    w[:cout] = weight.detach().float().cpu().reshape(cout, cin // 64, 64, kh, kw).permute(0, 1, 3, 4, 2).reshape(cout, -1)
     b = torch.zeros(cpad, dtype=torch.float32)
     if bias is not None:
         b[:cout] = bias.detach().float().cpu()

@@ -158,7 +158,7 @@ int dafne_gather_detections_hip(const float* d_corners, const float* d_scores, c
 /*
  * Activations: NHWC bf16 with a zero halo of 1 pixel: [N, H+2, W+2, C]; producers
  * write the interior only, so the halo stays zero and a 3x3 tap never needs a
- * bounds check.  Weights: bf16 [Cout_pad][KH*KW*Cin], k = (kh, kw, cin), rows
+ * bounds check.  Weights: bf16 [Cout_pad][Cin/64][KH][KW][64] (k = slab, kh, kw, cin%64), rows
  * beyond Cout zero; Cout_pad = dafne_conv2d_cout_pad(Cout).  Bias: fp32 [Cout_pad]
  * (FrozenBN folded into weight scale + bias).
  */
