@@ -117,7 +117,7 @@ def conv_kernel_profile(model, batch, reps=3):
     from dafne_amd import engine, _lib
     n, _, h, w = batch.shape
     plan = model.plan(n, h, w)
-    model.detect_packed(batch)          # fills stem_in etc.
+    model.detect_packed(batch)          # builds the whole-batch plan, fills stem_in etc.
     torch.cuda.synchronize()
     stream = _lib.current_stream()
     stats = {}
@@ -222,6 +222,8 @@ def main():
     ap.add_argument("--batch", type=int, default=8, help="images per GPU per step")
     ap.add_argument("--depth", type=int, default=101, choices=[50, 101])
     ap.add_argument("--size", type=int, default=1024)
+    ap.add_argument("--splits", type=int, default=1,
+                    help="cut the per-GPU batch into sub-batches on concurrent HIP streams (measured: no gain)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip roofline profile pass, R50 and NMS side metrics")
     args = ap.parse_args()
@@ -249,7 +251,7 @@ def main():
     def step():
         # NMS + gather (+ the RCCL detection gather) ride a side stream and overlap the next
         # step's convolutions; every step still runs the whole path on its own batch.
-        rows, counts = model.detect_packed(batch, pipelined=True)
+        rows, counts = model.detect_packed(batch, pipelined=True, splits=args.splits)
         if distributed:
             with torch.cuda.stream(model.side_stream):
                 gather_detections(rows, counts, dst=0)
@@ -291,7 +293,7 @@ def main():
         out["rotated_nms_ms_per_img"] = nms_ms_per_image(device)
         if world == 1 and args.depth == 101:
             cfg50, m50, _ = build_model(50, device, seed=0)
-            dt50 = time_steps(lambda: m50.detect_packed(batch, pipelined=True), max(args.steps // 2, 3), 2, False)
+            dt50 = time_steps(lambda: m50.detect_packed(batch, pipelined=True, splits=args.splits), max(args.steps // 2, 3), 2, False)
             out["configs1_r50_b8"] = {"images_per_sec": args.batch * max(args.steps // 2, 3) / dt50,
                                       "workload": "DOTA-1.0 1024x1024 R50-FPN bf16, batch 8, 1 GPU"}
             del m50

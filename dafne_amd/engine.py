@@ -152,6 +152,7 @@ class DensePlan:
         self.device = device
         self.calls = []
         self.flops = 0
+        self.graph = None
         L = _lib.load()
         P = weights
         pool = Pool(device)
@@ -222,9 +223,25 @@ class DensePlan:
         self.head = HeadPlan(weights, self.features, num_classes, device, pool, self) if with_head else None
 
     def run(self, stream=None):
+        if self.graph is not None and stream is None:
+            self.graph.replay()
+            return
         stream = stream if stream is not None else _lib.current_stream()
         for c in self.calls:
             c(stream)
+
+    def capture(self):
+        """Capture the launch list into a HIP graph (one host call per replay instead of
+        ~150): the kernels, their arguments and buffers are static for a given plan."""
+        if self.graph is not None:
+            return
+        self.run()                       # warm-up outside capture (function attributes, lazy init)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            for c in self.calls:
+                c(_lib.current_stream())
+        self.graph = g
 
 
 class CallList:

@@ -39,6 +39,8 @@ class OneStageDetector(nn.Module):
         self._plans = {}
         self._graphs = {}
         self.side_stream = None
+        self.use_graphs = False     # optional: replay each sub-batch's dense plan from a HIP graph (no gain
+                                    # measured at batch 8: the GPU, not the host, is the bottleneck)
         self.eval()
 
     @property
@@ -64,25 +66,29 @@ class OneStageDetector(nn.Module):
             self._packed = engine.pack_model_weights(self.state_dict(), self.depth, self.device)
         return self._packed
 
-    def plan(self, n, h, w):
-        key = (n, h, w)
+    def plan(self, n, h, w, slot=0, graph=False):
+        key = (n, h, w, slot)
         if key not in self._plans:
             nc = self.proposal_generator.dafne_head.num_classes
             self._plans[key] = engine.DensePlan(self._weights(), n, h, w, self.depth, nc, self.device)
+        if graph:
+            self._plans[key].capture()
         return self._plans[key]
 
     # ------------------------------------------------------------ fused path
     def detect_packed(self, images_u8, valid_hw=None, out_hw=None, layout_hwc=False, do_postprocess=True,
-                      pipelined=False):
+                      pipelined=False, splits=1):
         """images_u8: device uint8 [N,3,H,W] (or [N,H,W,3] with layout_hwc) BGR.
         valid_hw: optional per-image (h, w) true sizes; out_hw: optional per-image
         requested output (height, width).  Returns (rows [N,k_cap,18], counts [N])
         on the device, no host synchronisation.
 
-        pipelined=True: rotated NMS + gather (latency-bound, few CUs) run on a side HIP
-        stream so that they overlap the next call's convolutions; candidates are double
-        buffered.  The returned tensors are then produced on `self.side_stream`: wait on
-        it (or torch.cuda.synchronize()) before reading them."""
+        pipelined=True: the batch is cut into `splits` contiguous sub-batches, each on its
+        own HIP stream (independent images: short, latency-bound kernels of one sub-batch
+        fill the gaps of another), and rotated NMS + gather run on further side streams so
+        that they overlap the next call's convolutions; candidates are double buffered.
+        The returned tensors are then produced on `self.side_stream`: wait on it (or
+        torch.cuda.synchronize()) before reading them."""
         if not images_u8.is_cuda or images_u8.dtype != torch.uint8:
             raise RuntimeError("detect_packed needs a uint8 CUDA tensor (the MI355X engine has no CPU path)")
         L = _lib.load()
@@ -91,51 +97,73 @@ class OneStageDetector(nn.Module):
         else:
             n, _, h, w = images_u8.shape
         hn, wn = (h + 31) // 32 * 32, (w + 31) // 32 * 32
-        with torch.cuda.device(images_u8.device):
-            plan = self.plan(n, hn, wn)
-            vt = None
-            if valid_hw is not None:
-                vt = torch.tensor(valid_hw, dtype=torch.int32).reshape(n, 2).to(self.device, non_blocking=True)
-            mean = (ctypes.c_float * 3)(*[float(v) for v in self.cfg.MODEL.PIXEL_MEAN])
-            std = (ctypes.c_float * 3)(*[float(v) for v in self.cfg.MODEL.PIXEL_STD])
-            images_u8 = images_u8.contiguous()
-            sizes = None
-            if valid_hw is None:
-                valid_hw = [(h, w)] * n
-            if out_hw is None:
-                out_hw = valid_hw
-            sizes = [(vh, vw, oh, ow, vh, vw) for (vh, vw), (oh, ow) in zip(valid_hw, out_hw)]
-            outs = self.proposal_generator.dafne_outputs
-            strides = self.proposal_generator.fpn_strides
+        mean = (ctypes.c_float * 3)(*[float(v) for v in self.cfg.MODEL.PIXEL_MEAN])
+        std = (ctypes.c_float * 3)(*[float(v) for v in self.cfg.MODEL.PIXEL_STD])
+        if valid_hw is None:
+            valid_hw = [(h, w)] * n
+        if out_hw is None:
+            out_hw = valid_hw
+        sizes = [(vh, vw, oh, ow, vh, vw) for (vh, vw), (oh, ow) in zip(valid_hw, out_hw)]
+        outs = self.proposal_generator.dafne_outputs
+        strides = self.proposal_generator.fpn_strides
 
-            _lib.check(L.dafne_preprocess_image_hip(_lib.ptr(images_u8), int(layout_hwc), n, h, w, _lib.ptr(vt),
+        def dense(imgs, lo, hi, plan):
+            vt = torch.tensor(valid_hw[lo:hi], dtype=torch.int32).reshape(hi - lo, 2).to(self.device, non_blocking=True)
+            _lib.check(L.dafne_preprocess_image_hip(_lib.ptr(imgs), int(layout_hwc), hi - lo, h, w, _lib.ptr(vt),
                                                     mean, std, hn, wn, _lib.ptr(plan.stem_in),
                                                     _lib.current_stream()), "dafne_preprocess_image_hip")
             plan.run()
+
+        with torch.cuda.device(images_u8.device):
+            images_u8 = images_u8.contiguous()
             if not pipelined:
+                plan = self.plan(n, hn, wn)
+                dense(images_u8, 0, n, plan)
                 return outs.predict_packed(head_levels(plan.head, strides), sizes=sizes,
                                            scale_corners=do_postprocess)
-            # ---- two-stream pipeline: [preprocess, convs, decode] | [NMS, gather]
+            # ---- multi-stream pipeline: per sub-batch [preprocess, convs, decode] | [NMS, gather]
+            splits = max(1, min(int(splits), n))
             main = torch.cuda.current_stream()
             if self.side_stream is None:
                 self.side_stream = torch.cuda.Stream(device=images_u8.device)
                 self._pipe = {}
-            st = self._pipe.setdefault((n, hn, wn), {"i": 0, "cand": [None, None], "done": [None, None]})
+            st = self._pipe.setdefault((n, hn, wn, splits), {
+                "i": 0, "cs": [torch.cuda.Stream() for _ in range(splits)],
+                "ns": [torch.cuda.Stream()] * splits,      # ONE NMS stream: its LDS-heavy waves would
+                                                           # otherwise crowd the conv blocks off the CUs
+                "cand": [[None, None] for _ in range(splits)], "done": [[None, None] for _ in range(splits)]})
             slot = st["i"] & 1
             st["i"] += 1
-            if st["done"][slot] is not None:
-                main.wait_event(st["done"][slot])        # the side stream is done with this buffer
-            cand = outs.decode_packed(head_levels(plan.head, strides), out=st["cand"][slot])
-            st["cand"][slot] = cand
-            ready = torch.cuda.Event()
-            ready.record(main)
+            inputs_ready = torch.cuda.Event()
+            inputs_ready.record(main)
+            bounds = [(k * n) // splits for k in range(splits + 1)]
+            parts, dones = [], []
+            for k in range(splits):
+                lo, hi = bounds[k], bounds[k + 1]
+                cs, ns = st["cs"][k], st["ns"][k]
+                plan = self.plan(hi - lo, hn, wn, slot=k, graph=self.use_graphs)
+                with torch.cuda.stream(cs):
+                    cs.wait_event(inputs_ready)
+                    if st["done"][k][slot] is not None:
+                        cs.wait_event(st["done"][k][slot])       # NMS stream is done with this buffer
+                    dense(images_u8[lo:hi], lo, hi, plan)
+                    cand = outs.decode_packed(head_levels(plan.head, strides), out=st["cand"][k][slot])
+                    st["cand"][k][slot] = cand
+                    ready = torch.cuda.Event()
+                    ready.record(cs)
+                with torch.cuda.stream(ns):
+                    ns.wait_event(ready)
+                    parts.append(outs.select_packed(cand, sizes=sizes[lo:hi], scale_corners=do_postprocess))
+                    done = torch.cuda.Event()
+                    done.record(ns)
+                st["done"][k][slot] = done
+                dones.append(done)
             with torch.cuda.stream(self.side_stream):
-                self.side_stream.wait_event(ready)
-                res = outs.select_packed(cand, sizes=sizes, scale_corners=do_postprocess)
-                done = torch.cuda.Event()
-                done.record(self.side_stream)
-            st["done"][slot] = done
-            return res
+                for d in dones:
+                    self.side_stream.wait_event(d)
+                if splits == 1:
+                    return parts[0]
+                return torch.cat([p[0] for p in parts], 0), torch.cat([p[1] for p in parts], 0)
 
     def forward(self, batched_inputs, do_postprocess=True):
         if self.training:

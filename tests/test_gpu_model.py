@@ -175,14 +175,14 @@ def test_tta_merge_vs_oracle():
 def test_pipelined_side_stream_equals_serial():
     cfg, m, P = build("dota-1.0_r50.yaml", seed=13)
     g = torch.Generator().manual_seed(6)
-    batches = [torch.randint(0, 256, (2, 3, 128, 160), generator=g, dtype=torch.uint8).to(dev()) for _ in range(4)]
+    batches = [torch.randint(0, 256, (3, 3, 128, 160), generator=g, dtype=torch.uint8).to(dev()) for _ in range(4)]
     serial = [m.detect_packed(b) for b in batches]
     torch.cuda.synchronize()
     serial = [(r.clone(), c.clone()) for r, c in serial]
-    piped = [m.detect_packed(b, pipelined=True) for b in batches]      # no sync in between
+    piped = [m.detect_packed(b, pipelined=True, splits=2) for b in batches]      # no sync in between
     torch.cuda.synchronize()
     for (r0, c0), (r1, c1) in zip(serial, piped):
         assert torch.equal(c0, c1)
-        for i in range(2):
+        for i in range(3):
             k = int(c0[i])
             assert torch.equal(r0[i, :k], r1[i, :k])
