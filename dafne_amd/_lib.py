@@ -7,7 +7,7 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libdafne_amd.so")
+LIB_PATH = os.environ.get("DAFNE_AMD_LIB") or os.path.join(_HERE, "libdafne_amd.so")   # override: debug builds
 _lib = None
 
 c_void_p = ctypes.c_void_p

@@ -96,6 +96,13 @@ __global__ void __launch_bounds__(WC * WP * 64) conv_igemm_kernel(ConvDev P) {
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wc = wave / WP, wp = wave % WP;
+#ifdef DAFNE_CONV_TIMING
+    unsigned long long ts[6];
+    ts[0] = __builtin_readcyclecounter();
+#define TSTAMP(i) ts[i] = __builtin_readcyclecounter()
+#else
+#define TSTAMP(i)
+#endif
 
     const int bid = xcd_remap(blockIdx.x, P.mtiles * P.ntiles);
     const int nt = bid % P.ntiles;
@@ -242,16 +249,22 @@ __global__ void __launch_bounds__(WC * WP * 64) conv_igemm_kernel(ConvDev P) {
                 for (int b = 0; b < TP; b++) bfr[k2][b] = *(const bf16x8*)(sb + (brow0 + b * 32) * 64 + hroff[k2]);
             }
         };
-        auto mma_half = [&]() {
-            __builtin_amdgcn_s_setprio(1);
+        // 16 MFMAs; the phase's two load pieces are issued in the shadow of the matrix pipe
+        // (after the 4th and the 8th MFMA) instead of in front of it
+        auto mma_half_ld = [&](int s0, int h0, int i0) {
 #pragma unroll
             for (int k2 = 0; k2 < 2; k2++)
 #pragma unroll
-                for (int a = 0; a < TC; a++)
+                for (int a = 0; a < TC; a++) {
 #pragma unroll
                     for (int b = 0; b < TP; b++)
                         acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[k2][a], bfr[k2][b], acc[a][b], 0, 0, 0);
-            __builtin_amdgcn_s_setprio(0);
+                    if (k2 == 0) {
+                        __builtin_amdgcn_sched_barrier(0);
+                        piece(s0, h0, i0 + a);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
         };
         auto phase_end = [&](bool odd, int t) {       // t = global phase index
             if (odd) {
@@ -274,21 +287,20 @@ __global__ void __launch_bounds__(WC * WP * 64) conv_igemm_kernel(ConvDev P) {
         if (K > 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         phase_end(false, -1);
+        TSTAMP(1);
         if (grp == 0) {
             for (int j = 0; j < K; j++) {
                 const int cur = j & 1;
                 piece(j + 1, 1, 0); piece(j + 1, 1, 1);        // t = 4j    : L0
                 read_half(cur, 0);
                 phase_end(false, 4 * j);
-                piece(j + 1, 1, 2); piece(j + 1, 1, 3);        // t = 4j+1  : M0
-                mma_half();
+                mma_half_ld(j + 1, 1, 2);                      // t = 4j+1  : M0
                 phase_end(true, 4 * j + 1);
                 advance_to(j + 2);
                 piece(j + 2, 0, 0); piece(j + 2, 0, 1);        // t = 4j+2  : L1
                 read_half(cur, 1);
                 phase_end(false, 4 * j + 2);
-                piece(j + 2, 0, 2); piece(j + 2, 0, 3);        // t = 4j+3  : M1
-                mma_half();
+                mma_half_ld(j + 2, 0, 2);                      // t = 4j+3  : M1
                 phase_end(true, 4 * j + 3);
             }
         } else {
@@ -300,14 +312,12 @@ __global__ void __launch_bounds__(WC * WP * 64) conv_igemm_kernel(ConvDev P) {
                 read_half(cur, 0);
                 phase_end(true, 4 * j + 1);
                 advance_to(j + 2);
-                piece(j + 2, 0, 0); piece(j + 2, 0, 1);        // t = 4j+2  : M0
-                mma_half();
+                mma_half_ld(j + 2, 0, 0);                      // t = 4j+2  : M0
                 phase_end(false, 4 * j + 2);
                 piece(j + 2, 0, 2); piece(j + 2, 0, 3);        // t = 4j+3  : L1
                 read_half(cur, 1);
                 phase_end(true, 4 * j + 3);
-                piece(j + 2, 1, 0); piece(j + 2, 1, 1);        // t = 4j+4  : M1
-                mma_half();
+                mma_half_ld(j + 2, 1, 0);                      // t = 4j+4  : M1
                 if (j + 1 < K) phase_end(false, 4 * j + 4);
             }
         }
@@ -335,6 +345,7 @@ __global__ void __launch_bounds__(WC * WP * 64) conv_igemm_kernel(ConvDev P) {
     }
     }
 
+    TSTAMP(2);
     // ------------------------------------------------------------ epilogue
     // Accumulators go through LDS as fp32 [pixel][channel] so that global traffic is
     // coalesced: every lane then owns 8 consecutive channels (16 B bf16) of one pixel,
@@ -350,6 +361,98 @@ __global__ void __launch_bounds__(WC * WP * 64) conv_igemm_kernel(ConvDev P) {
     char* stg = lds;
     float* red = (float*)(lds + BM * ROWF);   // [NW][CH][2]
 
+    if (!has_res && !has_up && !out_f32) {
+        // ---- plain bf16 output: bias / ReLU / GN sums in the accumulator layout, bf16 tile
+        // staged ONCE through LDS ([px][cout], 16-B row pad), then 16-byte coalesced stores.
+        constexpr int ROWB = BN * 2 + 16;
+        constexpr int CHB = BN / 8;
+        float4 bia4[TC][4];
+#pragma unroll
+        for (int a = 0; a < TC; a++)
+#pragma unroll
+            for (int g = 0; g < 4; g++)
+                bia4[a][g] = P.bias ? *(const float4*)(P.bias + nt * BN + (wc * TC + a) * 32 + 8 * g + 4 * half)
+                                    : make_float4(0.f, 0.f, 0.f, 0.f);
+        float gsum[TC][4], gsq[TC][4];
+#pragma unroll
+        for (int a = 0; a < TC; a++)
+#pragma unroll
+            for (int g = 0; g < 4; g++) gsum[a][g] = gsq[a][g] = 0.f;
+        __syncthreads();   // every wave is done reading the stage buffers
+#pragma unroll
+        for (int b = 0; b < TP; b++) {
+            const int px = (wp * TP + b) * 32 + frow;
+            const bool valid = m0 + px < HW;
+#pragma unroll
+            for (int a = 0; a < TC; a++)
+#pragma unroll
+                for (int g = 0; g < 4; g++) {
+                    float v0 = acc[a][b][4 * g] + bia4[a][g].x, v1 = acc[a][b][4 * g + 1] + bia4[a][g].y;
+                    float v2 = acc[a][b][4 * g + 2] + bia4[a][g].z, v3 = acc[a][b][4 * g + 3] + bia4[a][g].w;
+                    if (relu) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f); }
+                    if (gn && valid) {
+                        gsum[a][g] += (v0 + v1) + (v2 + v3);
+                        gsq[a][g] += (v0 * v0 + v1 * v1) + (v2 * v2 + v3 * v3);
+                    }
+                    uint2 pk;
+                    pk.x = (unsigned)f2bf(v0) | ((unsigned)f2bf(v1) << 16);
+                    pk.y = (unsigned)f2bf(v2) | ((unsigned)f2bf(v3) << 16);
+                    const int co = (wc * TC + a) * 32 + 8 * g + 4 * half;
+                    *(uint2*)(stg + px * ROWB + co * 2) = pk;
+                }
+        }
+        float* redb = (float*)(lds + BM * ROWB);   // [NW][TC*4][2]
+        if (gn) {
+            // deterministic: butterfly over the wave (32 pixels x 2 channel halves), then a
+            // fixed-order sum over the WP pixel-waves through LDS
+#pragma unroll
+            for (int a = 0; a < TC; a++)
+#pragma unroll
+                for (int g = 0; g < 4; g++) {
+                    float sv = gsum[a][g], qv = gsq[a][g];
+#pragma unroll
+                    for (int o = 32; o > 0; o >>= 1) {
+                        sv += __shfl_xor(sv, o, 64);
+                        qv += __shfl_xor(qv, o, 64);
+                    }
+                    if (lane == 0) {
+                        redb[(wave * TC * 4 + a * 4 + g) * 2 + 0] = sv;
+                        redb[(wave * TC * 4 + a * 4 + g) * 2 + 1] = qv;
+                    }
+                }
+        }
+        __syncthreads();
+        if (gn && tid < BN / 8) {
+            const int wcc = tid / (TC * 4), ag = tid % (TC * 4);
+            float sv = 0.f, qv = 0.f;
+#pragma unroll
+            for (int p2 = 0; p2 < WP; p2++) {
+                sv += redb[((wcc * WP + p2) * TC * 4 + ag) * 2 + 0];
+                qv += redb[((wcc * WP + p2) * TC * 4 + ag) * 2 + 1];
+            }
+            const int group = (nt * BN) / 8 + tid;
+            if (group < P.Cout / 8) {
+                float* o = P.gn_partial + ((size_t)mt * (P.Cout / 8) + group) * 2;
+                o[0] = sv;
+                o[1] = qv;
+            }
+        }
+        constexpr int CPT = BM * CHB / NT;       // 16-byte chunks per thread
+#pragma unroll
+        for (int i = 0; i < CPT; i++) {
+            const int idx = tid + i * NT;
+            const int p = idx / CHB, cc = idx - p * CHB;
+            const int m = m0 + p;
+            if (m < HW) {
+                const int ho = m / S.Wout, wo = m - ho * S.Wout;
+                const size_t opix = ((size_t)(img * (S.Hout + 2) + ho + 1) * (S.Wout + 2) + wo + 1);
+                const uint4 v = *(const uint4*)(stg + p * ROWB + cc * 16);
+                *(uint4*)(S.out + (opix * P.Cout + nt * BN + cc * 8) * 2) = v;
+            }
+        }
+        TSTAMP(3);
+        TSTAMP(4);
+    } else
 #pragma unroll
     for (int ep = 0; ep < EPASS; ep++) {
         __syncthreads();   // previous readers of this LDS region are done
@@ -437,6 +540,7 @@ __global__ void __launch_bounds__(WC * WP * 64) conv_igemm_kernel(ConvDev P) {
                 *(uint4*)(S.out + (opix * P.Cout + cobase) * 2) = pk;
             }
         }
+        TSTAMP(3 + ep);
         if (gn) {
             // deterministic: butterfly over the lanes that share a channel group, then a
             // fixed-order sum over the waves through LDS
@@ -466,6 +570,13 @@ __global__ void __launch_bounds__(WC * WP * 64) conv_igemm_kernel(ConvDev P) {
             }
         }
     }
+#ifdef DAFNE_CONV_TIMING
+    // debug build only (scratch/conv_timeline.py): per-wave cycle stamps into d_gn_partial
+    if (lane == 0 && P.gn_partial && !(P.flags & DAFNE_CONV_GN_STATS)) {
+        unsigned long long* o = (unsigned long long*)P.gn_partial + ((size_t)blockIdx.x * NW + wave) * 8;
+        for (int k = 0; k < 5; k++) o[k] = ts[k];
+    }
+#endif
 }
 
 struct Cfg {
@@ -544,7 +655,9 @@ int launch(const ConvDev& D, hipStream_t st) {
     constexpr int BN = WC * TC * 32, BM = WP * TP * 32, NW = WC * WP;
     constexpr int EN = BN > 128 ? 128 : BN;
     constexpr int stage2 = 2 * ROWS * kRowBytes;
-    constexpr int epi = BM * (EN * 4 + 16) + NW * (EN / 8) * 2 * 4;
+    constexpr int epi_f32 = BM * (EN * 4 + 16) + NW * (EN / 8) * 2 * 4;
+    constexpr int epi_b16 = BM * (BN * 2 + 16) + NW * (WC * TC * 32 / 8) * 2 * 4;
+    constexpr int epi = epi_f32 > epi_b16 ? epi_f32 : epi_b16;
     constexpr int smem = stage2 > epi ? stage2 : epi;
     static bool attr_done = false;   // idempotent attribute; a benign race sets it twice
     if (!attr_done) {
