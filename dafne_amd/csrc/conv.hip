@@ -161,6 +161,28 @@ __global__ void __launch_bounds__(WC * WP * 64) conv_igemm_kernel(ConvDev P) {
         }
     };
 
+    // Residual / top-down rows of single-pass tiles are fetched NOW (16 B per lane, coalesced):
+    // the HBM read stream then runs under the K loop instead of colliding with the output
+    // write burst of the epilogue.
+    constexpr int PPT0 = BM / (NT / CH);
+    constexpr bool kEarlyRes = (EPASS == 1);
+    uint4 rr0[kEarlyRes ? PPT0 : 1];
+    if (kEarlyRes && (P.flags & (DAFNE_CONV_RESIDUAL | DAFNE_CONV_UPSAMPLE_ADD))) {
+        const bool up = P.flags & DAFNE_CONV_UPSAMPLE_ADD;
+        const int cob = nt * BN + (tid % CH) * 8;
+#pragma unroll
+        for (int i = 0; i < PPT0; i++) {
+            const int p = tid / CH + i * (NT / CH);
+            int m = m0 + p;
+            m = m < HW ? m : HW - 1;
+            const int ho = m / S.Wout, wo = m - ho * S.Wout;
+            const size_t rpix = up
+                ? ((size_t)(img * (S.Hout / 2 + 2) + ho / 2 + 1) * (S.Wout / 2 + 2) + wo / 2 + 1)
+                : ((size_t)(img * (S.Hout + 2) + ho + 1) * (S.Wout + 2) + wo + 1);
+            rr0[kEarlyRes ? i : 0] = *(const uint4*)(S.res + (rpix * P.Cout + cob) * 2);
+        }
+    }
+
     f32x16 acc[TC][TP];
 #pragma unroll
     for (int a = 0; a < TC; a++)
@@ -487,7 +509,10 @@ __global__ void __launch_bounds__(WC * WP * 64) conv_igemm_kernel(ConvDev P) {
         constexpr int PPT = BM / (NT / CH);     // pixels per thread per pass
         // residual / top-down rows first: all PPT 16-byte loads in flight together
         uint4 rr[PPT];
-        if (has_res || has_up) {
+        if (kEarlyRes) {
+#pragma unroll
+            for (int i = 0; i < PPT; i++) rr[i] = rr0[kEarlyRes ? i : 0];
+        } else if (has_res || has_up) {
 #pragma unroll
             for (int i = 0; i < PPT; i++) {
                 const int p = tid / CH + i * (NT / CH);
@@ -586,9 +611,10 @@ struct Cfg {
 // Tile choice: 256x256 (8 waves, 1 block/CU) halves the L2->LDS operand traffic per
 // FLOP, but only pays when the launch still has >= 2 blocks per CU; otherwise the
 // 128x128 (4 waves, 2 blocks/CU) tile keeps the 256 CUs busy.
-Cfg pick_cfg(int Cout, long long blocks256 = 0) {
+Cfg pick_cfg(int Cout, long long blocks256 = 0, unsigned flags = 0) {
     static const bool big = getenv("DAFNE_CONV_NO256") == nullptr;
-    if (big && Cout % 256 == 0 && blocks256 >= 512) return {256, 256};
+    const bool res = flags & (DAFNE_CONV_RESIDUAL | DAFNE_CONV_UPSAMPLE_ADD);   // HBM-bound epilogue: prefer 2 blocks/CU
+    if (big && !res && Cout % 256 == 0 && blocks256 >= 512) return {256, 256};
     if (Cout >= 128) return {128, 128};
     if (Cout > 32) return {64, 256};
     return {32, 256};
@@ -608,7 +634,7 @@ int build(ConvDev& D, const dafne_conv_params* p, const dafne_conv_seg* segs) {
     long long b256 = 0;
     for (int s = 0; s < p->n_segs; s++)
         b256 += (long long)((segs[s].Hout * segs[s].Wout + 255) / 256) * p->n_images * (p->Cout / 256);
-    Cfg c = pick_cfg(p->Cout, b256);
+    Cfg c = pick_cfg(p->Cout, b256, p->flags);
     D.bn = c.bn;
     D.bm = c.bm;
     D.Cout_pad = (p->Cout + c.bn - 1) / c.bn * c.bn;
