@@ -98,6 +98,7 @@ __global__ void __launch_bounds__(WC * WP * 64) conv_igemm_kernel(ConvDev P) {
     const int wc = wave / WP, wp = wave % WP;
 #ifdef DAFNE_CONV_TIMING
     unsigned long long ts[6];
+    const unsigned long long rt0 = __builtin_amdgcn_s_memrealtime();   // 100 MHz, chip-wide
     ts[0] = __builtin_readcyclecounter();
 #define TSTAMP(i) ts[i] = __builtin_readcyclecounter()
 #else
@@ -600,6 +601,8 @@ __global__ void __launch_bounds__(WC * WP * 64) conv_igemm_kernel(ConvDev P) {
     if (lane == 0 && P.gn_partial && !(P.flags & DAFNE_CONV_GN_STATS)) {
         unsigned long long* o = (unsigned long long*)P.gn_partial + ((size_t)blockIdx.x * NW + wave) * 8;
         for (int k = 0; k < 5; k++) o[k] = ts[k];
+        o[5] = rt0;
+        o[6] = __builtin_amdgcn_s_memrealtime();
     }
 #endif
 }

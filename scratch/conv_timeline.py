@@ -29,6 +29,13 @@ def run(cin, cout, k, H, W, N=8, res=False, label=""):
     names = ["setup+prologue loads", "K loop", "epilogue pass 0", "epilogue pass 1"]
     for i, nme in enumerate(names):
         print("  %-22s median %8.0f  p90 %8.0f" % (nme, np.median(seg[:, i]), np.percentile(seg[:, i], 90)))
-    print("  block total median", np.median(d[:, 4] - d[:, 0]), " kernel span", d[:, 4].max())
+    print("  block total median", np.median(d[:, 4] - d[:, 0]))
+    rt0, rt1 = t[:, 5].astype(np.float64), t[:, 6].astype(np.float64)
+    base = rt0.min()
+    s_us, e_us = (rt0 - base) / 100.0, (rt1 - base) / 100.0
+    print("  realtime: kernel span %.1f us; block dur median %.1f us; first-round starts <= %.1f us (p99 of first %d), second-round start median %.1f us"
+          % (e_us.max(), np.median(e_us - s_us), np.percentile(np.sort(s_us)[:256 * nw], 99), 256, np.median(np.sort(s_us)[256 * nw:]) if len(s_us) > 256 * nw else -1))
+    hist = np.histogram(s_us, bins=8)[0]
+    print("  start-time histogram (8 bins over span):", hist.tolist())
 run(256, 1024, 1, 64, 64, res=True, label="res4 conv3 (+res)")
 run(256, 256, 3, 128, 128, label="head-like 3x3")

@@ -79,3 +79,38 @@ def test_tta_mapper_geometry_and_inverse_transforms():
         got = v["transforms"].inverse().apply_coords(torch.from_numpy(c).reshape(-1, 2).double()).reshape(5, 8).float()
         exp = opp.tta_invert_corners(c, (128 / nw, 96 / nh), hf, vf, (nh, nw))
         assert np.array_equal(got.numpy(), exp)
+
+
+def test_checkpoint_loading_pth_and_c2_pkl(tmp_path):
+    """CPU: .pth ({"model": sd}) and Caffe2-named .pkl trunks load into the
+    engine's parameter containers (no kernels)."""
+    import pickle
+    import numpy as np
+    import dafne_amd.modeling  # noqa: F401
+    from dafne_amd.checkpoint import load_weights, _c2_to_d2
+    from dafne_amd.registry import build_model
+    m = build_model(_cfg())
+    P = om.make_params(50, 15, seed=21)
+    pth = str(tmp_path / "model_final.pth")
+    torch.save({"model": P, "iteration": 1}, pth)
+    missing, unexpected = load_weights(m, pth, strict=True)
+    assert not missing and not unexpected
+    assert torch.equal(m.state_dict()["backbone.bottom_up.res3.0.conv2.weight"], P["backbone.bottom_up.res3.0.conv2.weight"])
+    # Caffe2 names
+    assert _c2_to_d2("conv1_w") == "stem.conv1.weight"
+    assert _c2_to_d2("res_conv1_bn_s") == "stem.conv1.norm.weight"
+    assert _c2_to_d2("res2_0_branch2a_w") == "res2.0.conv1.weight"
+    assert _c2_to_d2("res4_22_branch2c_bn_b") == "res4.22.conv3.norm.bias"
+    assert _c2_to_d2("res3_0_branch1_bn_s") == "res3.0.shortcut.norm.weight"
+    assert _c2_to_d2("fc1000_w") is None
+    c2 = {"conv1_w": np.ones((64, 3, 7, 7), np.float32) * 0.5, "res_conv1_bn_s": np.full(64, 2.0, np.float32),
+          "res2_0_branch2a_w": np.zeros((64, 64, 1, 1), np.float32), "fc1000_w": np.zeros((1000, 2048), np.float32)}
+    pkl = str(tmp_path / "R-50.pkl")
+    with open(pkl, "wb") as f:
+        pickle.dump({"model": c2, "matching_heuristics": True}, f)
+    m2 = build_model(_cfg())
+    missing, unexpected = load_weights(m2, pkl)
+    assert not unexpected and "backbone.bottom_up.stem.conv1.weight" not in missing
+    sd2 = m2.state_dict()
+    assert float(sd2["backbone.bottom_up.stem.conv1.weight"].mean()) == 0.5
+    assert float(sd2["backbone.bottom_up.stem.conv1.norm.weight"][0]) == 2.0
