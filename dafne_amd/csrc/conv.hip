@@ -350,6 +350,7 @@ __global__ void __launch_bounds__(WC * WP * 64) conv_igemm_kernel(ConvDev P) {
         const int cur = step & 1;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
+        if (step == 0) { TSTAMP(1); }
         if (step + 1 < P.ksteps) issue(cur ^ 1, step + 1);
         const char* sb = lds + cur * STAGE;
 #pragma unroll

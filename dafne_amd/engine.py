@@ -146,7 +146,7 @@ def conv_out_hw(h, w, k, stride, pad):
 class DensePlan:
     """Backbone + FPN + head for one (N, H, W): buffers + ordered launches."""
 
-    def __init__(self, weights, n, h, w, depth, num_classes, device, with_head=True):
+    def __init__(self, weights, n, h, w, depth, num_classes, device, with_head=True, head_outputs=None):
         assert h % 32 == 0 and w % 32 == 0
         self.n, self.h, self.w = n, h, w
         self.device = device
@@ -220,7 +220,7 @@ class DensePlan:
         p7 = conv("p7", p6r, 3, 2, 1, 0)
         outs["p6"], outs["p7"] = p6, p7
         self.features = [outs[k] for k in ("p3", "p4", "p5", "p6", "p7")]
-        self.head = HeadPlan(weights, self.features, num_classes, device, pool, self) if with_head else None
+        self.head = HeadPlan(weights, self.features, num_classes, device, pool, self, head_outputs) if with_head else None
 
     def run(self, stream=None):
         if self.graph is not None and stream is None:
@@ -244,6 +244,26 @@ class DensePlan:
         self.graph = g
 
 
+class HeadOutputs:
+    """Whole-batch head outputs shared by the sub-batch plans of a split batch; quacks like
+    a HeadPlan for dafne.head_levels()."""
+
+    def __init__(self, n, h, w, num_classes, scales, device):
+        p5 = (h // 32, w // 32)
+        p6 = ((p5[0] + 1) // 2, (p5[1] + 1) // 2)             # 3x3 stride-2 pad-1 convs
+        p7 = ((p6[0] + 1) // 2, (p6[1] + 1) // 2)
+        sizes = [(h // 8, w // 8), (h // 16, w // 16), p5, p6, p7]
+        f32 = torch.float32
+        self.logits = [torch.empty(n, a, b, num_classes, dtype=f32, device=device) for a, b in sizes]
+        self.center = [torch.empty(n, a, b, 2, dtype=f32, device=device) for a, b in sizes]
+        self.delta_ctr = [torch.empty(n, a, b, 9, dtype=f32, device=device) for a, b in sizes]
+        self.scales = scales
+
+    def views(self, lo, hi):
+        return {"logits": [t[lo:hi] for t in self.logits], "center": [t[lo:hi] for t in self.center],
+                "delta_ctr": [t[lo:hi] for t in self.delta_ctr]}
+
+
 class CallList:
     """Bare launch list (what HeadPlan needs from its owner)."""
 
@@ -262,7 +282,9 @@ class HeadPlan:
     levels: dafne.py:350-494): 12 tower convs (+GroupNorm+ReLU) and 3 prediction
     convs; outputs fp32 NHWC logits / [delta8|ctrness] / center."""
 
-    def __init__(self, P, feats, num_classes, device, pool, plan):
+    def __init__(self, P, feats, num_classes, device, pool, plan, outputs=None):
+        """outputs: optional {"logits"|"center"|"delta_ctr": [5 fp32 NHWC tensors]} to write
+        into (views of a larger batch's buffers when the batch is split over streams)."""
         L = _lib.load()
         n = feats[0].n
         self.levels = feats
@@ -309,17 +331,21 @@ class HeadPlan:
         ctr_t = tower("center_tower", feats)
         cor_t = tower("corners_tower", ctr_t)
 
-        def pred(key, ins, cout):
+        def pred(key, ins, cout, name):
             wgt, bias = P[key]
-            outs = [torch.empty(n, f.h, f.w, cout, dtype=torch.float32, device=device) for f in ins]
+            if outputs is not None:
+                outs = outputs[name]
+                assert all(o.is_contiguous() and tuple(o.shape) == (n, f.h, f.w, cout) for o, f in zip(outs, ins))
+            else:
+                outs = [torch.empty(n, f.h, f.w, cout, dtype=torch.float32, device=device) for f in ins]
             c = ConvCall(wgt, bias, C, cout, 3, 1, 1, F_F32, seg_list(ins, outs, f32=True), n)
             calls.append(c)
             plan.flops += c.flops
             return outs
 
-        self.logits = pred("cls_logits", cls_t, num_classes)
-        self.center = pred("center_pred", ctr_t, 2)
-        self.delta_ctr = pred("corners_ctrness", cor_t, 9)     # corners_pred (8) + ctrness (1) fused
+        self.logits = pred("cls_logits", cls_t, num_classes, "logits")
+        self.center = pred("center_pred", ctr_t, 2, "center")
+        self.delta_ctr = pred("corners_ctrness", cor_t, 9, "delta_ctr")     # corners_pred (8) + ctrness (1) fused
         self.scales = P["scales"]
 
 

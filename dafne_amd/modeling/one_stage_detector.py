@@ -39,6 +39,7 @@ class OneStageDetector(nn.Module):
         self._plans = {}
         self._graphs = {}
         self.side_stream = None
+        self._consts = {}
         self.use_graphs = False     # optional: replay each sub-batch's dense plan from a HIP graph (no gain
                                     # measured at batch 8: the GPU, not the host, is the bottleneck)
         self.eval()
@@ -66,6 +67,18 @@ class OneStageDetector(nn.Module):
             self._packed = engine.pack_model_weights(self.state_dict(), self.depth, self.device)
         return self._packed
 
+    def _dev_const(self, values, dtype, shape):
+        """Small constant device tensors (per-image sizes) are uploaded once and reused: a
+        pageable host->device copy would make the host wait for the stream every call."""
+        key = (dtype, shape, tuple(map(tuple, values)))
+        t = self._consts.get(key)
+        if t is None:
+            t = torch.tensor(values, dtype=dtype).reshape(shape).to(self.device)
+            if len(self._consts) > 256:
+                self._consts.clear()
+            self._consts[key] = t
+        return t
+
     def plan(self, n, h, w, slot=0, graph=False):
         key = (n, h, w, slot)
         if key not in self._plans:
@@ -83,10 +96,11 @@ class OneStageDetector(nn.Module):
         requested output (height, width).  Returns (rows [N,k_cap,18], counts [N])
         on the device, no host synchronisation.
 
-        pipelined=True: the batch is cut into `splits` contiguous sub-batches, each on its
-        own HIP stream (independent images: short, latency-bound kernels of one sub-batch
-        fill the gaps of another), and rotated NMS + gather run on further side streams so
-        that they overlap the next call's convolutions; candidates are double buffered.
+        pipelined=True: the dense part runs as `splits` contiguous sub-batches on their own
+        HIP streams, enqueued layer by layer (independent images: the prologue / write-burst
+        bubbles of one sub-batch's kernel are filled by another's); decode runs once on the
+        whole batch, and rotated NMS + gather run on a side stream so that they overlap the
+        next call's convolutions; candidates are double buffered.
         The returned tensors are then produced on `self.side_stream`: wait on it (or
         torch.cuda.synchronize()) before reading them."""
         if not images_u8.is_cuda or images_u8.dtype != torch.uint8:
@@ -99,16 +113,18 @@ class OneStageDetector(nn.Module):
         hn, wn = (h + 31) // 32 * 32, (w + 31) // 32 * 32
         mean = (ctypes.c_float * 3)(*[float(v) for v in self.cfg.MODEL.PIXEL_MEAN])
         std = (ctypes.c_float * 3)(*[float(v) for v in self.cfg.MODEL.PIXEL_STD])
+        all_full = valid_hw is None or all(tuple(v) == (h, w) for v in valid_hw)
         if valid_hw is None:
             valid_hw = [(h, w)] * n
         if out_hw is None:
             out_hw = valid_hw
-        sizes = [(vh, vw, oh, ow, vh, vw) for (vh, vw), (oh, ow) in zip(valid_hw, out_hw)]
+        sizes = self._dev_const([(vh, vw, oh, ow, vh, vw) for (vh, vw), (oh, ow) in zip(valid_hw, out_hw)],
+                                torch.float32, (n, 6))
         outs = self.proposal_generator.dafne_outputs
         strides = self.proposal_generator.fpn_strides
 
         def dense(imgs, lo, hi, plan):
-            vt = torch.tensor(valid_hw[lo:hi], dtype=torch.int32).reshape(hi - lo, 2).to(self.device, non_blocking=True)
+            vt = None if all_full else self._dev_const(valid_hw[lo:hi], torch.int32, (hi - lo, 2))
             _lib.check(L.dafne_preprocess_image_hip(_lib.ptr(imgs), int(layout_hwc), hi - lo, h, w, _lib.ptr(vt),
                                                     mean, std, hn, wn, _lib.ptr(plan.stem_in),
                                                     _lib.current_stream()), "dafne_preprocess_image_hip")
@@ -121,49 +137,70 @@ class OneStageDetector(nn.Module):
                 dense(images_u8, 0, n, plan)
                 return outs.predict_packed(head_levels(plan.head, strides), sizes=sizes,
                                            scale_corners=do_postprocess)
-            # ---- multi-stream pipeline: per sub-batch [preprocess, convs, decode] | [NMS, gather]
+            # ---- pipeline: [preprocess, convs (split over `splits` streams), decode] | [NMS, gather]
             splits = max(1, min(int(splits), n))
             main = torch.cuda.current_stream()
             if self.side_stream is None:
                 self.side_stream = torch.cuda.Stream(device=images_u8.device)
                 self._pipe = {}
-            st = self._pipe.setdefault((n, hn, wn, splits), {
-                "i": 0, "cs": [torch.cuda.Stream() for _ in range(splits)],
-                "ns": [torch.cuda.Stream()] * splits,      # ONE NMS stream: its LDS-heavy waves would
-                                                           # otherwise crowd the conv blocks off the CUs
-                "cand": [[None, None] for _ in range(splits)], "done": [[None, None] for _ in range(splits)]})
+            key = (n, hn, wn, splits)
+            if key not in self._pipe:
+                nc = self.proposal_generator.dafne_head.num_classes
+                ho = engine.HeadOutputs(n, hn, wn, nc, self._weights()["scales"], self.device)
+                bounds = [(k * n) // splits for k in range(splits + 1)]
+                plans = []
+                for k in range(splits):
+                    lo, hi = bounds[k], bounds[k + 1]
+                    plans.append(engine.DensePlan(self._weights(), hi - lo, hn, wn, self.depth, nc, self.device,
+                                                  head_outputs=ho.views(lo, hi)))
+                self._pipe[key] = {"i": 0, "cs": [torch.cuda.Stream() for _ in range(splits)], "ho": ho,
+                                   "plans": plans, "bounds": bounds, "cand": [None, None], "done": [None, None],
+                                   "decoded": None}
+            st = self._pipe[key]
             slot = st["i"] & 1
             st["i"] += 1
+            cs, plans, bounds = st["cs"], st["plans"], st["bounds"]
             inputs_ready = torch.cuda.Event()
             inputs_ready.record(main)
-            bounds = [(k * n) // splits for k in range(splits + 1)]
-            parts, dones = [], []
+            vts = []
             for k in range(splits):
                 lo, hi = bounds[k], bounds[k + 1]
-                cs, ns = st["cs"][k], st["ns"][k]
-                plan = self.plan(hi - lo, hn, wn, slot=k, graph=self.use_graphs)
-                with torch.cuda.stream(cs):
-                    cs.wait_event(inputs_ready)
-                    if st["done"][k][slot] is not None:
-                        cs.wait_event(st["done"][k][slot])       # NMS stream is done with this buffer
-                    dense(images_u8[lo:hi], lo, hi, plan)
-                    cand = outs.decode_packed(head_levels(plan.head, strides), out=st["cand"][k][slot])
-                    st["cand"][k][slot] = cand
-                    ready = torch.cuda.Event()
-                    ready.record(cs)
-                with torch.cuda.stream(ns):
-                    ns.wait_event(ready)
-                    parts.append(outs.select_packed(cand, sizes=sizes[lo:hi], scale_corners=do_postprocess))
-                    done = torch.cuda.Event()
-                    done.record(ns)
-                st["done"][k][slot] = done
-                dones.append(done)
+                cs[k].wait_event(inputs_ready)
+                if st["decoded"] is not None:
+                    cs[k].wait_event(st["decoded"])       # previous call's decode has read the head outputs
+                with torch.cuda.stream(cs[k]):
+                    vt = None if all_full else self._dev_const(valid_hw[lo:hi], torch.int32, (hi - lo, 2))
+                    vts.append(vt)
+                    sub = images_u8[lo:hi]
+                    _lib.check(L.dafne_preprocess_image_hip(_lib.ptr(sub), int(layout_hwc), hi - lo, h, w, _lib.ptr(vt),
+                                                            mean, std, hn, wn, _lib.ptr(plans[k].stem_in),
+                                                            _lib.current_stream()), "dafne_preprocess_image_hip")
+            # layer-interleaved enqueue: launch j of every sub-batch before launch j+1, so that the
+            # prologue / epilogue bubbles of one sub-batch's kernel are filled by another's
+            sp = [ctypes.c_void_p(s.cuda_stream) for s in cs]
+            ncalls = len(plans[0].calls)
+            for j in range(ncalls):
+                for k in range(splits):
+                    plans[k].calls[j](sp[k])
+            for k in range(1, splits):
+                ev = torch.cuda.Event()
+                ev.record(cs[k])
+                cs[0].wait_event(ev)
+            with torch.cuda.stream(cs[0]):
+                if st["done"][slot] is not None:
+                    cs[0].wait_event(st["done"][slot])        # NMS stream is done with this candidate buffer
+                cand = outs.decode_packed(head_levels(st["ho"], strides), out=st["cand"][slot])
+                st["cand"][slot] = cand
+                ready = torch.cuda.Event()
+                ready.record(cs[0])
+            st["decoded"] = ready
             with torch.cuda.stream(self.side_stream):
-                for d in dones:
-                    self.side_stream.wait_event(d)
-                if splits == 1:
-                    return parts[0]
-                return torch.cat([p[0] for p in parts], 0), torch.cat([p[1] for p in parts], 0)
+                self.side_stream.wait_event(ready)
+                res = outs.select_packed(cand, sizes=sizes, scale_corners=do_postprocess)
+                done = torch.cuda.Event()
+                done.record(self.side_stream)
+            st["done"][slot] = done
+            return res
 
     def forward(self, batched_inputs, do_postprocess=True):
         if self.training:

@@ -103,7 +103,7 @@ def gather(cand, keep, num_keep, sizes=None, k_cap=None, scale_corners=True):
     with torch.cuda.device(dev):
         out = torch.empty(n, k_cap, _lib.DET_ROW, dtype=torch.float32, device=dev)
         cnt = torch.zeros(n, dtype=torch.int32, device=dev)
-        if sizes is not None:
+        if sizes is not None and not (isinstance(sizes, torch.Tensor) and sizes.is_cuda):
             sizes = torch.as_tensor(sizes, dtype=torch.float32).reshape(n, 6).to(dev, non_blocking=True)
         _lib.check(L.dafne_gather_detections_hip(
             _lib.ptr(cand.corners), _lib.ptr(cand.scores), _lib.ptr(cand.ctr), _lib.ptr(cand.classes),

@@ -38,4 +38,6 @@ def run(cin, cout, k, H, W, N=8, res=False, label=""):
     hist = np.histogram(s_us, bins=8)[0]
     print("  start-time histogram (8 bins over span):", hist.tolist())
 run(256, 1024, 1, 64, 64, res=True, label="res4 conv3 (+res)")
+run(256, 256, 3, 64, 64, label="res4 conv2 3x3 (128 tile)")
+run(1024, 256, 1, 64, 64, label="res4 conv1 1x1 K=1024 (128 tile)")
 run(256, 256, 3, 128, 128, label="head-like 3x3")
