@@ -186,3 +186,23 @@ def test_pipelined_side_stream_equals_serial():
         for i in range(3):
             k = int(c0[i])
             assert torch.equal(r0[i, :k], r1[i, :k])
+
+
+@pytest.mark.parametrize("cfgname,h,w", [("hrsc_r50.yaml", 800, 1216), ("ucas_aod_r101.yaml", 256, 320),
+                                          ("dota-1.0_r101.yaml", 192, 256)])
+def test_released_configs_run_end_to_end(cfgname, h, w):
+    """BASELINE.json configs: #1 (HRSC R50, one 800x1216 image) and the other released heads
+    (C = 1 / 2 / 15) build and produce well-formed detections."""
+    cfg, m, P = build(cfgname, seed=17)
+    g = torch.Generator().manual_seed(3)
+    img = torch.randint(0, 256, (3, h, w), generator=g, dtype=torch.uint8)
+    out = m([{"image": img, "height": h, "width": w}])[0]["instances"]
+    C = cfg.MODEL.DAFNE.NUM_CLASSES
+    assert 0 < len(out) <= cfg.MODEL.DAFNE.POST_NMS_TOPK_TEST + 8
+    assert out.pred_corners.shape == (len(out), 8) and out.pred_boxes.tensor.shape == (len(out), 4)
+    assert int(out.pred_classes.max()) < C and int(out.pred_classes.min()) >= 0
+    s = out.scores.cpu().numpy()
+    assert np.all(np.diff(s) <= 0) and s.min() > 0 and s.max() <= 1
+    b = out.pred_boxes.tensor.cpu().numpy()
+    assert b[:, 0].min() >= 0 and b[:, 2].max() <= w and b[:, 1].min() >= 0 and b[:, 3].max() <= h
+    assert torch.isfinite(out.pred_corners).all()
