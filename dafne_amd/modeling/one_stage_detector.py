@@ -98,9 +98,9 @@ class OneStageDetector(nn.Module):
 
         pipelined=True: the dense part runs as `splits` contiguous sub-batches on their own
         HIP streams, enqueued layer by layer (independent images: the prologue / write-burst
-        bubbles of one sub-batch's kernel are filled by another's); decode runs once on the
-        whole batch, and rotated NMS + gather run on a side stream so that they overlap the
-        next call's convolutions; candidates are double buffered.
+        bubbles of one sub-batch's kernel are filled by another's); decode, rotated NMS and
+        gather run once on the whole batch on a side stream, overlapping the next call's
+        convolutions (two plan sets / head-output buffers alternate).
         The returned tensors are then produced on `self.side_stream`: wait on it (or
         torch.cuda.synchronize()) before reading them."""
         if not images_u8.is_cuda or images_u8.dtype != torch.uint8:
@@ -146,28 +146,30 @@ class OneStageDetector(nn.Module):
             key = (n, hn, wn, splits)
             if key not in self._pipe:
                 nc = self.proposal_generator.dafne_head.num_classes
-                ho = engine.HeadOutputs(n, hn, wn, nc, self._weights()["scales"], self.device)
                 bounds = [(k * n) // splits for k in range(splits + 1)]
-                plans = []
-                for k in range(splits):
-                    lo, hi = bounds[k], bounds[k + 1]
-                    plans.append(engine.DensePlan(self._weights(), hi - lo, hn, wn, self.depth, nc, self.device,
-                                                  head_outputs=ho.views(lo, hi)))
-                self._pipe[key] = {"i": 0, "cs": [torch.cuda.Stream() for _ in range(splits)], "ho": ho,
-                                   "plans": plans, "bounds": bounds, "cand": [None, None], "done": [None, None],
-                                   "decoded": None}
+                # two complete plan sets (A/B) with their own head-output buffers: decode + NMS of
+                # call i run on the side stream while call i+1's convolutions already write set B
+                hos, plan_sets = [], []
+                for _ in range(2):
+                    ho = engine.HeadOutputs(n, hn, wn, nc, self._weights()["scales"], self.device)
+                    hos.append(ho)
+                    plan_sets.append([engine.DensePlan(self._weights(), bounds[k + 1] - bounds[k], hn, wn, self.depth,
+                                                       nc, self.device, head_outputs=ho.views(bounds[k], bounds[k + 1]))
+                                      for k in range(splits)])
+                self._pipe[key] = {"i": 0, "cs": [torch.cuda.Stream() for _ in range(splits)], "ho": hos,
+                                   "plans": plan_sets, "bounds": bounds, "cand": [None, None], "done": [None, None]}
             st = self._pipe[key]
             slot = st["i"] & 1
             st["i"] += 1
-            cs, plans, bounds = st["cs"], st["plans"], st["bounds"]
+            cs, plans, bounds = st["cs"], st["plans"][slot], st["bounds"]
             inputs_ready = torch.cuda.Event()
             inputs_ready.record(main)
             vts = []
             for k in range(splits):
                 lo, hi = bounds[k], bounds[k + 1]
                 cs[k].wait_event(inputs_ready)
-                if st["decoded"] is not None:
-                    cs[k].wait_event(st["decoded"])       # previous call's decode has read the head outputs
+                if st["done"][slot] is not None:
+                    cs[k].wait_event(st["done"][slot])    # side stream finished with plan set `slot` (2 calls ago)
                 with torch.cuda.stream(cs[k]):
                     vt = None if all_full else self._dev_const(valid_hw[lo:hi], torch.int32, (hi - lo, 2))
                     vts.append(vt)
@@ -182,20 +184,13 @@ class OneStageDetector(nn.Module):
             for j in range(ncalls):
                 for k in range(splits):
                     plans[k].calls[j](sp[k])
-            for k in range(1, splits):
-                ev = torch.cuda.Event()
-                ev.record(cs[k])
-                cs[0].wait_event(ev)
-            with torch.cuda.stream(cs[0]):
-                if st["done"][slot] is not None:
-                    cs[0].wait_event(st["done"][slot])        # NMS stream is done with this candidate buffer
-                cand = outs.decode_packed(head_levels(st["ho"], strides), out=st["cand"][slot])
-                st["cand"][slot] = cand
-                ready = torch.cuda.Event()
-                ready.record(cs[0])
-            st["decoded"] = ready
             with torch.cuda.stream(self.side_stream):
-                self.side_stream.wait_event(ready)
+                for k in range(splits):
+                    ev = torch.cuda.Event()
+                    ev.record(cs[k])
+                    self.side_stream.wait_event(ev)
+                cand = outs.decode_packed(head_levels(st["ho"][slot], strides), out=st["cand"][slot])
+                st["cand"][slot] = cand
                 res = outs.select_packed(cand, sizes=sizes, scale_corners=do_postprocess)
                 done = torch.cuda.Event()
                 done.record(self.side_stream)
