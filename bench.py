@@ -263,7 +263,7 @@ def main():
     ap.add_argument("--batch", type=int, default=8, help="images per GPU per step")
     ap.add_argument("--depth", type=int, default=101, choices=[50, 101])
     ap.add_argument("--size", type=int, default=1024)
-    ap.add_argument("--splits", type=int, default=2,
+    ap.add_argument("--splits", type=int, default=3,
                     help="dense part runs as this many sub-batches on concurrent HIP streams")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip roofline profile pass, R50 and NMS side metrics")

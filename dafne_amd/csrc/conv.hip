@@ -617,8 +617,9 @@ struct Cfg {
 // 128x128 (4 waves, 2 blocks/CU) tile keeps the 256 CUs busy.
 Cfg pick_cfg(int Cout, long long blocks256 = 0, unsigned flags = 0) {
     static const bool big = getenv("DAFNE_CONV_NO256") == nullptr;
+    static const long long min_blocks = getenv("DAFNE_CONV_BIG_MIN_BLOCKS") ? atoll(getenv("DAFNE_CONV_BIG_MIN_BLOCKS")) : 512;
     const bool res = flags & (DAFNE_CONV_RESIDUAL | DAFNE_CONV_UPSAMPLE_ADD);   // HBM-bound epilogue: prefer 2 blocks/CU
-    if (big && !res && Cout % 256 == 0 && blocks256 >= 512) return {256, 256};
+    if (big && !res && Cout % 256 == 0 && blocks256 >= min_blocks) return {256, 256};
     if (Cout >= 128) return {128, 128};
     if (Cout > 32) return {64, 256};
     return {32, 256};
