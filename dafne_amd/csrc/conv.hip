@@ -29,6 +29,9 @@ typedef __attribute__((ext_vector_type(8))) short bf16x8;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((address_space(1))) const void gvoid;
 typedef __attribute__((address_space(3))) void lvoid;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
 
 constexpr int kMaxSegs = 5;
 constexpr int kBK = 64;           // K step (bf16 elements) = one 128-byte row slab
@@ -608,6 +611,318 @@ __global__ void __launch_bounds__(WC * WP * 64) conv_igemm_kernel(ConvDev P) {
 #endif
 }
 
+// ---------------------------------------------------------------------------------------
+// Persistent streaming variant (128 cout x 128 px tiles, 4 waves, 2 blocks per CU).
+//
+// The 1x1 convolutions of the bottlenecks have K = 64..1024: a tile is 2..32 half-K stages
+// of MFMA work between a prologue (address set-up, first-load latency) and an epilogue
+// (residual read, output write).  Launched one tile per workgroup, every K step waited a
+// full memory latency (one stage of prefetch) and prologue/epilogue were never overlapped:
+// those layers ran at ~2.8 TB/s and ~15 % of the matrix peak.  Here a workgroup walks over
+// many tiles and the operand stream never stops:
+//   * ring of kSNS half-K stages (32 channels = 64-byte rows, 16 KiB per stage), filled by
+//     `global_load_lds`; the loads of tile i+1's first stages are issued during the last
+//     iterations of tile i, so they are in flight under tile i's epilogue;
+//   * waits are counted (`s_waitcnt vmcnt(n)`, n = the vector-memory instructions issued
+//     after the stage being waited for) -- never a drain except for the very last stage;
+//   * the residual tile is DMA'd (`global_load_lds`, source-side XOR swizzle) into a bf16
+//     [px][cout] LDS tile at the first iteration of its tile; the epilogue adds it in
+//     fp32 in the accumulator layout, rounds once, writes the bf16 result back IN PLACE,
+//     and the tile leaves with 16-byte coalesced stores.
+// gfx950 counts stores in vmcnt as well: every store of the epilogue is issued
+// unconditionally (ragged tiles re-write their last valid pixel) so that the counts hold.
+constexpr int kSNS = 3;                 // ring depth in half-K stages
+constexpr int kSHS = 256 * 64;          // one half-K stage: 128 weight rows + 128 pixel rows x 64 B
+constexpr int kSRes = 128 * 256;        // bf16 [128 px][128 cout] residual / output staging tile
+
+struct TileInfo {
+    int nt, si, img, m0;
+};
+
+__device__ __forceinline__ TileInfo tile_info(const ConvDev& P, int logical) {
+    TileInfo t;
+    t.nt = logical % P.ntiles;
+    const int mt = logical / P.ntiles;
+    int si = 0;
+#pragma unroll
+    for (int k = 1; k < kMaxSegs; k++)
+        if (k < P.n_segs && mt >= P.seg[k].tile0) si = k;
+    t.si = si;
+    t.img = (mt - P.seg[si].tile0) / P.seg[si].tiles_per_img;
+    t.m0 = ((mt - P.seg[si].tile0) % P.seg[si].tiles_per_img) * 128;
+    return t;
+}
+
+// m / W for 0 <= m < 2^20, W <= 2^10 (checked on the host): exact via one fp32 multiply
+__device__ __forceinline__ void divmod_small(int m, int W, float invW, int& q, int& r) {
+    q = (int)(((float)m + 0.5f) * invW);
+    r = m - q * W;
+}
+
+#define DAFNE_VMCNT(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
+
+__global__ void __launch_bounds__(256, 2) conv_stream_kernel(ConvDev P) {
+    constexpr int NW = 4, WP = 2, TC = 2, TP = 2;
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    char* ring = lds;
+    char* resb = lds + kSNS * kSHS;
+    const unsigned resb_off = (unsigned)(size_t)(__attribute__((address_space(3))) char*)resb;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wc = wave / WP, wp = wave % WP;
+    const int frow = lane & 31, half = lane >> 5;
+    const int T = P.mtiles * P.ntiles;
+    const int G = gridDim.x;
+    const int my_tiles = (T - (int)blockIdx.x + G - 1) / G;
+    const int H = 2 * P.ksteps;
+    const bool has_res = P.flags & DAFNE_CONV_RESIDUAL;
+    const bool relu = P.flags & DAFNE_CONV_RELU;
+
+    // ---- issue cursor: runs kSNS-1 half-K stages ahead of the consumer, across tiles --------
+    int ic_tile = 0, ic_h = 0, ic_slot = 0, ic_Wp = 0;
+    int kh = 0, kw = 0, c0 = 0;
+    unsigned offX = 0;
+    unsigned hofs[4];
+    const char* xin = nullptr;
+    auto setup_issue = [&](int seq) {
+        const TileInfo t = tile_info(P, xcd_remap((int)blockIdx.x + seq * G, T));
+        const SegDev& S = P.seg[t.si];
+        const int HW = S.Hout * S.Wout;
+        const int Wp = S.Win + 2, Hp = S.Hin + 2;
+        const float invW = 1.0f / (float)S.Wout;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const int r = (i * NW + wave) * 16 + (lane >> 2);
+            const int q = (lane & 3) ^ ((r >> 2) & 3);
+            if (i < 2) {
+                hofs[i] = (unsigned)(t.nt * 128 + r) * (unsigned)P.kbytes + (unsigned)q * 16u;
+            } else {
+                int pix = t.m0 + (r - 128);
+                pix = pix < HW ? pix : HW - 1;
+                int ho, wo;
+                divmod_small(pix, S.Wout, invW, ho, wo);
+                const unsigned row = (unsigned)(t.img * Hp + ho * P.stride + 1 - P.pad);
+                const unsigned colp = (unsigned)(wo * P.stride + 1 - P.pad);
+                hofs[i] = (row * (unsigned)Wp + colp) * (unsigned)(P.Cin * 2) + (unsigned)q * 16u;
+            }
+        }
+        xin = S.in;
+        ic_Wp = Wp;
+        kh = kw = c0 = 0;
+        offX = 0;
+    };
+    auto issue_next = [&]() {
+        if (ic_tile >= my_tiles) return;
+        const unsigned hb = (unsigned)(ic_h & 1) * 64u;
+        const unsigned koffW = (unsigned)(ic_h >> 1) * (unsigned)kRowBytes + hb;
+        const unsigned koffX = offX + hb;
+        char* dst = ring + ic_slot * kSHS + wave * 1024;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const char* base = i < 2 ? P.w : xin;
+            const unsigned off = hofs[i] + (i < 2 ? koffW : koffX);
+            __builtin_amdgcn_global_load_lds((gvoid*)(base + off), (lvoid*)(dst + i * 4096), 16, 0, 0);
+        }
+        ic_slot = ic_slot == kSNS - 1 ? 0 : ic_slot + 1;
+        if (ic_h & 1) {
+            if (++kw == P.KW) { kw = 0; if (++kh == P.KH) { kh = 0; c0 += kBK; } }
+            offX = (unsigned)((kh * ic_Wp + kw) * P.Cin + c0) * 2u;
+        }
+        if (++ic_h == H) {
+            ic_h = 0;
+            if (++ic_tile < my_tiles) setup_issue(ic_tile);
+        }
+    };
+
+    // fragment read offsets inside a half-K stage (64-byte rows, chunk ^ ((row>>2)&3))
+    const int fsw4 = (frow >> 2) & 3;
+    unsigned hroff[2];
+#pragma unroll
+    for (int k2 = 0; k2 < 2; k2++) hroff[k2] = (unsigned)frow * 64u + (unsigned)(((2 * k2 + half) ^ fsw4) * 16);
+    const int arow0 = wc * TC * 32;
+    const int brow0 = 128 + wp * TP * 32;
+
+    if (my_tiles > 0) setup_issue(0);
+#pragma unroll
+    for (int k = 0; k < kSNS - 1; k++) issue_next();
+
+    int slot = 0;
+    for (int kk = 0; kk < my_tiles; kk++) {
+        const TileInfo t = tile_info(P, xcd_remap((int)blockIdx.x + kk * G, T));
+        const SegDev& S = P.seg[t.si];
+        const int HW = S.Hout * S.Wout;
+        const float invW = 1.0f / (float)S.Wout;
+        const bool last_tile = kk == my_tiles - 1;
+
+        f32x16 acc[TC][TP];
+#pragma unroll
+        for (int a = 0; a < TC; a++)
+#pragma unroll
+            for (int b = 0; b < TP; b++)
+#pragma unroll
+                for (int k = 0; k < 16; k++) acc[a][b][k] = 0.f;
+
+        auto lds_barrier = [&]() {
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        auto compute = [&]() {
+            const char* sb = ring + slot * kSHS;
+            slot = slot == kSNS - 1 ? 0 : slot + 1;
+            bf16x8 af[2][TC], bfr[2][TP];
+#pragma unroll
+            for (int k2 = 0; k2 < 2; k2++) {
+#pragma unroll
+                for (int a = 0; a < TC; a++) af[k2][a] = *(const bf16x8*)(sb + (arow0 + a * 32) * 64 + hroff[k2]);
+#pragma unroll
+                for (int b = 0; b < TP; b++) bfr[k2][b] = *(const bf16x8*)(sb + (brow0 + b * 32) * 64 + hroff[k2]);
+            }
+#pragma unroll
+            for (int k2 = 0; k2 < 2; k2++)
+#pragma unroll
+                for (int a = 0; a < TC; a++)
+#pragma unroll
+                    for (int b = 0; b < TP; b++)
+                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[k2][a], bfr[k2][b], acc[a][b], 0, 0, 0);
+        };
+
+        // ---- h = 0.  Waits: n = vector-memory instructions issued after the stage's 4 pieces.
+        // Issued after stage (kk,0): [4 pieces of (kk,1)] [8 stores of tile kk-1]
+        if (last_tile && H == 1) DAFNE_VMCNT(0);
+        else if (kk) DAFNE_VMCNT(12);
+        else DAFNE_VMCNT(4);
+        lds_barrier();
+        if (has_res) {
+            // residual tile -> LDS: piece = 4 pixel rows x 256 B; lane = (row, physical chunk),
+            // fetches logical chunk = physical ^ (row & 15)
+#pragma unroll
+            for (int i = 0; i < 8; i++) {
+                const int p = (i * NW + wave) * 4 + (lane >> 4);
+                const int q = (lane & 15) ^ (p & 15);
+                int m = t.m0 + p;
+                m = m < HW ? m : HW - 1;
+                int ho, wo;
+                divmod_small(m, S.Wout, invW, ho, wo);
+                const unsigned rpix = (unsigned)((t.img * (S.Hout + 2) + ho + 1) * (S.Wout + 2) + wo + 1);
+                const unsigned off = (rpix * (unsigned)P.Cout + (unsigned)(t.nt * 128 + q * 8)) * 2u;
+                __builtin_amdgcn_global_load_lds((gvoid*)(S.res + off), (lvoid*)(resb + (i * NW + wave) * 1024), 16, 0, 0);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        issue_next();
+        __builtin_amdgcn_sched_barrier(0);
+        compute();
+
+        // ---- h = 1: issued after stage (kk,1): [8 stores of tile kk-1] [8 residual pieces] [4 pieces]
+        if (last_tile && H == 2) DAFNE_VMCNT(0);
+        else if (kk && has_res) DAFNE_VMCNT(20);
+        else if (kk || has_res) DAFNE_VMCNT(12);
+        else DAFNE_VMCNT(4);
+        lds_barrier();
+        issue_next();
+        __builtin_amdgcn_sched_barrier(0);
+        compute();
+
+        // ---- h >= 2: [4 pieces]
+        for (int h = 2; h < H; h++) {
+            if (last_tile && h == H - 1) DAFNE_VMCNT(0); else DAFNE_VMCNT(4);
+            lds_barrier();
+            issue_next();
+            __builtin_amdgcn_sched_barrier(0);
+            compute();
+        }
+
+        // ------------------------------------------------------------ epilogue
+        // this wave's residual pieces have landed: after them came >= 8 ring pieces
+        if (last_tile) DAFNE_VMCNT(0); else DAFNE_VMCNT(8);
+        lds_barrier();     // every wave's residual pieces are in LDS
+        // bias through the scalar cache (s_load does not touch vmcnt, so the operand stream
+        // stays in flight); lanes pick their half of each 8-channel group
+        const float* bc = P.bias + t.nt * 128 + wc * TC * 32;
+        const unsigned rmask = has_res ? 0xffffffffu : 0u;
+        const float lo = relu ? 0.f : -__builtin_huge_valf();
+#pragma unroll
+        for (int a = 0; a < TC; a++) {
+            f32x4 bl[4], bh[4];
+            asm volatile(
+                "s_load_dwordx4 %0, %8, 0x0\n\ts_load_dwordx4 %1, %8, 0x10\n\t"
+                "s_load_dwordx4 %2, %8, 0x20\n\ts_load_dwordx4 %3, %8, 0x30\n\t"
+                "s_load_dwordx4 %4, %8, 0x40\n\ts_load_dwordx4 %5, %8, 0x50\n\t"
+                "s_load_dwordx4 %6, %8, 0x60\n\ts_load_dwordx4 %7, %8, 0x70\n\ts_waitcnt lgkmcnt(0)"
+                : "=&s"(bl[0]), "=&s"(bh[0]), "=&s"(bl[1]), "=&s"(bh[1]), "=&s"(bl[2]), "=&s"(bh[2]), "=&s"(bl[3]), "=&s"(bh[3])
+                : "s"(bc + a * 32)
+                : "memory");
+            // LDS accesses of the epilogue are inline asm: the compiler drains vmcnt in front of
+            // every LDS access it cannot disambiguate from a pending LDS-DMA (the ring prefetch)
+            u32x2 rc[4][TP];
+            unsigned caddr[4][TP];
+#pragma unroll
+            for (int g = 0; g < 4; g++)
+#pragma unroll
+                for (int b = 0; b < TP; b++) {
+                    const int px = (wp * TP + b) * 32 + frow;
+                    const int chunk = (wc * TC + a) * 4 + g;            // 16-byte chunk = 8 channels
+                    caddr[g][b] = resb_off + (unsigned)(px * 256 + ((chunk ^ (px & 15)) * 16) + 8 * half);
+                    asm volatile("ds_read_b64 %0, %1" : "=v"(rc[g][b]) : "v"(caddr[g][b]) : "memory");
+                }
+            asm volatile("s_waitcnt lgkmcnt(0)"
+                         : "+v"(rc[0][0]), "+v"(rc[0][1]), "+v"(rc[1][0]), "+v"(rc[1][1]), "+v"(rc[2][0]), "+v"(rc[2][1]),
+                           "+v"(rc[3][0]), "+v"(rc[3][1])
+                         :
+                         : "memory");
+#pragma unroll
+            for (int g = 0; g < 4; g++) {
+                const f32x4 bv = half ? bh[g] : bl[g];
+#pragma unroll
+                for (int b = 0; b < TP; b++) {
+                    u32x2 r = rc[g][b];
+                    r.x &= rmask;
+                    r.y &= rmask;
+                    const float v0 = fmaxf(acc[a][b][4 * g] + bv[0] + bf2f((unsigned short)(r.x & 0xffff)), lo);
+                    const float v1 = fmaxf(acc[a][b][4 * g + 1] + bv[1] + bf2f((unsigned short)(r.x >> 16)), lo);
+                    const float v2 = fmaxf(acc[a][b][4 * g + 2] + bv[2] + bf2f((unsigned short)(r.y & 0xffff)), lo);
+                    const float v3 = fmaxf(acc[a][b][4 * g + 3] + bv[3] + bf2f((unsigned short)(r.y >> 16)), lo);
+                    u32x2 pk;
+                    pk.x = (unsigned)f2bf(v0) | ((unsigned)f2bf(v1) << 16);
+                    pk.y = (unsigned)f2bf(v2) | ((unsigned)f2bf(v3) << 16);
+                    asm volatile("ds_write_b64 %0, %1" ::"v"(caddr[g][b]), "v"(pk) : "memory");
+                }
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        lds_barrier();
+        {
+            const int cc = tid & 15;
+            const int plast = HW - 1 - t.m0;      // last valid pixel row of a ragged tile
+            u32x4 ov[8];
+            int pr[8];
+#pragma unroll
+            for (int i = 0; i < 8; i++) {
+                int p = (tid >> 4) + 16 * i;
+                p = p < plast ? p : plast;
+                pr[i] = p;
+                const unsigned ad = resb_off + (unsigned)(p * 256 + ((cc ^ (p & 15)) * 16));
+                asm volatile("ds_read_b128 %0, %1" : "=v"(ov[i]) : "v"(ad) : "memory");
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)"
+                         : "+v"(ov[0]), "+v"(ov[1]), "+v"(ov[2]), "+v"(ov[3]), "+v"(ov[4]), "+v"(ov[5]), "+v"(ov[6]), "+v"(ov[7])
+                         :
+                         : "memory");
+#pragma unroll
+            for (int i = 0; i < 8; i++) {
+                int ho, wo;
+                divmod_small(t.m0 + pr[i], S.Wout, invW, ho, wo);
+                const size_t opix = (size_t)((t.img * (S.Hout + 2) + ho + 1) * (S.Wout + 2) + wo + 1);
+                *(u32x4*)(S.out + (opix * P.Cout + t.nt * 128 + cc * 8) * 2) = ov[i];
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
 struct Cfg {
     int bn, bm;
 };
@@ -700,6 +1015,37 @@ int launch(const ConvDev& D, hipStream_t st) {
     return dafne::check_launch("conv_igemm");
 }
 
+// The persistent streaming kernel takes the bf16-output 128x128-tile layers without GroupNorm
+// statistics / top-down add (those keep the one-tile-per-workgroup kernel).
+bool stream_eligible(const ConvDev& D) {
+    static const int mode = getenv("DAFNE_CONV_STREAM") ? atoi(getenv("DAFNE_CONV_STREAM")) : 2;
+    if (!mode || D.stem || D.bn != 128 || D.bm != 128) return false;
+    if (D.flags & (DAFNE_CONV_UPSAMPLE_ADD | DAFNE_CONV_OUT_F32 | DAFNE_CONV_GN_STATS)) return false;
+    if (D.Cout % 128 || !D.bias || D.ksteps < 1) return false;
+    for (int s = 0; s < D.n_segs; s++)
+        if (D.seg[s].Wout > 1024 || (long long)D.seg[s].Hout * D.seg[s].Wout > (1 << 20)) return false;
+    // 3x3 layers are LDS-read bound at this tile shape and lose to the full-K-step loop (measured
+    // 700 vs 860 TFLOP/s on res4): only mode 1 (experiments) sends them here
+    if (mode == 2 && D.KH != 1) return false;
+    return true;
+}
+
+int launch_stream(const ConvDev& D, hipStream_t st) {
+    constexpr int smem = kSNS * kSHS + kSRes;
+    static int slots = 0;   // resident workgroups: 2 per CU
+    if (!slots) {
+        int dev = 0, cus = 0;
+        DAFNE_HIP_TRY(hipGetDevice(&dev));
+        DAFNE_HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+        DAFNE_HIP_TRY(hipFuncSetAttribute((const void*)conv_stream_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+        slots = 2 * (cus > 0 ? cus : 256);
+    }
+    const int T = D.mtiles * D.ntiles;
+    const int G = T < slots ? T : slots;
+    hipLaunchKernelGGL(conv_stream_kernel, dim3(G), dim3(256), smem, st, D);
+    return dafne::check_launch("conv_stream");
+}
+
 }  // namespace
 
 extern "C" {
@@ -727,6 +1073,7 @@ int dafne_conv2d_nhwc_bf16_hip(const dafne_conv_params* prm, const dafne_conv_se
     int rc = build(D, prm, segs);
     if (rc) return rc;
     hipStream_t st = (hipStream_t)stream;
+    if (stream_eligible(D)) return launch_stream(D, st);
     if (D.bn == 256) return launch<4, 2, 2, 4>(D, st);
     if (D.bn == 128) return launch<2, 2, 2, 2>(D, st);
     if (D.bn == 64) return launch<1, 4, 2, 2>(D, st);

@@ -104,6 +104,32 @@ def test_conv_relu_residual_and_upsample_add():
     close_bf16(got, ref)
 
 
+@pytest.mark.parametrize("cin,cout,H,W,N,with_res,relu", [
+    (128, 256, 150, 131, 2, True, True),     # 616 tiles > 512 resident workgroups: several tiles per workgroup, ragged
+    (64, 128, 97, 113, 3, True, False),      # H = 2 half-K stages per tile (shortest K), one N tile
+    (256, 1024, 40, 40, 3, True, True),      # res4-conv3 shape: 8 N tiles share each pixel tile
+    (64, 256, 150, 131, 2, False, True),     # no residual: staging tile is write-only
+    (1024, 256, 24, 24, 2, False, True),     # long K (32 half-K stages)
+])
+def test_streaming_1x1_kernel(cin, cout, H, W, N, with_res, relu):
+    """Persistent streaming 1x1 kernel (conv.hip: conv_stream_kernel): residual DMA tile, in-place
+    epilogue, counted vmcnt waits across tile boundaries."""
+    from dafne_amd import engine
+    g = torch.Generator().manual_seed(cin + cout + H)
+    x = bfr(torch.randn(N, cin, H, W, generator=g))
+    w = bfr(torch.randn(cout, cin, 1, 1, generator=g) / cin ** 0.5)
+    b = torch.randn(cout, generator=g) * 0.1
+    res = bfr(torch.randn(N, cout, H, W, generator=g)) if with_res else None
+    ref = F.conv2d(x, w, b)
+    if with_res:
+        ref = ref + res
+    if relu:
+        ref = F.relu(ref)
+    flags = (engine.F_RELU if relu else 0) | (engine.F_RES if with_res else 0)
+    got, _, _ = run_conv(x, w, b, 1, 1, 0, flags=flags, res=res)
+    close_bf16(got, bfr(ref))
+
+
 @pytest.mark.parametrize("cout", [15, 9, 2, 1, 16])
 def test_prediction_conv_f32_output(cout):
     g = torch.Generator().manual_seed(cout)
