@@ -22,6 +22,7 @@
 // issued right after the barrier and land under the current step's 16 MFMAs/wave.
 #include "common.h"
 #include <stdlib.h>
+#include <type_traits>
 
 namespace {
 
@@ -65,6 +66,16 @@ __device__ __forceinline__ unsigned short f2bf(float f) {
     unsigned u = __float_as_uint(f);
     u += 0x7fffu + ((u >> 16) & 1u);   // round to nearest even (inputs are finite)
     return (unsigned short)(u >> 16);
+}
+
+// two fp32 -> packed bf16x2 with the hardware converter (v_cvt_pk_bf16_f32: round to nearest even,
+// the same rounding as f2bf for finite inputs); one instruction instead of eight
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+__device__ __forceinline__ unsigned pack_bf16(float lo, float hi) {
+    const f32x2 v = {lo, hi};
+    const bf16x2_t w = __builtin_convertvector(v, bf16x2_t);
+    return __builtin_bit_cast(unsigned, w);
 }
 
 __device__ __forceinline__ float bf2f(unsigned short h) { return __uint_as_float((unsigned)h << 16); }
@@ -422,8 +433,8 @@ __global__ void __launch_bounds__(WC * WP * 64) conv_igemm_kernel(ConvDev P) {
                         gsq[a][g] += (v0 * v0 + v1 * v1) + (v2 * v2 + v3 * v3);
                     }
                     uint2 pk;
-                    pk.x = (unsigned)f2bf(v0) | ((unsigned)f2bf(v1) << 16);
-                    pk.y = (unsigned)f2bf(v2) | ((unsigned)f2bf(v3) << 16);
+                    pk.x = pack_bf16(v0, v1);
+                    pk.y = pack_bf16(v2, v3);
                     const int co = (wc * TC + a) * 32 + 8 * g + 4 * half;
                     *(uint2*)(stg + px * ROWB + co * 2) = pk;
                 }
@@ -563,10 +574,10 @@ __global__ void __launch_bounds__(WC * WP * 64) conv_igemm_kernel(ConvDev P) {
             } else {
                 const size_t opix = ((size_t)(img * (S.Hout + 2) + ho + 1) * (S.Wout + 2) + wo + 1);
                 uint4 pk;
-                pk.x = (unsigned)f2bf(v[0]) | ((unsigned)f2bf(v[1]) << 16);
-                pk.y = (unsigned)f2bf(v[2]) | ((unsigned)f2bf(v[3]) << 16);
-                pk.z = (unsigned)f2bf(v[4]) | ((unsigned)f2bf(v[5]) << 16);
-                pk.w = (unsigned)f2bf(v[6]) | ((unsigned)f2bf(v[7]) << 16);
+                pk.x = pack_bf16(v[0], v[1]);
+                pk.y = pack_bf16(v[2], v[3]);
+                pk.z = pack_bf16(v[4], v[5]);
+                pk.w = pack_bf16(v[6], v[7]);
                 *(uint4*)(S.out + (opix * P.Cout + cobase) * 2) = pk;
             }
         }
@@ -886,8 +897,8 @@ __global__ void __launch_bounds__(256, 2) conv_stream_kernel(ConvDev P) {
                     const float v2 = fmaxf(acc[a][b][4 * g + 2] + bv[2] + bf2f((unsigned short)(r.y & 0xffff)), lo);
                     const float v3 = fmaxf(acc[a][b][4 * g + 3] + bv[3] + bf2f((unsigned short)(r.y >> 16)), lo);
                     u32x2 pk;
-                    pk.x = (unsigned)f2bf(v0) | ((unsigned)f2bf(v1) << 16);
-                    pk.y = (unsigned)f2bf(v2) | ((unsigned)f2bf(v3) << 16);
+                    pk.x = pack_bf16(v0, v1);
+                    pk.y = pack_bf16(v2, v3);
                     asm volatile("ds_write_b64 %0, %1" ::"v"(caddr[g][b]), "v"(pk) : "memory");
                 }
             }
@@ -920,6 +931,319 @@ __global__ void __launch_bounds__(256, 2) conv_stream_kernel(ConvDev P) {
             }
         }
         __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// Weight-stationary streaming kernel for the 1x1 layers with Cin <= 256 (res2/res3/res4 conv3
+// and the stage shortcuts: K = 64..256, HBM-bound, residual read + 4x wider output).
+//
+// A workgroup keeps its 128 output channels' weights in REGISTERS (MFMA A fragments, loaded
+// once; the tile order keeps the channel tile fixed per workgroup) and streams pixel tiles:
+// the LDS ring then carries only the pixel operand (8 KiB half-K stages, 6 deep = 5 in
+// flight, against 2 in the generic streaming kernel), LDS fragment reads halve, and the
+// L2->LDS traffic per tile drops from 128 KiB to 64 KiB (Cin = 256).
+// vmcnt bookkeeping is exact: K is a template parameter, so the number of vector-memory
+// instructions issued after any awaited stage (ring pieces, residual DMA pieces, output stores
+// of earlier tiles) is a compile-time function of the position in the tile (ws_after).
+constexpr int kWNS = 6;                 // ring depth in half-K stages of the pixel operand
+constexpr int kWHS = 128 * 64;          // 128 pixel rows x 64 B
+
+constexpr int ws_after(int h, int H, bool res) {
+    int n = 2 * (kWNS - 2);                                       // ring pieces of the kWNS-2 younger stages
+    for (int d = 1; d <= kWNS - 1; d++)
+        if (((h - d) % H + H) % H == H - 1) n += res ? 16 : 8;    // a tile end: [8 residual loads of the next tile] 8 output stores
+    return n;
+}
+
+template <int N>
+__device__ __forceinline__ void vmcnt_le() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, N>(f);
+    }
+}
+
+// residual reads and output stores are streamed once: the non-temporal hint keeps them from evicting
+// the pixel tiles that the 2..8 channel-tile siblings of a workgroup re-read from L2 (measured
+// 116 vs 125 us on res2 conv3, 44 vs 47 us on res4 conv3)
+#define WS_NT " nt"
+#define WS_STORE(p, v) __builtin_nontemporal_store(v, p)
+
+template <int WC, int WP, int KS, bool RES>
+__global__ void __launch_bounds__(256, 2) conv_ws_kernel(ConvDev P) {
+    constexpr int NW = 4, TC = 4 / WC, TP = 4 / WP, H = 2 * KS, NS = kWNS;
+    constexpr int KSAFE = (NS - 1 + H - 1) / H + 1;     // tiles before the steady-state counts hold
+    static_assert(WC * WP == NW && ws_after(H - 1, H, true) <= 63, "configuration");
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    char* ring = lds;
+    char* resb = lds + NS * kWHS;
+    const unsigned resb_off = (unsigned)(size_t)(__attribute__((address_space(3))) char*)resb;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wc = wave / WP, wp = wave % WP;
+    const int frow = lane & 31, half = lane >> 5;
+    const int T = P.mtiles * P.ntiles;
+    const int G = gridDim.x;
+    const int my_tiles = (T - (int)blockIdx.x + G - 1) / G;
+    const int total = my_tiles * H;
+    const bool relu = P.flags & DAFNE_CONV_RELU;
+
+    // ---- issue cursor: kWNS-1 half-K stages ahead of the consumer, across tiles ---------------
+    int ic_tile = 0, ic_h = 0, ic_slot = 0;
+    unsigned hofs[2];
+    const char* xin = nullptr;
+    auto setup_issue = [&](int seq) {
+        const TileInfo t = tile_info(P, xcd_remap((int)blockIdx.x + seq * G, T));
+        const SegDev& S = P.seg[t.si];
+        const int HW = S.Hout * S.Wout;
+        const int Wp = S.Win + 2, Hp = S.Hin + 2;
+        const float invW = 1.0f / (float)S.Wout;
+#pragma unroll
+        for (int i = 0; i < 2; i++) {
+            const int r = (i * NW + wave) * 16 + (lane >> 2);
+            const int q = (lane & 3) ^ ((r >> 2) & 3);
+            int pix = t.m0 + r;
+            pix = pix < HW ? pix : HW - 1;
+            int ho, wo;
+            divmod_small(pix, S.Wout, invW, ho, wo);
+            const unsigned row = (unsigned)(t.img * Hp + ho * P.stride + 1 - P.pad);
+            const unsigned colp = (unsigned)(wo * P.stride + 1 - P.pad);
+            hofs[i] = (row * (unsigned)Wp + colp) * (unsigned)(P.Cin * 2) + (unsigned)q * 16u;
+        }
+        xin = S.in;
+    };
+    auto issue_next = [&]() {
+        if (ic_tile >= my_tiles) return;
+        char* dst = ring + ic_slot * kWHS + wave * 1024;
+#pragma unroll
+        for (int i = 0; i < 2; i++)
+            __builtin_amdgcn_global_load_lds((gvoid*)(xin + hofs[i] + (unsigned)ic_h * 64u), (lvoid*)(dst + i * 4096), 16, 0, 0);
+        ic_slot = ic_slot == NS - 1 ? 0 : ic_slot + 1;
+        if (++ic_h == H) {
+            ic_h = 0;
+            if (++ic_tile < my_tiles) setup_issue(ic_tile);
+        }
+    };
+
+    const int fsw4 = (frow >> 2) & 3;
+    unsigned hroff[2];
+#pragma unroll
+    for (int k2 = 0; k2 < 2; k2++) hroff[k2] = (unsigned)frow * 64u + (unsigned)(((2 * k2 + half) ^ fsw4) * 16);
+    const int brow0 = wp * TP * 32;
+
+    // residual rows of a tile live in registers (16 B per lane and row: lane = (pixel row tid/16 + 16 i,
+    // chunk tid%16), the mapping of the output stores).  They are fetched a whole tile ahead -- at the
+    // start of the previous tile's epilogue -- because vmcnt retires in order: a residual load issued
+    // next to ring pieces would make every later ring wait sit out its HBM latency.
+    u32x4 rr[RES ? 8 : 1];
+    auto fetch_residual = [&](int seq) {
+        const TileInfo t = tile_info(P, xcd_remap((int)blockIdx.x + seq * G, T));
+        const SegDev& S = P.seg[t.si];
+        const int HW = S.Hout * S.Wout;
+        const float invW = 1.0f / (float)S.Wout;
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            int m = t.m0 + (tid >> 4) + 16 * i;
+            m = m < HW ? m : HW - 1;
+            int ho, wo;
+            divmod_small(m, S.Wout, invW, ho, wo);
+            const size_t rpix = (size_t)((t.img * (S.Hout + 2) + ho + 1) * (S.Wout + 2) + wo + 1);
+            const char* src = S.res + (rpix * P.Cout + t.nt * 128 + (tid & 15) * 8) * 2;
+            asm volatile("global_load_dwordx4 %0, %1, off" WS_NT : "=v"(rr[RES ? i : 0]) : "v"(src) : "memory");
+        }
+    };
+    if (RES && my_tiles > 0) fetch_residual(0);
+    if (my_tiles > 0) setup_issue(0);
+#pragma unroll
+    for (int k = 0; k < NS - 1; k++) issue_next();
+
+#ifdef DAFNE_WS_TIMING
+    // debug build only (scratch/ws_timeline.py): cycle stamps of wave 0 into d_gn_partial, 64 slots per workgroup
+    unsigned long long* tlog = (unsigned long long*)P.gn_partial + (size_t)blockIdx.x * 64;
+    int tl = 2;
+    if (tid == 0 && P.gn_partial) { tlog[0] = __builtin_amdgcn_s_memrealtime(); tlog[1] = __builtin_readcyclecounter(); }
+#define WS_STAMP() do { if (tid == 0 && P.gn_partial && tl < 64) tlog[tl++] = __builtin_readcyclecounter(); } while (0)
+#else
+#define WS_STAMP()
+#endif
+    bf16x8 afr[TC][KS * 4];      // this wave's weights: [channel tile][16-deep K chunk]
+    int cur_nt = -1;
+    int slot = 0;
+    auto lds_barrier = [&]() {
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+    };
+
+    for (int kk = 0; kk < my_tiles; kk++) {
+        const TileInfo t = tile_info(P, xcd_remap((int)blockIdx.x + kk * G, T));
+        const SegDev& S = P.seg[t.si];
+        const int HW = S.Hout * S.Wout;
+        const float invW = 1.0f / (float)S.Wout;
+        if (t.nt != cur_nt) {
+            cur_nt = t.nt;
+#pragma unroll
+            for (int a = 0; a < TC; a++) {
+                const char* wr = P.w + (size_t)(t.nt * 128 + (wc * TC + a) * 32 + frow) * (size_t)P.kbytes + half * 16;
+                // inline asm: a compiler-visible load would make it drain vmcnt in front of the first
+                // MFMA of EVERY tile (it cannot see that the reload is rare)
+#pragma unroll
+                for (int kc = 0; kc < KS * 4; kc++)
+                    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(afr[a][kc]) : "v"(wr + kc * 32) : "memory");
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int a = 0; a < TC; a++)
+#pragma unroll
+                for (int kc = 0; kc < KS * 4; kc++) asm volatile("" : "+v"(afr[a][kc]));
+        }
+        f32x16 acc[TC][TP];
+#pragma unroll
+        for (int a = 0; a < TC; a++)
+#pragma unroll
+            for (int b = 0; b < TP; b++)
+#pragma unroll
+                for (int k = 0; k < 16; k++) acc[a][b][k] = 0.f;
+        WS_STAMP();      // tile start (weights resident)
+
+        static_for<0, H>([&](auto hc) {
+            constexpr int h = decltype(hc)::value;
+            // wait for half-K stage (kk, h): at most n younger vector-memory instructions may be pending
+            if (kk * H + h + NS - 2 >= total) vmcnt_le<0>();             // tail: the cursor has run dry
+            else if (kk < KSAFE) vmcnt_le<2 * (NS - 2)>();               // start-up: ring pieces only
+            else vmcnt_le<ws_after(h, H, RES)>();
+            lds_barrier();
+            issue_next();
+            __builtin_amdgcn_sched_barrier(0);
+            const char* sb = ring + slot * kWHS;
+            slot = slot == NS - 1 ? 0 : slot + 1;
+            bf16x8 bfr[2][TP];
+#pragma unroll
+            for (int k2 = 0; k2 < 2; k2++)
+#pragma unroll
+                for (int b = 0; b < TP; b++) bfr[k2][b] = *(const bf16x8*)(sb + (brow0 + b * 32) * 64 + hroff[k2]);
+#pragma unroll
+            for (int k2 = 0; k2 < 2; k2++)
+#pragma unroll
+                for (int a = 0; a < TC; a++)
+#pragma unroll
+                    for (int b = 0; b < TP; b++)
+                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[a][2 * h + k2], bfr[k2][b], acc[a][b], 0, 0, 0);
+        });
+
+        WS_STAMP();      // K loop done
+        // ------------------------------------------------------------ epilogue
+        if (RES) {
+            // this tile's residual registers have landed: after their loads came the previous tile's 8
+            // stores (not for the first tile) and this tile's 2H ring pieces
+            if ((kk + 1) * H + NS - 2 >= total) vmcnt_le<0>();
+            else if (kk == 0) vmcnt_le<2 * H>();
+            else vmcnt_le<2 * H + 8>();
+#pragma unroll
+            for (int i = 0; i < 8; i++) {
+                asm volatile("" : "+v"(rr[i]));
+                const int p = (tid >> 4) + 16 * i;
+                const unsigned ad = resb_off + (unsigned)(p * 256 + (((tid & 15) ^ (p & 15)) * 16));
+                asm volatile("ds_write_b128 %0, %1" ::"v"(ad), "v"(rr[i]) : "memory");
+            }
+            // next tile's residual (the last tile re-reads its own: the instruction count stays fixed)
+            fetch_residual(kk + 1 < my_tiles ? kk + 1 : kk);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            lds_barrier();     // the residual tile is complete in LDS
+        }
+        WS_STAMP();      // residual tile in LDS
+        const unsigned rmask = RES ? 0xffffffffu : 0u;
+        const float lo = relu ? 0.f : -__builtin_huge_valf();
+        const float* bc = P.bias + t.nt * 128 + wc * TC * 32;
+#pragma unroll
+        for (int a = 0; a < TC; a++) {
+            f32x4 bl[4], bh[4];
+            asm volatile(
+                "s_load_dwordx4 %0, %8, 0x0\n\ts_load_dwordx4 %1, %8, 0x10\n\t"
+                "s_load_dwordx4 %2, %8, 0x20\n\ts_load_dwordx4 %3, %8, 0x30\n\t"
+                "s_load_dwordx4 %4, %8, 0x40\n\ts_load_dwordx4 %5, %8, 0x50\n\t"
+                "s_load_dwordx4 %6, %8, 0x60\n\ts_load_dwordx4 %7, %8, 0x70\n\ts_waitcnt lgkmcnt(0)"
+                : "=&s"(bl[0]), "=&s"(bh[0]), "=&s"(bl[1]), "=&s"(bh[1]), "=&s"(bl[2]), "=&s"(bh[2]), "=&s"(bl[3]), "=&s"(bh[3])
+                : "s"(bc + a * 32)
+                : "memory");
+            // LDS accesses of the epilogue are inline asm (see conv_stream_kernel)
+            u32x2 rc[4][TP];
+            unsigned caddr[4][TP];
+#pragma unroll
+            for (int g = 0; g < 4; g++)
+#pragma unroll
+                for (int b = 0; b < TP; b++) {
+                    const int px = (wp * TP + b) * 32 + frow;
+                    const int chunk = (wc * TC + a) * 4 + g;            // 16-byte chunk = 8 channels
+                    caddr[g][b] = resb_off + (unsigned)(px * 256 + ((chunk ^ (px & 15)) * 16) + 8 * half);
+                    if (RES) asm volatile("ds_read_b64 %0, %1" : "=v"(rc[g][b]) : "v"(caddr[g][b]) : "memory");
+                    else rc[g][b] = u32x2{0u, 0u};
+                }
+            if (RES) {
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+                for (int g = 0; g < 4; g++)
+#pragma unroll
+                    for (int b = 0; b < TP; b++) asm volatile("" : "+v"(rc[g][b]));   // uses stay behind the wait
+            }
+#pragma unroll
+            for (int g = 0; g < 4; g++) {
+                const f32x4 bv = half ? bh[g] : bl[g];
+#pragma unroll
+                for (int b = 0; b < TP; b++) {
+                    u32x2 r = rc[g][b];
+                    r.x &= rmask;
+                    r.y &= rmask;
+                    const float v0 = fmaxf(acc[a][b][4 * g] + bv[0] + bf2f((unsigned short)(r.x & 0xffff)), lo);
+                    const float v1 = fmaxf(acc[a][b][4 * g + 1] + bv[1] + bf2f((unsigned short)(r.x >> 16)), lo);
+                    const float v2 = fmaxf(acc[a][b][4 * g + 2] + bv[2] + bf2f((unsigned short)(r.y & 0xffff)), lo);
+                    const float v3 = fmaxf(acc[a][b][4 * g + 3] + bv[3] + bf2f((unsigned short)(r.y >> 16)), lo);
+                    u32x2 pk;
+                    pk.x = pack_bf16(v0, v1);
+                    pk.y = pack_bf16(v2, v3);
+                    asm volatile("ds_write_b64 %0, %1" ::"v"(caddr[g][b]), "v"(pk) : "memory");
+                }
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        lds_barrier();
+        WS_STAMP();      // accumulator pass done
+        {
+            const int cc = tid & 15;
+            const int plast = HW - 1 - t.m0;      // last valid pixel row of a ragged tile
+            u32x4 ov[8];
+            int pr[8];
+#pragma unroll
+            for (int i = 0; i < 8; i++) {
+                int p = (tid >> 4) + 16 * i;
+                p = p < plast ? p : plast;
+                pr[i] = p;
+                const unsigned ad = resb_off + (unsigned)(p * 256 + ((cc ^ (p & 15)) * 16));
+                asm volatile("ds_read_b128 %0, %1" : "=v"(ov[i]) : "v"(ad) : "memory");
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)"
+                         : "+v"(ov[0]), "+v"(ov[1]), "+v"(ov[2]), "+v"(ov[3]), "+v"(ov[4]), "+v"(ov[5]), "+v"(ov[6]), "+v"(ov[7])
+                         :
+                         : "memory");
+#pragma unroll
+            for (int i = 0; i < 8; i++) {
+                int ho, wo;
+                divmod_small(t.m0 + pr[i], S.Wout, invW, ho, wo);
+                const size_t opix = (size_t)((t.img * (S.Hout + 2) + ho + 1) * (S.Wout + 2) + wo + 1);
+                WS_STORE((u32x4*)(S.out + (opix * P.Cout + t.nt * 128 + cc * 8) * 2), ov[i]);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // the staging tile is re-written (residual DMA) right after the next tile's first barrier:
+        // every wave has finished its staging reads by then (they precede its stores above)
     }
 }
 
@@ -1026,8 +1350,48 @@ bool stream_eligible(const ConvDev& D) {
         if (D.seg[s].Wout > 1024 || (long long)D.seg[s].Hout * D.seg[s].Wout > (1 << 20)) return false;
     // 3x3 layers are LDS-read bound at this tile shape and lose to the full-K-step loop (measured
     // 700 vs 860 TFLOP/s on res4): only mode 1 (experiments) sends them here
-    if (mode == 2 && D.KH != 1) return false;
+    if (mode == 2 && (D.KH != 1 || D.Cin > 512)) return false;   // K >= 1024: the one-tile kernel is ahead (29 vs 32 us)
     return true;
+}
+
+bool ws_eligible(const ConvDev& D) {
+    static const bool on = getenv("DAFNE_CONV_WS") == nullptr || atoi(getenv("DAFNE_CONV_WS")) != 0;
+    return on && D.KH == 1 && D.KW == 1 && (D.Cin == 64 || D.Cin == 128 || D.Cin == 256);
+}
+
+int resident_slots(int* out) {
+    static int slots = 0;   // resident workgroups: 2 per CU
+    if (!slots) {
+        int dev = 0, cus = 0;
+        DAFNE_HIP_TRY(hipGetDevice(&dev));
+        DAFNE_HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+        slots = 2 * (cus > 0 ? cus : 256);
+    }
+    *out = slots;
+    return DAFNE_OK;
+}
+
+template <int WC, int WP, int KS, bool RES>
+int launch_ws_cfg(const ConvDev& D, hipStream_t st) {
+    constexpr int smem = kWNS * kWHS + kSRes;
+    static bool attr_done = false;
+    if (!attr_done) {
+        DAFNE_HIP_TRY(hipFuncSetAttribute((const void*)conv_ws_kernel<WC, WP, KS, RES>, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+        attr_done = true;
+    }
+    int slots = 0;
+    if (int rc = resident_slots(&slots)) return rc;
+    const int T = D.mtiles * D.ntiles;
+    const int G = T < slots ? T : slots;
+    hipLaunchKernelGGL((conv_ws_kernel<WC, WP, KS, RES>), dim3(G), dim3(256), smem, st, D);
+    return dafne::check_launch("conv_ws");
+}
+
+int launch_ws(const ConvDev& D, hipStream_t st) {
+    const bool res = D.flags & DAFNE_CONV_RESIDUAL;
+    if (D.Cin == 256) return res ? launch_ws_cfg<4, 1, 4, true>(D, st) : launch_ws_cfg<4, 1, 4, false>(D, st);
+    if (D.Cin == 128) return res ? launch_ws_cfg<2, 2, 2, true>(D, st) : launch_ws_cfg<2, 2, 2, false>(D, st);
+    return res ? launch_ws_cfg<2, 2, 1, true>(D, st) : launch_ws_cfg<2, 2, 1, false>(D, st);
 }
 
 int launch_stream(const ConvDev& D, hipStream_t st) {
@@ -1073,7 +1437,10 @@ int dafne_conv2d_nhwc_bf16_hip(const dafne_conv_params* prm, const dafne_conv_se
     int rc = build(D, prm, segs);
     if (rc) return rc;
     hipStream_t st = (hipStream_t)stream;
-    if (stream_eligible(D)) return launch_stream(D, st);
+    if (stream_eligible(D)) {
+        if (ws_eligible(D)) return launch_ws(D, st);
+        return launch_stream(D, st);
+    }
     if (D.bn == 256) return launch<4, 2, 2, 4>(D, st);
     if (D.bn == 128) return launch<2, 2, 2, 2>(D, st);
     if (D.bn == 64) return launch<1, 4, 2, 2>(D, st);
