@@ -18,8 +18,8 @@ batch 8, one GPU) is measured in the same run at N=1 and reported under
 "configs1_r50_b8".  Random-init weights (seeded), synthetic images.
 
 Extra objects on the JSON line:
-  roofline      dominant kernel = the conv_igemm_kernel<...> instantiation with the
-                most time per step (128x128 tile <2,2,2,2> or 256x256 tile <4,2,2,4>):
+  roofline      dominant kernel = the conv kernel (conv.hip: conv_igemm_kernel<...> tile
+                instantiations, conv_ws_kernel, conv_stream_kernel) with the most time per step:
                 algorithmic FLOPs of its launches / their HIP-event time, vs the
                 dense bf16 MFMA peak (2.5 PFLOP/s); every instantiation is listed
                 under "kernels"
@@ -141,13 +141,7 @@ def conv_kernel_profile(model, batch, splits, reps=3):
                     c(sp[k])
         torch.cuda.synchronize()
         for c, a, b in evs:
-            cout = c.prm.Cout
-            if cout <= 32:
-                cfgname = "conv_igemm<1,4,1,2>"
-            elif cout <= 64:
-                cfgname = "conv_igemm<1,4,2,2>"
-            else:
-                cfgname = "conv_igemm<2,2,2,2>" if c.tile_pixels() == 128 else "conv_igemm<4,2,2,4>"
+            cfgname = c.kernel_name()
             s = stats.setdefault(cfgname, {"ms": 0.0, "flops": 0.0, "launches": 0})
             s["ms"] += a.elapsed_time(b)
             s["flops"] += c.flops
@@ -184,9 +178,7 @@ def conv_kernel_profile_isolated(model, batch, reps=3):
                 c(stream)
         torch.cuda.synchronize()
         for c, a, b in evs:
-            cout = c.prm.Cout
-            name = "conv_igemm<1,4,1,2>" if cout <= 32 else "conv_igemm<1,4,2,2>" if cout <= 64 else \
-                ("conv_igemm<2,2,2,2>" if c.tile_pixels() == 128 else "conv_igemm<4,2,2,4>")
+            name = c.kernel_name()
             s = stats.setdefault(name, {"ms": 0.0, "flops": 0.0, "launches": 0})
             s["ms"] += a.elapsed_time(b) / reps
             s["flops"] += c.flops / reps
@@ -324,7 +316,7 @@ def main():
         if dom:
             out["roofline"] = {"bound": "mfma", "achieved": dom["tflops"], "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                                "frac": dom["tflops"] / PEAK_BF16_TFLOPS, "traffic": None,
-                               "kernel": domname.replace("conv_igemm", "conv_igemm_kernel"), "launches_per_step": dom["launches"],
+                               "kernel": domname.replace("conv_igemm", "conv_igemm_kernel") if "igemm" in domname else domname + "_kernel", "launches_per_step": dom["launches"],
                                "avg_launch_us": dom["avg_launch_us"],
                                "algorithmic_gflop_per_step": dom["flops"] / 1e9}
             out["roofline"]["concurrent_streams"] = args.splits

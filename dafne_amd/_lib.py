@@ -58,6 +58,9 @@ SIGNATURES = {
     "dafne_poly_nms_hip": (c_int, [c_void_p, c_int, c_double, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "dafne_poly_nms_batched_hip": (c_int, [c_void_p, c_void_p, c_int, c_int, c_double, c_int, c_void_p,
                                            c_void_p, c_void_p, c_size_t, c_void_p]),
+    "dafne_poly_nms_f64_workspace_bytes": (c_size_t, [c_int, c_int]),
+    "dafne_poly_nms_f64_batched_hip": (c_int, [c_void_p, c_void_p, c_int, c_int, c_double, c_int, c_void_p,
+                                               c_void_p, c_void_p, c_size_t, c_void_p]),
     "dafne_select_over_all_levels_hip": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int,
                                                  c_double, c_int, c_void_p, c_void_p, c_void_p, c_size_t,
                                                  c_void_p]),
@@ -69,6 +72,7 @@ SIGNATURES = {
                                                              c_void_p]),
     "dafne_conv2d_nhwc_bf16_hip": (c_int, [ctypes.POINTER(ConvParams), ctypes.POINTER(ConvSeg), c_void_p]),
     "dafne_conv2d_num_tiles": (c_int, [ctypes.POINTER(ConvParams), ctypes.POINTER(ConvSeg)]),
+    "dafne_conv2d_kernel_id": (c_int, [ctypes.POINTER(ConvParams), ctypes.POINTER(ConvSeg)]),
     "dafne_conv2d_cout_pad": (c_int, [c_int]),
     "dafne_conv2d_tile_pixels": (c_int, [ctypes.POINTER(ConvParams), ctypes.POINTER(ConvSeg)]),
     "dafne_preprocess_image_hip": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p,

@@ -194,6 +194,29 @@ __device__ __forceinline__ double iou_group16(Scratch s, Quad A, Quad B, int lan
     return inter / uni;
 }
 
+__device__ __forceinline__ Quad load_quad_f64(const double* p) {
+    Quad q;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        q.v[k].x = p[2 * k];
+        q.v[k].y = p[2 * k + 1];
+    }
+    return q;
+}
+
+// strict overlap of the axis-aligned hulls, in the rows' own fp64 arithmetic
+// (ResultMerge_multi_process.py:80-98: w = max(0, xx2 - xx1) > 0 and h > 0)
+__device__ __forceinline__ bool hulls_overlap_strict(const Quad& a, const Quad& b) {
+    const double ax0 = fmin(fmin(a.v[0].x, a.v[1].x), fmin(a.v[2].x, a.v[3].x)), ax1 = fmax(fmax(a.v[0].x, a.v[1].x), fmax(a.v[2].x, a.v[3].x));
+    const double ay0 = fmin(fmin(a.v[0].y, a.v[1].y), fmin(a.v[2].y, a.v[3].y)), ay1 = fmax(fmax(a.v[0].y, a.v[1].y), fmax(a.v[2].y, a.v[3].y));
+    const double bx0 = fmin(fmin(b.v[0].x, b.v[1].x), fmin(b.v[2].x, b.v[3].x)), bx1 = fmax(fmax(b.v[0].x, b.v[1].x), fmax(b.v[2].x, b.v[3].x));
+    const double by0 = fmin(fmin(b.v[0].y, b.v[1].y), fmin(b.v[2].y, b.v[3].y)), by1 = fmax(fmax(b.v[0].y, b.v[1].y), fmax(b.v[2].y, b.v[3].y));
+    const double wd = fmax(0.0, fmin(ax1, bx1) - fmax(ax0, bx0)), hd = fmax(0.0, fmin(ay1, by1) - fmax(ay0, by0));
+    const double inter = wd * hd;
+    const double aa = (ax1 - ax0 + 1) * (ay1 - ay0 + 1), ab = (bx1 - bx0 + 1) * (by1 - by0 + 1);
+    return inter / (aa + ab - inter) > 0.0;          // h_inds = np.where(hbb_ovr > 0)
+}
+
 __device__ __forceinline__ Quad load_quad_f32(const float* p) {
     Quad q;
 #pragma unroll
@@ -241,11 +264,13 @@ struct NmsWs {
     unsigned* pair_cnt;        // [N][nblk]  pairs appended per row block (may exceed pair_cap)
     u64* pairs;                // [N][nblk][pair_cap]  (row | col << 32), sorted positions
     unsigned char* tile_flag;  // [N][ntiles]  tile did not fit the pair list
+    double* dbox;              // [N][Mp][8] fp64 rows in sorted order (fp64 entry point only, else null)
+    int strict;                // ResultMerge predicate: suppress iff hulls overlap strictly AND IoU > thresh
     int Mp, nblk, pair_cap;    // pair_cap: per row block
     size_t mask_words;         // per image
 };
 
-size_t carve(NmsWs& w, void* base, int N, int m_cap) {
+size_t carve(NmsWs& w, void* base, int N, int m_cap, bool f64 = false) {
     int Mp = (m_cap + kTile - 1) / kTile * kTile;
     if (Mp == 0) Mp = kTile;
     int nblk = Mp / kTile;
@@ -266,6 +291,8 @@ size_t carve(NmsWs& w, void* base, int N, int m_cap) {
     w.hull = c.take<float4>(n * Mp);
     w.area = c.take<double>(n * Mp);
     w.dets9 = c.take<float>(n * Mp * 9);
+    w.dbox = f64 ? c.take<double>(n * Mp * 8) : nullptr;
+    w.strict = 0;
     w.mask_words = ntiles * kTile;
     w.mask = c.take<u64>(n * w.mask_words);
     return dafne::align_up(c.off, 256);
@@ -392,6 +419,61 @@ __global__ void __launch_bounds__(256) nms_prep_kernel(const float* __restrict__
     if ((threadIdx.x & 63) == 0 && amax > 0.f) atomicMax(&w.meta[img * 4 + 0], __float_as_uint(amax));
 }
 
+// fp64 rows (tile ResultMerge: coordinates are (tile poly + offset) / rate in float64,
+// ResultMerge_multi_process.py:175-187,217-228).  Same rank-by-counting sort on the fp64 scores; the
+// rows are kept in fp64 (dbox) for the clip, the fp32 hull is rounded OUTWARD so that the hull
+// pre-filter can only over-select.
+__global__ void __launch_bounds__(256) nms_prep_f64_kernel(const double* __restrict__ dets9, int row_cap,
+                                                           const int* __restrict__ counts, int m_cap,
+                                                           NmsWs w) {
+    const int img = blockIdx.y;
+    const int M = img_count(counts, img, m_cap);
+    if ((int)(blockIdx.x * blockDim.x) >= M) return;
+    const double* d = dets9 + (size_t)img * row_cap * 9;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool live = i < M;
+    const double si = live ? d[(size_t)i * 9 + 8] : 0.0;
+    __shared__ double ss[256];
+    int rank = 0;
+    for (int j0 = 0; j0 < M; j0 += 256) {
+        const int j = j0 + threadIdx.x;
+        ss[threadIdx.x] = j < M ? d[(size_t)j * 9 + 8] : -INFINITY;
+        __syncthreads();
+#pragma unroll 8
+        for (int jj = 0; jj < 256; jj++) {
+            const double v = ss[jj];
+            rank += (v > si) || (v == si && j0 + jj > i);     // argsort(kind="stable")[::-1]
+        }
+        __syncthreads();
+    }
+    float amax = 0.f;
+    if (live) {
+        const size_t base = (size_t)img * w.Mp + rank;
+        double v[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) v[k] = d[(size_t)i * 9 + k];
+        w.order[base] = i;
+        w.sscore[base] = (float)si;
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            w.dbox[base * 8 + k] = v[k];
+            w.sbox[base * 8 + k] = (float)v[k];
+        }
+        const double xmin = fmin(fmin(v[0], v[2]), fmin(v[4], v[6])), xmax = fmax(fmax(v[0], v[2]), fmax(v[4], v[6]));
+        const double ymin = fmin(fmin(v[1], v[3]), fmin(v[5], v[7])), ymax = fmax(fmax(v[1], v[3]), fmax(v[5], v[7]));
+        w.hull[base] = make_float4(__double2float_rd(xmin), __double2float_rd(ymin), __double2float_ru(xmax),
+                                   __double2float_ru(ymax));
+        Quad q;
+#pragma unroll
+        for (int k = 0; k < 4; k++) { q.v[k].x = v[2 * k]; q.v[k].y = v[2 * k + 1]; }
+        w.area[base] = fabs(quad_area(q));
+#pragma unroll
+        for (int k = 0; k < 8; k++) amax = fmaxf(amax, __double2float_ru(fabs(v[k])));
+    }
+    for (int o = 32; o > 0; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o, 64));
+    if ((threadIdx.x & 63) == 0 && amax > 0.f) atomicMax(&w.meta[img * 4 + 0], __float_as_uint(amax));
+}
+
 // ------------------------------------------------------------------ nms_mask
 __device__ __forceinline__ int kth_set_bit(u64 m, int t) {
     int pos = 0;
@@ -443,6 +525,7 @@ __device__ __forceinline__ u64 tile_candidates(const NmsWs& w, int img, int M, i
     const float4 ch = colv ? w.hull[ibase + gcol] : make_float4(0, 0, 0, 0);
     const float R = __uint_as_float(w.meta[img * 4 + 0]);
     const bool prefilter = thresh >= 1e-6;
+    const bool strict = w.strict != 0;
     const double guard = 256.0 * (2e-13 * (double)R * (double)R + 1e-6) / (prefilter ? thresh : 1.0);
     // area_r + area_c > guard is implied by either area alone exceeding it (areas >= 0);
     // testing the two flags keeps fp64 out of the 64-step loop (never skips more than
@@ -460,7 +543,8 @@ __device__ __forceinline__ u64 tile_candidates(const NmsWs& w, int img, int M, i
     for (int r = 0; r < rlim; r++) {
         const float4 h = rhull[r];
         const bool apart = (ch.x > h.z) | (h.x > ch.z) | (ch.y > h.w) | (h.y > ch.w);
-        const bool skip = prefilter & apart & (bigc | (bool)((rowbig >> r) & 1ull));
+        // strict mode: separated hulls never suppress (py_cpu_nms_poly_fast: hbb_ovr == 0 keeps the box)
+        const bool skip = strict ? apart : (prefilter & apart & (bigc | (bool)((rowbig >> r) & 1ull)));
         const bool c = colv & !skip & (offdiag | (lane > r));
         const u64 b = __ballot(c);
         if (lane == r) mycand = b;
@@ -554,10 +638,10 @@ __global__ void __launch_bounds__(64) nms_iou_kernel(const int* __restrict__ cou
         const bool live = k < n_pairs && en != ~0ull;
         if (en == ~0ull) en = 0ull;                      // skip marker: clip row 0 with itself, discard
         const int r = (int)(unsigned)en, c = (int)(en >> 32);
-        Quad A = load_quad_f32(w.sbox + (ibase + r) * 8);
-        Quad B = load_quad_f32(w.sbox + (ibase + c) * 8);
+        Quad A = w.dbox ? load_quad_f64(w.dbox + (ibase + r) * 8) : load_quad_f32(w.sbox + (ibase + r) * 8);
+        Quad B = w.dbox ? load_quad_f64(w.dbox + (ibase + c) * 8) : load_quad_f32(w.sbox + (ibase + c) * 8);
         const double iou = iou_group16(s, A, B, lane);
-        if (live && (lane & 15) == 0 && iou > thresh) {
+        if (live && (lane & 15) == 0 && iou > thresh && (!w.strict || hulls_overlap_strict(A, B))) {
             atomicOr(&w.mask[(size_t)img * w.mask_words + tile_id(r >> 6, c >> 6, nb) * kTile + (r & 63)], 1ull << (c & 63));
             atomicOr(&w.rowflag[(size_t)img * nb + (r >> 6)], 1ull << (r & 63));
         }
@@ -591,10 +675,10 @@ __global__ void __launch_bounds__(64) nms_iou_kernel(const int* __restrict__ cou
             const int row = lo;
             const int col = kth_set_bit(cand_s[wv][row], kk - pre_s[wv][row]);
             const int r = rb * kTile + row, c = cb * kTile + col;
-            Quad A = load_quad_f32(w.sbox + (ibase + r) * 8);
-            Quad B = load_quad_f32(w.sbox + (ibase + c) * 8);
+            Quad A = w.dbox ? load_quad_f64(w.dbox + (ibase + r) * 8) : load_quad_f32(w.sbox + (ibase + r) * 8);
+            Quad B = w.dbox ? load_quad_f64(w.dbox + (ibase + c) * 8) : load_quad_f32(w.sbox + (ibase + c) * 8);
             const double iou = iou_group16(s, A, B, lane);
-            if (live && (lane & 15) == 0 && iou > thresh) {
+            if (live && (lane & 15) == 0 && iou > thresh && (!w.strict || hulls_overlap_strict(A, B))) {
                 atomicOr(&w.mask[(size_t)img * w.mask_words + (size_t)t * kTile + row], 1ull << col);
                 atomicOr(&w.rowflag[(size_t)img * nb + rb], 1ull << row);
             }
@@ -738,12 +822,15 @@ __global__ void __launch_bounds__(kReduceThreads) nms_reduce_kernel(
 
 int run_nms(const float* d_dets9, int row_cap, const int* d_counts, int N, int m_cap, double thresh,
             int post_topk, int64_t* d_keep, int32_t* d_num_keep, NmsWs& w, hipStream_t st,
-            bool meta_zeroed) {
+            bool meta_zeroed, const double* d_dets9_f64 = nullptr) {
     if (!meta_zeroed) {
         DAFNE_HIP_TRY(hipMemsetAsync(w.meta, 0, zero_bytes(w, N), st));
     }
     dim3 gp((m_cap + 255) / 256, N);
-    hipLaunchKernelGGL(nms_prep_kernel, gp, dim3(256), 0, st, d_dets9, row_cap, d_counts, m_cap, w);
+    if (d_dets9_f64)
+        hipLaunchKernelGGL(nms_prep_f64_kernel, gp, dim3(256), 0, st, d_dets9_f64, row_cap, d_counts, m_cap, w);
+    else
+        hipLaunchKernelGGL(nms_prep_kernel, gp, dim3(256), 0, st, d_dets9, row_cap, d_counts, m_cap, w);
     int rc = dafne::check_launch("nms_prep");
     if (rc) return rc;
     long long ntiles = (long long)w.nblk * (w.nblk + 1) / 2;
@@ -796,6 +883,30 @@ int dafne_poly_nms_batched_hip(const float* d_dets9, const int32_t* d_counts, in
     if (ws_bytes < need) return dafne::fail(DAFNE_E_WORKSPACE, "poly_nms: workspace %zu < %zu", ws_bytes, need);
     if (w.nblk > kMaxBlk) return dafne::fail(DAFNE_E_UNSUPPORTED, "poly_nms: m_cap %d > %d", m_cap, kMaxBlk * kTile);
     return run_nms(d_dets9, m_cap, d_counts, n_images, m_cap, thresh, post_topk, d_keep, d_num_keep, w, st, false);
+}
+
+size_t dafne_poly_nms_f64_workspace_bytes(int n_images, int m_cap) {
+    if (n_images <= 0 || m_cap < 0) return 0;
+    NmsWs w;
+    return carve(w, nullptr, n_images, m_cap, true);
+}
+
+int dafne_poly_nms_f64_batched_hip(const double* d_dets9, const int32_t* d_counts, int n_images,
+                                   int m_cap, double thresh, int strict_hbb, int64_t* d_keep,
+                                   int32_t* d_num_keep, void* d_ws, size_t ws_bytes, void* stream) {
+    if (n_images <= 0 || m_cap < 0 || !d_num_keep) return dafne::fail(DAFNE_E_INVALID, "poly_nms_f64: bad args");
+    hipStream_t st = (hipStream_t)stream;
+    if (m_cap == 0) {
+        DAFNE_HIP_TRY(hipMemsetAsync(d_num_keep, 0, sizeof(int32_t) * n_images, st));
+        return DAFNE_OK;
+    }
+    if (!d_dets9 || !d_keep || !d_ws) return dafne::fail(DAFNE_E_INVALID, "poly_nms_f64: null pointer");
+    NmsWs w;
+    size_t need = carve(w, d_ws, n_images, m_cap, true);
+    if (ws_bytes < need) return dafne::fail(DAFNE_E_WORKSPACE, "poly_nms_f64: workspace %zu < %zu", ws_bytes, need);
+    if (w.nblk > kMaxBlk) return dafne::fail(DAFNE_E_UNSUPPORTED, "poly_nms_f64: m_cap %d > %d", m_cap, kMaxBlk * kTile);
+    w.strict = strict_hbb ? 1 : 0;
+    return run_nms(nullptr, m_cap, d_counts, n_images, m_cap, thresh, 0, d_keep, d_num_keep, w, st, false, d_dets9);
 }
 
 int dafne_poly_nms_hip(const float* d_dets9, int M, double thresh, int64_t* d_keep,

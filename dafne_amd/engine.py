@@ -122,6 +122,13 @@ class ConvCall:
     def tile_pixels(self):
         return _lib.load().dafne_conv2d_tile_pixels(ctypes.byref(self.prm), self.segs)
 
+    KERNEL_NAMES = ("conv_igemm<1,4,1,2>", "conv_igemm<1,4,2,2>", "conv_igemm<2,2,2,2>", "conv_igemm<4,2,2,4>",
+                    "conv_stream", "conv_ws")
+
+    def kernel_name(self):
+        """The HIP kernel this call dispatches to (conv.hip), for per-kernel attribution in bench.py."""
+        return self.KERNEL_NAMES[_lib.load().dafne_conv2d_kernel_id(ctypes.byref(self.prm), self.segs)]
+
     def __call__(self, stream):
         rc = self.fn(ctypes.byref(self.prm), self.segs, stream)
         if rc:

@@ -21,6 +21,19 @@ from ..structures import ImageList
 from .dafne.dafne import head_levels
 
 
+_STREAMS = {}
+
+
+def _shared_stream(device, kind, k):
+    """Process-wide HIP streams of the pipelined path.  They are shared by every detector instance (TTA
+    wrapper, a second model in the same process): each new stream may land on a hardware queue that
+    is already in use, and two sub-batches on one queue serialise."""
+    key = (str(device), kind, k)
+    if key not in _STREAMS:
+        _STREAMS[key] = torch.cuda.Stream(device=device, priority=-1 if kind == "compute" else 0)
+    return _STREAMS[key]
+
+
 @META_ARCH_REGISTRY.register()
 class OneStageDetector(nn.Module):
     def __init__(self, cfg):
@@ -141,7 +154,7 @@ class OneStageDetector(nn.Module):
             splits = max(1, min(int(splits), n))
             main = torch.cuda.current_stream()
             if self.side_stream is None:
-                self.side_stream = torch.cuda.Stream(device=images_u8.device)
+                self.side_stream = _shared_stream(images_u8.device, "side", 0)
                 self._pipe = {}
             key = (n, hn, wn, splits)
             if key not in self._pipe:
@@ -160,7 +173,7 @@ class OneStageDetector(nn.Module):
                 # of hardware queues, and two sub-batches landing on one queue serialise (dense part alone,
                 # 4 splits: 714 -> 960 img/s); the high-priority pool gives each its own queue.  With the
                 # post-process stream in the mix 3 splits measured best (scratch/split_sweep.sh)
-                self._pipe[key] = {"i": 0, "cs": [torch.cuda.Stream(priority=-1) for _ in range(splits)], "ho": hos,
+                self._pipe[key] = {"i": 0, "cs": [_shared_stream(images_u8.device, "compute", k) for k in range(splits)], "ho": hos,
                                    "plans": plan_sets, "bounds": bounds, "cand": [None, None], "done": [None, None]}
             st = self._pipe[key]
             slot = st["i"] & 1

@@ -60,6 +60,21 @@ int dafne_poly_iou_pairs_hip(const double* d_p, const double* d_q, int64_t n,
 
 /* --------------------------------------------------------------- rotated NMS */
 /*
+ * Tile ResultMerge NMS (dafne/utils/ResultMerge_multi_process.py:61-121 py_cpu_nms_poly_fast, called from
+ * nmsbynamedict :160-176 for every original image of a Task1_<class>.txt file; tools/prepare_dota has the
+ * same file).  Rows are FLOAT64 [x1..y4, score] exactly as mergesingle builds them ((tile poly + offset) /
+ * rate, :217-228); order = argsort(score, stable)[::-1]; row j is dropped iff a kept earlier row i has
+ * iou_poly(i, j) > thresh (polyiou.cpp, fp64) AND, when strict_hbb != 0, their axis-aligned hulls pass the
+ * reference's `hbb_ovr > 0` test (:80-98).  strict_hbb == 0 gives py_cpu_nms_poly (:24-58).
+ * d_dets9 [n_images][m_cap][9] doubles, d_counts [n_images] or NULL (= m_cap rows each); d_keep
+ * [n_images][m_cap] original row indices in descending-score order, d_num_keep [n_images].
+ */
+size_t dafne_poly_nms_f64_workspace_bytes(int n_images, int m_cap);
+int dafne_poly_nms_f64_batched_hip(const double* d_dets9, const int32_t* d_counts, int n_images, int m_cap,
+                                   double thresh, int strict_hbb, int64_t* d_keep, int32_t* d_num_keep,
+                                   void* d_ws, size_t ws_bytes, void* stream);
+
+/*
  * Greedy polygon NMS, the replacement for poly_nms.poly_gpu_nms (nms.py:91).
  *   d_dets9   [M,9] float32, C-contiguous: 8 corner coordinates + score
  *   thresh    a box is suppressed iff IoU(kept, box) > thresh (fp64 compare)
@@ -196,6 +211,11 @@ int dafne_conv2d_cout_pad(int Cout);
 int dafne_conv2d_tile_pixels(const dafne_conv_params* prm, const dafne_conv_seg* segs);
 /* number of M tiles the call above launches (= rows of d_gn_partial), -1 on error */
 int dafne_conv2d_num_tiles(const dafne_conv_params* prm, const dafne_conv_seg* segs);
+/* which kernel the call dispatches to (profiling / bench attribution), -1 on error:
+ * 0 conv_igemm_kernel<1,4,1,2> (32 cout x 256 px)   1 conv_igemm_kernel<1,4,2,2> (64 x 256)
+ * 2 conv_igemm_kernel<2,2,2,2> (128 x 128)           3 conv_igemm_kernel<4,2,2,4> (256 x 256, 8 waves)
+ * 4 conv_stream_kernel (persistent, 1x1, Cin 512)    5 conv_ws_kernel (persistent, weights in registers, 1x1, Cin <= 256) */
+int dafne_conv2d_kernel_id(const dafne_conv_params* prm, const dafne_conv_seg* segs);
 
 /*
  * OneStageDetector.preprocess_image (one_stage_detector.py:100-107) + ImageList

@@ -7,6 +7,7 @@ this package; nothing under ``dafne_amd/`` does (tests/test_abi.py greps for it)
   poly_oracle.c        fp64 quad IoU + greedy polygon NMS      (C, liboracle.so)
   ref_shim.cpp + _ref  the reference's own polyiou.cpp, compiled here
   postprocess.py       decode / corner sort / class offsets / cap / rescale (numpy)
+  evaluation.py        Task1 writer, tile ResultMerge, voc_eval mAP (numpy; next rows of SURVEY 8f)
   model.py             ResNet-FPN + DAFNe head in plain torch fp32
 """
 import ctypes
@@ -51,6 +52,8 @@ def lib():
             f = getattr(L, name)
             f.restype = ctypes.c_int64
             f.argtypes = [fp, ctypes.c_int64, ctypes.c_double, ip]
+        L.orc_poly_nms_f64.restype = ctypes.c_int64
+        L.orc_poly_nms_f64.argtypes = [dp, ctypes.c_int64, ctypes.c_double, ctypes.c_int, ip]
         L.orc_build_dets9.restype = None
         L.orc_build_dets9.argtypes = [fp, fp, ip, ctypes.c_int64, fp]
         _LIB = L
@@ -125,6 +128,16 @@ def ref_iou_poly_pairs(p, q):
     if p.shape[0]:
         R.ref_iou_poly_pairs(_dp(p), _dp(q), p.shape[0], _dp(out))
     return out
+
+
+def poly_nms_f64(dets9, thresh, strict_hbb=True):
+    """ResultMerge NMS on float64 [M,9] rows (py_cpu_nms_poly_fast / py_cpu_nms_poly); kept row
+    indices in descending-score order."""
+    dets9 = np.ascontiguousarray(dets9, dtype=np.float64).reshape(-1, 9)
+    keep = np.empty(dets9.shape[0], dtype=np.int64)
+    n = lib().orc_poly_nms_f64(_dp(dets9), dets9.shape[0], float(thresh), int(bool(strict_hbb)), _ip(keep)) \
+        if dets9.shape[0] else 0
+    return keep[:n].tolist()
 
 
 def score_order(dets9):

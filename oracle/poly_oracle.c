@@ -262,6 +262,68 @@ int64_t orc_poly_nms_fast(const float *dets9, int64_t m, double thresh, int64_t 
     return nk;
 }
 
+/* ---- tile ResultMerge NMS on float64 rows ------------------------------------ */
+typedef struct { double s; int64_t i; } didx_t;
+
+static int cmp_desc_d(const void *pa, const void *pb) {
+    const didx_t *a = (const didx_t *)pa, *b = (const didx_t *)pb;
+    if (a->s > b->s) return -1;
+    if (a->s < b->s) return 1;
+    if (a->i > b->i) return -1; /* equal scores: larger index first (stable argsort, reversed) */
+    if (a->i < b->i) return 1;
+    return 0;
+}
+
+/*
+ * dafne/utils/ResultMerge_multi_process.py:61-121 (py_cpu_nms_poly_fast; strict_hbb != 0) and :24-58
+ * (py_cpu_nms_poly; strict_hbb == 0) on a float64 [m,9] array, the array nmsbynamedict (:160-176)
+ * builds with np.array(nameboxdict[imgname]).  Greedy in descending score; with strict_hbb a
+ * remaining row is compared through iou_poly only when the reference's axis-aligned pre-test
+ * `hbb_ovr > 0` holds (:80-98: areas with +1, intersection without), otherwise its overlap value
+ * stays 0 and it is kept.  Order convention for equal scores: argsort(kind="stable")[::-1].
+ */
+int64_t orc_poly_nms_f64(const double *dets9, int64_t m, double thresh, int strict_hbb, int64_t *keep) {
+    if (m <= 0) return 0;
+    didx_t *v = (didx_t *)malloc(sizeof(didx_t) * (size_t)m);
+    unsigned char *dead = (unsigned char *)calloc((size_t)m, 1);
+    double *hb = (double *)malloc(sizeof(double) * 5 * (size_t)m);
+    for (int64_t i = 0; i < m; i++) { v[i].s = dets9[9 * i + 8]; v[i].i = i; }
+    qsort(v, (size_t)m, sizeof(didx_t), cmp_desc_d);
+    for (int64_t r = 0; r < m; r++) {
+        const double *q = dets9 + 9 * v[r].i;
+        double *h = hb + 5 * r;
+        h[0] = h[2] = q[0]; h[1] = h[3] = q[1];
+        for (int k = 1; k < 4; k++) {
+            if (q[2 * k] < h[0]) h[0] = q[2 * k];
+            if (q[2 * k] > h[2]) h[2] = q[2 * k];
+            if (q[2 * k + 1] < h[1]) h[1] = q[2 * k + 1];
+            if (q[2 * k + 1] > h[3]) h[3] = q[2 * k + 1];
+        }
+        h[4] = (h[2] - h[0] + 1) * (h[3] - h[1] + 1);
+    }
+    int64_t nk = 0;
+    for (int64_t r = 0; r < m; r++) {
+        if (dead[r]) continue;
+        keep[nk++] = v[r].i;
+        const double *hr = hb + 5 * r;
+        for (int64_t s = r + 1; s < m; s++) {
+            if (dead[s]) continue;
+            if (strict_hbb) {
+                const double *hs = hb + 5 * s;
+                double xx1 = hr[0] > hs[0] ? hr[0] : hs[0], yy1 = hr[1] > hs[1] ? hr[1] : hs[1];
+                double xx2 = hr[2] < hs[2] ? hr[2] : hs[2], yy2 = hr[3] < hs[3] ? hr[3] : hs[3];
+                double w = xx2 - xx1 > 0.0 ? xx2 - xx1 : 0.0, h = yy2 - yy1 > 0.0 ? yy2 - yy1 : 0.0;
+                double inter = w * h;
+                if (!(inter / (hr[4] + hs[4] - inter) > 0.0)) continue;
+            }
+            double iou = orc_iou_poly(dets9 + 9 * v[r].i, dets9 + 9 * v[s].i);
+            if (iou > thresh) dead[s] = 1;
+        }
+    }
+    free(v); free(dead); free(hb);
+    return nk;
+}
+
 /*
  * nms.py:74-90: build the float32 [m,9] array from boxes[m,8], scores[m],
  * classes[m]:  class 5 -> 4, offset = float(class) * (max - min + 1) in fp32,

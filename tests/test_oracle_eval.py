@@ -1,0 +1,85 @@
+"""CPU: the oracle's restatement of tile ResultMerge / voc_eval / the Task1 writer against the
+fixture produced by the reference's own functions (tests/golden/make_golden_eval.py)."""
+import os
+import types
+
+import numpy as np
+import pytest
+
+from oracle import evaluation as oev
+import oracle
+
+G = np.load(os.path.join(os.path.dirname(__file__), "golden", "eval_merge.npz"))
+
+
+@pytest.mark.parametrize("cls", ["plane", "ship", "small-vehicle"])
+def test_merge_matches_reference(cls):
+    got = oev.merge_file_lines([str(x) for x in G["merge_in_" + cls]])
+    want = [str(x) for x in G["merge_out_" + cls]]
+    assert got == want          # same rows, same order, same float repr
+
+
+def _gt_by_image():
+    out = {}
+    for img, txt in zip(G["val_images"], G["val_gt"]):
+        rows = []
+        for line in str(txt).splitlines():
+            t = line.strip().split(" ")
+            if len(t) >= 9:
+                rows.append(([float(v) for v in t[:8]], t[8], int(t[9]) if len(t) == 10 else 0))
+        out[str(img)] = rows
+    return out
+
+
+@pytest.mark.parametrize("cls", ["plane", "ship"])
+@pytest.mark.parametrize("thr", [0.5, 0.75])
+def test_voc_eval_matches_reference(cls, thr):
+    rec, prec, ap = oev.voc_eval_lines([str(x) for x in G["val_det_" + cls]], _gt_by_image(), cls, ovthresh=thr)
+    tag = "%s_%d" % (cls, int(thr * 100))
+    assert np.array_equal(rec, G["val_rec_" + tag]) and np.array_equal(prec, G["val_prec_" + tag])
+    assert ap == float(G["val_ap_" + tag])
+
+
+def test_voc_ap_area_metric():
+    for cls in ("plane", "ship"):
+        _, _, ap = oev.voc_eval_lines([str(x) for x in G["val_det_" + cls]], _gt_by_image(), cls, 0.5, use_07_metric=False)
+        assert ap == pytest.approx(float(G["val_ap_area_" + cls]), abs=1e-15)
+
+
+def test_merge_nms_predicates_differ_only_on_degenerates():
+    """py_cpu_nms_poly_fast keeps a zero-area duplicate (its hull test fails), py_cpu_nms_poly drops it."""
+    pt = [100.0] * 8
+    d = np.array([pt + [0.9], pt + [0.8], [0, 0, 4, 0, 4, 4, 0, 4, 0.7], [1, 0, 5, 0, 5, 4, 1, 4, 0.6]])
+    assert oracle.poly_nms_f64(d, 0.1, strict_hbb=True) == [0, 1, 2]
+    assert oracle.poly_nms_f64(d, 0.1, strict_hbb=False) == [0, 2]
+    # ties: stable argsort reversed -> the LATER of two equal scores comes first
+    t = np.array([[0, 0, 4, 0, 4, 4, 0, 4, 0.5], [0, 0, 4, 0, 4, 4, 0, 4, 0.5]], dtype=np.float64)
+    assert oracle.poly_nms_f64(t, 0.1) == [1]
+
+
+def test_task1_writer_format(tmp_path):
+    """_generate_task_1_files: file names, score = score^2 / centerness in fp32, %.4f / %.2f fields."""
+    from dafne_amd.evaluation import dota_evaluation as de
+    cfg = types.SimpleNamespace(MODEL=types.SimpleNamespace(DAFNE=types.SimpleNamespace(CENTERNESS="plain", CENTERNESS_USE_IN_SCORE=False)),
+                                DATASETS=types.SimpleNamespace(DOTA_REMOVE_CONTAINER_CRANE=True))
+    rng = np.random.default_rng(5)
+    corners = rng.uniform(0, 1024, (5, 8)).astype(np.float32)
+    scores = rng.uniform(0.05, 1, 5).astype(np.float32)
+    ctr = rng.uniform(0.2, 1, 5).astype(np.float32)
+    labels = np.array([0, 2, 0, 15, 14])
+    preds = [{"file_name": "/data/val/images/P0003__1__0___0.png", "height": 1024, "width": 1024,
+              "corners": corners, "labels": labels, "scores": scores, "centerness": ctr}]
+    names = de.CLASSNAMES_DOTA_1_0 + ["container-crane"]
+    t1 = tmp_path / "Task1"
+    t1.mkdir()
+    de._generate_task_1_files(None, preds, str(tmp_path), str(t1), names, cfg)
+    plane = (t1 / "Task1_plane.txt").read_text().splitlines()
+    assert len(plane) == 2 and (t1 / "Task1_container-crane.txt").read_text() == ""     # label 15 skipped
+    s0 = np.float32(scores[0]) ** 2 / np.float32(ctr[0])
+    assert plane[0] == oev.task1_line("P0003__1__0___0", float(s0), corners[0])
+    assert (tmp_path / "imageset.txt").read_text() == "P0003__1__0___0"
+    # parse_gt: header lines skipped, 9 fields -> difficult 0
+    gt = tmp_path / "gt.txt"
+    gt.write_text("imagesource:GoogleEarth\ngsd:0.1\n1 2 3 4 5 6 7 8 plane 1\n1 2 3 4 5 6 7 8 ship\n")
+    objs = de.parse_gt(str(gt))
+    assert [o["difficult"] for o in objs] == [1, 0] and objs[1]["name"] == "ship" and objs[0]["bbox"][7] == 8.0
