@@ -42,7 +42,8 @@ class ConvParams(ctypes.Structure):
     _fields_ = [("n_images", c_i32), ("n_segs", c_i32), ("Cin", c_i32), ("Cout", c_i32),
                 ("KH", c_i32), ("KW", c_i32), ("stride", c_i32), ("pad", c_i32),
                 ("flags", c_u32), ("d_weight", c_void_p), ("d_bias", c_void_p),
-                ("d_gn_partial", c_void_p)]
+                ("d_gn_partial", c_void_p), ("d_in_gn_stats", c_void_p), ("d_in_gn_gamma", c_void_p),
+                ("d_in_gn_beta", c_void_p)]
 
 
 class GnSeg(ctypes.Structure):
@@ -73,6 +74,9 @@ SIGNATURES = {
     "dafne_conv2d_nhwc_bf16_hip": (c_int, [ctypes.POINTER(ConvParams), ctypes.POINTER(ConvSeg), c_void_p]),
     "dafne_conv2d_num_tiles": (c_int, [ctypes.POINTER(ConvParams), ctypes.POINTER(ConvSeg)]),
     "dafne_conv2d_kernel_id": (c_int, [ctypes.POINTER(ConvParams), ctypes.POINTER(ConvSeg)]),
+    "dafne_conv2d_tiles_per_image": (c_int, [ctypes.POINTER(ConvParams), ctypes.POINTER(ConvSeg), c_void_p]),
+    "dafne_groupnorm_finalize_hip": (c_int, [ctypes.POINTER(GnSeg), c_int, c_int, c_int, c_void_p, c_void_p,
+                                             ctypes.c_float, c_void_p]),
     "dafne_conv2d_cout_pad": (c_int, [c_int]),
     "dafne_conv2d_tile_pixels": (c_int, [ctypes.POINTER(ConvParams), ctypes.POINTER(ConvSeg)]),
     "dafne_preprocess_image_hip": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p,

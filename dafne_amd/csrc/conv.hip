@@ -43,8 +43,9 @@ struct SegDev {
     char* out;
     const char* res;
     int Hin, Win, Hout, Wout;
-    int tiles_per_img;   // ceil(Hout*Wout / BM)
+    int tiles_per_img;   // ceil(Hout*Wout / BM); patch kernel: tiles_x * ceil(Hout/8)
     int tile0;           // first M tile of this segment
+    int tiles_x;         // patch kernel: ceil(Wout/32)
 };
 
 struct ConvDev {
@@ -60,6 +61,10 @@ struct ConvDev {
     int mtiles, ntiles;
     int bn, bm;        // chosen tile
     int stem;          // 7x7 s2 stem on the 4-channel padded image
+    int patch;         // 3x3 patch kernel (2-D tiles)
+    const float* in_stats;   // GN_INPUT: [n_segs][N][Cin/8][2] mean, rstd of the input
+    const float* in_gamma;   //           [Cin]
+    const float* in_beta;    //           [Cin]
 };
 
 __device__ __forceinline__ unsigned short f2bf(float f) {
@@ -1255,6 +1260,393 @@ __global__ void __launch_bounds__(256, 2) conv_ws_kernel(ConvDev P) {
     }
 }
 
+// ---------------------------------------------------------------------------------------
+// 3x3 stride-1 convolution fed from an LDS-staged input PATCH (im2col inside LDS).
+//
+// The implicit-GEMM kernel above re-fetches the pixel operand once per tap: 9 x 32 KiB of
+// L2->LDS traffic per 64-channel slab and tile.  Here the output tile is a 2-D block of 8 rows x
+// 32 columns, and the (8+2) x (32+2) input pixels it needs are DMA'd ONCE per slab into LDS
+// (43 KiB, double-buffered across slabs); the nine taps read their B fragments straight out of
+// that patch at a tap-dependent row offset.  Per K step the L2->LDS volume drops from 64 KiB to
+// 32 KiB (weights) + 4.8 KiB (patch share), and the LDS-DMA write traffic with it -- this tile
+// shape sits at the L2->CU ingest and LDS bandwidth limits otherwise.
+//   * patch row p = (py, px) holds 64 channels (128 B), XOR-swizzled by (px>>1)&7 on the SOURCE side
+//     of the DMA: a B-fragment read (32 consecutive px of one patch line) is bank-conflict free;
+//   * weights stream exactly like in the 8-wave loop above (half-K pieces, counted vmcnt, two wave
+//     groups one phase apart), one piece per wave and phase; the 6 patch pieces of the NEXT slab
+//     ride along in taps 0..5 and are added to the allowed-outstanding count of the waits;
+//   * GN_INPUT: the input is the RAW output of the previous tower convolution; its GroupNorm + ReLU
+//     (dafne.py:330-344) is applied to the patch in LDS, once per slab, by the wave that loaded the
+//     piece (halo / out-of-image pixels stay zero: padding follows the activation).  This removes the
+//     separate normalisation pass (read + write of the whole map) between tower convolutions.
+constexpr int kPH = 8, kPW = 32;
+constexpr int kPCols = kPW + 2;
+constexpr int kPRows = (kPH + 2) * kPCols;      // 340 input pixels
+constexpr int kPPieces = (kPRows + 7) / 8;      // 43 DMA pieces of 8 pixels x 128 B
+constexpr int kPBuf = kPPieces * 1024;
+constexpr int kPAHalf = 256 * 64;               // weights of half a K step: 256 rows x 64 B
+constexpr int kPAStage = 2 * kPAHalf;
+constexpr int kPOffPatch = 2 * kPAStage;
+constexpr int kPOffTab = kPOffPatch + 2 * kPBuf;
+constexpr int kPTabMaxC = 512;
+constexpr int kPSmem = kPOffTab + kPTabMaxC * 9;   // stats [C/8][2] + gamma [C] + beta [C]
+
+template <bool GNIN>
+__global__ void __launch_bounds__(512) conv3x3_patch_kernel(ConvDev P) {
+    constexpr int NW = 8, WP = 2, TC = 2, TP = 4, BN = 256, BM = 256, NT = 512;
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wc = wave / WP, wp = wave % WP;
+    const int grp = wave >> 2;
+    const int frow = lane & 31, half = lane >> 5;
+
+    const int T = P.mtiles * P.ntiles;
+    const int bid = xcd_remap(blockIdx.x, T);
+    const int nt = bid % P.ntiles;
+    const int mt = bid / P.ntiles;
+    int si = 0;
+#pragma unroll
+    for (int k = 1; k < kMaxSegs; k++)
+        if (k < P.n_segs && mt >= P.seg[k].tile0) si = k;
+    const SegDev& S = P.seg[si];
+    const int tloc = mt - S.tile0;
+    const int img = tloc / S.tiles_per_img;
+    const int tt = tloc - img * S.tiles_per_img;
+    const int ty = tt / S.tiles_x, tx = tt - ty * S.tiles_x;
+    const int Y0 = ty * kPH, X0 = tx * kPW;
+    const int H = S.Hout, W = S.Wout, Hp = H + 2, Wp = W + 2;
+    const int K = P.ksteps;                 // 9 * Cin/64
+    const int nslab = P.Cin / kBK;
+
+    // ---- GroupNorm table of this image (input side) -> LDS, before any DMA is in flight
+    float* tab_stats = (float*)(lds + kPOffTab);
+    float* tab_gamma = tab_stats + P.Cin / 4;
+    float* tab_beta = tab_gamma + P.Cin;
+    if (GNIN) {
+        const float* st = P.in_stats + ((size_t)si * P.N + img) * (P.Cin / 8) * 2;
+        for (int k = tid; k < P.Cin / 4; k += NT) tab_stats[k] = st[k];
+        for (int k = tid; k < P.Cin; k += NT) {
+            tab_gamma[k] = P.in_gamma[k];
+            tab_beta[k] = P.in_beta[k];
+        }
+        __syncthreads();
+    }
+    const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) char*)lds;
+
+    // ---- per-lane source offsets ------------------------------------------------------------
+    unsigned hofs[2];                      // weight rows of this wave's two pieces per K half
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+        const int r = (i * NW + wave) * 16 + (lane >> 2);
+        const int q = (lane & 3) ^ ((r >> 2) & 3);
+        hofs[i] = (unsigned)(nt * BN + r) * (unsigned)P.kbytes + (unsigned)q * 16u;
+    }
+    unsigned pofs[6];                      // patch pixels of this wave's six pieces per slab
+    int ppi[6];
+#pragma unroll
+    for (int i = 0; i < 6; i++) {
+        int pi = i * NW + wave;
+        if (pi >= kPPieces) pi -= NW;      // pieces 43..47: the wave re-fetches its previous piece
+        ppi[i] = pi;
+        int r = pi * 8 + (lane >> 3);
+        r = r < kPRows ? r : kPRows - 1;
+        const int py = r / kPCols, px = r - py * kPCols;
+        int gy = Y0 + py, gx = X0 + px;
+        gy = gy < Hp ? gy : Hp - 1;
+        gx = gx < Wp ? gx : Wp - 1;
+        const int q = (lane & 7) ^ ((px >> 1) & 7);
+        pofs[i] = ((unsigned)(img * Hp + gy) * (unsigned)Wp + (unsigned)gx) * (unsigned)(P.Cin * 2) + (unsigned)q * 16u;
+    }
+    // B-fragment offsets inside a patch line: pixel column frow+kw, chunk (2ks+half) ^ swizzle
+    unsigned boff[3][4];
+#pragma unroll
+    for (int kw = 0; kw < 3; kw++)
+#pragma unroll
+        for (int ks = 0; ks < 4; ks++)
+            boff[kw][ks] = (unsigned)(frow + kw) * 128u + (unsigned)(((2 * ks + half) ^ (((frow + kw) >> 1) & 7)) * 16);
+    const int fsw4 = (frow >> 2) & 3;
+    unsigned hroff[2];
+#pragma unroll
+    for (int k2 = 0; k2 < 2; k2++) hroff[k2] = (unsigned)frow * 64u + (unsigned)(((2 * k2 + half) ^ fsw4) * 16);
+    const int arow0 = wc * TC * 32;
+
+    // Weight half-steps are walked in the order u = ((slab*3 + kw)*2 + half)*3 + kh: the three kh taps of
+    // one (kw, K half) are consecutive, so the B fragments of 6 patch lines are read ONCE and serve all
+    // three (fragment reads per MFMA: 0.75 -> 0.5; this loop is LDS-read bound).  4 half-step buffers.
+    const int U = 2 * K;                    // half-steps in total
+    auto piece_a = [&](int u, int i) {
+        if (u >= U) return;
+        const int kh = u % 3, g = u / 3;
+        const int h = g & 1, g2 = g >> 1;
+        const int kw = g2 % 3, sl = g2 / 3;
+        const unsigned koff = (unsigned)((sl * 9 + kh * 3 + kw) * kRowBytes + h * 64);
+        char* dst = lds + (u & 3) * kPAHalf + (i * NW + wave) * 1024;
+        __builtin_amdgcn_global_load_lds((gvoid*)(P.w + hofs[i] + koff), (lvoid*)dst, 16, 0, 0);
+    };
+    auto piece_p = [&](int slab, int i) {
+        char* dst = lds + kPOffPatch + (slab & 1) * kPBuf + ppi[i] * 1024;
+        __builtin_amdgcn_global_load_lds((gvoid*)(S.in + pofs[i] + (unsigned)slab * 128u), (lvoid*)dst, 16, 0, 0);
+    };
+    // GroupNorm + ReLU of one landed patch piece, in place (inline-asm LDS ops: see conv_ws_kernel).
+    // A lane always handles LOGICAL chunk lane&7 (8 channels = one group) of pixel row lane>>3 of the piece --
+    // wherever the swizzle put it -- so mean / rstd / gamma / beta are per-lane constants of the slab
+    // of the slab.
+    // The constants are re-read from the LDS table in front of every pair of pieces (5 LDS reads): they
+    // are live only in the head of a read phase, where the A/B fragment registers are dead.
+    auto gn_pieces = [&](int slab, int i0, int n) {
+        const int ch = slab * kBK + (lane & 7) * 8;
+        const unsigned ts = lds_base + (unsigned)(kPOffTab + (ch >> 3) * 8);
+        const unsigned tg = lds_base + (unsigned)(kPOffTab + P.Cin + ch * 4);
+        const unsigned tb = tg + (unsigned)P.Cin * 4u;
+        u32x2 ms;
+        f32x4 g0, g1, b0, b1;
+        asm volatile("ds_read_b64 %0, %5\n\tds_read_b128 %1, %6\n\tds_read_b128 %2, %6 offset:16\n\t"
+                     "ds_read_b128 %3, %7\n\tds_read_b128 %4, %7 offset:16\n\ts_waitcnt lgkmcnt(0)"
+                     : "=&v"(ms), "=&v"(g0), "=&v"(g1), "=&v"(b0), "=&v"(b1)
+                     : "v"(ts), "v"(tg), "v"(tb)
+                     : "memory");
+        const float gmean = __uint_as_float(ms.x), grstd = __uint_as_float(ms.y);
+        const float gam[8] = {g0[0], g0[1], g0[2], g0[3], g1[0], g1[1], g1[2], g1[3]};
+        const float bet[8] = {b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]};
+        for (int i = i0; i < i0 + n; i++) {
+            if (i == 5 && 5 * NW + wave >= kPPieces) continue;        // duplicate of piece i = 4
+            const int pi = ppi[i];
+            const int r = pi * 8 + (lane >> 3);
+            const int py = r / kPCols, px = r - py * kPCols;
+            const int gy = Y0 + py, gx = X0 + px;
+            const bool inside = gy >= 1 && gy <= H && gx >= 1 && gx <= W && r < kPRows;
+            const int phys = (lane & 7) ^ ((px >> 1) & 7);
+            const unsigned ad = lds_base + (unsigned)(kPOffPatch + (slab & 1) * kPBuf + pi * 1024 + (lane >> 3) * 128 + phys * 16);
+            u32x4 v;
+            asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(v) : "v"(ad) : "memory");
+            const unsigned u[4] = {v.x, v.y, v.z, v.w};
+            float y[8];
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                const float x = bf2f((unsigned short)(k & 1 ? u[k >> 1] >> 16 : u[k >> 1] & 0xffff));
+                y[k] = fmaxf((x - gmean) * grstd * gam[k] + bet[k], 0.f);      // expression of gn_apply_kernel
+            }
+            u32x4 o;
+            o.x = inside ? pack_bf16(y[0], y[1]) : 0u;
+            o.y = inside ? pack_bf16(y[2], y[3]) : 0u;
+            o.z = inside ? pack_bf16(y[4], y[5]) : 0u;
+            o.w = inside ? pack_bf16(y[6], y[7]) : 0u;
+            asm volatile("ds_write_b128 %0, %1" ::"v"(ad), "v"(o) : "memory");
+        }
+    };
+
+    f32x16 acc[TC][TP];
+#pragma unroll
+    for (int a = 0; a < TC; a++)
+#pragma unroll
+        for (int b = 0; b < TP; b++)
+#pragma unroll
+            for (int k = 0; k < 16; k++) acc[a][b][k] = 0.f;
+    bf16x8 af[2][TC], bfr[2][TP + 2];
+    auto read_a = [&](int u) {
+        const char* sb = lds + (u & 3) * kPAHalf;
+#pragma unroll
+        for (int k2 = 0; k2 < 2; k2++)
+#pragma unroll
+            for (int a = 0; a < TC; a++) af[k2][a] = *(const bf16x8*)(sb + (arow0 + a * 32) * 64 + hroff[k2]);
+    };
+    auto read_b6 = [&](int slab, int kw, int h) {      // patch lines wp*4 .. wp*4+5 at column offset kw
+        const char* pb = lds + kPOffPatch + (slab & 1) * kPBuf;
+#pragma unroll
+        for (int k2 = 0; k2 < 2; k2++)
+#pragma unroll
+            for (int rr = 0; rr < TP + 2; rr++)
+                bfr[k2][rr] = *(const bf16x8*)(pb + ((wp * TP + rr) * kPCols) * 128 + boff[kw][2 * h + k2]);
+    };
+    auto mma16 = [&](int kh) {
+#pragma unroll
+        for (int k2 = 0; k2 < 2; k2++)
+#pragma unroll
+            for (int a = 0; a < TC; a++)
+#pragma unroll
+                for (int b = 0; b < TP; b++)
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[k2][a], bfr[k2][b + kh], acc[a][b], 0, 0, 0);
+    };
+    // one weight piece per wave and phase; odd phases wait: the 4 youngest weight pieces (+1 patch piece
+    // when one was issued within the last 4 phases) may stay in flight across the barrier
+    auto phase_end = [&](bool odd, int t, bool patch_in_window) {
+        if (odd) {
+            if (t <= 4 * K - 7) {
+                if (patch_in_window) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            } else {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+    };
+
+    // ---- prologue: patch of slab 0, weights of half-steps 0..2 ------------------------------------------
+#pragma unroll
+    for (int i = 0; i < 6; i++) piece_p(0, i);
+    piece_a(0, 0); piece_a(0, 1); piece_a(1, 0); piece_a(1, 1); piece_a(2, 0); piece_a(2, 1);
+    if (GNIN) {
+        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");      // this wave's patch pieces have landed
+        gn_pieces(0, 0, 6);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");          // half-step 0 is complete
+    phase_end(false, -1, false);
+
+    // Global phase t = 2 u + p (u = half-step, p = 0: fragment reads of group 0 / MFMAs of group 1,
+    // p = 1: the reverse) issues weight piece p of half-step u + 3.  Patch pieces of slab+1: one at p = 0
+    // of half-steps 0, 2, .., 10 of the slab (all landed by the wait that ends half-step 12); their
+    // GroupNorm runs in the read phases of half-steps 13, 14, 15.
+    // G = (kw, half): half-steps 3G .. 3G+2 = kh 0..2; UU = 3G is the half-step index inside the slab.
+#define PATCH_HS_G0(UU, KW_, H_, KH_)                                                                        \
+    {                                                                                                        \
+        const int u = slab * 18 + (UU);                                                                      \
+        const bool pw = more && (UU) <= 11;                                                                  \
+        piece_a(u + 3, 0);                                                                                   \
+        if (more && (UU) <= 10 && ((UU) & 1) == 0) piece_p(slab + 1, (UU) / 2 <= 5 ? (UU) / 2 : 0);          \
+        if (GNIN && more && (UU) >= 13 && (UU) <= 15) gn_pieces(slab + 1, 2 * ((UU) - 13), 2);               \
+        read_a(u);                                                                                           \
+        if ((KH_) == 0) read_b6(slab, KW_, H_);                                                              \
+        phase_end(false, 2 * u, pw);                                                                         \
+        piece_a(u + 3, 1);                                                                                   \
+        mma16(KH_);                                                                                          \
+        phase_end(true, 2 * u + 1, pw);                                                                      \
+    }
+    // group 1 runs one phase behind: reads in p = 1 of half-step u, MFMAs in p = 0 of half-step u + 1
+#define PATCH_HS_G1(UU, KW_, H_, KH_)                                                                        \
+    {                                                                                                        \
+        const int u = slab * 18 + (UU);                                                                      \
+        const bool pw = more && (UU) <= 11;                                                                  \
+        piece_a(u + 3, 1);                                                                                   \
+        if (GNIN && more && (UU) >= 13 && (UU) <= 15) gn_pieces(slab + 1, 2 * ((UU) - 13), 2);               \
+        read_a(u);                                                                                           \
+        if ((KH_) == 0) read_b6(slab, KW_, H_);                                                              \
+        phase_end(true, 2 * u + 1, pw);                                                                      \
+        piece_a(u + 4, 0);                                                                                   \
+        {                                                                                                    \
+            const bool nxt_patch = (UU) < 17 ? (more && (UU) + 1 <= 10 && (((UU) + 1) & 1) == 0) : (slab + 2 < nslab); \
+            if (nxt_patch) piece_p((UU) < 17 ? slab + 1 : slab + 2, (UU) < 17 ? (((UU) + 1) / 2 <= 5 ? ((UU) + 1) / 2 : 0) : 0); \
+            const bool pwn = (UU) < 17 ? (more && (UU) + 1 <= 11) : (slab + 2 < nslab);                      \
+            mma16(KH_);                                                                                      \
+            if (u + 1 < U) phase_end(false, 2 * u + 2, pwn);                                                 \
+        }                                                                                                    \
+    }
+#define PATCH_SLAB(M)                                                                                        \
+    M(0, 0, 0, 0) M(1, 0, 0, 1) M(2, 0, 0, 2) M(3, 0, 1, 0) M(4, 0, 1, 1) M(5, 0, 1, 2)                      \
+    M(6, 1, 0, 0) M(7, 1, 0, 1) M(8, 1, 0, 2) M(9, 1, 1, 0) M(10, 1, 1, 1) M(11, 1, 1, 2)                    \
+    M(12, 2, 0, 0) M(13, 2, 0, 1) M(14, 2, 0, 2) M(15, 2, 1, 0) M(16, 2, 1, 1) M(17, 2, 1, 2)
+    if (grp == 0) {
+        for (int slab = 0; slab < nslab; slab++) {
+            const bool more = slab + 1 < nslab;
+            PATCH_SLAB(PATCH_HS_G0)
+        }
+    } else {
+        // phase 0 of the whole loop: this group idles one phase (issues its share of the loads only)
+        piece_a(3, 0);
+        if (nslab > 1) piece_p(1, 0);
+        phase_end(false, 0, nslab > 1);
+        for (int slab = 0; slab < nslab; slab++) {
+            const bool more = slab + 1 < nslab;
+            PATCH_SLAB(PATCH_HS_G1)
+        }
+    }
+#undef PATCH_SLAB
+#undef PATCH_HS_G0
+#undef PATCH_HS_G1
+
+    // ------------------------------------------------------------ epilogue (bias, ReLU, GN sums, bf16)
+    const bool relu = P.flags & DAFNE_CONV_RELU;
+    const bool gn = P.flags & DAFNE_CONV_GN_STATS;
+    constexpr int ROWB = BN * 2 + 16;
+    constexpr int CHB = BN / 8;
+    char* stg = lds;
+    float4 bia4[TC][4];
+#pragma unroll
+    for (int a = 0; a < TC; a++)
+#pragma unroll
+        for (int g = 0; g < 4; g++)
+            bia4[a][g] = P.bias ? *(const float4*)(P.bias + nt * BN + (wc * TC + a) * 32 + 8 * g + 4 * half)
+                                : make_float4(0.f, 0.f, 0.f, 0.f);
+    float gsum[TC][4], gsq[TC][4];
+#pragma unroll
+    for (int a = 0; a < TC; a++)
+#pragma unroll
+        for (int g = 0; g < 4; g++) gsum[a][g] = gsq[a][g] = 0.f;
+    __syncthreads();   // every wave is done with the weight stages and the patch
+#pragma unroll
+    for (int b = 0; b < TP; b++) {
+        const int px = (wp * TP + b) * 32 + frow;
+        const bool valid = (Y0 + wp * TP + b) < H && (X0 + frow) < W;
+#pragma unroll
+        for (int a = 0; a < TC; a++)
+#pragma unroll
+            for (int g = 0; g < 4; g++) {
+                float v0 = acc[a][b][4 * g] + bia4[a][g].x, v1 = acc[a][b][4 * g + 1] + bia4[a][g].y;
+                float v2 = acc[a][b][4 * g + 2] + bia4[a][g].z, v3 = acc[a][b][4 * g + 3] + bia4[a][g].w;
+                if (relu) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f); }
+                if (gn && valid) {
+                    gsum[a][g] += (v0 + v1) + (v2 + v3);
+                    gsq[a][g] += (v0 * v0 + v1 * v1) + (v2 * v2 + v3 * v3);
+                }
+                uint2 pk;
+                pk.x = pack_bf16(v0, v1);
+                pk.y = pack_bf16(v2, v3);
+                const int co = (wc * TC + a) * 32 + 8 * g + 4 * half;
+                *(uint2*)(stg + px * ROWB + co * 2) = pk;
+            }
+    }
+    float* redb = (float*)(lds + BM * ROWB);   // [NW][TC*4][2]
+    if (gn) {
+#pragma unroll
+        for (int a = 0; a < TC; a++)
+#pragma unroll
+            for (int g = 0; g < 4; g++) {
+                float sv = gsum[a][g], qv = gsq[a][g];
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) {
+                    sv += __shfl_xor(sv, o, 64);
+                    qv += __shfl_xor(qv, o, 64);
+                }
+                if (lane == 0) {
+                    redb[(wave * TC * 4 + a * 4 + g) * 2 + 0] = sv;
+                    redb[(wave * TC * 4 + a * 4 + g) * 2 + 1] = qv;
+                }
+            }
+    }
+    __syncthreads();
+    if (gn && tid < BN / 8) {
+        const int wcc = tid / (TC * 4), ag = tid % (TC * 4);
+        float sv = 0.f, qv = 0.f;
+#pragma unroll
+        for (int p2 = 0; p2 < WP; p2++) {
+            sv += redb[((wcc * WP + p2) * TC * 4 + ag) * 2 + 0];
+            qv += redb[((wcc * WP + p2) * TC * 4 + ag) * 2 + 1];
+        }
+        const int group = (nt * BN) / 8 + tid;
+        if (group < P.Cout / 8) {
+            float* o = P.gn_partial + ((size_t)mt * (P.Cout / 8) + group) * 2;
+            o[0] = sv;
+            o[1] = qv;
+        }
+    }
+    constexpr int CPT = BM * CHB / NT;       // 16-byte chunks per thread
+#pragma unroll
+    for (int i = 0; i < CPT; i++) {
+        const int idx = tid + i * NT;
+        const int p = idx / CHB, cc = idx - p * CHB;
+        const int gy = Y0 + (p >> 5), gx = X0 + (p & 31);
+        if (gy < H && gx < W) {
+            const size_t opix = (size_t)(img * Hp + gy + 1) * Wp + gx + 1;
+            const uint4 v = *(const uint4*)(stg + p * ROWB + cc * 16);
+            *(uint4*)(S.out + (opix * P.Cout + nt * BN + cc * 8) * 2) = v;
+        }
+    }
+}
+
 struct Cfg {
     int bn, bm;
 };
@@ -1270,6 +1662,24 @@ Cfg pick_cfg(int Cout, long long blocks256 = 0, unsigned flags = 0) {
     if (Cout >= 128) return {128, 128};
     if (Cout > 32) return {64, 256};
     return {32, 256};
+}
+
+// 3x3 / stride 1 / pad 1 layers with Cout % 256 == 0 and a plain bf16 output go to the patch kernel when
+// the launch has enough 8x32 tiles to fill the chip (the head towers, the FPN output convolutions).
+bool patch_eligible(const dafne_conv_params* p, const dafne_conv_seg* segs) {
+    static const int mode = getenv("DAFNE_CONV_PATCH") ? atoi(getenv("DAFNE_CONV_PATCH")) : 1;
+    if (!mode) return false;
+    if (p->KH != 3 || p->KW != 3 || p->stride != 1 || p->pad != 1) return false;
+    if (p->Cin % kBK || p->Cout % 256 || !p->d_bias) return false;
+    if (p->flags & (DAFNE_CONV_RESIDUAL | DAFNE_CONV_UPSAMPLE_ADD | DAFNE_CONV_OUT_F32)) return false;
+    if ((p->flags & DAFNE_CONV_GN_INPUT) && p->Cin > kPTabMaxC) return false;
+    long long tiles = 0;
+    for (int s = 0; s < p->n_segs; s++) {
+        if (segs[s].Hin != segs[s].Hout || segs[s].Win != segs[s].Wout) return false;
+        tiles += (long long)((segs[s].Hout + kPH - 1) / kPH) * ((segs[s].Wout + kPW - 1) / kPW) * p->n_images;
+    }
+    static const long long min_tiles = getenv("DAFNE_CONV_PATCH_MIN_TILES") ? atoll(getenv("DAFNE_CONV_PATCH_MIN_TILES")) : 200;
+    return (p->flags & DAFNE_CONV_GN_INPUT) || tiles * (p->Cout / 256) >= min_tiles;
 }
 
 int build(ConvDev& D, const dafne_conv_params* p, const dafne_conv_seg* segs) {
@@ -1302,6 +1712,18 @@ int build(ConvDev& D, const dafne_conv_params* p, const dafne_conv_seg* segs) {
     D.stem = stem ? 1 : 0;
     D.ksteps = stem ? 4 : p->KH * p->KW * p->Cin / kBK;
     D.kbytes = D.ksteps * kRowBytes;
+    D.in_stats = p->d_in_gn_stats; D.in_gamma = p->d_in_gn_gamma; D.in_beta = p->d_in_gn_beta;
+    D.patch = patch_eligible(p, segs) ? 1 : 0;
+    if ((p->flags & DAFNE_CONV_GN_INPUT) && !D.patch)
+        return dafne::fail(DAFNE_E_UNSUPPORTED, "conv: GN_INPUT needs the 3x3 patch kernel (3x3 s1 p1, Cout %% 256 == 0, Cin <= 512, bias, "
+                                                "no residual / fp32 output, enough tiles)");
+    if ((p->flags & DAFNE_CONV_GN_INPUT) && (!p->d_in_gn_stats || !p->d_in_gn_gamma || !p->d_in_gn_beta))
+        return dafne::fail(DAFNE_E_INVALID, "conv: GN_INPUT without statistics / affine pointers");
+    if (D.patch) {
+        D.bn = 256; D.bm = 256;
+        D.Cout_pad = p->Cout;
+        c.bn = 256; c.bm = 256;
+    }
     int t = 0;
     for (int s = 0; s < p->n_segs; s++) {
         const dafne_conv_seg& g = segs[s];
@@ -1318,7 +1740,8 @@ int build(ConvDev& D, const dafne_conv_params* p, const dafne_conv_seg* segs) {
         SegDev& o = D.seg[s];
         o.in = (const char*)g.d_in; o.out = (char*)g.d_out; o.res = (const char*)g.d_res;
         o.Hin = g.Hin; o.Win = g.Win; o.Hout = g.Hout; o.Wout = g.Wout;
-        o.tiles_per_img = (g.Hout * g.Wout + c.bm - 1) / c.bm;
+        o.tiles_x = (g.Wout + kPW - 1) / kPW;
+        o.tiles_per_img = D.patch ? o.tiles_x * ((g.Hout + kPH - 1) / kPH) : (g.Hout * g.Wout + c.bm - 1) / c.bm;
         o.tile0 = t;
         t += o.tiles_per_img * p->n_images;
     }
@@ -1360,6 +1783,19 @@ bool stream_eligible(const ConvDev& D) {
     // 700 vs 860 TFLOP/s on res4): only mode 1 (experiments) sends them here
     if (mode == 2 && (D.KH != 1 || D.Cin > 512)) return false;   // K >= 1024: the one-tile kernel is ahead (29 vs 32 us)
     return true;
+}
+
+int launch_patch(const ConvDev& D, hipStream_t st) {
+    static bool attr_done = false;
+    if (!attr_done) {
+        DAFNE_HIP_TRY(hipFuncSetAttribute((const void*)conv3x3_patch_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, kPSmem));
+        DAFNE_HIP_TRY(hipFuncSetAttribute((const void*)conv3x3_patch_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, kPSmem));
+        attr_done = true;
+    }
+    const dim3 grid(D.mtiles * D.ntiles), block(512);
+    if (D.flags & DAFNE_CONV_GN_INPUT) hipLaunchKernelGGL(conv3x3_patch_kernel<true>, grid, block, kPSmem, st, D);
+    else hipLaunchKernelGGL(conv3x3_patch_kernel<false>, grid, block, kPSmem, st, D);
+    return dafne::check_launch("conv3x3_patch");
 }
 
 bool ws_eligible(const ConvDev& D) {
@@ -1440,9 +1876,19 @@ int dafne_conv2d_num_tiles(const dafne_conv_params* prm, const dafne_conv_seg* s
     return D.mtiles;
 }
 
+int dafne_conv2d_tiles_per_image(const dafne_conv_params* prm, const dafne_conv_seg* segs, int32_t* out) {
+    ConvDev D;
+    int rc = build(D, prm, segs);
+    if (rc) return rc;
+    if (!out) return dafne::fail(DAFNE_E_INVALID, "conv: null output");
+    for (int s = 0; s < D.n_segs; s++) out[s] = D.seg[s].tiles_per_img;
+    return DAFNE_OK;
+}
+
 int dafne_conv2d_kernel_id(const dafne_conv_params* prm, const dafne_conv_seg* segs) {
     ConvDev D;
     if (build(D, prm, segs)) return -1;
+    if (D.patch) return 6;
     if (stream_eligible(D)) return ws_eligible(D) ? 5 : 4;
     return D.bn == 256 ? 3 : D.bn == 128 ? 2 : D.bn == 64 ? 1 : 0;
 }
@@ -1452,6 +1898,7 @@ int dafne_conv2d_nhwc_bf16_hip(const dafne_conv_params* prm, const dafne_conv_se
     int rc = build(D, prm, segs);
     if (rc) return rc;
     hipStream_t st = (hipStream_t)stream;
+    if (D.patch) return launch_patch(D, st);
     if (stream_eligible(D)) {
         if (ws_eligible(D)) return launch_ws(D, st);
         return launch_stream(D, st);

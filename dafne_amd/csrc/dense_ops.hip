@@ -238,6 +238,22 @@ int dafne_maxpool3x3s2_nhwc_bf16_hip(const void* d_in, void* d_out, int n_images
     return dafne::check_launch("maxpool");
 }
 
+int dafne_groupnorm_finalize_hip(const dafne_gn_seg* segs, int n_segs, int n_images, int C, const float* d_partial,
+                                 float* d_stats, float eps, void* stream) {
+    if (!segs || n_segs < 1 || n_segs > 5 || n_images < 1 || (C % 8) || !d_partial || !d_stats)
+        return dafne::fail(DAFNE_E_INVALID, "groupnorm_finalize: bad args");
+    GnDev D;
+    D.n_segs = n_segs; D.N = n_images; D.C = C; D.partial = d_partial; D.stats = d_stats;
+    D.gamma = nullptr; D.beta = nullptr; D.eps = eps;
+    for (int s = 0; s < n_segs; s++) {
+        if (segs[s].H < 1 || segs[s].W < 1) return dafne::fail(DAFNE_E_INVALID, "groupnorm_finalize: segment %d", s);
+        D.seg[s].x = (char*)segs[s].d_x; D.seg[s].H = segs[s].H; D.seg[s].W = segs[s].W;
+        D.seg[s].tile0 = segs[s].tile0; D.seg[s].tiles_per_img = segs[s].tiles_per_img;
+    }
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3(n_segs * n_images), dim3(256), 0, (hipStream_t)stream, D);
+    return dafne::check_launch("gn_finalize");
+}
+
 int dafne_groupnorm_relu_nhwc_bf16_hip(const dafne_gn_seg* segs, int n_segs, int n_images, int C,
                                        const float* d_partial, float* d_stats, const float* d_gamma,
                                        const float* d_beta, float eps, void* stream) {

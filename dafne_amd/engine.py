@@ -11,6 +11,7 @@ dafne/modeling/backbone/fpn.py:16-37,58-91 and dafne/modeling/dafne/dafne.py:
 350-494 (center-to-corner branch).
 """
 import ctypes
+import os
 
 import torch
 
@@ -19,7 +20,7 @@ from . import _lib
 BF16 = torch.bfloat16
 STAGE_BLOCKS = {50: (3, 4, 6, 3), 101: (3, 4, 23, 3)}
 
-F_RELU, F_RES, F_UP, F_F32, F_GN = 1, 2, 4, 8, 16
+F_RELU, F_RES, F_UP, F_F32, F_GN, F_GNIN = 1, 2, 4, 8, 16, 32
 
 
 # ------------------------------------------------------------------ activations
@@ -99,12 +100,15 @@ def fold_frozen_bn(weight, bn_w, bn_b, bn_mean, bn_var, eps=1e-5):
 class ConvCall:
     """One dafne_conv2d_nhwc_bf16_hip launch with its argument structs kept alive."""
 
-    def __init__(self, w, b, cin, cout, k, stride, pad, flags, segs, n_images, gn_partial=None):
+    def __init__(self, w, b, cin, cout, k, stride, pad, flags, segs, n_images, gn_partial=None, gn_in=None):
+        """gn_in: (stats [n_segs,N,Cin/8,2], gamma [Cin], beta [Cin]) of the INPUT maps when they hold the raw
+        output of the previous tower convolution (flag F_GNIN: GroupNorm + ReLU applied on load)."""
         L = _lib.load()
-        self.keep = (w, b, gn_partial, [s for s in segs])
+        self.keep = (w, b, gn_partial, [s for s in segs], gn_in)
+        gi = [t.data_ptr() for t in gn_in] if gn_in is not None else [None, None, None]
         self.prm = _lib.ConvParams(n_images, len(segs), cin, cout, k, k, stride, pad, flags,
                                    w.data_ptr(), b.data_ptr() if b is not None else None,
-                                   gn_partial.data_ptr() if gn_partial is not None else None)
+                                   gn_partial.data_ptr() if gn_partial is not None else None, gi[0], gi[1], gi[2])
         arr = (_lib.ConvSeg * len(segs))()
         for i, (tin, tout, tres, hin, win, hout, wout) in enumerate(segs):
             arr[i] = _lib.ConvSeg(tin.data_ptr(), tout.data_ptr(), tres.data_ptr() if tres is not None else None,
@@ -123,11 +127,21 @@ class ConvCall:
         return _lib.load().dafne_conv2d_tile_pixels(ctypes.byref(self.prm), self.segs)
 
     KERNEL_NAMES = ("conv_igemm<1,4,1,2>", "conv_igemm<1,4,2,2>", "conv_igemm<2,2,2,2>", "conv_igemm<4,2,2,4>",
-                    "conv_stream", "conv_ws")
+                    "conv_stream", "conv_ws", "conv3x3_patch")
+
+    def kernel_id(self):
+        """-1 when the library cannot run this call (e.g. F_GNIN on a layer the patch kernel does not take)."""
+        return _lib.load().dafne_conv2d_kernel_id(ctypes.byref(self.prm), self.segs)
 
     def kernel_name(self):
         """The HIP kernel this call dispatches to (conv.hip), for per-kernel attribution in bench.py."""
-        return self.KERNEL_NAMES[_lib.load().dafne_conv2d_kernel_id(ctypes.byref(self.prm), self.segs)]
+        return self.KERNEL_NAMES[self.kernel_id()]
+
+    def tiles_per_image(self):
+        out = (ctypes.c_int32 * self.prm.n_segs)()
+        _lib.check(_lib.load().dafne_conv2d_tiles_per_image(ctypes.byref(self.prm), self.segs, out),
+                   "dafne_conv2d_tiles_per_image")
+        return list(out)
 
     def __call__(self, stream):
         rc = self.fn(ctypes.byref(self.prm), self.segs, stream)
@@ -298,40 +312,57 @@ class HeadPlan:
         C = feats[0].c
         self.num_classes = num_classes
         calls = plan.calls
+        fuse_gn = os.environ.get("DAFNE_FUSE_GN", "1") != "0"
 
         def seg_list(ins, outs, f32=False):
             return [(i.t, (o if f32 else o.t), None, i.h, i.w, i.h, i.w) for i, o in zip(ins, outs)]
 
         def tower(name, ins):
-            cur = ins
+            """4 x [conv3x3 -> GroupNorm(32) -> ReLU].  When the library's 3x3 patch kernel takes the layer
+            (kernel id 6 with F_GNIN), the GroupNorm + ReLU of layer i is applied by layer i+1 while it loads
+            its input patch: only the statistics are finalised between the two convolutions, and the separate
+            normalisation pass (a read + write of all five levels) disappears for 3 of the 4 layers."""
+            cur, cur_gn = ins, None
             for i in range(4):
                 wgt, bias = P["%s.%d" % (name, 3 * i)]
                 gamma, beta = P["%s.%d.gn" % (name, 3 * i + 1)]
                 outs = [pool.get(n, f.h, f.w, C) for f in cur]
-                # M-tile count comes from the library (the kernel config picks the tile size)
-                probe = ConvCall(wgt, bias, C, C, 3, 1, 1, 0, seg_list(cur, outs), n)
+                flags = F_GN | (F_GNIN if cur_gn is not None else 0)
+                # M-tile geometry comes from the library (the kernel choice fixes the tile shape)
+                probe = ConvCall(wgt, bias, C, C, 3, 1, 1, flags & ~F_GN, seg_list(cur, outs), n, gn_in=cur_gn)
                 nt = probe.num_tiles()
                 partial = torch.empty(nt, C // 8, 2, dtype=torch.float32, device=device)
-                c = ConvCall(wgt, bias, C, C, 3, 1, 1, F_GN, seg_list(cur, outs), n, gn_partial=partial)
+                c = ConvCall(wgt, bias, C, C, 3, 1, 1, flags, seg_list(cur, outs), n, gn_partial=partial, gn_in=cur_gn)
                 calls.append(c)
                 plan.flops += c.flops
                 stats = torch.empty(len(outs), n, C // 8, 2, dtype=torch.float32, device=device)
                 gsegs = (_lib.GnSeg * len(outs))()
                 t0 = 0
-                bm = probe.tile_pixels()
-                for k, o in enumerate(outs):
-                    tpi = (o.h * o.w + bm - 1) // bm
+                for k, (o, tpi) in enumerate(zip(outs, c.tiles_per_image())):
                     gsegs[k] = _lib.GnSeg(o.t.data_ptr(), o.h, o.w, t0, tpi)
                     t0 += tpi * n
                 assert t0 == nt == c.num_tiles()
-                calls.append(FnCall(L.dafne_groupnorm_relu_nhwc_bf16_hip,
-                                    (gsegs, len(outs), n, C, _lib.ptr(partial), _lib.ptr(stats), _lib.ptr(gamma),
-                                     _lib.ptr(beta), ctypes.c_float(1e-5)), (outs, partial, stats, gamma, beta),
-                                    "groupnorm"))
+                fuse_next = False
+                if i < 3 and fuse_gn:
+                    wn, bn_ = P["%s.%d" % (name, 3 * (i + 1))]
+                    nxt = ConvCall(wn, bn_, C, C, 3, 1, 1, F_GNIN, seg_list(outs, outs), n,
+                                   gn_in=(stats, gamma, beta))
+                    fuse_next = nxt.kernel_id() == 6
+                if fuse_next:
+                    calls.append(FnCall(L.dafne_groupnorm_finalize_hip,
+                                        (gsegs, len(outs), n, C, _lib.ptr(partial), _lib.ptr(stats), ctypes.c_float(1e-5)),
+                                        (outs, partial, stats), "groupnorm_finalize"))
+                    nxt_gn = (stats, gamma, beta)
+                else:
+                    calls.append(FnCall(L.dafne_groupnorm_relu_nhwc_bf16_hip,
+                                        (gsegs, len(outs), n, C, _lib.ptr(partial), _lib.ptr(stats), _lib.ptr(gamma),
+                                         _lib.ptr(beta), ctypes.c_float(1e-5)), (outs, partial, stats, gamma, beta),
+                                        "groupnorm"))
+                    nxt_gn = None
                 if i > 0:
                     for a in cur:
                         pool.put(a)
-                cur = outs
+                cur, cur_gn = outs, nxt_gn
             return cur
 
         cls_t = tower("cls_tower", feats)

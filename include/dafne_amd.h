@@ -182,6 +182,7 @@ int dafne_gather_detections_hip(const float* d_corners, const float* d_scores, c
 #define DAFNE_CONV_UPSAMPLE_ADD 4u /* += nearest-2x upsample of d_res [N,H/2+2,W/2+2,C] */
 #define DAFNE_CONV_OUT_F32 8u      /* fp32 un-haloed NHWC output [N,Hout,Wout,Cout]     */
 #define DAFNE_CONV_GN_STATS 16u    /* emit per-(M tile, group of 8 ch) sum and sum-sq   */
+#define DAFNE_CONV_GN_INPUT 32u    /* GroupNorm + ReLU of the INPUT applied on load (3x3 patch kernel only) */
 
 typedef struct dafne_conv_seg {
     const void* d_in;   /* bf16 [N, Hin+2, Win+2, Cin]; stem: [N, Hin, Win, 4] pre-padded */
@@ -197,6 +198,11 @@ typedef struct dafne_conv_params {
     const void* d_weight;
     const float* d_bias;        /* or NULL */
     float* d_gn_partial;        /* GN_STATS: [num_tiles][Cout/8][2] fp32 */
+    /* GN_INPUT: the input maps are the RAW output of the previous tower convolution; GroupNorm(Cin/8
+     * groups) + ReLU is applied on load from these statistics (dafne_groupnorm_finalize_hip) */
+    const float* d_in_gn_stats; /* [n_segs][n_images][Cin/8][2] mean, rstd */
+    const float* d_in_gn_gamma; /* [Cin] */
+    const float* d_in_gn_beta;  /* [Cin] */
 } dafne_conv_params;
 
 /*
@@ -214,8 +220,11 @@ int dafne_conv2d_num_tiles(const dafne_conv_params* prm, const dafne_conv_seg* s
 /* which kernel the call dispatches to (profiling / bench attribution), -1 on error:
  * 0 conv_igemm_kernel<1,4,1,2> (32 cout x 256 px)   1 conv_igemm_kernel<1,4,2,2> (64 x 256)
  * 2 conv_igemm_kernel<2,2,2,2> (128 x 128)           3 conv_igemm_kernel<4,2,2,4> (256 x 256, 8 waves)
- * 4 conv_stream_kernel (persistent, 1x1, Cin 512)    5 conv_ws_kernel (persistent, weights in registers, 1x1, Cin <= 256) */
+ * 4 conv_stream_kernel (persistent, 1x1, Cin 512)    5 conv_ws_kernel (persistent, weights in registers, 1x1, Cin <= 256)
+ * 6 conv3x3_patch_kernel (3x3 s1, 256 cout x 8x32 px tiles, input patch staged once per 64-channel slab) */
 int dafne_conv2d_kernel_id(const dafne_conv_params* prm, const dafne_conv_seg* segs);
+/* M tiles per image of every segment (out[n_segs]): where a segment's rows sit in d_gn_partial */
+int dafne_conv2d_tiles_per_image(const dafne_conv_params* prm, const dafne_conv_seg* segs, int32_t* out);
 
 /*
  * OneStageDetector.preprocess_image (one_stage_detector.py:100-107) + ImageList
@@ -237,6 +246,13 @@ typedef struct dafne_gn_seg {
     int32_t H, W;
     int32_t tile0, tiles_per_img;   /* where this segment's tiles sit in d_partial */
 } dafne_gn_seg;
+/*
+ * Statistics half of the call below: tile partials -> mean / rstd in d_stats, no normalisation pass.
+ * For layers whose consumer applies GroupNorm + ReLU on load (DAFNE_CONV_GN_INPUT).  d_x of the segments
+ * is not touched.
+ */
+int dafne_groupnorm_finalize_hip(const dafne_gn_seg* segs, int n_segs, int n_images, int C,
+                                 const float* d_partial, float* d_stats, float eps, void* stream);
 /*
  * GroupNorm(C/8 groups, eps) + ReLU (dafne.py:330-344) from the conv's tile
  * partials: fixed-order reduction -> mean/rstd per (segment, image, group) in

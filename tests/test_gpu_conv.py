@@ -130,6 +130,100 @@ def test_streaming_1x1_kernel(cin, cout, H, W, N, with_res, relu):
     close_bf16(got, bfr(ref))
 
 
+def _gn_ref(y, gamma, beta, groups, eps=1e-5):
+    return F.relu(F.group_norm(y, groups, gamma, beta, eps))
+
+
+@pytest.mark.parametrize("cin,cout,H,W,N,relu", [
+    (256, 256, 64, 64, 13, False),      # 13 x 16 tiles of 8x32, FPN-output-like (the library wants >= 200 tiles)
+    (64, 256, 40, 100, 10, True),       # one slab, ragged in both directions (40 = 5x8, 100 = 3x32 + 4)
+    (128, 512, 33, 47, 10, True),       # two channel tiles, ragged rows (33) and columns (47)
+    (320, 256, 24, 64, 36, False),      # five slabs
+])
+def test_patch_kernel_vs_torch(cin, cout, H, W, N, relu):
+    """3x3 patch kernel (conv.hip: conv3x3_patch_kernel): 2-D tiles, patch DMA with halo, tap-offset reads."""
+    from dafne_amd import engine
+    g = torch.Generator().manual_seed(cin + cout + H + W)
+    x = bfr(torch.randn(N, cin, H, W, generator=g))
+    w = bfr(torch.randn(cout, cin, 3, 3, generator=g) / (cin * 9) ** 0.5)
+    b = torch.randn(cout, generator=g) * 0.1
+    ref = F.conv2d(x, w, b, padding=1)
+    if relu:
+        ref = F.relu(ref)
+    got, _, call = run_conv(x, w, b, 3, 1, 1, flags=engine.F_RELU if relu else 0)
+    assert call.kernel_name() == "conv3x3_patch"
+    close_bf16(got, bfr(ref))
+
+
+def test_patch_kernel_gn_stats_and_gn_input_chain():
+    """Two tower layers over three levels: layer 1 emits raw output + tile partials, the statistics are
+    finalised, layer 2 applies GroupNorm + ReLU while loading its patch (F_GNIN).  Compared with the
+    unfused pipeline (conv -> groupnorm_relu pass -> conv) bit for bit, and with torch within bf16 noise."""
+    from dafne_amd import engine, _lib
+    d = dev()
+    L = _lib.load()
+    g = torch.Generator().manual_seed(77)
+    C, N = 256, 16
+    sizes = [(40, 72), (16, 32), (8, 8)]        # 15 + 2 + 1 tiles per image
+    xs = [bfr(torch.randn(N, C, h, w, generator=g)) for h, w in sizes]
+    w1 = bfr(torch.randn(C, C, 3, 3, generator=g) / (C * 9) ** 0.5)
+    w2 = bfr(torch.randn(C, C, 3, 3, generator=g) / (C * 9) ** 0.5)
+    b1, b2 = torch.randn(C, generator=g) * 0.1, torch.randn(C, generator=g) * 0.1
+    gamma = (1 + 0.2 * torch.randn(C, generator=g)).to(d)
+    beta = (0.3 * torch.randn(C, generator=g)).to(d)
+    ins = [engine.Act.from_nchw(x.to(d)) for x in xs]
+    wp1, bp1 = engine.pack_conv(w1, b1, d)
+    wp2, bp2 = engine.pack_conv(w2, b2, d)
+    st = _lib.current_stream()
+
+    def layer1(outs):
+        segs = [(i.t, o.t, None, i.h, i.w, i.h, i.w) for i, o in zip(ins, outs)]
+        probe = engine.ConvCall(wp1, bp1, C, C, 3, 1, 1, 0, segs, N)
+        partial = torch.zeros(probe.num_tiles(), C // 8, 2, dtype=torch.float32, device=d)
+        c = engine.ConvCall(wp1, bp1, C, C, 3, 1, 1, engine.F_GN, segs, N, gn_partial=partial)
+        assert c.kernel_name() == "conv3x3_patch"
+        c(st)
+        stats = torch.zeros(len(outs), N, C // 8, 2, dtype=torch.float32, device=d)
+        gsegs = (_lib.GnSeg * len(outs))()
+        t0 = 0
+        for k, (o, tpi) in enumerate(zip(outs, c.tiles_per_image())):
+            gsegs[k] = _lib.GnSeg(o.t.data_ptr(), o.h, o.w, t0, tpi)
+            t0 += tpi * N
+        assert t0 == c.num_tiles()
+        return partial, stats, gsegs
+
+    # fused: finalize only, layer 2 normalises on load
+    raw = [engine.Act(N, h, w, C, d) for h, w in sizes]
+    partial, stats, gsegs = layer1(raw)
+    _lib.check(L.dafne_groupnorm_finalize_hip(gsegs, len(raw), N, C, _lib.ptr(partial), _lib.ptr(stats),
+                                              ctypes.c_float(1e-5), st), "finalize")
+    out_f = [engine.Act(N, h, w, C, d) for h, w in sizes]
+    segs2 = [(i.t, o.t, None, i.h, i.w, i.h, i.w) for i, o in zip(raw, out_f)]
+    c2 = engine.ConvCall(wp2, bp2, C, C, 3, 1, 1, engine.F_GNIN, segs2, N, gn_in=(stats, gamma, beta))
+    assert c2.kernel_id() == 6
+    c2(st)
+    # unfused: normalisation pass in place, plain layer 2
+    raw_u = [engine.Act(N, h, w, C, d) for h, w in sizes]
+    partial_u, stats_u, gsegs_u = layer1(raw_u)
+    _lib.check(L.dafne_groupnorm_relu_nhwc_bf16_hip(gsegs_u, len(raw_u), N, C, _lib.ptr(partial_u), _lib.ptr(stats_u),
+                                                    _lib.ptr(gamma), _lib.ptr(beta), ctypes.c_float(1e-5), st), "gn")
+    out_u = [engine.Act(N, h, w, C, d) for h, w in sizes]
+    segs2u = [(i.t, o.t, None, i.h, i.w, i.h, i.w) for i, o in zip(raw_u, out_u)]
+    engine.ConvCall(wp2, bp2, C, C, 3, 1, 1, 0, segs2u, N)(st)
+    torch.cuda.synchronize()
+    assert torch.equal(stats, stats_u)
+    for a, b_ in zip(out_f, out_u):
+        assert torch.equal(a.t, b_.t)                       # same arithmetic, same rounding points
+        assert float(a.t[:, 0].abs().max()) == 0 and float(a.t[:, :, -1].abs().max()) == 0
+    # torch reference of the whole chain (bf16 rounding after conv1 and after GN+ReLU, like the engine)
+    for x, a in zip(xs, out_f):
+        y1 = bfr(F.conv2d(x, w1, b1, padding=1))
+        y1n = bfr(_gn_ref(F.conv2d(x, w1, b1, padding=1), gamma.cpu(), beta.cpu(), C // 8))
+        ref = bfr(F.conv2d(y1n, w2, b2, padding=1))
+        got = a.nchw_float().cpu()
+        assert (got - ref).abs().max() < 0.06 * ref.abs().max()      # stats from fp32 conv vs bf16 map: noise floor
+
+
 @pytest.mark.parametrize("cout", [15, 9, 2, 1, 16])
 def test_prediction_conv_f32_output(cout):
     g = torch.Generator().manual_seed(cout)
