@@ -316,9 +316,22 @@ def main():
         if dom:
             out["roofline"] = {"bound": "mfma", "achieved": dom["tflops"], "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                                "frac": dom["tflops"] / PEAK_BF16_TFLOPS, "traffic": None,
-                               "kernel": domname.replace("conv_igemm", "conv_igemm_kernel") if "igemm" in domname else domname + "_kernel", "launches_per_step": dom["launches"],
+                               "kernel": domname.replace("conv_igemm", "conv_igemm_kernel") if "igemm" in domname else domname + "_kernel",
+                               "algorithmic_bytes_per_step": dom.get("bytes"), "launches_per_step": dom["launches"],
                                "avg_launch_us": dom["avg_launch_us"],
                                "algorithmic_gflop_per_step": dom["flops"] / 1e9}
+            # HBM bytes per launch of that kernel from the PMC passes committed under profiles/ (rocprofv3
+            # --pmc FETCH_SIZE / WRITE_SIZE in separate runs of this same command; counters cannot be read
+            # from inside the process).  null when no PMC summary is present for the kernel.
+            try:
+                pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+                key = out["roofline"]["kernel"].replace(" ", "")
+                cands = [v for k, v in pmc["kernels"].items() if k == key or k.startswith(key + "<")]
+                if cands:
+                    out["roofline"]["traffic"] = 1e6 * sum(c["hbm_mb_per_launch"] for c in cands) / len(cands)
+                    out["roofline"]["traffic_unit"] = "bytes per launch (2 x FETCH_SIZE + WRITE_SIZE), " + pmc["source"]
+            except (OSError, KeyError, ValueError):
+                pass
             out["roofline"]["concurrent_streams"] = args.splits
             out["roofline"]["note"] = ("launches of %d sub-batches share the GPU on concurrent streams: a launch's "
                                        "duration includes that sharing (as rocprofv3 reports it); see "
