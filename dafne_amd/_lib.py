@@ -73,6 +73,9 @@ SIGNATURES = {
                                                              c_void_p]),
     "dafne_conv2d_nhwc_bf16_hip": (c_int, [ctypes.POINTER(ConvParams), ctypes.POINTER(ConvSeg), c_void_p]),
     "dafne_conv2d_num_tiles": (c_int, [ctypes.POINTER(ConvParams), ctypes.POINTER(ConvSeg)]),
+    "dafne_resize_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
+    "dafne_resize_bilinear_u8_hip": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p,
+                                             c_void_p, c_size_t, c_void_p]),
     "dafne_conv2d_kernel_id": (c_int, [ctypes.POINTER(ConvParams), ctypes.POINTER(ConvSeg)]),
     "dafne_conv2d_tiles_per_image": (c_int, [ctypes.POINTER(ConvParams), ctypes.POINTER(ConvSeg), c_void_p]),
     "dafne_groupnorm_finalize_hip": (c_int, [ctypes.POINTER(GnSeg), c_int, c_int, c_int, c_void_p, c_void_p,

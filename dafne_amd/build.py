@@ -20,6 +20,7 @@ COMMON = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno
 PER_FILE = {
     "poly_nms.hip": ["-ffp-contract=off"],
     "decode.hip": ["-ffp-contract=off"],
+    "resize.hip": ["-ffp-contract=off"],
 }
 
 

@@ -9,18 +9,18 @@ inverse transforms (un-flip, then un-resize; float64 like detectron2's
 apply_coords on the numpy copy, :244-259) and all views are merged by ONE rotated
 NMS + cap (`select_over_all_levels`, :264-268) -- up to 27 x 1000 quads, on the GPU.
 
-The pixel resampling itself (detectron2 uses PIL bilinear on uint8 [recalled]) is
-done with torch bilinear interpolation here; it is SURVEY 8(f) row 4 ("next") and
-not part of the pinned path.  Rotation TTA (ROTATION_ANGLES) is empty in every
+The pixel resampling (detectron2's ResizeTransform is PIL bilinear on uint8 [recalled]) and the flips run on
+the GPU in `dafne_resize_bilinear_u8_hip`, bit-exact to Pillow's 8-bit resampler (pinned
+against Pillow itself in tests/test_oracle_resize.py).  Rotation TTA (ROTATION_ANGLES) is empty in every
 released config and not built.
 """
 import copy
 from itertools import count
 
 import torch
-import torch.nn.functional as F
 from torch import nn
 
+from .. import _lib
 from ..structures import Instances
 from .one_stage_detector import OneStageDetector
 
@@ -31,11 +31,8 @@ class ResizeT:
     def __init__(self, h, w, new_h, new_w):
         self.h, self.w, self.new_h, self.new_w = h, w, new_h, new_w
 
-    def apply_image(self, img):            # uint8 CHW
-        if (self.h, self.w) == (self.new_h, self.new_w):
-            return img
-        x = F.interpolate(img[None].float(), size=(self.new_h, self.new_w), mode="bilinear", align_corners=False)
-        return x[0].round().clamp(0, 255).to(torch.uint8)
+    def apply_image(self, img, hflip=False, vflip=False):            # uint8 CHW on the GPU
+        return resize_u8(img, self.new_h, self.new_w, hflip, vflip)
 
     def apply_coords(self, c):             # [n,2] float64
         c = c.clone()
@@ -45,6 +42,28 @@ class ResizeT:
 
     def inverse(self):
         return ResizeT(self.new_h, self.new_w, self.h, self.w)
+
+
+def resize_u8(img, new_h, new_w, hflip=False, vflip=False):
+    """uint8 [C,H,W] CUDA tensor -> uint8 [C,new_h,new_w]: Pillow-exact bilinear resize + optional flips in
+    one pass pair on the device.  No CPU path."""
+    if img.dtype != torch.uint8 or img.dim() != 3:
+        raise ValueError("resize_u8 takes a uint8 CHW tensor")
+    if not img.is_cuda:
+        raise _lib.DafneHipError("resize_u8: the MI355X engine has no CPU path (got a CPU tensor)")
+    c, h, w = (int(v) for v in img.shape)
+    if (h, w) == (new_h, new_w) and not hflip and not vflip:
+        return img
+    L = _lib.load()
+    with torch.cuda.device(img.device):
+        src = img.contiguous()
+        out = torch.empty((c, new_h, new_w), dtype=torch.uint8, device=img.device)
+        nbytes = L.dafne_resize_workspace_bytes(c, h, new_w)
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=img.device)
+        _lib.check(L.dafne_resize_bilinear_u8_hip(_lib.ptr(src), 0, c, h, w, new_h, new_w, int(hflip), int(vflip),
+                                                  _lib.ptr(out), _lib.ptr(ws), nbytes, _lib.current_stream()),
+                   "dafne_resize_bilinear_u8_hip")
+    return out
 
 
 class HFlipT:
@@ -136,11 +155,10 @@ class DotaDatasetMapperTTA:
                 cands.append([rs, HFlipT(nw)])
             if self.vflip:
                 cands.append([rs, VFlipT(nh)])
-            base = rs.apply_image(image)
             for tf in cands:
-                im = base
-                for t in tf[1:]:
-                    im = t.apply_image(im)
+                # resize and flip of a view in one device call (flips are exact index reversals)
+                im = rs.apply_image(image, hflip=any(isinstance(t, HFlipT) for t in tf[1:]),
+                                    vflip=any(isinstance(t, VFlipT) for t in tf[1:]))
                 dic = {k: v for k, v in dataset_dict.items() if k != "image"}
                 dic = copy.deepcopy(dic)
                 dic["transforms"] = pre + TransformList(tf)
@@ -182,6 +200,9 @@ class OneStageRCNNWithTTA(nn.Module):
         return {"instances": self._merge_detections(instances)}
 
     def _get_augmented_inputs(self, input):
+        if not input["image"].is_cuda:          # dataset tensors arrive on the host: one upload, views are built on the GPU
+            input = dict(input)
+            input["image"] = input["image"].to(self.model.device)
         augmented_inputs = self.tta_mapper(input)
         tfms = [x.pop("transforms") for x in augmented_inputs]
         return augmented_inputs, tfms

@@ -237,6 +237,16 @@ int dafne_conv2d_tiles_per_image(const dafne_conv_params* prm, const dafne_conv_
 int dafne_preprocess_image_hip(const uint8_t* d_img, int layout_hwc, int n_images, int H, int W,
                                const int32_t* d_valid_hw, const float* mean3, const float* std3,
                                int Hn, int Wn, void* d_out, void* stream);
+/*
+ * detectron2 ResizeShortestEdge / ResizeTransform.apply_image on uint8 images = PIL.Image.resize(BILINEAR)
+ * [recalled; dafne/modeling/tta.py:71-99 builds its views with it], bit-exact to Pillow's 8-bit resampler
+ * (two separable passes, 22-bit fixed-point coefficients, uint8 intermediate), plus the horizontal / vertical
+ * flip of a TTA view folded into the store.  d_in: [C,H,W] (layout_hwc = 0) or [H,W,C] (= 1) uint8;
+ * d_out: [C,new_h,new_w] uint8; d_ws: dafne_resize_workspace_bytes(C, H, new_w) bytes.
+ */
+size_t dafne_resize_workspace_bytes(int C, int H, int new_w);
+int dafne_resize_bilinear_u8_hip(const uint8_t* d_in, int layout_hwc, int C, int H, int W, int new_h, int new_w,
+                                 int hflip, int vflip, uint8_t* d_out, void* d_ws, size_t ws_bytes, void* stream);
 /* 3x3 stride-2 pad-1 max pool of a post-ReLU map: [N,Hin+2,Win+2,C] -> [N,Hin/2+2,Win/2+2,C] */
 int dafne_maxpool3x3s2_nhwc_bf16_hip(const void* d_in, void* d_out, int n_images, int Hin, int Win,
                                      int C, void* stream);

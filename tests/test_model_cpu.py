@@ -55,7 +55,7 @@ def test_cpu_input_fails_loudly():
         m([{"image": torch.zeros(3, 64, 64, dtype=torch.uint8), "height": 64, "width": 64}])
 
 
-def test_tta_mapper_geometry_and_inverse_transforms():
+def test_tta_mapper_geometry_and_inverse_transforms(monkeypatch):
     """CPU: view list, sizes and inverse coordinate maps of the TTA mapper
     (tta.py:48-135, 244-262) -- no kernels involved."""
     import numpy as np
@@ -66,6 +66,13 @@ def test_tta_mapper_geometry_and_inverse_transforms():
     assert shortest_edge_size(600, 1000, 800, 1200) == (720, 1200)      # capped by MAX_SIZE
     mapper = DotaDatasetMapperTTA(cfg)
     img = torch.randint(0, 256, (3, 96, 128), dtype=torch.uint8)
+    with pytest.raises(Exception):              # the product resampler has no CPU path
+        mapper({"image": img, "height": 96, "width": 128, "image_id": 7})
+    # geometry under test here: stand the oracle's Pillow-exact resampler in for the device kernel
+    import dafne_amd.modeling.tta as tta_mod
+    from oracle import resize as orz
+    monkeypatch.setattr(tta_mod, "resize_u8", lambda im, nh, nw, hf=False, vf=False: torch.from_numpy(
+        orz.resize_bilinear_u8(im.numpy(), nh, nw, hf, vf)))
     views = mapper({"image": img, "height": 96, "width": 128, "image_id": 7})
     assert len(views) == 27                                               # 9 sizes x {none, hflip, vflip}
     v_plain, v_h, v_v = views[0], views[1], views[2]
