@@ -22,6 +22,7 @@
 //
 // Wave64 throughout: one ballot == one 64-column tile row.
 #include "common.h"
+#include <stdlib.h>
 #include <algorithm>
 
 namespace {
@@ -409,6 +410,70 @@ __global__ void __launch_bounds__(256) nms_prep_kernel(const float* __restrict__
         float xmax = fmaxf(fmaxf(v[0], v[2]), fmaxf(v[4], v[6]));
         float ymin = fminf(fminf(v[1], v[3]), fminf(v[5], v[7]));
         float ymax = fmaxf(fmaxf(v[1], v[3]), fmaxf(v[5], v[7]));
+        w.hull[base] = make_float4(xmin, ymin, xmax, ymax);
+        Quad q = load_quad_f32(v);
+        w.area[base] = fabs(quad_area(q));
+#pragma unroll
+        for (int k = 0; k < 8; k++) amax = fmaxf(amax, fabsf(v[k]));
+    }
+    for (int o = 32; o > 0; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o, 64));
+    if ((threadIdx.x & 63) == 0 && amax > 0.f) atomicMax(&w.meta[img * 4 + 0], __float_as_uint(amax));
+}
+
+// Same result as nms_prep_kernel for M <= 16384 rows, without the O(M^2) rank-by-counting: one workgroup per
+// image sorts 64-bit keys (order-preserving score bits << 32 | row index) in LDS with a bitonic network --
+// descending keys = score descending, larger index first on ties = argsort(kind="stable")[::-1] -- and then
+// gathers the rows into sorted order.  (10 000 rows: 8 x 10^8 compares -> 1.2 x 10^6 compare-exchanges.)
+constexpr int kSortMax = 16384;
+__global__ void __launch_bounds__(1024) nms_sort_prep_kernel(const float* __restrict__ dets9, int row_cap,
+                                                             const int* __restrict__ counts, int m_cap, NmsWs w) {
+    extern __shared__ u64 skey[];
+    const int img = blockIdx.x;
+    const int M = img_count(counts, img, m_cap);
+    if (M == 0) return;
+    const float* d = dets9 + (size_t)img * row_cap * 9;
+    int n = 64;
+    while (n < M) n <<= 1;
+    for (int i = threadIdx.x; i < n; i += 1024) {
+        u64 key = 0ull;                                    // padding sorts to the end
+        if (i < M) {
+            unsigned u = __float_as_uint(d[(size_t)i * 9 + 8]);
+            u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);    // float order -> unsigned order
+            key = ((u64)u << 32) | (u64)(unsigned)i;
+            if (key == 0ull) key = 1ull;                   // keep real rows above the padding (score = -NaN pattern only)
+        }
+        skey[i] = key;
+    }
+    __syncthreads();
+    for (int k = 2; k <= n; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int t = threadIdx.x; t < (n >> 1); t += 1024) {
+                const int lo = ((t & ~(j - 1)) << 1) | (t & (j - 1));      // index with bit j clear
+                const int hi = lo | j;
+                const u64 a = skey[lo], b = skey[hi];
+                const bool desc = (lo & k) == 0;           // overall descending order
+                if (desc ? a < b : a > b) {
+                    skey[lo] = b;
+                    skey[hi] = a;
+                }
+            }
+            __syncthreads();
+        }
+    }
+    float amax = 0.f;
+    for (int p = threadIdx.x; p < M; p += 1024) {
+        const int i = (int)(unsigned)skey[p];
+        const size_t base = (size_t)img * w.Mp + p;
+        float v[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) v[k] = d[(size_t)i * 9 + k];
+        w.order[base] = i;
+        w.sscore[base] = d[(size_t)i * 9 + 8];
+        float4* sb = reinterpret_cast<float4*>(w.sbox + base * 8);
+        sb[0] = make_float4(v[0], v[1], v[2], v[3]);
+        sb[1] = make_float4(v[4], v[5], v[6], v[7]);
+        const float xmin = fminf(fminf(v[0], v[2]), fminf(v[4], v[6])), xmax = fmaxf(fmaxf(v[0], v[2]), fmaxf(v[4], v[6]));
+        const float ymin = fminf(fminf(v[1], v[3]), fminf(v[5], v[7])), ymax = fmaxf(fmaxf(v[1], v[3]), fmaxf(v[5], v[7]));
         w.hull[base] = make_float4(xmin, ymin, xmax, ymax);
         Quad q = load_quad_f32(v);
         w.area[base] = fabs(quad_area(q));
@@ -829,7 +894,18 @@ int run_nms(const float* d_dets9, int row_cap, const int* d_counts, int N, int m
     dim3 gp((m_cap + 255) / 256, N);
     if (d_dets9_f64)
         hipLaunchKernelGGL(nms_prep_f64_kernel, gp, dim3(256), 0, st, d_dets9_f64, row_cap, d_counts, m_cap, w);
-    else
+    else if (m_cap <= kSortMax && getenv("DAFNE_NMS_COUNTING_SORT") == nullptr) {
+        static bool attr_done = false;
+        if (!attr_done) {
+            DAFNE_HIP_TRY(hipFuncSetAttribute((const void*)nms_sort_prep_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                              kSortMax * (int)sizeof(u64)));
+            attr_done = true;
+        }
+        int n = 64;
+        while (n < m_cap) n <<= 1;
+        hipLaunchKernelGGL(nms_sort_prep_kernel, dim3(N), dim3(1024), (size_t)n * sizeof(u64), st, d_dets9, row_cap, d_counts,
+                           m_cap, w);
+    } else
         hipLaunchKernelGGL(nms_prep_kernel, gp, dim3(256), 0, st, d_dets9, row_cap, d_counts, m_cap, w);
     int rc = dafne::check_launch("nms_prep");
     if (rc) return rc;
