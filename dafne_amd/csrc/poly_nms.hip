@@ -268,6 +268,7 @@ struct NmsWs {
     double* dbox;              // [N][Mp][8] fp64 rows in sorted order (fp64 entry point only, else null)
     int strict;                // ResultMerge predicate: suppress iff hulls overlap strictly AND IoU > thresh
     int sat;                   // separating-axis second stage of the pre-filter (fp32-row path)
+    int fast;                  // convex fast path for the decision, exact path for the rest
     int Mp, nblk, pair_cap;    // pair_cap: per row block
     size_t mask_words;         // per image
 };
@@ -296,6 +297,7 @@ size_t carve(NmsWs& w, void* base, int N, int m_cap, bool f64 = false) {
     w.dbox = f64 ? c.take<double>(n * Mp * 8) : nullptr;
     w.strict = 0;
     w.sat = (!f64 && getenv("DAFNE_NMS_NO_SAT") == nullptr) ? 1 : 0;
+    w.fast = getenv("DAFNE_NMS_NO_FAST") == nullptr ? 1 : 0;
     w.mask_words = ntiles * kTile;
     w.mask = c.take<u64>(n * w.mask_words);
     return dafne::align_up(c.off, 256);
@@ -744,6 +746,77 @@ __global__ void __launch_bounds__(256) nms_scan_kernel(const int* __restrict__ c
     }
 }
 
+// ---------------------------------------------------------------- convex fast path
+// Most candidate pairs are two ordinary convex quads whose IoU is far from the threshold.  For those the
+// DECISION `iou_poly > thresh` does not need polyiou.cpp's 16 x 3 half-plane cuts in its exact order: one
+// lane clips quad A by the 4 edges of quad B (Sutherland-Hodgman, <= 8 vertices) and gets the geometric IoU
+// to ~1e-12.  The reference value differs from the geometric one only by fp64 rounding and by its 1e-8
+// `sig()` snapping -- slivers of width <= 1e-8/|edge| along each cut, i.e. <= 3e-5 px^2 per cut for edges
+// >= 1 px and chords <= 3000 px, <= 1.5e-3 px^2 over the 48 cuts, <= 1e-4 in IoU once the union is >= 16
+// px^2.  So with BOTH quads strictly convex, every edge >= 1 px and union >= 16 px^2, a fast IoU outside
+// thresh +- 1e-3 fixes the decision; everything else (non-convex, degenerate, tiny, near the threshold)
+// goes through the reference-order computation (iou_group16).  Keep lists are unchanged (all fixtures).
+__device__ __forceinline__ bool quad_fast_ok(Quad& q, double& area) {
+    quad_orient(q);                       // counter-clockwise (polyiou.cpp:96-97)
+    area = quad_area(q);
+    bool ok = true;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const P2 a = q.v[i], b = q.v[(i + 1) & 3], c = q.v[(i + 2) & 3];
+        const double ex = b.x - a.x, ey = b.y - a.y, fx = c.x - b.x, fy = c.y - b.y;
+        ok &= (ex * fy - ey * fx) > 1e-3;              // strictly convex corner
+        ok &= (ex * ex + ey * ey) >= 1.0;              // edge >= 1 px
+    }
+    return ok;
+}
+
+// returns 0: IoU < thresh - margin, 1: IoU > thresh + margin, 2: undecided (use the exact path)
+__device__ __forceinline__ int fast_decision(Scratch s, Quad A, Quad B, double thresh) {
+    double aa, ab;
+    const bool oka = quad_fast_ok(A, aa), okb = quad_fast_ok(B, ab);
+    if (!(oka && okb)) return 2;
+    P2* cur = s.p;      // <= 8 of the kCapP slots
+    P2* out = s.pp;
+    int n = 4;
+#pragma unroll
+    for (int k = 0; k < 4; k++) cur[k * kTile] = A.v[k];
+    for (int e = 0; e < 4 && n > 0; e++) {
+        const P2 a = B.v[e], b = B.v[(e + 1) & 3];
+        const double ex = b.x - a.x, ey = b.y - a.y;
+        int m = 0;
+        P2 P = cur[0];
+        double dP = ex * (P.y - a.y) - ey * (P.x - a.x);
+        for (int i = 0; i < n; i++) {
+            const P2 Q = cur[((i + 1 == n) ? 0 : i + 1) * kTile];
+            const double dQ = ex * (Q.y - a.y) - ey * (Q.x - a.x);
+            if (dP >= 0) out[(m++) * kTile] = P;
+            if ((dP > 0 && dQ < 0) || (dP < 0 && dQ > 0)) {
+                const double t = dP / (dP - dQ);
+                P2 X;
+                X.x = P.x + (Q.x - P.x) * t;
+                X.y = P.y + (Q.y - P.y) * t;
+                out[(m++) * kTile] = X;
+            }
+            P = Q;
+            dP = dQ;
+        }
+        P2* tmp = cur; cur = out; out = tmp;
+        n = m < 9 ? m : 9;
+    }
+    double inter = 0;
+    for (int i = 0; i < n; i++) {
+        const P2 a = cur[i * kTile], b = cur[((i + 1 == n) ? 0 : i + 1) * kTile];
+        inter += a.x * b.y - a.y * b.x;
+    }
+    inter = fabs(inter) * 0.5;
+    const double uni = aa + ab - inter;
+    if (!(uni >= 16.0)) return 2;
+    const double iou = inter / uni;
+    if (iou > thresh + 1e-3) return 1;
+    if (iou < thresh - 1e-3) return 0;
+    return 2;
+}
+
 // ------------------------------------------------------------------- nms_iou
 // Persistent waves over the pair list: 16 lanes clip one pair, 4 pairs per wave step.
 __global__ void __launch_bounds__(64) nms_iou_kernel(const int* __restrict__ counts, int m_cap, double thresh,
@@ -764,25 +837,51 @@ __global__ void __launch_bounds__(64) nms_iou_kernel(const int* __restrict__ cou
     Scratch s{lds_p[wv] + lane, lds_pp[wv] + lane};
     const int gw = blockIdx.x, nw = gridDim.x;                   // wave id / waves per image
     const int nbu = (M + kTile - 1) / kTile;
-    const int chunks = w.pair_cap / 4;                           // 4 pairs per wave step
+    // Phase A per 64-pair chunk: one lane per pair takes the convex fast path; the undecided pairs are
+    // queued and clipped 4 at a time (16 lanes each) in polyiou.cpp's own operation order.
+    __shared__ u64 exq[kTile];
+    const int chunks = w.pair_cap / kTile;
+    auto record = [&](int r, int c) {
+        atomicOr(&w.mask[(size_t)img * w.mask_words + tile_id(r >> 6, c >> 6, nb) * kTile + (r & 63)], 1ull << (c & 63));
+        atomicOr(&w.rowflag[(size_t)img * nb + (r >> 6)], 1ull << (r & 63));
+    };
     for (long long item = gw; item < (long long)nbu * chunks; item += nw) {
         const int lrb = (int)(item / chunks);
-        const unsigned p0 = (unsigned)(item % chunks) * 4u;
+        const unsigned p0 = (unsigned)(item % chunks) * (unsigned)kTile;
         const unsigned n_pairs = min(w.pair_cnt[(size_t)img * nb + lrb], (unsigned)w.pair_cap);
         if (p0 >= n_pairs) continue;
         const u64* list = w.pairs + ((size_t)img * nb + lrb) * w.pair_cap;
-        const unsigned k = p0 + (unsigned)(lane >> 4);
-        u64 en = list[k < n_pairs ? k : n_pairs - 1];
-        const bool live = k < n_pairs && en != ~0ull;
-        if (en == ~0ull) en = 0ull;                      // skip marker: clip row 0 with itself, discard
-        const int r = (int)(unsigned)en, c = (int)(en >> 32);
-        Quad A = w.dbox ? load_quad_f64(w.dbox + (ibase + r) * 8) : load_quad_f32(w.sbox + (ibase + r) * 8);
-        Quad B = w.dbox ? load_quad_f64(w.dbox + (ibase + c) * 8) : load_quad_f32(w.sbox + (ibase + c) * 8);
-        const double iou = iou_group16(s, A, B, lane);
-        if (live && (lane & 15) == 0 && iou > thresh && (!w.strict || hulls_overlap_strict(A, B))) {
-            atomicOr(&w.mask[(size_t)img * w.mask_words + tile_id(r >> 6, c >> 6, nb) * kTile + (r & 63)], 1ull << (c & 63));
-            atomicOr(&w.rowflag[(size_t)img * nb + (r >> 6)], 1ull << (r & 63));
+        int dec = 0;
+        u64 en = 0ull;
+        if (p0 + (unsigned)lane < n_pairs) {
+            en = list[p0 + lane];
+            if (en != ~0ull) {                                   // not a skip marker
+                dec = 2;
+                if (w.fast) {
+                    const int r = (int)(unsigned)en, c = (int)(en >> 32);
+                    const Quad A = w.dbox ? load_quad_f64(w.dbox + (ibase + r) * 8) : load_quad_f32(w.sbox + (ibase + r) * 8);
+                    const Quad B = w.dbox ? load_quad_f64(w.dbox + (ibase + c) * 8) : load_quad_f32(w.sbox + (ibase + c) * 8);
+                    dec = fast_decision(s, A, B, thresh);
+                    if (dec == 1 && (!w.strict || hulls_overlap_strict(A, B))) record(r, c);
+                }
+            }
         }
+        const u64 need = __ballot(dec == 2);
+        if (need == 0ull) continue;
+        if (dec == 2) exq[__popcll(need & ((1ull << lane) - 1ull))] = en;
+        __builtin_amdgcn_wave_barrier();
+        const int nq = __popcll(need);
+        for (int q0 = 0; q0 < nq; q0 += 4) {
+            const int k = q0 + (lane >> 4);
+            const bool live = k < nq;
+            const u64 e2 = exq[live ? k : nq - 1];
+            const int r = (int)(unsigned)e2, c = (int)(e2 >> 32);
+            Quad A = w.dbox ? load_quad_f64(w.dbox + (ibase + r) * 8) : load_quad_f32(w.sbox + (ibase + r) * 8);
+            Quad B = w.dbox ? load_quad_f64(w.dbox + (ibase + c) * 8) : load_quad_f32(w.sbox + (ibase + c) * 8);
+            const double iou = iou_group16(s, A, B, lane);
+            if (live && (lane & 15) == 0 && iou > thresh && (!w.strict || hulls_overlap_strict(A, B))) record(r, c);
+        }
+        __builtin_amdgcn_wave_barrier();
     }
     if (w.meta[img * 4 + 3] == 0u) return;
     // overflow phase: tiles whose pairs did not fit the list are clipped in place

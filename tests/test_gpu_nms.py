@@ -149,3 +149,48 @@ def test_full_size_properties():
             cand = k[(s[k] > s[t]) | ((s[k] == s[t]) & (k > t))]
             iou_t = oracle.iou_poly_pairs(np.repeat(d9[t:t + 1, :8], len(cand), 0), d9[cand, :8])
             assert (iou_t > 0.1).any()
+
+
+def test_fast_path_decisions_around_the_threshold():
+    """The convex fast path of nms_iou decides `IoU > thresh` from a geometric clip and hands anything within
+    1e-3 of the threshold (or non-convex / tiny / degenerate) to the reference-order clip: 6000 two-box images
+    whose IoU is spread tightly around 0.1, plus concave, self-intersecting, sub-pixel and huge-offset pairs,
+    must give the oracle's keep lists."""
+    from dafne_amd import _lib
+    L = _lib.load()
+    rng = np.random.default_rng(2024)
+    n = 6000
+    dets = np.zeros((n, 2, 9), dtype=np.float32)
+    for i in range(n):
+        w, h = rng.uniform(4, 200), rng.uniform(4, 60)
+        ang = rng.uniform(0, np.pi)
+        ca, sa = np.cos(ang), np.sin(ang)
+        base = np.array([[-w / 2, -h / 2], [w / 2, -h / 2], [w / 2, h / 2], [-w / 2, h / 2]])
+        rot = np.array([[ca, -sa], [sa, ca]])
+        a = base @ rot.T + rng.uniform(0, 900, 2)
+        # shift along the long side: IoU of two equal rectangles shifted by s*w is (1-s)/(1+s); target ~0.1 -> s ~ 9/11
+        target = 0.1 + rng.normal(0, 2e-3) if i % 3 else rng.uniform(0.0, 0.3)
+        s = (1 - target) / (1 + target)
+        b = a + s * w * np.array([ca, sa])
+        kind = i % 10
+        if kind == 7:       # concave arrowhead
+            b[2] = b.mean(0)
+        elif kind == 8:     # self-intersecting bow tie
+            b[[2, 3]] = b[[3, 2]]
+        elif kind == 9:     # sub-pixel pair
+            a, b = a * 1e-2, b * 1e-2
+        if i % 50 == 0:     # class-offset magnitude
+            a, b = a + 30000.0, b + 30000.0
+        dets[i, 0, :8], dets[i, 1, :8] = a.reshape(-1), b.reshape(-1)
+        dets[i, 0, 8], dets[i, 1, 8] = 0.9, 0.8
+    d = torch.from_numpy(dets).to(dev())
+    keep = torch.empty((n, 2), dtype=torch.int64, device=dev())
+    nk = torch.zeros(n, dtype=torch.int32, device=dev())
+    nbytes = L.dafne_poly_nms_workspace_bytes(n, 2)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=dev())
+    _lib.check(L.dafne_poly_nms_batched_hip(_lib.ptr(d), None, n, 2, 0.1, 0, _lib.ptr(keep), _lib.ptr(nk), _lib.ptr(ws), nbytes,
+                                            _lib.current_stream()), "nms")
+    got = nk.cpu().numpy()
+    want = np.array([len(oracle.poly_nms(dets[i], 0.1)) for i in range(n)])
+    assert np.array_equal(got, want), np.nonzero(got != want)[0][:10]
+    assert 0.2 < (want == 1).mean() < 0.8          # the set really straddles the threshold
