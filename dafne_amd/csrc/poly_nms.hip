@@ -267,7 +267,6 @@ struct NmsWs {
     unsigned char* tile_flag;  // [N][ntiles]  tile did not fit the pair list
     double* dbox;              // [N][Mp][8] fp64 rows in sorted order (fp64 entry point only, else null)
     int strict;                // ResultMerge predicate: suppress iff hulls overlap strictly AND IoU > thresh
-    int sat;                   // separating-axis second stage of the pre-filter (fp32-row path)
     int fast;                  // convex fast path for the decision, exact path for the rest
     int Mp, nblk, pair_cap;    // pair_cap: per row block
     size_t mask_words;         // per image
@@ -296,7 +295,6 @@ size_t carve(NmsWs& w, void* base, int N, int m_cap, bool f64 = false) {
     w.dets9 = c.take<float>(n * Mp * 9);
     w.dbox = f64 ? c.take<double>(n * Mp * 8) : nullptr;
     w.strict = 0;
-    w.sat = (!f64 && getenv("DAFNE_NMS_NO_SAT") == nullptr) ? 1 : 0;
     w.fast = getenv("DAFNE_NMS_NO_FAST") == nullptr ? 1 : 0;
     w.mask_words = ntiles * kTile;
     w.mask = c.take<u64>(n * w.mask_words);
@@ -579,41 +577,6 @@ __device__ __forceinline__ void tile_rc(long long t, int nb, int& rb, int& cb) {
     cb = r + (int)(t - ((long long)r * nb - (long long)r * (r - 1) / 2));
 }
 
-// Separating-axis test on the 8 edge normals of two quads, fp64, coordinates taken relative to a[0] (class
-// offsets of ~1e4 px drop out).  True means the two VERTEX SETS are separated by a line with margin, so
-// their convex hulls -- and every triangle of the two fans -- are disjoint: the true intersection is 0 and
-// the fan sum of the IoU is pure rounding noise, exactly the situation of the hull pre-filter below (same
-// area guard applies).  The margin (1e-9 x |n|_1 x extent, rounding of a projection is ~1e-15 x that) keeps
-// the decision on the safe side of fp64 rounding.
-__device__ __forceinline__ bool sat_separated(const float* a, const float* b) {
-    double ax[4], ay[4], bx[4], by[4];
-    const double ox = a[0], oy = a[1];
-    double ext = 0.0;
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-        ax[k] = (double)a[2 * k] - ox; ay[k] = (double)a[2 * k + 1] - oy;
-        bx[k] = (double)b[2 * k] - ox; by[k] = (double)b[2 * k + 1] - oy;
-        ext = fmax(ext, fmax(fmax(fabs(ax[k]), fabs(ay[k])), fmax(fabs(bx[k]), fabs(by[k]))));
-    }
-    bool sep = false;
-#pragma unroll
-    for (int e = 0; e < 8; e++) {
-        const double ex = e < 4 ? ax[(e + 1) & 3] - ax[e] : bx[(e + 1) & 3] - bx[e & 3];
-        const double ey = e < 4 ? ay[(e + 1) & 3] - ay[e] : by[(e + 1) & 3] - by[e & 3];
-        const double nx = -ey, ny = ex;
-        double amin = INFINITY, amax = -INFINITY, bmin = INFINITY, bmax = -INFINITY;
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-            const double pa = nx * ax[k] + ny * ay[k], pb = nx * bx[k] + ny * by[k];
-            amin = fmin(amin, pa); amax = fmax(amax, pa);
-            bmin = fmin(bmin, pb); bmax = fmax(bmax, pb);
-        }
-        const double tol = 1e-9 * (fabs(nx) + fabs(ny)) * ext;
-        sep |= (amax < bmin - tol) | (bmax < amin - tol);
-    }
-    return sep;
-}
-
 // Hull pre-filter of one 64x64 tile by one wave.  Lane r ends up with the 64-bit set
 // of columns row r must be clipped against.  Guard: see oracle/poly_oracle.c
 // (orc_poly_nms_fast): separated hulls mean a true intersection of 0; the fp64 fan
@@ -663,8 +626,6 @@ __device__ __forceinline__ u64 tile_candidates(const NmsWs& w, int img, int M, i
 __global__ void __launch_bounds__(256) nms_scan_kernel(const int* __restrict__ counts, int m_cap,
                                                        double thresh, NmsWs w, long long ntiles) {
     __shared__ float4 rhull_s[4][kTile];
-    __shared__ u64 cand_s[4][kTile];
-    __shared__ int pre_s[4][kTile];
     const int img = blockIdx.y;
     const int M = img_count(counts, img, m_cap);
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
@@ -676,49 +637,15 @@ __global__ void __launch_bounds__(256) nms_scan_kernel(const int* __restrict__ c
     const size_t ibase = (size_t)img * w.Mp;
     const int grow = rb * kTile + lane;
     w.mask[(size_t)img * w.mask_words + (size_t)t * kTile + lane] = 0ull;
-    u64 mycand = tile_candidates(w, img, M, rb, cb, thresh, rhull_s[wv]);
-    int cnt = __popcll(mycand);
+    const u64 mycand = tile_candidates(w, img, M, rb, cb, thresh, rhull_s[wv]);
+    const int cnt = __popcll(mycand);
     int incl = cnt;
     for (int o = 1; o < 64; o <<= 1) {
         const int v = __shfl_up(incl, o, 64);
         if (lane >= o) incl += v;
     }
-    int total = __shfl(incl, 63, 64);
+    const int total = __shfl(incl, 63, 64);
     if (total == 0) return;
-    if (w.sat && thresh >= 1e-6) {
-        // second stage: the hull test is loose for thin rotated boxes.  One lane per surviving pair runs
-        // the separating-axis test; separated pairs whose areas pass the guard leave the candidate set.
-        const float R = __uint_as_float(w.meta[img * 4 + 0]);
-        const double guard = 256.0 * (2e-13 * (double)R * (double)R + 1e-6) / thresh;
-        cand_s[wv][lane] = mycand;
-        pre_s[wv][lane] = incl - cnt;
-        __builtin_amdgcn_wave_barrier();
-        for (int base0 = 0; base0 < total; base0 += 64) {
-            const int k = base0 + lane;
-            if (k < total) {
-                int lo = 0, hi = 63;       // largest row with pre[row] <= k
-                while (lo < hi) {
-                    const int mid = (lo + hi + 1) >> 1;
-                    if (pre_s[wv][mid] <= k) lo = mid; else hi = mid - 1;
-                }
-                const int row = lo;
-                const int col = kth_set_bit(cand_s[wv][row], k - pre_s[wv][row]);
-                const size_t r = ibase + rb * kTile + row, c = ibase + cb * kTile + col;
-                if ((w.area[r] > guard || w.area[c] > guard) && sat_separated(w.sbox + r * 8, w.sbox + c * 8))
-                    atomicAnd(&cand_s[wv][row], ~(1ull << col));
-            }
-        }
-        __builtin_amdgcn_wave_barrier();
-        mycand = cand_s[wv][lane];
-        cnt = __popcll(mycand);
-        incl = cnt;
-        for (int o = 1; o < 64; o <<= 1) {
-            const int v = __shfl_up(incl, o, 64);
-            if (lane >= o) incl += v;
-        }
-        total = __shfl(incl, 63, 64);
-        if (total == 0) return;
-    }
     unsigned base = 0;
     // one list per (image, row block): the counters of different row blocks sit on
     // different addresses, so the appends do not serialise on one L2 atomic unit
