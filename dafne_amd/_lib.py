@@ -107,6 +107,10 @@ def load():
             raise DafneHipError(
                 "libdafne_amd.so not found at %s -- build it with `python -m dafne_amd.build` "
                 "(there is no CPU fallback for the MI355X path)" % LIB_PATH)
+        # torch first: its wheel ships its own libamdhip64.so.7 / libhsa-runtime64; the library must bind to
+        # THAT runtime instance (same soname -> the loader reuses it).  Loaded the other way round, torch
+        # and this library end up on two HIP runtimes and the second one sees no device.
+        import torch  # noqa: F401
         L = ctypes.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             f = getattr(L, name)   # AttributeError if the .so lacks a declared symbol
