@@ -859,6 +859,7 @@ __device__ __forceinline__ u64 readlane64(u64 v, int l) {
 }
 
 constexpr int kReduceThreads = 1024;
+constexpr int kFastBlk = 160;      // <= 10240 rows: tiles of the current row block are parked in LDS (83 KiB)
 constexpr int kMaxBlk = 1024;  // up to 65536 rows per image
 
 __global__ void __launch_bounds__(kReduceThreads) nms_reduce_kernel(
@@ -877,7 +878,6 @@ __global__ void __launch_bounds__(kReduceThreads) nms_reduce_kernel(
     __shared__ u64 kept[kMaxBlk];
     __shared__ int kpre[kMaxBlk + 1];
     __shared__ u64 kcur;
-    __shared__ u64 dsh[2][kTile];
     const int tid = threadIdx.x;
     for (int k = tid; k < nb; k += kReduceThreads) {
         remv[k] = 0ull;
@@ -885,51 +885,92 @@ __global__ void __launch_bounds__(kReduceThreads) nms_reduce_kernel(
     }
     __syncthreads();
 
-    // diag words of block 0; later blocks are prefetched one iteration ahead by wave 1
-    if (tid < 64) {
-        const int row = tid;
-        dsh[0][tid] = row < M ? mask[tile_id(0, 0, nb) * kTile + tid] : 0ull;
-    }
-    __syncthreads();
+    // Greedy scan, one 64-row block per iteration.  Two things keep the serial chain short:
+    //  * the 64 diagonal words of a block sit one per lane in wave 0 and the in-block scan is wave-uniform
+    //    scalar code reading them with v_readlane (no LDS round trip per step);
+    //  * (fast == true, <= kFastBlk blocks) the words of tiles (b, b+1..) are fetched one iteration AHEAD into
+    //    registers, coalesced (a tile is 512 contiguous bytes), then parked in LDS, so the OR phase of block b
+    //    reads LDS instead of chasing global loads that depend on the scan's result.
+    const bool fast = nbu <= kFastBlk;
+    extern __shared__ u64 tbuf[];                     // fast: [kFastBlk][65] tile rows of the current block
+    constexpr int R = kFastBlk * kTile / kReduceThreads;
+    u64 pre[R];
+    auto fetch_tiles = [&](int rbk) {                 // tiles (rbk, rbk+1 ..): element e = (wd - rbk - 1) * 64 + row
+#pragma unroll
+        for (int k = 0; k < R; k++) {
+            const int e = tid + k * kReduceThreads;
+            const int wd = rbk + 1 + (e >> 6);
+            pre[k] = (rbk < nbu && wd < nbu) ? mask[tile_id(rbk, wd, nb) * kTile + (e & 63)] : 0ull;
+        }
+    };
+    u64 dcur = 0ull, dnext = 0ull;                    // wave 0: this lane's diagonal word of block b / b+1
+    if (tid < 64) dcur = tid < M ? mask[tile_id(0, 0, nb) * kTile + tid] : 0ull;
+    if (fast) fetch_tiles(0);
     for (int b = 0; b < nbu; b++) {
-        u64 dnext = 0ull;
-        if (tid >= 64 && tid < 128 && b + 1 < nbu) {
-            const int row = (b + 1) * kTile + (tid - 64);
-            dnext = row < M ? mask[tile_id(b + 1, b + 1, nb) * kTile + (tid - 64)] : 0ull;   // lands under the scan below
+        if (fast) {
+#pragma unroll
+            for (int k = 0; k < R; k++) {
+                const int e = tid + k * kReduceThreads;
+                tbuf[(e >> 6) * 65 + (e & 63)] = pre[k];
+            }
+            fetch_tiles(b + 1);                       // lands under this iteration's scan + OR phase
         }
         if (tid < 64) {
-            // greedy scan inside the block.  rem only grows and row r's bit can only be set
-            // by rows < r (upper-triangular words), so kept = ~rem_final; only rows whose
-            // diag word is non-zero can change rem -> one lane walks just those, in order.
-            const u64 nz = __ballot(dsh[b & 1][tid] != 0ull);
-            if (tid == 0) {
-                u64 rem = remv[b];
-                const int valid = min(kTile, M - b * kTile);
-                if (valid < 64) rem |= ~0ull << valid;
-                u64 bits = nz;
-                while (bits) {
-                    const int r = __ffsll((long long)bits) - 1;
-                    bits &= bits - 1;
-                    if (!((rem >> r) & 1ull)) rem |= dsh[b & 1][r];
+            if (b + 1 < nbu) {
+                const int row = (b + 1) * kTile + tid;
+                dnext = row < M ? mask[tile_id(b + 1, b + 1, nb) * kTile + tid] : 0ull;
+            }
+            // rem only grows and row r's bit can only be set by rows < r (upper-triangular words), so
+            // kept = ~rem_final; only rows whose diag word is non-zero can change rem -> walk just those.
+            u64 bits = __ballot(dcur != 0ull);
+            const unsigned dlo = (unsigned)dcur, dhi = (unsigned)(dcur >> 32);
+            u64 rem = remv[b];                        // same address in every lane: wave-uniform
+            rem = ((u64)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(rem >> 32)) << 32) |
+                  (u64)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)rem);
+            const int valid = min(kTile, M - b * kTile);
+            if (valid < 64) rem |= ~0ull << valid;
+            while (bits) {
+                const int r = __builtin_amdgcn_readfirstlane(__ffsll((long long)bits) - 1);
+                bits &= bits - 1;
+                if (!((rem >> r) & 1ull)) {
+                    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)dlo, r);
+                    const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)dhi, r);
+                    rem |= ((u64)hi << 32) | (u64)lo;
                 }
+            }
+            if (tid == 0) {
                 const u64 K = ~rem;
                 kept[b] = K;
                 kcur = K & rowflag[b];
             }
+            dcur = dnext;
         }
-        if (tid >= 64 && tid < 128) dsh[(b + 1) & 1][tid - 64] = dnext;
         __syncthreads();
         const u64 K2 = kcur;
         if (K2) {
-            for (int wd = b + 1 + tid; wd < nbu; wd += kReduceThreads) {
-                u64 acc = 0ull;
-                u64 bits = K2;
-                while (bits) {
-                    int r = __ffsll((long long)bits) - 1;
-                    bits &= bits - 1;
-                    acc |= mask[tile_id(b, wd, nb) * kTile + r];
+            if (fast) {
+                const int wd = b + 1 + tid;
+                if (wd < nbu) {
+                    u64 acc = 0ull;
+                    u64 bits = K2;
+                    while (bits) {
+                        const int r = __ffsll((long long)bits) - 1;
+                        bits &= bits - 1;
+                        acc |= tbuf[tid * 65 + r];
+                    }
+                    remv[wd] |= acc;
                 }
-                remv[wd] |= acc;
+            } else {
+                for (int wd = b + 1 + tid; wd < nbu; wd += kReduceThreads) {
+                    u64 acc = 0ull;
+                    u64 bits = K2;
+                    while (bits) {
+                        int r = __ffsll((long long)bits) - 1;
+                        bits &= bits - 1;
+                        acc |= mask[tile_id(b, wd, nb) * kTile + r];
+                    }
+                    remv[wd] |= acc;
+                }
             }
         }
         __syncthreads();
@@ -1018,7 +1059,13 @@ int run_nms(const float* d_dets9, int row_cap, const int* d_counts, int N, int m
     hipLaunchKernelGGL(nms_iou_kernel, dim3(iou_blocks, N), dim3(64), 0, st, d_counts, m_cap, thresh, w, ntiles);
     rc = dafne::check_launch("nms_iou");
     if (rc) return rc;
-    hipLaunchKernelGGL(nms_reduce_kernel, dim3(N), dim3(kReduceThreads), 0, st, d_counts, m_cap,
+    static bool reduce_attr = false;
+    if (!reduce_attr) {
+        DAFNE_HIP_TRY(hipFuncSetAttribute((const void*)nms_reduce_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                          kFastBlk * 65 * (int)sizeof(u64)));
+        reduce_attr = true;
+    }
+    hipLaunchKernelGGL(nms_reduce_kernel, dim3(N), dim3(kReduceThreads), (size_t)kFastBlk * 65 * sizeof(u64), st, d_counts, m_cap,
                        post_topk, w, reinterpret_cast<long long*>(d_keep), d_num_keep);
     return dafne::check_launch("nms_reduce");
 }
