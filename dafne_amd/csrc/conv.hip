@@ -665,6 +665,13 @@ struct TileInfo {
 
 __device__ __forceinline__ TileInfo tile_info(const ConvDev& P, int logical) {
     TileInfo t;
+#ifdef DAFNE_EXP_CHEAP_ADDR     // experiment: res4 conv3 shape only (ntiles = 8, 32 tiles per image, Wout = 64)
+    t.nt = logical & 7;
+    t.si = 0;
+    t.img = (logical >> 3) >> 5;
+    t.m0 = ((logical >> 3) & 31) * 128;
+    return t;
+#endif
     t.nt = logical % P.ntiles;
     const int mt = logical / P.ntiles;
     int si = 0;
@@ -679,6 +686,11 @@ __device__ __forceinline__ TileInfo tile_info(const ConvDev& P, int logical) {
 
 // m / W for 0 <= m < 2^20, W <= 2^10 (checked on the host): exact via one fp32 multiply
 __device__ __forceinline__ void divmod_small(int m, int W, float invW, int& q, int& r) {
+#ifdef DAFNE_EXP_CHEAP_ADDR
+    q = m >> 6;
+    r = m & 63;
+    return;
+#endif
     q = (int)(((float)m + 0.5f) * invW);
     r = m - q * W;
 }
@@ -959,12 +971,18 @@ __global__ void __launch_bounds__(256, 2) conv_stream_kernel(ConvDev P) {
 // vmcnt bookkeeping is exact: K is a template parameter, so the number of vector-memory
 // instructions issued after any awaited stage (ring pieces, residual DMA pieces, output stores
 // of earlier tiles) is a compile-time function of the position in the tile (ws_after).
-constexpr int kWNS = 6;                 // ring depth in half-K stages of the pixel operand
-constexpr int kWHS = 128 * 64;          // 128 pixel rows x 64 B
+// Ring geometry by row bytes RB: 64 -> half-K stages (32 channels, 8 KiB, 6 deep), 128 -> full K steps (64
+// channels, 16 KiB, 3 deep).  Same 48 KiB; the half-K ring keeps more loads in flight (HBM-bound K = 64/128
+// layers), the full-step ring halves the barriers per MFMA (res4 conv3, K = 256: an iteration is ~950 cycles of
+// which only 256-512 are MFMA issue).
+constexpr int ws_ns(int RB) { return RB == 128 ? 3 : 6; }
+constexpr int ws_pps(int RB) { return RB == 128 ? 4 : 2; }       // DMA pieces per wave and stage
+constexpr int kWRing = 6 * 128 * 64;                             // = 3 * 128 * 128
 
-constexpr int ws_after(int h, int H, bool res) {
-    int n = 2 * (kWNS - 2);                                       // ring pieces of the kWNS-2 younger stages
-    for (int d = 1; d <= kWNS - 1; d++)
+constexpr int ws_after(int h, int H, bool res, int RB) {
+    const int NS = ws_ns(RB);
+    int n = ws_pps(RB) * (NS - 2);                                // ring pieces of the NS-2 younger stages
+    for (int d = 1; d <= NS - 1; d++)
         if (((h - d) % H + H) % H == H - 1) n += res ? 16 : 8;    // a tile end: [8 residual loads of the next tile] 8 output stores
     return n;
 }
@@ -988,14 +1006,17 @@ __device__ __forceinline__ void static_for(F&& f) {
 #define WS_NT " nt"
 #define WS_STORE(p, v) __builtin_nontemporal_store(v, p)
 
-template <int WC, int WP, int KS, bool RES>
+template <int WC, int WP, int KS, bool RES, int RB>
 __global__ void __launch_bounds__(256, 2) conv_ws_kernel(ConvDev P) {
-    constexpr int NW = 4, TC = 4 / WC, TP = 4 / WP, H = 2 * KS, NS = kWNS;
-    constexpr int KSAFE = (NS - 1 + H - 1) / H + 1;     // tiles before the steady-state counts hold
-    static_assert(WC * WP == NW && ws_after(H - 1, H, true) <= 63, "configuration");
+    constexpr int NW = 4, TC = 4 / WC, TP = 4 / WP, NS = ws_ns(RB), PPS = ws_pps(RB);
+    constexpr int H = KS * (128 / RB);            // stages per tile
+    constexpr int CPS = RB / 32;                  // 16-deep K chunks per stage
+    constexpr int STAGE = 128 * RB;               // bytes
+    constexpr int RPP = 1024 / RB;                // pixel rows per DMA piece
+    static_assert(WC * WP == NW && ws_after(H - 1, H, true, RB) <= 63 && ws_after(0, H, true, RB) <= 63, "configuration");
     extern __shared__ __attribute__((aligned(16))) char lds[];
     char* ring = lds;
-    char* resb = lds + NS * kWHS;
+    char* resb = lds + kWRing;
     const unsigned resb_off = (unsigned)(size_t)(__attribute__((address_space(3))) char*)resb;
 
     const int tid = threadIdx.x;
@@ -1011,7 +1032,7 @@ __global__ void __launch_bounds__(256, 2) conv_ws_kernel(ConvDev P) {
 
     // ---- issue cursor: kWNS-1 half-K stages ahead of the consumer, across tiles ---------------
     int ic_tile = 0, ic_h = 0, ic_slot = 0;
-    unsigned hofs[2];
+    unsigned hofs[PPS];
     const char* xin = nullptr;
     auto setup_issue = [&](int seq) {
         const TileInfo t = tile_info(P, xcd_remap((int)blockIdx.x + seq * G, T));
@@ -1020,9 +1041,9 @@ __global__ void __launch_bounds__(256, 2) conv_ws_kernel(ConvDev P) {
         const int Wp = S.Win + 2, Hp = S.Hin + 2;
         const float invW = 1.0f / (float)S.Wout;
 #pragma unroll
-        for (int i = 0; i < 2; i++) {
-            const int r = (i * NW + wave) * 16 + (lane >> 2);
-            const int q = (lane & 3) ^ ((r >> 2) & 3);
+        for (int i = 0; i < PPS; i++) {
+            const int r = (i * NW + wave) * RPP + (RB == 128 ? lane >> 3 : lane >> 2);
+            const int q = RB == 128 ? (lane & 7) ^ ((r >> 1) & 7) : (lane & 3) ^ ((r >> 2) & 3);
             int pix = t.m0 + r;
             pix = pix < HW ? pix : HW - 1;
             int ho, wo;
@@ -1035,10 +1056,10 @@ __global__ void __launch_bounds__(256, 2) conv_ws_kernel(ConvDev P) {
     };
     auto issue_next = [&]() {
         if (ic_tile >= my_tiles) return;
-        char* dst = ring + ic_slot * kWHS + wave * 1024;
+        char* dst = ring + ic_slot * STAGE + wave * 1024;
 #pragma unroll
-        for (int i = 0; i < 2; i++)
-            __builtin_amdgcn_global_load_lds((gvoid*)(xin + hofs[i] + (unsigned)ic_h * 64u), (lvoid*)(dst + i * 4096), 16, 0, 0);
+        for (int i = 0; i < PPS; i++)
+            __builtin_amdgcn_global_load_lds((gvoid*)(xin + hofs[i] + (unsigned)ic_h * (unsigned)RB), (lvoid*)(dst + i * 4096), 16, 0, 0);
         ic_slot = ic_slot == NS - 1 ? 0 : ic_slot + 1;
         if (++ic_h == H) {
             ic_h = 0;
@@ -1046,10 +1067,10 @@ __global__ void __launch_bounds__(256, 2) conv_ws_kernel(ConvDev P) {
         }
     };
 
-    const int fsw4 = (frow >> 2) & 3;
-    unsigned hroff[2];
+    const int fsw = RB == 128 ? (frow >> 1) & 7 : (frow >> 2) & 3;
+    unsigned hroff[CPS];
 #pragma unroll
-    for (int k2 = 0; k2 < 2; k2++) hroff[k2] = (unsigned)frow * 64u + (unsigned)(((2 * k2 + half) ^ fsw4) * 16);
+    for (int k2 = 0; k2 < CPS; k2++) hroff[k2] = (unsigned)frow * (unsigned)RB + (unsigned)(((2 * k2 + half) ^ fsw) * 16);
     const int brow0 = wp * TP * 32;
 
     // residual rows of a tile live in registers (16 B per lane and row: lane = (pixel row tid/16 + 16 i,
@@ -1131,25 +1152,27 @@ __global__ void __launch_bounds__(256, 2) conv_ws_kernel(ConvDev P) {
             constexpr int h = decltype(hc)::value;
             // wait for half-K stage (kk, h): at most n younger vector-memory instructions may be pending
             if (kk * H + h + NS - 2 >= total) vmcnt_le<0>();             // tail: the cursor has run dry
-            else if (kk < KSAFE) vmcnt_le<2 * (NS - 2)>();               // start-up: ring pieces only
-            else vmcnt_le<ws_after(h, H, RES)>();
+            else if (kk * H + h < NS - 1) vmcnt_le<PPS * (NS - 2)>();    // window reaches into the prologue: ring pieces only
+            else vmcnt_le<ws_after(h, H, RES, RB)>();
             lds_barrier();
+#ifdef DAFNE_WS_TIMING_ITER
+            WS_STAMP();
+#endif
             issue_next();
             __builtin_amdgcn_sched_barrier(0);
-            const char* sb = ring + slot * kWHS;
+            const char* sb = ring + slot * STAGE;
             slot = slot == NS - 1 ? 0 : slot + 1;
-            bf16x8 bfr[2][TP];
 #pragma unroll
-            for (int k2 = 0; k2 < 2; k2++)
+            for (int k2 = 0; k2 < CPS; k2++) {
+                bf16x8 bfr[TP];
 #pragma unroll
-                for (int b = 0; b < TP; b++) bfr[k2][b] = *(const bf16x8*)(sb + (brow0 + b * 32) * 64 + hroff[k2]);
-#pragma unroll
-            for (int k2 = 0; k2 < 2; k2++)
+                for (int b = 0; b < TP; b++) bfr[b] = *(const bf16x8*)(sb + (brow0 + b * 32) * RB + hroff[k2]);
 #pragma unroll
                 for (int a = 0; a < TC; a++)
 #pragma unroll
                     for (int b = 0; b < TP; b++)
-                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[a][2 * h + k2], bfr[k2][b], acc[a][b], 0, 0, 0);
+                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[a][CPS * h + k2], bfr[b], acc[a][b], 0, 0, 0);
+            }
         });
 
         WS_STAMP();      // K loop done
@@ -1158,8 +1181,8 @@ __global__ void __launch_bounds__(256, 2) conv_ws_kernel(ConvDev P) {
             // this tile's residual registers have landed: after their loads came the previous tile's 8
             // stores (not for the first tile) and this tile's 2H ring pieces
             if ((kk + 1) * H + NS - 2 >= total) vmcnt_le<0>();
-            else if (kk == 0) vmcnt_le<2 * H>();
-            else vmcnt_le<2 * H + 8>();
+            else if (kk == 0) vmcnt_le<PPS * H>();
+            else vmcnt_le<PPS * H + 8>();
 #pragma unroll
             for (int i = 0; i < 8; i++) {
                 asm volatile("" : "+v"(rr[i]));
@@ -1815,27 +1838,36 @@ int resident_slots(int* out) {
     return DAFNE_OK;
 }
 
-template <int WC, int WP, int KS, bool RES>
+template <int WC, int WP, int KS, bool RES, int RB>
 int launch_ws_cfg(const ConvDev& D, hipStream_t st) {
-    constexpr int smem = kWNS * kWHS + kSRes;
+    constexpr int smem = kWRing + kSRes;
     static bool attr_done = false;
     if (!attr_done) {
-        DAFNE_HIP_TRY(hipFuncSetAttribute((const void*)conv_ws_kernel<WC, WP, KS, RES>, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+        DAFNE_HIP_TRY(hipFuncSetAttribute((const void*)conv_ws_kernel<WC, WP, KS, RES, RB>, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
         attr_done = true;
     }
     int slots = 0;
     if (int rc = resident_slots(&slots)) return rc;
     const int T = D.mtiles * D.ntiles;
     const int G = T < slots ? T : slots;
-    hipLaunchKernelGGL((conv_ws_kernel<WC, WP, KS, RES>), dim3(G), dim3(256), smem, st, D);
+    hipLaunchKernelGGL((conv_ws_kernel<WC, WP, KS, RES, RB>), dim3(G), dim3(256), smem, st, D);
     return dafne::check_launch("conv_ws");
 }
 
 int launch_ws(const ConvDev& D, hipStream_t st) {
     const bool res = D.flags & DAFNE_CONV_RESIDUAL;
-    if (D.Cin == 256) return res ? launch_ws_cfg<4, 1, 4, true>(D, st) : launch_ws_cfg<4, 1, 4, false>(D, st);
-    if (D.Cin == 128) return res ? launch_ws_cfg<2, 2, 2, true>(D, st) : launch_ws_cfg<2, 2, 2, false>(D, st);
-    return res ? launch_ws_cfg<2, 2, 1, true>(D, st) : launch_ws_cfg<2, 2, 1, false>(D, st);
+    static const int rb = getenv("DAFNE_WS_RB") ? atoi(getenv("DAFNE_WS_RB")) : 0;     // experiments: force 64 / 128
+    const bool full256 = rb ? rb == 128 : true, full_small = rb == 128;
+    if (D.Cin == 256) {
+        if (full256) return res ? launch_ws_cfg<4, 1, 4, true, 128>(D, st) : launch_ws_cfg<4, 1, 4, false, 128>(D, st);
+        return res ? launch_ws_cfg<4, 1, 4, true, 64>(D, st) : launch_ws_cfg<4, 1, 4, false, 64>(D, st);
+    }
+    if (D.Cin == 128) {
+        if (full_small) return res ? launch_ws_cfg<2, 2, 2, true, 128>(D, st) : launch_ws_cfg<2, 2, 2, false, 128>(D, st);
+        return res ? launch_ws_cfg<2, 2, 2, true, 64>(D, st) : launch_ws_cfg<2, 2, 2, false, 64>(D, st);
+    }
+    if (full_small) return res ? launch_ws_cfg<2, 2, 1, true, 128>(D, st) : launch_ws_cfg<2, 2, 1, false, 128>(D, st);
+    return res ? launch_ws_cfg<2, 2, 1, true, 64>(D, st) : launch_ws_cfg<2, 2, 1, false, 64>(D, st);
 }
 
 int launch_stream(const ConvDev& D, hipStream_t st) {

@@ -103,20 +103,30 @@ struct GnDev {
     float eps;
 };
 
-// one 256-thread block per (segment, image): thread = (tile slice 0..7, group 0..31+);
-// every slice sums its tiles in order, then the 8 slices are added in order: the
+// one 1024-thread block per (segment, image): thread = (tile slice 0..31, group 0..31+);
+// every slice sums its tiles in order (loads batched 4 deep: the chain of dependent global
+// loads was the whole cost of this kernel), then the 32 slices are added in order: the
 // result does not depend on launch geometry or timing.
-__global__ void __launch_bounds__(256) gn_finalize_kernel(GnDev P) {
+constexpr int kGnSlices = 32;
+__global__ void __launch_bounds__(1024) gn_finalize_kernel(GnDev P) {
     const int G = P.C / 8;
     const int n = blockIdx.x % P.N, s = blockIdx.x / P.N;
     const GnSeg& S = P.seg[s];
-    __shared__ float part[8][64][2];
+    __shared__ float part[kGnSlices][32][2];
     const int t0 = S.tile0 + n * S.tiles_per_img;
     for (int g0 = 0; g0 < G; g0 += 32) {
         const int g = g0 + (threadIdx.x & 31), sl = threadIdx.x >> 5;
         float sum = 0.f, sq = 0.f;
         if (g < G) {
-            for (int t = sl; t < S.tiles_per_img; t += 8) {
+            int t = sl;
+            for (; t + 3 * kGnSlices < S.tiles_per_img; t += 4 * kGnSlices) {
+                float2 p[4];
+#pragma unroll
+                for (int k = 0; k < 4; k++) p[k] = *(const float2*)(P.partial + ((size_t)(t0 + t + k * kGnSlices) * G + g) * 2);
+#pragma unroll
+                for (int k = 0; k < 4; k++) { sum += p[k].x; sq += p[k].y; }
+            }
+            for (; t < S.tiles_per_img; t += kGnSlices) {
                 const float2 p = *(const float2*)(P.partial + ((size_t)(t0 + t) * G + g) * 2);
                 sum += p.x;
                 sq += p.y;
@@ -128,7 +138,7 @@ __global__ void __launch_bounds__(256) gn_finalize_kernel(GnDev P) {
         if (threadIdx.x < 32 && g < G) {
             float a = 0.f, b = 0.f;
 #pragma unroll
-            for (int k = 0; k < 8; k++) {
+            for (int k = 0; k < kGnSlices; k++) {
                 a += part[k][threadIdx.x][0];
                 b += part[k][threadIdx.x][1];
             }
@@ -250,7 +260,7 @@ int dafne_groupnorm_finalize_hip(const dafne_gn_seg* segs, int n_segs, int n_ima
         D.seg[s].x = (char*)segs[s].d_x; D.seg[s].H = segs[s].H; D.seg[s].W = segs[s].W;
         D.seg[s].tile0 = segs[s].tile0; D.seg[s].tiles_per_img = segs[s].tiles_per_img;
     }
-    hipLaunchKernelGGL(gn_finalize_kernel, dim3(n_segs * n_images), dim3(256), 0, (hipStream_t)stream, D);
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3(n_segs * n_images), dim3(1024), 0, (hipStream_t)stream, D);
     return dafne::check_launch("gn_finalize");
 }
 
@@ -268,7 +278,7 @@ int dafne_groupnorm_relu_nhwc_bf16_hip(const dafne_gn_seg* segs, int n_segs, int
         D.seg[s].tile0 = segs[s].tile0; D.seg[s].tiles_per_img = segs[s].tiles_per_img;
     }
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(gn_finalize_kernel, dim3(n_segs * n_images), dim3(256), 0, st, D);
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3(n_segs * n_images), dim3(1024), 0, st, D);
     int rc = dafne::check_launch("gn_finalize");
     if (rc) return rc;
     GnApplyDev A;
