@@ -94,6 +94,14 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
     return start + idx;
 }
 
+// m / W without an integer division (a ~40-instruction sequence on this ISA), for 0 <= m < H*W <= 2^20
+// (checked on the host): (m + 0.5) / W is at least 0.5/W away from an integer, the fp32 product is off by
+// at most H * 2^-23, so truncation is exact while H*W < 2^22.
+__device__ __forceinline__ void divmod_small(int m, int W, float invW, int& q, int& r) {
+    q = (int)(((float)m + 0.5f) * invW);
+    r = m - q * W;
+}
+
 template <int WC, int WP, int TC, int TP>
 __global__ void __launch_bounds__(WC * WP * 64) conv_igemm_kernel(ConvDev P) {
     constexpr int NW = WC * WP;            // waves per block
@@ -135,6 +143,7 @@ __global__ void __launch_bounds__(WC * WP * 64) conv_igemm_kernel(ConvDev P) {
     const int img = (mt - S.tile0) / S.tiles_per_img;
     const int m0 = ((mt - S.tile0) % S.tiles_per_img) * BM;
     const int HW = S.Hout * S.Wout;
+    const float invW = 1.0f / (float)S.Wout;
     const int Wp = P.stem ? S.Win : S.Win + 2;   // input row pitch in pixels (stem: already padded)
     const int Hp = P.stem ? S.Hin : S.Hin + 2;
     const int cpx = P.stem ? 8 : P.Cin * 2;      // bytes per input pixel
@@ -150,7 +159,8 @@ __global__ void __launch_bounds__(WC * WP * 64) conv_igemm_kernel(ConvDev P) {
         } else {
             int pix = m0 + (r - BN);
             pix = pix < HW ? pix : HW - 1;             // ragged last tile: stay in bounds
-            const int ho = pix / S.Wout, wo = pix - ho * S.Wout;
+            int ho, wo;
+            divmod_small(pix, S.Wout, invW, ho, wo);
             const unsigned row = (unsigned)(img * Hp + ho * P.stride + (P.stem ? 0 : 1 - P.pad));
             const unsigned col = (unsigned)(wo * P.stride + (P.stem ? 0 : 1 - P.pad));
             const unsigned lanepart = P.stem ? (unsigned)(q >> 2) * (unsigned)(Wp * 8) + (unsigned)(q & 3) * 16u
@@ -195,7 +205,8 @@ __global__ void __launch_bounds__(WC * WP * 64) conv_igemm_kernel(ConvDev P) {
             const int p = tid / CH + i * (NT / CH);
             int m = m0 + p;
             m = m < HW ? m : HW - 1;
-            const int ho = m / S.Wout, wo = m - ho * S.Wout;
+            int ho, wo;
+            divmod_small(m, S.Wout, invW, ho, wo);
             const size_t rpix = up
                 ? ((size_t)(img * (S.Hout / 2 + 2) + ho / 2 + 1) * (S.Wout / 2 + 2) + wo / 2 + 1)
                 : ((size_t)(img * (S.Hout + 2) + ho + 1) * (S.Wout + 2) + wo + 1);
@@ -248,7 +259,8 @@ __global__ void __launch_bounds__(WC * WP * 64) conv_igemm_kernel(ConvDev P) {
             } else {
                 int pix = m0 + (r - BN);
                 pix = pix < HW ? pix : HW - 1;
-                const int ho = pix / S.Wout, wo = pix - ho * S.Wout;
+                int ho, wo;
+            divmod_small(pix, S.Wout, invW, ho, wo);
                 const unsigned row = (unsigned)(img * Hp + ho * P.stride + 1 - P.pad);
                 const unsigned colp = (unsigned)(wo * P.stride + 1 - P.pad);
                 hofs[i] = (row * (unsigned)Wp + colp) * (unsigned)cpx + (unsigned)q * 16u;
@@ -495,7 +507,8 @@ __global__ void __launch_bounds__(WC * WP * 64) conv_igemm_kernel(ConvDev P) {
             const int p = idx / CHB, cc = idx - p * CHB;
             const int m = m0 + p;
             if (m < HW) {
-                const int ho = m / S.Wout, wo = m - ho * S.Wout;
+                int ho, wo;
+            divmod_small(m, S.Wout, invW, ho, wo);
                 const size_t opix = ((size_t)(img * (S.Hout + 2) + ho + 1) * (S.Wout + 2) + wo + 1);
                 const uint4 v = *(const uint4*)(stg + p * ROWB + cc * 16);
                 *(uint4*)(S.out + (opix * P.Cout + nt * BN + cc * 8) * 2) = v;
@@ -547,7 +560,8 @@ __global__ void __launch_bounds__(WC * WP * 64) conv_igemm_kernel(ConvDev P) {
                 const int p = tid / CH + i * (NT / CH);
                 int m = m0 + p;
                 m = m < HW ? m : HW - 1;
-                const int ho = m / S.Wout, wo = m - ho * S.Wout;
+                int ho, wo;
+            divmod_small(m, S.Wout, invW, ho, wo);
                 const size_t rpix = has_up
                     ? ((size_t)(img * (S.Hout / 2 + 2) + ho / 2 + 1) * (S.Wout / 2 + 2) + wo / 2 + 1)
                     : ((size_t)(img * (S.Hout + 2) + ho + 1) * (S.Wout + 2) + wo + 1);
@@ -559,7 +573,8 @@ __global__ void __launch_bounds__(WC * WP * 64) conv_igemm_kernel(ConvDev P) {
             const int p = tid / CH + i * (NT / CH);
             const int m = m0 + p;
             if (m >= HW) continue;
-            const int ho = m / S.Wout, wo = m - ho * S.Wout;
+            int ho, wo;
+            divmod_small(m, S.Wout, invW, ho, wo);
             const float4 x0 = *(const float4*)(stg + p * ROWF + col * 32);
             const float4 x1 = *(const float4*)(stg + p * ROWF + col * 32 + 16);
             float v[8] = {x0.x + bia[0], x0.y + bia[1], x0.z + bia[2], x0.w + bia[3],
@@ -665,13 +680,6 @@ struct TileInfo {
 
 __device__ __forceinline__ TileInfo tile_info(const ConvDev& P, int logical) {
     TileInfo t;
-#ifdef DAFNE_EXP_CHEAP_ADDR     // experiment: res4 conv3 shape only (ntiles = 8, 32 tiles per image, Wout = 64)
-    t.nt = logical & 7;
-    t.si = 0;
-    t.img = (logical >> 3) >> 5;
-    t.m0 = ((logical >> 3) & 31) * 128;
-    return t;
-#endif
     t.nt = logical % P.ntiles;
     const int mt = logical / P.ntiles;
     int si = 0;
@@ -684,16 +692,6 @@ __device__ __forceinline__ TileInfo tile_info(const ConvDev& P, int logical) {
     return t;
 }
 
-// m / W for 0 <= m < 2^20, W <= 2^10 (checked on the host): exact via one fp32 multiply
-__device__ __forceinline__ void divmod_small(int m, int W, float invW, int& q, int& r) {
-#ifdef DAFNE_EXP_CHEAP_ADDR
-    q = m >> 6;
-    r = m & 63;
-    return;
-#endif
-    q = (int)(((float)m + 0.5f) * invW);
-    r = m - q * W;
-}
 
 #define DAFNE_VMCNT(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
 
@@ -1760,6 +1758,8 @@ int build(ConvDev& D, const dafne_conv_params* p, const dafne_conv_seg* segs) {
         } else if ((g.Hout - 1) * 2 + 8 > g.Hin || (g.Wout - 1) * 2 + 8 > g.Win) {
             return dafne::fail(DAFNE_E_INVALID, "conv: stem input must be padded to 2*Hout+6");
         }
+        if ((long long)g.Hout * g.Wout > (1 << 20) || g.Wout > (1 << 12))
+            return dafne::fail(DAFNE_E_UNSUPPORTED, "conv: segment %d output %dx%d above 2^20 pixels per image", s, g.Hout, g.Wout);
         SegDev& o = D.seg[s];
         o.in = (const char*)g.d_in; o.out = (char*)g.d_out; o.res = (const char*)g.d_res;
         o.Hin = g.Hin; o.Win = g.Win; o.Hout = g.Hout; o.Wout = g.Wout;
