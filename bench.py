@@ -343,6 +343,10 @@ def main():
         out["model_tflops_end_to_end"] = tot_flops / (dt / args.steps) / 1e12
         out["mfma_frac_end_to_end"] = out["model_tflops_end_to_end"] / PEAK_BF16_TFLOPS
         out["rotated_nms_ms_per_img"] = nms_ms_per_image(device)
+        # SURVEY 8(d) candidate-set sizes: per-level / per-image worst cases and the 27-view TTA merge (one image)
+        out["rotated_nms_ms_per_img_by_m"] = {"500x8": nms_ms_per_image(device, m=500), "2000x8": nms_ms_per_image(device, m=2000),
+                                              "10000x8": out["rotated_nms_ms_per_img"],
+                                              "27000x1": nms_ms_per_image(device, m=27000, n_images=1)}
         if world == 1 and args.depth == 101:
             cfg50, m50, _ = build_model(50, device, seed=0)
             dt50 = time_steps(lambda: m50.detect_packed(batch, pipelined=True, splits=args.splits), max(args.steps // 2, 3), 2, False)

@@ -281,7 +281,9 @@ size_t carve(NmsWs& w, void* base, int N, int m_cap, bool f64 = false) {
     w.Mp = Mp;
     w.nblk = nblk;
     const size_t ntiles = (size_t)nblk * (nblk + 1) / 2;
-    w.pair_cap = kPairCap;
+    // a 64-row block of a TTA-merge-sized set (27 000 boxes in one tile) has ~10^4 candidate pairs: with the small
+    // list nearly every tile overflowed into the slower in-place path
+    w.pair_cap = Mp <= 12288 ? kPairCap : 16 * kPairCap;
     w.meta = c.take<unsigned>(n * 4);
     w.pair_cnt = c.take<unsigned>(n * nblk);
     w.rowflag = c.take<u64>(n * nblk);
@@ -859,9 +861,11 @@ __device__ __forceinline__ u64 readlane64(u64 v, int l) {
 }
 
 constexpr int kReduceThreads = 1024;
-constexpr int kFastBlk = 160;      // <= 10240 rows: tiles of the current row block are parked in LDS (83 KiB)
+constexpr int kFastBlk = 160;      // tiles of the current row block are parked in LDS 160 at a time (83 KiB)
+// fast path: up to kFastChunks * 160 row blocks (kFastChunks = 1: 10 240 rows)
 constexpr int kMaxBlk = 1024;  // up to 65536 rows per image
 
+template <int kFastChunks>
 __global__ void __launch_bounds__(kReduceThreads) nms_reduce_kernel(
     const int* __restrict__ counts, int m_cap, int post_topk, NmsWs w,
     long long* __restrict__ keep, int* __restrict__ num_keep) {
@@ -891,30 +895,38 @@ __global__ void __launch_bounds__(kReduceThreads) nms_reduce_kernel(
     //  * (fast == true, <= kFastBlk blocks) the words of tiles (b, b+1..) are fetched one iteration AHEAD into
     //    registers, coalesced (a tile is 512 contiguous bytes), then parked in LDS, so the OR phase of block b
     //    reads LDS instead of chasing global loads that depend on the scan's result.
-    const bool fast = nbu <= kFastBlk;
-    extern __shared__ u64 tbuf[];                     // fast: [kFastBlk][65] tile rows of the current block
-    constexpr int R = kFastBlk * kTile / kReduceThreads;
-    u64 pre[R];
-    auto fetch_tiles = [&](int rbk) {                 // tiles (rbk, rbk+1 ..): element e = (wd - rbk - 1) * 64 + row
+    const bool fast = nbu <= kFastChunks * kFastBlk;
+    extern __shared__ u64 tbuf[];                     // fast: [kFastBlk][65] tile rows of the current block, one chunk at a time
+    constexpr int RC = kFastBlk * kTile / kReduceThreads;      // registers per chunk of kFastBlk tiles
+    u64 pre[kFastChunks * RC];
+    const int nchunk = fast ? (nbu + kFastBlk - 1) / kFastBlk : 0;
+    auto fetch_chunk = [&](int rbk, int c) {          // tiles (rbk, rbk+1+c*kFastBlk ..): e = (wd - rbk - 1) * 64 + row
 #pragma unroll
-        for (int k = 0; k < R; k++) {
-            const int e = tid + k * kReduceThreads;
+        for (int k = 0; k < RC; k++) {
+            const int e = tid + (c * RC + k) * kReduceThreads;
             const int wd = rbk + 1 + (e >> 6);
-            pre[k] = (rbk < nbu && wd < nbu) ? mask[tile_id(rbk, wd, nb) * kTile + (e & 63)] : 0ull;
+            pre[c * RC + k] = (rbk < nbu && wd < nbu) ? mask[tile_id(rbk, wd, nb) * kTile + (e & 63)] : 0ull;
+        }
+    };
+    auto park_chunk = [&](int c) {
+#pragma unroll
+        for (int k = 0; k < RC; k++) {
+            const int e = tid + k * kReduceThreads;
+            tbuf[(e >> 6) * 65 + (e & 63)] = pre[c * RC + k];
         }
     };
     u64 dcur = 0ull, dnext = 0ull;                    // wave 0: this lane's diagonal word of block b / b+1
     if (tid < 64) dcur = tid < M ? mask[tile_id(0, 0, nb) * kTile + tid] : 0ull;
-    if (fast) fetch_tiles(0);
+    if (fast) {
+#pragma unroll
+        for (int c = 0; c < kFastChunks; c++)
+            if (c < nchunk) fetch_chunk(0, c);
+    }
     for (int b = 0; b < nbu; b++) {
         if (fast) {
-#pragma unroll
-            for (int k = 0; k < R; k++) {
-                const int e = tid + k * kReduceThreads;
-                tbuf[(e >> 6) * 65 + (e & 63)] = pre[k];
-            }
-            fetch_tiles(b + 1);                       // lands under this iteration's scan + OR phase
-        }
+            park_chunk(0);
+            fetch_chunk(b + 1, 0);                    // a chunk's registers refill right after it is parked:
+        }                                             // the loads land under this iteration's scan + OR phases
         if (tid < 64) {
             if (b + 1 < nbu) {
                 const int row = (b + 1) * kTile + tid;
@@ -947,10 +959,18 @@ __global__ void __launch_bounds__(kReduceThreads) nms_reduce_kernel(
         }
         __syncthreads();
         const u64 K2 = kcur;
-        if (K2) {
-            if (fast) {
-                const int wd = b + 1 + tid;
-                if (wd < nbu) {
+        if (fast) {
+#pragma unroll
+            for (int c = 0; c < kFastChunks; c++) {
+                if (c >= nchunk) break;
+                if (c > 0) {
+                    __syncthreads();                  // previous chunk's readers are done
+                    park_chunk(c);
+                    fetch_chunk(b + 1, c);
+                    __syncthreads();
+                }
+                const int wd = b + 1 + c * kFastBlk + tid;
+                if (K2 && tid < kFastBlk && wd < nbu) {
                     u64 acc = 0ull;
                     u64 bits = K2;
                     while (bits) {
@@ -960,17 +980,17 @@ __global__ void __launch_bounds__(kReduceThreads) nms_reduce_kernel(
                     }
                     remv[wd] |= acc;
                 }
-            } else {
-                for (int wd = b + 1 + tid; wd < nbu; wd += kReduceThreads) {
-                    u64 acc = 0ull;
-                    u64 bits = K2;
-                    while (bits) {
-                        int r = __ffsll((long long)bits) - 1;
-                        bits &= bits - 1;
-                        acc |= mask[tile_id(b, wd, nb) * kTile + r];
-                    }
-                    remv[wd] |= acc;
+            }
+        } else if (K2) {
+            for (int wd = b + 1 + tid; wd < nbu; wd += kReduceThreads) {
+                u64 acc = 0ull;
+                u64 bits = K2;
+                while (bits) {
+                    int r = __ffsll((long long)bits) - 1;
+                    bits &= bits - 1;
+                    acc |= mask[tile_id(b, wd, nb) * kTile + r];
                 }
+                remv[wd] |= acc;
             }
         }
         __syncthreads();
@@ -1061,12 +1081,14 @@ int run_nms(const float* d_dets9, int row_cap, const int* d_counts, int N, int m
     if (rc) return rc;
     static bool reduce_attr = false;
     if (!reduce_attr) {
-        DAFNE_HIP_TRY(hipFuncSetAttribute((const void*)nms_reduce_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+        DAFNE_HIP_TRY(hipFuncSetAttribute((const void*)nms_reduce_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                           kFastBlk * 65 * (int)sizeof(u64)));
         reduce_attr = true;
     }
-    hipLaunchKernelGGL(nms_reduce_kernel, dim3(N), dim3(kReduceThreads), (size_t)kFastBlk * 65 * sizeof(u64), st, d_counts, m_cap,
-                       post_topk, w, reinterpret_cast<long long*>(d_keep), d_num_keep);
+    // more than 160 row blocks (the 27 000-box TTA merge): the kernel falls back to its OR phase on global memory --
+    // a 3-chunk LDS variant (nms_reduce_kernel<3>) spilled and lost 2x, so it is not instantiated
+    hipLaunchKernelGGL(nms_reduce_kernel<1>, dim3(N), dim3(kReduceThreads), (size_t)kFastBlk * 65 * sizeof(u64), st, d_counts,
+                       m_cap, post_topk, w, reinterpret_cast<long long*>(d_keep), d_num_keep);
     return dafne::check_launch("nms_reduce");
 }
 
