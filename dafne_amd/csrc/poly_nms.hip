@@ -32,7 +32,8 @@ typedef unsigned long long u64;
 constexpr int kTile = 64;
 constexpr int kCapP = 10;   // clipped polygon capacity (reference: Point p[10])
 constexpr int kCapPP = 12;  // raw cut output capacity
-constexpr int kPairCap = 1024;   // candidate pairs listed per 64-row block (more: clipped in place)
+constexpr int kPairCap = 4096;   // candidate pairs listed per 64-row block (more: clipped in place); class-major
+                                 // order concentrates a class's top rows in one block: ~1800 at M = 10 000
 constexpr double kEps = 1E-8;
 
 struct P2 {
@@ -268,6 +269,10 @@ struct NmsWs {
     double* dbox;              // [N][Mp][8] fp64 rows in sorted order (fp64 entry point only, else null)
     int strict;                // ResultMerge predicate: suppress iff hulls overlap strictly AND IoU > thresh
     int fast;                  // convex fast path for the decision, exact path for the rest
+    unsigned char* cls;        // [N][Mp]  merged class of every ORIGINAL row (select path), else null
+    int* perm;                 // [N][Mp]  score-sorted position -> position in the order the tiles use
+    unsigned char* bcls;       // [N][nblk][2]  min / max class of every 64-row block in that order
+    int use_perm;              // sort_prep path: sbox/hull/area/order are in class-major order, perm/bcls valid
     int Mp, nblk, pair_cap;    // pair_cap: per row block
     size_t mask_words;         // per image
 };
@@ -283,7 +288,7 @@ size_t carve(NmsWs& w, void* base, int N, int m_cap, bool f64 = false) {
     const size_t ntiles = (size_t)nblk * (nblk + 1) / 2;
     // a 64-row block of a TTA-merge-sized set (27 000 boxes in one tile) has ~10^4 candidate pairs: with the small
     // list nearly every tile overflowed into the slower in-place path
-    w.pair_cap = Mp <= 12288 ? kPairCap : 16 * kPairCap;
+    w.pair_cap = Mp <= 12288 ? kPairCap : 4 * kPairCap;
     w.meta = c.take<unsigned>(n * 4);
     w.pair_cnt = c.take<unsigned>(n * nblk);
     w.rowflag = c.take<u64>(n * nblk);
@@ -296,6 +301,10 @@ size_t carve(NmsWs& w, void* base, int N, int m_cap, bool f64 = false) {
     w.area = c.take<double>(n * Mp);
     w.dets9 = c.take<float>(n * Mp * 9);
     w.dbox = f64 ? c.take<double>(n * Mp * 8) : nullptr;
+    w.cls = c.take<unsigned char>(n * Mp);
+    w.perm = c.take<int>(n * Mp);
+    w.bcls = c.take<unsigned char>(n * nblk * 2);
+    w.use_perm = 0;
     w.strict = 0;
     w.fast = getenv("DAFNE_NMS_NO_FAST") == nullptr ? 1 : 0;
     w.mask_words = ntiles * kTile;
@@ -352,7 +361,7 @@ __global__ void __launch_bounds__(256) nms_offset_kernel(const float* __restrict
                                                          const int* __restrict__ classes,
                                                          const int* __restrict__ counts, int m_cap,
                                                          int Mp, const unsigned* __restrict__ meta,
-                                                         float* __restrict__ dets9) {
+                                                         float* __restrict__ dets9, unsigned char* __restrict__ cls) {
     const int img = blockIdx.y;
     const int M = img_count(counts, img, m_cap);
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -366,6 +375,7 @@ __global__ void __launch_bounds__(256) nms_offset_kernel(const float* __restrict
 #pragma unroll
     for (int k = 0; k < 8; k++) d[k] = b[k] + off;           // nms.py:83
     d[8] = scores[(size_t)img * m_cap + i];
+    cls[(size_t)img * Mp + i] = (unsigned char)(c < 0 ? 255 : (c > 255 ? 255 : c));
 }
 
 // ------------------------------------------------------------------ nms_prep
@@ -464,25 +474,108 @@ __global__ void __launch_bounds__(1024) nms_sort_prep_kernel(const float* __rest
             __syncthreads();
         }
     }
+    // ---- class-major tile order -------------------------------------------------------------------
+    // Boxes of different classes sit >= 1 px apart after the class offsets (nms.py:81-83), so they never
+    // suppress each other -- unless BOTH have exactly zero area (the reference's union == 0 -> IoU 1 quirk).
+    // With at most one zero-area box in the image the greedy result is the same whether the rows are walked
+    // in global score order or class by class (score order inside a class); laid out class by class, a
+    // 64x64 tile of two blocks without a common class has no candidates and nms_scan skips it (1/15 of the
+    // tiles remain for 15 classes).  perm maps the global score order to that layout; the keep list is
+    // still emitted in global score order (nms_reduce walks perm).
+    constexpr int kMaxCls = 64;
+    __shared__ int ccnt[kMaxCls], cbase[kMaxCls + 1], crun[kMaxCls];
+    __shared__ int wcnt[16][kMaxCls];
+    __shared__ int nzero, badcls, ncls_s;
+    unsigned char* scls = reinterpret_cast<unsigned char*>(skey + n);      // class per sorted position (after the keys)
+    const bool have_cls = w.cls != nullptr && w.use_perm;
+    if (threadIdx.x < kMaxCls) { ccnt[threadIdx.x] = 0; crun[threadIdx.x] = 0; }
+    if (threadIdx.x == 0) { nzero = 0; badcls = 0; ncls_s = 1; }
+    __syncthreads();
+    if (have_cls) {
+        for (int p = threadIdx.x; p < M; p += 1024) {
+            const int i = (int)(unsigned)skey[p];
+            float v[8];
+#pragma unroll
+            for (int k = 0; k < 8; k++) v[k] = d[(size_t)i * 9 + k];
+            Quad q = load_quad_f32(v);
+            if (quad_area(q) == 0.0) atomicAdd(&nzero, 1);
+            const int c = w.cls[(size_t)img * w.Mp + i];
+            scls[p] = (unsigned char)c;
+            if (c >= kMaxCls) badcls = 1;
+            else { atomicAdd(&ccnt[c], 1); atomicMax(&ncls_s, c + 1); }
+        }
+    }
+    __syncthreads();
+    const bool cm = have_cls && nzero < 2 && !badcls;
+    const int ncls = cm ? ncls_s : 1;
+    if (threadIdx.x == 0) {
+        int run = 0;
+        for (int c = 0; c < kMaxCls; c++) { cbase[c] = run; run += cm ? ccnt[c] : 0; }
+        cbase[kMaxCls] = run;
+    }
+    __syncthreads();
     float amax = 0.f;
-    for (int p = threadIdx.x; p < M; p += 1024) {
-        const int i = (int)(unsigned)skey[p];
-        const size_t base = (size_t)img * w.Mp + p;
-        float v[8];
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    for (int p0 = 0; p0 < M; p0 += 1024) {
+        const int p = p0 + threadIdx.x;
+        const bool live = p < M;
+        int pos = p;
+        if (cm) {                                  // stable partition by class: rank among equal classes before p
+            const int myc = live ? scls[p] : -1;
+            int myrank = 0;
+            for (int c = 0; c < ncls; c++) {
+                const u64 m = __ballot(myc == c);
+                if (myc == c) myrank = __popcll(m & ((1ull << lane) - 1ull));
+                if (lane == 0) wcnt[wv][c] = __popcll(m);
+            }
+            __syncthreads();
+            if (live) {
+                int off = crun[myc];
+                for (int w2 = 0; w2 < wv; w2++) off += wcnt[w2][myc];
+                pos = cbase[myc] + off + myrank;
+            }
+            __syncthreads();
+            if (threadIdx.x < ncls) {
+                int t = 0;
+                for (int w2 = 0; w2 < 16; w2++) t += wcnt[w2][threadIdx.x];
+                crun[threadIdx.x] += t;
+            }
+            __syncthreads();
+        }
+        if (live) {
+            const int i = (int)(unsigned)skey[p];
+            const size_t gbase = (size_t)img * w.Mp + p;       // score order
+            const size_t base = (size_t)img * w.Mp + pos;      // tile order
+            float v[8];
 #pragma unroll
-        for (int k = 0; k < 8; k++) v[k] = d[(size_t)i * 9 + k];
-        w.order[base] = i;
-        w.sscore[base] = d[(size_t)i * 9 + 8];
-        float4* sb = reinterpret_cast<float4*>(w.sbox + base * 8);
-        sb[0] = make_float4(v[0], v[1], v[2], v[3]);
-        sb[1] = make_float4(v[4], v[5], v[6], v[7]);
-        const float xmin = fminf(fminf(v[0], v[2]), fminf(v[4], v[6])), xmax = fmaxf(fmaxf(v[0], v[2]), fmaxf(v[4], v[6]));
-        const float ymin = fminf(fminf(v[1], v[3]), fminf(v[5], v[7])), ymax = fmaxf(fmaxf(v[1], v[3]), fmaxf(v[5], v[7]));
-        w.hull[base] = make_float4(xmin, ymin, xmax, ymax);
-        Quad q = load_quad_f32(v);
-        w.area[base] = fabs(quad_area(q));
+            for (int k = 0; k < 8; k++) v[k] = d[(size_t)i * 9 + k];
+            w.perm[gbase] = pos;
+            w.sscore[gbase] = d[(size_t)i * 9 + 8];
+            w.order[base] = i;
+            float4* sb = reinterpret_cast<float4*>(w.sbox + base * 8);
+            sb[0] = make_float4(v[0], v[1], v[2], v[3]);
+            sb[1] = make_float4(v[4], v[5], v[6], v[7]);
+            const float xmin = fminf(fminf(v[0], v[2]), fminf(v[4], v[6])), xmax = fmaxf(fmaxf(v[0], v[2]), fmaxf(v[4], v[6]));
+            const float ymin = fminf(fminf(v[1], v[3]), fminf(v[5], v[7])), ymax = fmaxf(fmaxf(v[1], v[3]), fmaxf(v[5], v[7]));
+            w.hull[base] = make_float4(xmin, ymin, xmax, ymax);
+            Quad q = load_quad_f32(v);
+            w.area[base] = fabs(quad_area(q));
 #pragma unroll
-        for (int k = 0; k < 8; k++) amax = fmaxf(amax, fabsf(v[k]));
+            for (int k = 0; k < 8; k++) amax = fmaxf(amax, fabsf(v[k]));
+        }
+    }
+    // class range of every 64-row block in tile order (classes ascend with the position)
+    for (int b = threadIdx.x; b < w.nblk; b += 1024) {
+        int cmin = 0, cmax = 255;
+        if (cm && b * kTile < M) {
+            const int first = b * kTile, last = min(M, (b + 1) * kTile) - 1;
+            cmin = 0;
+            while (cmin + 1 < kMaxCls && cbase[cmin + 1] <= first) cmin++;
+            cmax = cmin;
+            while (cmax + 1 < kMaxCls && cbase[cmax + 1] <= last) cmax++;
+        }
+        w.bcls[((size_t)img * w.nblk + b) * 2 + 0] = (unsigned char)cmin;
+        w.bcls[((size_t)img * w.nblk + b) * 2 + 1] = (unsigned char)cmax;
     }
     for (int o = 32; o > 0; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o, 64));
     if ((threadIdx.x & 63) == 0 && amax > 0.f) atomicMax(&w.meta[img * 4 + 0], __float_as_uint(amax));
@@ -639,6 +732,10 @@ __global__ void __launch_bounds__(256) nms_scan_kernel(const int* __restrict__ c
     const size_t ibase = (size_t)img * w.Mp;
     const int grow = rb * kTile + lane;
     w.mask[(size_t)img * w.mask_words + (size_t)t * kTile + lane] = 0ull;
+    if (w.use_perm) {          // class-major layout: two blocks without a common class have no candidate pair
+        const unsigned char* bc = w.bcls + (size_t)img * w.nblk * 2;
+        if (bc[rb * 2] > bc[cb * 2 + 1] || bc[cb * 2] > bc[rb * 2 + 1]) return;
+    }
     const u64 mycand = tile_candidates(w, img, M, rb, cb, thresh, rhull_s[wv]);
     const int cnt = __popcll(mycand);
     int incl = cnt;
@@ -996,6 +1093,61 @@ __global__ void __launch_bounds__(kReduceThreads) nms_reduce_kernel(
         __syncthreads();
     }
 
+    if (w.use_perm) {
+        // The kept bits live in tile (class-major) order; the keep list is emitted in GLOBAL score order:
+        // thread t walks score-order positions [t*cs, (t+1)*cs) through perm.
+        const int* perm = w.perm + ibase;
+        __shared__ int tcnt[kReduceThreads + 1];
+        __shared__ int n_out2;
+        const int cs = (M + kReduceThreads - 1) / kReduceThreads;
+        const int p_lo = min(M, tid * cs), p_hi = min(M, p_lo + cs);
+        int mine = 0;
+        for (int p = p_lo; p < p_hi; p++) {
+            const int q = perm[p];
+            mine += (int)((kept[q >> 6] >> (q & 63)) & 1ull);
+        }
+        tcnt[tid] = mine;
+        __syncthreads();
+        if (tid == 0) {
+            int run = 0;
+            for (int k = 0; k < kReduceThreads; k++) { const int c = tcnt[k]; tcnt[k] = run; run += c; }
+            tcnt[kReduceThreads] = run;
+            n_out2 = run;
+        }
+        __syncthreads();
+        const int total = tcnt[kReduceThreads];
+        // cap (dafne_outputs.py:916-923): keep every row whose score >= the post_topk-th best kept score;
+        // kept rows are walked in descending score order, so that is a prefix (+ the ties behind it)
+        if (post_topk > 0 && total > post_topk) {
+            if (tcnt[tid] < post_topk && tcnt[tid] + mine >= post_topk) {      // exactly one thread
+                int seen = tcnt[tid], p = p_lo;
+                for (; p < p_hi; p++) {
+                    const int q = perm[p];
+                    if ((kept[q >> 6] >> (q & 63)) & 1ull)
+                        if (++seen == post_topk) break;
+                }
+                const float thr = w.sscore[ibase + p];
+                int n = post_topk;
+                for (p = p + 1; p < M; p++) {
+                    const int q = perm[p];
+                    if ((kept[q >> 6] >> (q & 63)) & 1ull) {
+                        if (w.sscore[ibase + p] >= thr) n++; else break;
+                    }
+                }
+                n_out2 = n;
+            }
+            __syncthreads();
+        }
+        const int nout = n_out2;
+        int o = tcnt[tid];
+        for (int p = p_lo; p < p_hi && o < nout; p++) {
+            const int q = perm[p];
+            if ((kept[q >> 6] >> (q & 63)) & 1ull) kout[o++] = (long long)w.order[ibase + q];
+        }
+        if (tid == 0) num_keep[img] = nout;
+        return;
+    }
+
     // ordered compaction of the kept sorted positions
     if (tid == 0) {
         int run = 0;
@@ -1058,12 +1210,14 @@ int run_nms(const float* d_dets9, int row_cap, const int* d_counts, int N, int m
         static bool attr_done = false;
         if (!attr_done) {
             DAFNE_HIP_TRY(hipFuncSetAttribute((const void*)nms_sort_prep_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                              kSortMax * (int)sizeof(u64)));
+                                              kSortMax * ((int)sizeof(u64) + 1)));
             attr_done = true;
         }
         int n = 64;
         while (n < m_cap) n <<= 1;
-        hipLaunchKernelGGL(nms_sort_prep_kernel, dim3(N), dim3(1024), (size_t)n * sizeof(u64), st, d_dets9, row_cap, d_counts,
+        w.use_perm = 1;
+        if (getenv("DAFNE_NMS_NO_CLASS_ORDER")) w.cls = nullptr;      // experiments: score order is the tile order
+        hipLaunchKernelGGL(nms_sort_prep_kernel, dim3(N), dim3(1024), (size_t)n * (sizeof(u64) + 1), st, d_dets9, row_cap, d_counts,
                            m_cap, w);
     } else
         hipLaunchKernelGGL(nms_prep_kernel, gp, dim3(256), 0, st, d_dets9, row_cap, d_counts, m_cap, w);
@@ -1126,6 +1280,7 @@ int dafne_poly_nms_batched_hip(const float* d_dets9, const int32_t* d_counts, in
     size_t need = carve(w, d_ws, n_images, m_cap);
     if (ws_bytes < need) return dafne::fail(DAFNE_E_WORKSPACE, "poly_nms: workspace %zu < %zu", ws_bytes, need);
     if (w.nblk > kMaxBlk) return dafne::fail(DAFNE_E_UNSUPPORTED, "poly_nms: m_cap %d > %d", m_cap, kMaxBlk * kTile);
+    w.cls = nullptr;           // plain [M,9] rows carry no class: score order is the tile order
     return run_nms(d_dets9, m_cap, d_counts, n_images, m_cap, thresh, post_topk, d_keep, d_num_keep, w, st, false);
 }
 
@@ -1182,7 +1337,7 @@ int dafne_select_over_all_levels_hip(const float* d_boxes8, const float* d_score
     int rc = dafne::check_launch("nms_minmax");
     if (rc) return rc;
     hipLaunchKernelGGL(nms_offset_kernel, dim3((m_cap + 255) / 256, n_images), dim3(256), 0, st, d_boxes8,
-                       d_scores, d_classes, d_counts, m_cap, w.Mp, w.meta, w.dets9);
+                       d_scores, d_classes, d_counts, m_cap, w.Mp, w.meta, w.dets9, w.cls);
     rc = dafne::check_launch("nms_offset");
     if (rc) return rc;
     return run_nms(w.dets9, w.Mp, d_counts, n_images, m_cap, nms_thresh, post_topk, d_keep, d_num_keep, w, st, true);

@@ -194,3 +194,45 @@ def test_fast_path_decisions_around_the_threshold():
     want = np.array([len(oracle.poly_nms(dets[i], 0.1)) for i in range(n)])
     assert np.array_equal(got, want), np.nonzero(got != want)[0][:10]
     assert 0.2 < (want == 1).mean() < 0.8          # the set really straddles the threshold
+
+
+@pytest.mark.parametrize("n_zero", [0, 1, 2, 5])
+def test_class_major_tile_order_matches_global_greedy(n_zero):
+    """select_over_all_levels lays the rows out class by class (tiles of blocks without a common class are
+    skipped).  That is only equivalent to the global greedy pass while at most ONE box has exactly zero area
+    (two zero-area boxes have IoU 1 whatever their class: polyiou.cpp's union == 0 branch); with more the
+    kernels fall back to score order.  Checked against the oracle, incl. quantised scores (ties across
+    classes), class 5 -> 4 merging, a post-NMS cap with ties, and an image with a single class."""
+    from dafne_amd import _lib
+    L = _lib.load()
+    rng = np.random.default_rng(100 + n_zero)
+    N, cap = 4, 3000
+    counts = [3000, 1500, 700, 64]
+    boxes = np.zeros((N, cap, 8), np.float32)
+    scores = np.zeros((N, cap), np.float32)
+    classes = np.zeros((N, cap), np.int32)
+    for i, m in enumerate(counts):
+        boxes[i, :m] = rrects(m, rng, extent=500.0)
+        scores[i, :m] = np.round(rng.uniform(0.05, 1, m), 2)          # many exact ties
+        classes[i, :m] = 7 if i == 2 else rng.integers(0, 16, m)
+        zi = rng.choice(m, n_zero, replace=False)
+        for k, z in enumerate(zi):                                     # exact zero area, different classes
+            boxes[i, z] = np.tile(boxes[i, z, :2], 4)
+            classes[i, z] = (3 * k + i) % 16
+    d = dev()
+    tb, ts, tc = (torch.from_numpy(a).to(d) for a in (boxes, scores, classes))
+    tn = torch.tensor(counts, dtype=torch.int32, device=d)
+    keep = torch.full((N, cap), -1, dtype=torch.int64, device=d)
+    nk = torch.zeros(N, dtype=torch.int32, device=d)
+    nbytes = L.dafne_poly_nms_workspace_bytes(N, cap)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=d)
+    post = 300
+    _lib.check(L.dafne_select_over_all_levels_hip(_lib.ptr(tb), _lib.ptr(ts), _lib.ptr(tc), _lib.ptr(tn), N, cap, 0.1, post,
+                                                  _lib.ptr(keep), _lib.ptr(nk), _lib.ptr(ws), nbytes, _lib.current_stream()))
+    torch.cuda.synchronize()
+    for i, m in enumerate(counts):
+        exp_keep = pp.batched_nms_poly(boxes[i, :m], scores[i, :m], classes[i, :m].astype(np.int64), 0.1, fast=True)
+        if len(exp_keep) > post:
+            kth = np.sort(scores[i][exp_keep])[len(exp_keep) - post]
+            exp_keep = exp_keep[scores[i][exp_keep] >= kth]
+        assert keep[i, :int(nk[i])].cpu().tolist() == exp_keep.tolist(), (i, n_zero)
