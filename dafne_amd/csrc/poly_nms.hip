@@ -272,6 +272,7 @@ struct NmsWs {
     unsigned char* cls;        // [N][Mp]  merged class of every ORIGINAL row (select path), else null
     int* perm;                 // [N][Mp]  score-sorted position -> position in the order the tiles use
     unsigned char* bcls;       // [N][nblk][2]  min / max class of every 64-row block in that order
+    int* cbase;                // [N][65]  first row of every class in that order (class-major images)
     int use_perm;              // sort_prep path: sbox/hull/area/order are in class-major order, perm/bcls valid
     int Mp, nblk, pair_cap;    // pair_cap: per row block
     size_t mask_words;         // per image
@@ -304,6 +305,7 @@ size_t carve(NmsWs& w, void* base, int N, int m_cap, bool f64 = false) {
     w.cls = c.take<unsigned char>(n * Mp);
     w.perm = c.take<int>(n * Mp);
     w.bcls = c.take<unsigned char>(n * nblk * 2);
+    w.cbase = c.take<int>(n * 65);
     w.use_perm = 0;
     w.strict = 0;
     w.fast = getenv("DAFNE_NMS_NO_FAST") == nullptr ? 1 : 0;
@@ -378,6 +380,52 @@ __global__ void __launch_bounds__(256) nms_offset_kernel(const float* __restrict
     cls[(size_t)img * Mp + i] = (unsigned char)(c < 0 ? 255 : (c > 255 ? 255 : c));
 }
 
+// Class layout for the rank-by-counting path (M > 16384: the TTA merge): class histogram, zero-area census,
+// first row of every class and the class range of every 64-row block -- what nms_sort_prep computes in place.
+__global__ void __launch_bounds__(1024) nms_cls_layout_kernel(const float* __restrict__ dets9, int row_cap,
+                                                              const int* __restrict__ counts, int m_cap, NmsWs w) {
+    constexpr int kMaxCls = 64;
+    const int img = blockIdx.x;
+    const int M = img_count(counts, img, m_cap);
+    __shared__ int ccnt[kMaxCls], cbase[kMaxCls + 1];
+    __shared__ int nzero, badcls, ncls_s;
+    if (threadIdx.x < kMaxCls) ccnt[threadIdx.x] = 0;
+    if (threadIdx.x == 0) { nzero = 0; badcls = 0; ncls_s = 1; }
+    __syncthreads();
+    const float* d = dets9 + (size_t)img * row_cap * 9;
+    for (int i = threadIdx.x; i < M; i += 1024) {
+        float v[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) v[k] = d[(size_t)i * 9 + k];
+        Quad q = load_quad_f32(v);
+        if (quad_area(q) == 0.0) atomicAdd(&nzero, 1);
+        const int c = w.cls[(size_t)img * w.Mp + i];
+        if (c >= kMaxCls) badcls = 1;
+        else { atomicAdd(&ccnt[c], 1); atomicMax(&ncls_s, c + 1); }
+    }
+    __syncthreads();
+    const bool cm = M > 0 && nzero < 2 && !badcls;
+    if (threadIdx.x == 0) {
+        int run = 0;
+        for (int c = 0; c < kMaxCls; c++) { cbase[c] = run; run += cm ? ccnt[c] : 0; }
+        cbase[kMaxCls] = run;
+        w.meta[img * 4 + 2] = cm ? (unsigned)ncls_s : 0u;
+    }
+    __syncthreads();
+    if (threadIdx.x <= kMaxCls) w.cbase[(size_t)img * 65 + threadIdx.x] = cbase[threadIdx.x];
+    for (int b = threadIdx.x; b < w.nblk; b += 1024) {
+        int cmin = 0, cmax = 255;
+        if (cm && b * kTile < M) {
+            const int first = b * kTile, last = min(M, (b + 1) * kTile) - 1;
+            while (cmin + 1 < kMaxCls && cbase[cmin + 1] <= first) cmin++;
+            cmax = cmin;
+            while (cmax + 1 < kMaxCls && cbase[cmax + 1] <= last) cmax++;
+        }
+        w.bcls[((size_t)img * w.nblk + b) * 2 + 0] = (unsigned char)cmin;
+        w.bcls[((size_t)img * w.nblk + b) * 2 + 1] = (unsigned char)cmax;
+    }
+}
+
 // ------------------------------------------------------------------ nms_prep
 __global__ void __launch_bounds__(256) nms_prep_kernel(const float* __restrict__ dets9, int row_cap,
                                                        const int* __restrict__ counts, int m_cap,
@@ -390,33 +438,45 @@ __global__ void __launch_bounds__(256) nms_prep_kernel(const float* __restrict__
     const bool live = i < M;
     const float si = live ? d[(size_t)i * 9 + 8] : 0.f;
     __shared__ __attribute__((aligned(16))) float ss[256];
-    int rank = 0;
+    __shared__ __attribute__((aligned(4))) unsigned char sc[256];
+    // class-major layout (see nms_sort_prep_kernel): the position among the rows of the same class is counted
+    // in the same pass (nms_cls_layout_kernel ran before and decided whether the image is class-major)
+    const bool cm = w.use_perm && w.cls != nullptr && w.meta[img * 4 + 2] != 0u;
+    const int ci = (cm && live) ? w.cls[(size_t)img * w.Mp + i] : -1;
+    int rank = 0, crank = 0;
     for (int j0 = 0; j0 < M; j0 += 256) {
         int j = j0 + threadIdx.x;
         ss[threadIdx.x] = j < M ? d[(size_t)j * 9 + 8] : -INFINITY;
+        if (cm) sc[threadIdx.x] = j < M ? w.cls[(size_t)img * w.Mp + j] : 255;
         __syncthreads();
-        const int lim = min(256, M - j0);
         const float4* ss4 = reinterpret_cast<const float4*>(ss);
+        const uchar4* sc4 = reinterpret_cast<const uchar4*>(sc);
 #pragma unroll 4
-        for (int j4 = 0; j4 < 64; j4++) {                 // entries beyond lim hold -inf: never counted
+        for (int j4 = 0; j4 < 64; j4++) {                 // entries beyond M hold -inf: never counted
             const float4 v = ss4[j4];
             const int jg = j0 + 4 * j4;
-            rank += (v.x > si) || (v.x == si && jg > i);  // argsort(kind="stable")[::-1]
-            rank += (v.y > si) || (v.y == si && jg + 1 > i);
-            rank += (v.z > si) || (v.z == si && jg + 2 > i);
-            rank += (v.w > si) || (v.w == si && jg + 3 > i);
+            const int a0 = (v.x > si) || (v.x == si && jg > i);  // argsort(kind="stable")[::-1]
+            const int a1 = (v.y > si) || (v.y == si && jg + 1 > i);
+            const int a2 = (v.z > si) || (v.z == si && jg + 2 > i);
+            const int a3 = (v.w > si) || (v.w == si && jg + 3 > i);
+            rank += a0 + a1 + a2 + a3;
+            if (cm) {
+                const uchar4 c4 = sc4[j4];
+                crank += (a0 & (c4.x == ci)) + (a1 & (c4.y == ci)) + (a2 & (c4.z == ci)) + (a3 & (c4.w == ci));
+            }
         }
-        (void)lim;
         __syncthreads();
     }
     float amax = 0.f;
     if (live) {
-        const size_t base = (size_t)img * w.Mp + rank;
+        const int pos = cm ? w.cbase[(size_t)img * 65 + ci] + crank : rank;
+        const size_t base = (size_t)img * w.Mp + pos;            // tile order
         float v[8];
 #pragma unroll
         for (int k = 0; k < 8; k++) v[k] = d[(size_t)i * 9 + k];
         w.order[base] = i;
-        w.sscore[base] = si;
+        w.sscore[(size_t)img * w.Mp + rank] = si;                 // score order
+        if (w.use_perm) w.perm[(size_t)img * w.Mp + rank] = pos;
         float4* sb = reinterpret_cast<float4*>(w.sbox + base * 8);
         sb[0] = make_float4(v[0], v[1], v[2], v[3]);
         sb[1] = make_float4(v[4], v[5], v[6], v[7]);
@@ -564,6 +624,8 @@ __global__ void __launch_bounds__(1024) nms_sort_prep_kernel(const float* __rest
             for (int k = 0; k < 8; k++) amax = fmaxf(amax, fabsf(v[k]));
         }
     }
+    if (threadIdx.x <= kMaxCls) w.cbase[(size_t)img * 65 + threadIdx.x] = cbase[threadIdx.x];
+    if (threadIdx.x == 0) w.meta[img * 4 + 2] = cm ? (unsigned)ncls : 0u;      // 0: score order
     // class range of every 64-row block in tile order (classes ascend with the position)
     for (int b = threadIdx.x; b < w.nblk; b += 1024) {
         int cmin = 0, cmax = 255;
@@ -732,7 +794,7 @@ __global__ void __launch_bounds__(256) nms_scan_kernel(const int* __restrict__ c
     const size_t ibase = (size_t)img * w.Mp;
     const int grow = rb * kTile + lane;
     w.mask[(size_t)img * w.mask_words + (size_t)t * kTile + lane] = 0ull;
-    if (w.use_perm) {          // class-major layout: two blocks without a common class have no candidate pair
+    if (w.use_perm && w.cls) { // class-major layout: two blocks without a common class have no candidate pair
         const unsigned char* bc = w.bcls + (size_t)img * w.nblk * 2;
         if (bc[rb * 2] > bc[cb * 2 + 1] || bc[cb * 2] > bc[rb * 2 + 1]) return;
     }
@@ -992,7 +1054,58 @@ __global__ void __launch_bounds__(kReduceThreads) nms_reduce_kernel(
     //  * (fast == true, <= kFastBlk blocks) the words of tiles (b, b+1..) are fetched one iteration AHEAD into
     //    registers, coalesced (a tile is 512 contiguous bytes), then parked in LDS, so the OR phase of block b
     //    reads LDS instead of chasing global loads that depend on the scan's result.
-    const bool fast = nbu <= kFastChunks * kFastBlk;
+    // Class-major image with enough classes: the classes are independent greedy problems.  One WAVE per class
+    // walks that class's blocks (a block shared by two classes is scanned by both, each on its own rows), so the
+    // serial chain is a class's ~M/(64 C) blocks instead of all M/64.
+    const int ncls = w.use_perm ? (int)w.meta[img * 4 + 2] : 0;
+    if (ncls >= 4) {
+        const int* cb = w.cbase + (size_t)img * 65;
+        const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+        for (int c = wave; c < ncls; c += kReduceThreads / 64) {
+            const int r0 = cb[c], r1 = cb[c + 1];
+            if (r1 <= r0) continue;
+            const int b0 = r0 >> 6, b1 = (r1 - 1) >> 6;
+            for (int b = b0; b <= b1; b++) {
+                const int lo = max(r0, b * kTile) - b * kTile, hi = min(r1, (b + 1) * kTile) - b * kTile;
+                const u64 rowmask = (hi >= 64 ? ~0ull : ((1ull << hi) - 1ull)) & ~((1ull << lo) - 1ull);
+                const u64 dw = ((rowmask >> lane) & 1ull) ? mask[tile_id(b, b, nb) * kTile + lane] : 0ull;
+                u64 bits = __ballot(dw != 0ull);
+                const unsigned dlo = (unsigned)dw, dhi = (unsigned)(dw >> 32);
+                u64 rem = remv[b];
+                rem = ((u64)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(rem >> 32)) << 32) |
+                      (u64)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)rem);
+                rem |= ~rowmask;
+                while (bits) {
+                    const int r = __builtin_amdgcn_readfirstlane(__ffsll((long long)bits) - 1);
+                    bits &= bits - 1;
+                    if (!((rem >> r) & 1ull)) {
+                        const unsigned l2 = (unsigned)__builtin_amdgcn_readlane((int)dlo, r);
+                        const unsigned h2 = (unsigned)__builtin_amdgcn_readlane((int)dhi, r);
+                        rem |= ((u64)h2 << 32) | (u64)l2;
+                    }
+                }
+                const u64 K = ~rem;                         // kept rows of this class in block b
+                if (lane == 0 && K) atomicOr(&kept[b], K);
+                const u64 K2 = K & rowflag[b];
+                if (K2) {
+                    for (int wd = b + 1 + lane; wd <= b1; wd += 64) {
+                        u64 acc = 0ull;
+                        u64 kb = K2;
+                        while (kb) {
+                            const int r = __ffsll((long long)kb) - 1;
+                            kb &= kb - 1;
+                            acc |= mask[tile_id(b, wd, nb) * kTile + r];
+                        }
+                        if (acc) atomicOr(&remv[wd], acc);
+                    }
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // this wave's LDS atomics are done
+                __builtin_amdgcn_wave_barrier();
+            }
+        }
+        __syncthreads();
+    }
+    const bool fast = ncls < 4 && nbu <= kFastChunks * kFastBlk;
     extern __shared__ u64 tbuf[];                     // fast: [kFastBlk][65] tile rows of the current block, one chunk at a time
     constexpr int RC = kFastBlk * kTile / kReduceThreads;      // registers per chunk of kFastBlk tiles
     u64 pre[kFastChunks * RC];
@@ -1019,7 +1132,7 @@ __global__ void __launch_bounds__(kReduceThreads) nms_reduce_kernel(
         for (int c = 0; c < kFastChunks; c++)
             if (c < nchunk) fetch_chunk(0, c);
     }
-    for (int b = 0; b < nbu; b++) {
+    for (int b = 0; b < (ncls >= 4 ? 0 : nbu); b++) {
         if (fast) {
             park_chunk(0);
             fetch_chunk(b + 1, 0);                    // a chunk's registers refill right after it is parked:
@@ -1219,8 +1332,12 @@ int run_nms(const float* d_dets9, int row_cap, const int* d_counts, int N, int m
         if (getenv("DAFNE_NMS_NO_CLASS_ORDER")) w.cls = nullptr;      // experiments: score order is the tile order
         hipLaunchKernelGGL(nms_sort_prep_kernel, dim3(N), dim3(1024), (size_t)n * (sizeof(u64) + 1), st, d_dets9, row_cap, d_counts,
                            m_cap, w);
-    } else
+    } else {
+        w.use_perm = 1;
+        if (getenv("DAFNE_NMS_NO_CLASS_ORDER")) w.cls = nullptr;
+        if (w.cls) hipLaunchKernelGGL(nms_cls_layout_kernel, dim3(N), dim3(1024), 0, st, d_dets9, row_cap, d_counts, m_cap, w);
         hipLaunchKernelGGL(nms_prep_kernel, gp, dim3(256), 0, st, d_dets9, row_cap, d_counts, m_cap, w);
+    }
     int rc = dafne::check_launch("nms_prep");
     if (rc) return rc;
     long long ntiles = (long long)w.nblk * (w.nblk + 1) / 2;

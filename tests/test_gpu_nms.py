@@ -236,3 +236,33 @@ def test_class_major_tile_order_matches_global_greedy(n_zero):
             kth = np.sort(scores[i][exp_keep])[len(exp_keep) - post]
             exp_keep = exp_keep[scores[i][exp_keep] >= kth]
         assert keep[i, :int(nk[i])].cpu().tolist() == exp_keep.tolist(), (i, n_zero)
+
+
+@pytest.mark.parametrize("n_zero", [0, 3])
+def test_class_major_order_on_the_counting_path(n_zero):
+    """Same equivalence for sets above 16384 rows (the TTA merge), where the layout comes from
+    nms_cls_layout + the rank-by-counting kernel instead of the in-LDS sort."""
+    from dafne_amd import _lib
+    L = _lib.load()
+    rng = np.random.default_rng(300 + n_zero)
+    m = 17000
+    boxes = rrects(m, rng, extent=1500.0)[None].copy()
+    scores = np.round(rng.uniform(0.05, 1, (1, m)), 3).astype(np.float32)
+    classes = rng.integers(0, 16, (1, m)).astype(np.int32)
+    for k, z in enumerate(rng.choice(m, n_zero, replace=False)):
+        boxes[0, z] = np.tile(boxes[0, z, :2], 4)
+        classes[0, z] = (5 * k + 1) % 16
+    d = dev()
+    tb, ts, tc = (torch.from_numpy(a).to(d) for a in (boxes, scores, classes))
+    keep = torch.full((1, m), -1, dtype=torch.int64, device=d)
+    nk = torch.zeros(1, dtype=torch.int32, device=d)
+    nbytes = L.dafne_poly_nms_workspace_bytes(1, m)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=d)
+    _lib.check(L.dafne_select_over_all_levels_hip(_lib.ptr(tb), _lib.ptr(ts), _lib.ptr(tc), None, 1, m, 0.1, 1000,
+                                                  _lib.ptr(keep), _lib.ptr(nk), _lib.ptr(ws), nbytes, _lib.current_stream()))
+    torch.cuda.synchronize()
+    exp_keep = pp.batched_nms_poly(boxes[0], scores[0], classes[0].astype(np.int64), 0.1, fast=True)
+    if len(exp_keep) > 1000:
+        kth = np.sort(scores[0][exp_keep])[len(exp_keep) - 1000]
+        exp_keep = exp_keep[scores[0][exp_keep] >= kth]
+    assert keep[0, :int(nk[0])].cpu().tolist() == exp_keep.tolist()
