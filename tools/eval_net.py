@@ -29,6 +29,8 @@ def main():
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--tta", action="store_true", help="TEST.AUG multi-scale / flip inference")
     ap.add_argument("--output", default="")
+    ap.add_argument("--task1-dir", default="", help="DOTA configs: write Task1_<class>.txt files here and merge the tiles "
+                                                    "(Task1_merged/) with the device NMS (dota_evaluation.py:110-184)")
     ap.add_argument("opts", nargs=argparse.REMAINDER, help="KEY VALUE config overrides")
     args = ap.parse_args()
 
@@ -56,7 +58,7 @@ def main():
     w = args.width or cfg.INPUT.MIN_SIZE_TEST
     g = torch.Generator().manual_seed(args.seed)
     inputs = [{"image": torch.randint(0, 256, (3, h, w), generator=g, dtype=torch.uint8), "height": h, "width": w,
-               "image_id": i, "file_name": "synthetic_%d" % i} for i in range(args.num_images)]
+               "image_id": i, "file_name": "P%04d__1__0___%d.png" % (i // 4, 824 * (i % 4))} for i in range(args.num_images)]
     runner = OneStageRCNNWithTTA(cfg, model) if args.tta else model
     outputs = []
     for inp in inputs:                       # batch size 1 like detectron2's inference_on_dataset
@@ -71,6 +73,18 @@ def main():
                                                              float(inst.scores.max()) if len(inst) else 0.0))
     if args.output:
         torch.save(preds, args.output)
+    if args.task1_dir:
+        from dafne_amd.evaluation import dota_evaluation as de
+        names = list(de.CLASSNAMES_DOTA_1_0) + (["container-crane"] if cfg.MODEL.DAFNE.NUM_CLASSES == 16 else [])
+        t1 = os.path.join(args.task1_dir, "Task1")
+        merged = os.path.join(args.task1_dir, "Task1_merged")
+        os.makedirs(t1, exist_ok=True)
+        os.makedirs(merged, exist_ok=True)
+        de._generate_task_1_files(None, preds, args.task1_dir, t1, names[:cfg.MODEL.DAFNE.NUM_CLASSES], cfg)
+        de.run_merge(t1, merged)
+        n_in = sum(len(open(os.path.join(t1, f)).readlines()) for f in os.listdir(t1))
+        n_out = sum(len(open(os.path.join(merged, f)).readlines()) for f in os.listdir(merged))
+        print("Task1: %d tile detections -> %d after the tile merge (%s)" % (n_in, n_out, merged))
     return preds
 
 
