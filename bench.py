@@ -40,6 +40,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_BF16_TFLOPS = 2500.0     # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
+PEAK_HBM_GBPS = 8000.0        # HBM3E spec (6.29 TB/s measured float4 copy, same guide)
 GFLOP_PER_IMG = {50: 505.97, 101: 661.13}   # SURVEY 8(d), 1024^2, C=15
 
 
@@ -142,13 +143,15 @@ def conv_kernel_profile(model, batch, splits, reps=3):
         torch.cuda.synchronize()
         for c, a, b in evs:
             cfgname = c.kernel_name()
-            s = stats.setdefault(cfgname, {"ms": 0.0, "flops": 0.0, "launches": 0})
+            s = stats.setdefault(cfgname, {"ms": 0.0, "flops": 0.0, "bytes": 0.0, "launches": 0})
             s["ms"] += a.elapsed_time(b)
             s["flops"] += c.flops
+            s["bytes"] += c.bytes
             s["launches"] += 1
     for s in stats.values():
         s["ms"] /= reps
         s["flops"] /= reps
+        s["bytes"] /= reps
         s["launches"] //= reps
         s["tflops"] = s["flops"] / (s["ms"] * 1e-3) / 1e12 if s["ms"] > 0 else 0.0
         s["avg_launch_us"] = 1e3 * s["ms"] / max(s["launches"], 1)
@@ -179,11 +182,14 @@ def conv_kernel_profile_isolated(model, batch, reps=3):
         torch.cuda.synchronize()
         for c, a, b in evs:
             name = c.kernel_name()
-            s = stats.setdefault(name, {"ms": 0.0, "flops": 0.0, "launches": 0})
+            s = stats.setdefault(name, {"ms": 0.0, "flops": 0.0, "bytes": 0.0, "launches": 0})
             s["ms"] += a.elapsed_time(b) / reps
             s["flops"] += c.flops / reps
+            s["bytes"] += c.bytes / reps
             s["launches"] += 1
     return {k: {"tflops": v["flops"] / (v["ms"] * 1e-3) / 1e12, "frac": v["flops"] / (v["ms"] * 1e-3) / 1e12 / PEAK_BF16_TFLOPS,
+                "hbm_gbps_algorithmic": v["bytes"] / (v["ms"] * 1e-3) / 1e9,
+                "hbm_frac": v["bytes"] / (v["ms"] * 1e-3) / 1e9 / PEAK_HBM_GBPS,
                 "ms_per_step": v["ms"], "launches": v["launches"] // reps} for k, v in stats.items()}
 
 
@@ -336,8 +342,16 @@ def main():
             out["roofline"]["note"] = ("launches of %d sub-batches share the GPU on concurrent streams: a launch's "
                                        "duration includes that sharing (as rocprofv3 reports it); see "
                                        "roofline_isolated for the same kernels with the GPU to themselves" % args.splits)
-        out["kernels"] = {k: {"tflops": v["tflops"], "ms_per_step": v["ms"], "launches": v["launches"]}
-                          for k, v in prof.items()}
+        out["kernels"] = {k: {"tflops": v["tflops"], "ms_per_step": v["ms"], "launches": v["launches"],
+                              "hbm_gbps_algorithmic": v["bytes"] / (v["ms"] * 1e-3) / 1e9} for k, v in prof.items()}
+        # the HBM-bound kernel family next to the MFMA-bound dominant one: persistent weight-stationary 1x1 layers
+        if "conv_ws" in prof:
+            wsk = prof["conv_ws"]
+            out["roofline_hbm"] = {"bound": "hbm", "kernel": "conv_ws_kernel", "achieved": wsk["bytes"] / (wsk["ms"] * 1e-3) / 1e9,
+                                   "peak": PEAK_HBM_GBPS, "unit": "GB/s", "frac": wsk["bytes"] / (wsk["ms"] * 1e-3) / 1e9 / PEAK_HBM_GBPS,
+                                   "launches_per_step": wsk["launches"], "avg_launch_us": wsk["avg_launch_us"],
+                                   "algorithmic_bytes_per_step": wsk["bytes"],
+                                   "note": "in the timed stream layout (3 sub-batches share the GPU); roofline_isolated has the same kernels alone"}
         out["roofline_isolated"] = conv_kernel_profile_isolated(model, batch)
         tot_flops = sum(v["flops"] for v in prof.values())
         out["model_tflops_end_to_end"] = tot_flops / (dt / args.steps) / 1e12

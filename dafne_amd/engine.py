@@ -116,9 +116,13 @@ class ConvCall:
         self.segs = arr
         self.fn = L.dafne_conv2d_nhwc_bf16_hip
         self.flops = 0
-        for (_, _, _, _, _, hout, wout) in segs:
+        self.bytes = w.numel() * w.element_size()       # algorithmic HBM bytes: every operand once
+        for (_, tout, tres, hin, win, hout, wout) in segs:
             kk = 49 * 3 if (cin == 4 and k == 7) else k * k * cin
             self.flops += 2 * n_images * hout * wout * cout * kk
+            self.bytes += n_images * (hin * win * cin * 2 + hout * wout * cout * (4 if flags & F_F32 else 2)
+                                      + (hout * wout * cout * 2 if (flags & F_RES) else 0)
+                                      + (hout * wout * cout // 2 if (flags & F_UP) else 0))
 
     def num_tiles(self):
         return _lib.load().dafne_conv2d_num_tiles(ctypes.byref(self.prm), self.segs)
