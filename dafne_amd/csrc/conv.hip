@@ -62,6 +62,7 @@ struct ConvDev {
     int bn, bm;        // chosen tile
     int stem;          // 7x7 s2 stem on the 4-channel padded image
     int patch;         // 3x3 patch kernel (2-D tiles)
+    int slab;          // 3x3 narrow-Cout fp32 kernel (2-D tiles, whole-slab operands)
     const float* in_stats;   // GN_INPUT: [n_segs][N][Cin/8][2] mean, rstd of the input
     const float* in_gamma;   //           [Cin]
     const float* in_beta;    //           [Cin]
@@ -1668,6 +1669,233 @@ __global__ void __launch_bounds__(512) conv3x3_patch_kernel(ConvDev P) {
     }
 }
 
+// ---------------------------------------------------------------------------------------
+// 3x3 stride-1 convolution with <= 32 output channels and fp32 NHWC output: the prediction convolutions of
+// the head (cls_logits 15, center_pred 2, corners_pred+ctrness 9; dafne.py:318-344).  1/8 of a tower layer's
+// MFMA work on the same input bytes: these layers are bound by operand staging and barriers, not by the matrix
+// pipe, so the structure is the opposite of the kernels above -- per 64-channel slab BOTH operands are complete
+// in LDS (input patch 10x34 px, 43.5 KB; weights 9 taps x 32 cout x 64 ch, 36 KB; both double-buffered) and
+// the nine taps run with NO barrier in between: two barriers per slab instead of 36.  8 waves = 4 pixel-row
+// pairs x 2 K halves (the halves are summed through LDS at the end); the B fragments of 4 patch lines serve
+// the three kh taps (7 fragment reads per 6 MFMAs).  GN_INPUT as in conv3x3_patch_kernel: the last tower
+// layer's GroupNorm + ReLU is applied to the patch in LDS, so no normalisation pass is left in the head.
+constexpr int kSlabPatch = kPRows * 128;            // 43 520 B (the last DMA piece is half masked)
+constexpr int kSlabW = 9 * 32 * 128;                // 36 864 B
+constexpr int kSlabOffW = 2 * kSlabPatch;
+constexpr int kSlabOffTab = kSlabOffW + 2 * kSlabW;
+constexpr int kSlabTabC = 256;                      // GN_INPUT: Cin <= 256 (stats + gamma + beta = 9 * Cin bytes)
+constexpr int kSlabSmem = kSlabOffTab + 9 * kSlabTabC;
+static_assert(kSlabSmem <= 160 * 1024, "LDS budget");
+
+template <bool GNIN>
+__global__ void __launch_bounds__(512) conv3x3_slab_kernel(ConvDev P) {
+    constexpr int NW = 8, NT = 512;
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int rp = wave & 3, kq = wave >> 2;         // pixel-row pair (rows 2rp, 2rp+1), K half (chunks 2kq, 2kq+1)
+    const int frow = lane & 31, half = lane >> 5;
+
+    const int mt = xcd_remap(blockIdx.x, P.mtiles);
+    int si = 0;
+#pragma unroll
+    for (int k = 1; k < kMaxSegs; k++)
+        if (k < P.n_segs && mt >= P.seg[k].tile0) si = k;
+    const SegDev& S = P.seg[si];
+    const int tloc = mt - S.tile0;
+    const int img = tloc / S.tiles_per_img;
+    const int tt = tloc - img * S.tiles_per_img;
+    const int ty = tt / S.tiles_x, tx = tt - ty * S.tiles_x;
+    const int Y0 = ty * kPH, X0 = tx * kPW;
+    const int H = S.Hout, W = S.Wout, Hp = H + 2, Wp = W + 2;
+    const int nslab = P.Cin / kBK;
+
+    float* tab_stats = (float*)(lds + kSlabOffTab);
+    float* tab_gamma = tab_stats + P.Cin / 4;
+    float* tab_beta = tab_gamma + P.Cin;
+    if (GNIN) {
+        const float* st = P.in_stats + ((size_t)si * P.N + img) * (P.Cin / 8) * 2;
+        for (int k = tid; k < P.Cin / 4; k += NT) tab_stats[k] = st[k];
+        for (int k = tid; k < P.Cin; k += NT) {
+            tab_gamma[k] = P.in_gamma[k];
+            tab_beta[k] = P.in_beta[k];
+        }
+        __syncthreads();
+    }
+    const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) char*)lds;
+
+    // ---- DMA maps: patch pieces (8 px x 128 B, 6 per wave) and weight pieces (8 rows x 128 B, 36 per slab)
+    unsigned pofs[6];
+    int ppi[6];
+#pragma unroll
+    for (int i = 0; i < 6; i++) {
+        int pi = i * NW + wave;
+        if (pi >= kPPieces) pi -= NW;
+        ppi[i] = pi;
+        int r = pi * 8 + (lane >> 3);
+        r = r < kPRows ? r : kPRows - 1;
+        const int py = r / kPCols, px = r - py * kPCols;
+        int gy = Y0 + py, gx = X0 + px;
+        gy = gy < Hp ? gy : Hp - 1;
+        gx = gx < Wp ? gx : Wp - 1;
+        const int q = (lane & 7) ^ ((px >> 1) & 7);
+        pofs[i] = ((unsigned)(img * Hp + gy) * (unsigned)Wp + (unsigned)gx) * (unsigned)(P.Cin * 2) + (unsigned)q * 16u;
+    }
+    auto load_slab = [&](int slab) {
+        char* pb = lds + (slab & 1) * kSlabPatch;
+#pragma unroll
+        for (int i = 0; i < 6; i++) {
+            // piece 42 holds patch pixels 336..339 only: its upper half would run into the next buffer
+            if (ppi[i] < kPPieces - 1 || lane < 32)
+                __builtin_amdgcn_global_load_lds((gvoid*)(S.in + pofs[i] + (unsigned)slab * 128u), (lvoid*)(pb + ppi[i] * 1024), 16, 0, 0);
+        }
+        char* wb = lds + kSlabOffW + (slab & 1) * kSlabW;
+        for (int p = wave; p < 36; p += NW) {             // piece p: tap p/4, weight rows (p%4)*8 .. +8
+            const int tap = p >> 2;
+            const int r = (p & 3) * 8 + (lane >> 3);
+            const int q = (lane & 7) ^ ((r >> 1) & 7);
+            const unsigned off = (unsigned)r * (unsigned)P.kbytes + (unsigned)((slab * 9 + tap) * kRowBytes) + (unsigned)q * 16u;
+            __builtin_amdgcn_global_load_lds((gvoid*)(P.w + off), (lvoid*)(wb + p * 1024), 16, 0, 0);
+        }
+    };
+    auto gn_slab = [&](int slab) {                         // this wave's patch pieces, in place (see conv3x3_patch_kernel)
+        const int ch = slab * kBK + (lane & 7) * 8;
+        const unsigned ts = lds_base + (unsigned)(kSlabOffTab + (ch >> 3) * 8);
+        const unsigned tg = lds_base + (unsigned)(kSlabOffTab + P.Cin + ch * 4);
+        const unsigned tb = tg + (unsigned)P.Cin * 4u;
+        u32x2 ms;
+        f32x4 g0, g1, b0, b1;
+        asm volatile("ds_read_b64 %0, %5\n\tds_read_b128 %1, %6\n\tds_read_b128 %2, %6 offset:16\n\t"
+                     "ds_read_b128 %3, %7\n\tds_read_b128 %4, %7 offset:16\n\ts_waitcnt lgkmcnt(0)"
+                     : "=&v"(ms), "=&v"(g0), "=&v"(g1), "=&v"(b0), "=&v"(b1)
+                     : "v"(ts), "v"(tg), "v"(tb)
+                     : "memory");
+        const float gmean = __uint_as_float(ms.x), grstd = __uint_as_float(ms.y);
+        const float gam[8] = {g0[0], g0[1], g0[2], g0[3], g1[0], g1[1], g1[2], g1[3]};
+        const float bet[8] = {b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]};
+        for (int i = 0; i < 6; i++) {
+            if (i == 5 && 5 * NW + wave >= kPPieces) continue;
+            const int pi = ppi[i];
+            const int r = pi * 8 + (lane >> 3);
+            if (r >= kPRows) continue;                     // masked half of the last piece
+            const int py = r / kPCols, px = r - py * kPCols;
+            const int gy = Y0 + py, gx = X0 + px;
+            const bool inside = gy >= 1 && gy <= H && gx >= 1 && gx <= W;
+            const int phys = (lane & 7) ^ ((px >> 1) & 7);
+            const unsigned ad = lds_base + (unsigned)((slab & 1) * kSlabPatch + pi * 1024 + (lane >> 3) * 128 + phys * 16);
+            u32x4 v;
+            asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(v) : "v"(ad) : "memory");
+            const unsigned u[4] = {v.x, v.y, v.z, v.w};
+            float y[8];
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                const float x = bf2f((unsigned short)(k & 1 ? u[k >> 1] >> 16 : u[k >> 1] & 0xffff));
+                y[k] = fmaxf((x - gmean) * grstd * gam[k] + bet[k], 0.f);      // expression of gn_apply_kernel
+            }
+            u32x4 o;
+            o.x = inside ? pack_bf16(y[0], y[1]) : 0u;
+            o.y = inside ? pack_bf16(y[2], y[3]) : 0u;
+            o.z = inside ? pack_bf16(y[4], y[5]) : 0u;
+            o.w = inside ? pack_bf16(y[6], y[7]) : 0u;
+            asm volatile("ds_write_b128 %0, %1" ::"v"(ad), "v"(o) : "memory");
+        }
+    };
+    auto wait_all = [&]() {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    auto barrier = [&]() {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+    };
+
+    // fragment offsets: weights (128-B rows, swizzle (row>>1)&7), patch lines (column frow + kw)
+    const int fsw = (frow >> 1) & 7;
+    unsigned aoff[2], boff[3][2];
+#pragma unroll
+    for (int c = 0; c < 2; c++) {
+        const int ks = 2 * kq + c;
+        aoff[c] = (unsigned)frow * 128u + (unsigned)(((2 * ks + half) ^ fsw) * 16);
+#pragma unroll
+        for (int kw = 0; kw < 3; kw++)
+            boff[kw][c] = (unsigned)(frow + kw) * 128u + (unsigned)(((2 * ks + half) ^ (((frow + kw) >> 1) & 7)) * 16);
+    }
+
+    f32x16 acc[2];
+#pragma unroll
+    for (int b = 0; b < 2; b++)
+#pragma unroll
+        for (int k = 0; k < 16; k++) acc[b][k] = 0.f;
+
+    load_slab(0);
+    wait_all();
+    if (GNIN) gn_slab(0);
+    for (int slab = 0; slab < nslab; slab++) {
+        barrier();                                    // slab's patch (normalised) and weights are complete in LDS
+        if (slab + 1 < nslab) load_slab(slab + 1);    // lands under the 36 MFMAs below
+        const char* pb = lds + (slab & 1) * kSlabPatch;
+        const char* wb = lds + kSlabOffW + (slab & 1) * kSlabW;
+#pragma unroll
+        for (int kw = 0; kw < 3; kw++)
+#pragma unroll
+            for (int c = 0; c < 2; c++) {
+                bf16x8 bfr[4], af[3];
+#pragma unroll
+                for (int rr = 0; rr < 4; rr++) bfr[rr] = *(const bf16x8*)(pb + ((2 * rp + rr) * kPCols) * 128 + boff[kw][c]);
+#pragma unroll
+                for (int kh = 0; kh < 3; kh++) af[kh] = *(const bf16x8*)(wb + (kh * 3 + kw) * 4096 + aoff[c]);
+#pragma unroll
+                for (int kh = 0; kh < 3; kh++)
+#pragma unroll
+                    for (int b = 0; b < 2; b++)
+                        acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[kh], bfr[b + kh], acc[b], 0, 0, 0);
+            }
+        if (slab + 1 < nslab) {
+            wait_all();                               // this wave's pieces of the next slab have landed
+            if (GNIN) gn_slab(slab + 1);
+        }
+    }
+
+    // ---- epilogue: sum the two K halves through LDS, bias, fp32 NHWC store (Cout <= 32 channels per pixel)
+    barrier();                                        // all waves are done with the operand buffers
+    float* stg = (float*)lds;                         // [256 px][33] fp32 (row pad against bank conflicts)
+    constexpr int ROW = 33;
+    if (kq == 1) {
+#pragma unroll
+        for (int b = 0; b < 2; b++) {
+            const int px = (2 * rp + b) * 32 + frow;
+#pragma unroll
+            for (int g = 0; g < 4; g++)
+#pragma unroll
+                for (int k = 0; k < 4; k++) stg[px * ROW + 8 * g + 4 * half + k] = acc[b][4 * g + k];
+        }
+    }
+    __syncthreads();
+    if (kq == 0) {
+#pragma unroll
+        for (int b = 0; b < 2; b++) {
+            const int px = (2 * rp + b) * 32 + frow;
+#pragma unroll
+            for (int g = 0; g < 4; g++)
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    const int co = 8 * g + 4 * half + k;
+                    stg[px * ROW + co] += acc[b][4 * g + k] + (P.bias && co < P.Cout ? P.bias[co] : 0.f);
+                }
+        }
+    }
+    __syncthreads();
+    float* out = (float*)S.out;
+    for (int idx = tid; idx < 256 * P.Cout; idx += NT) {
+        const int p = idx / P.Cout, c = idx - p * P.Cout;
+        const int gy = Y0 + (p >> 5), gx = X0 + (p & 31);
+        if (gy < H && gx < W) out[((size_t)(img * H + gy) * W + gx) * P.Cout + c] = stg[p * ROW + c];
+    }
+}
+
 struct Cfg {
     int bn, bm;
 };
@@ -1703,6 +1931,19 @@ bool patch_eligible(const dafne_conv_params* p, const dafne_conv_seg* segs) {
     return (p->flags & DAFNE_CONV_GN_INPUT) || tiles * (p->Cout / 256) >= min_tiles;
 }
 
+// 3x3 / stride 1 / pad 1 layers with Cout <= 32 and fp32 output (the prediction convolutions) go to the slab kernel.
+bool slab_eligible(const dafne_conv_params* p, const dafne_conv_seg* segs) {
+    static const int mode = getenv("DAFNE_CONV_SLAB") ? atoi(getenv("DAFNE_CONV_SLAB")) : 1;
+    if (!mode) return false;
+    if (p->KH != 3 || p->KW != 3 || p->stride != 1 || p->pad != 1) return false;
+    if (p->Cin % kBK || p->Cout > 32 || !(p->flags & DAFNE_CONV_OUT_F32)) return false;
+    if (p->flags & (DAFNE_CONV_RESIDUAL | DAFNE_CONV_UPSAMPLE_ADD | DAFNE_CONV_GN_STATS | DAFNE_CONV_RELU)) return false;
+    if ((p->flags & DAFNE_CONV_GN_INPUT) && p->Cin > kSlabTabC) return false;
+    for (int s = 0; s < p->n_segs; s++)
+        if (segs[s].Hin != segs[s].Hout || segs[s].Win != segs[s].Wout) return false;
+    return true;
+}
+
 int build(ConvDev& D, const dafne_conv_params* p, const dafne_conv_seg* segs) {
     if (!p || !segs) return dafne::fail(DAFNE_E_INVALID, "conv: null params");
     if (p->n_segs < 1 || p->n_segs > kMaxSegs || p->n_images < 1) return dafne::fail(DAFNE_E_INVALID, "conv: bad segment/image count");
@@ -1735,15 +1976,21 @@ int build(ConvDev& D, const dafne_conv_params* p, const dafne_conv_seg* segs) {
     D.kbytes = D.ksteps * kRowBytes;
     D.in_stats = p->d_in_gn_stats; D.in_gamma = p->d_in_gn_gamma; D.in_beta = p->d_in_gn_beta;
     D.patch = patch_eligible(p, segs) ? 1 : 0;
-    if ((p->flags & DAFNE_CONV_GN_INPUT) && !D.patch)
+    D.slab = !D.patch && slab_eligible(p, segs) ? 1 : 0;
+    if ((p->flags & DAFNE_CONV_GN_INPUT) && !D.patch && !D.slab)
         return dafne::fail(DAFNE_E_UNSUPPORTED, "conv: GN_INPUT needs the 3x3 patch kernel (3x3 s1 p1, Cout %% 256 == 0, Cin <= 512, bias, "
-                                                "no residual / fp32 output, enough tiles)");
+                                                "no residual / fp32 output) or the slab kernel (3x3 s1 p1, Cout <= 32, fp32 output, Cin <= 256)");
     if ((p->flags & DAFNE_CONV_GN_INPUT) && (!p->d_in_gn_stats || !p->d_in_gn_gamma || !p->d_in_gn_beta))
         return dafne::fail(DAFNE_E_INVALID, "conv: GN_INPUT without statistics / affine pointers");
     if (D.patch) {
         D.bn = 256; D.bm = 256;
         D.Cout_pad = p->Cout;
         c.bn = 256; c.bm = 256;
+    }
+    if (D.slab) {
+        D.bn = 32; D.bm = 256;
+        D.Cout_pad = 32;
+        c.bn = 32; c.bm = 256;
     }
     int t = 0;
     for (int s = 0; s < p->n_segs; s++) {
@@ -1764,7 +2011,7 @@ int build(ConvDev& D, const dafne_conv_params* p, const dafne_conv_seg* segs) {
         o.in = (const char*)g.d_in; o.out = (char*)g.d_out; o.res = (const char*)g.d_res;
         o.Hin = g.Hin; o.Win = g.Win; o.Hout = g.Hout; o.Wout = g.Wout;
         o.tiles_x = (g.Wout + kPW - 1) / kPW;
-        o.tiles_per_img = D.patch ? o.tiles_x * ((g.Hout + kPH - 1) / kPH) : (g.Hout * g.Wout + c.bm - 1) / c.bm;
+        o.tiles_per_img = (D.patch || D.slab) ? o.tiles_x * ((g.Hout + kPH - 1) / kPH) : (g.Hout * g.Wout + c.bm - 1) / c.bm;
         o.tile0 = t;
         t += o.tiles_per_img * p->n_images;
     }
@@ -1819,6 +2066,19 @@ int launch_patch(const ConvDev& D, hipStream_t st) {
     if (D.flags & DAFNE_CONV_GN_INPUT) hipLaunchKernelGGL(conv3x3_patch_kernel<true>, grid, block, kPSmem, st, D);
     else hipLaunchKernelGGL(conv3x3_patch_kernel<false>, grid, block, kPSmem, st, D);
     return dafne::check_launch("conv3x3_patch");
+}
+
+int launch_slab(const ConvDev& D, hipStream_t st) {
+    static bool attr_done = false;
+    if (!attr_done) {
+        DAFNE_HIP_TRY(hipFuncSetAttribute((const void*)conv3x3_slab_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, kSlabSmem));
+        DAFNE_HIP_TRY(hipFuncSetAttribute((const void*)conv3x3_slab_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, kSlabSmem));
+        attr_done = true;
+    }
+    const dim3 grid(D.mtiles), block(512);
+    if (D.flags & DAFNE_CONV_GN_INPUT) hipLaunchKernelGGL(conv3x3_slab_kernel<true>, grid, block, kSlabSmem, st, D);
+    else hipLaunchKernelGGL(conv3x3_slab_kernel<false>, grid, block, kSlabSmem, st, D);
+    return dafne::check_launch("conv3x3_slab");
 }
 
 bool ws_eligible(const ConvDev& D) {
@@ -1921,6 +2181,7 @@ int dafne_conv2d_kernel_id(const dafne_conv_params* prm, const dafne_conv_seg* s
     ConvDev D;
     if (build(D, prm, segs)) return -1;
     if (D.patch) return 6;
+    if (D.slab) return 7;
     if (stream_eligible(D)) return ws_eligible(D) ? 5 : 4;
     return D.bn == 256 ? 3 : D.bn == 128 ? 2 : D.bn == 64 ? 1 : 0;
 }
@@ -1931,6 +2192,7 @@ int dafne_conv2d_nhwc_bf16_hip(const dafne_conv_params* prm, const dafne_conv_se
     if (rc) return rc;
     hipStream_t st = (hipStream_t)stream;
     if (D.patch) return launch_patch(D, st);
+    if (D.slab) return launch_slab(D, st);
     if (stream_eligible(D)) {
         if (ws_eligible(D)) return launch_ws(D, st);
         return launch_stream(D, st);

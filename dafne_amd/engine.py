@@ -131,7 +131,7 @@ class ConvCall:
         return _lib.load().dafne_conv2d_tile_pixels(ctypes.byref(self.prm), self.segs)
 
     KERNEL_NAMES = ("conv_igemm<1,4,1,2>", "conv_igemm<1,4,2,2>", "conv_igemm<2,2,2,2>", "conv_igemm<4,2,2,4>",
-                    "conv_stream", "conv_ws", "conv3x3_patch")
+                    "conv_stream", "conv_ws", "conv3x3_patch", "conv3x3_slab")
 
     def kernel_id(self):
         """-1 when the library cannot run this call (e.g. F_GNIN on a layer the patch kernel does not take)."""
@@ -321,12 +321,15 @@ class HeadPlan:
         def seg_list(ins, outs, f32=False):
             return [(i.t, (o if f32 else o.t), None, i.h, i.w, i.h, i.w) for i, o in zip(ins, outs)]
 
-        def tower(name, ins):
+        def tower(name, ins, in_gn, consumers):
             """4 x [conv3x3 -> GroupNorm(32) -> ReLU].  When the library's 3x3 patch kernel takes the layer
             (kernel id 6 with F_GNIN), the GroupNorm + ReLU of layer i is applied by layer i+1 while it loads
             its input patch: only the statistics are finalised between the two convolutions, and the separate
-            normalisation pass (a read + write of all five levels) disappears for 3 of the 4 layers."""
-            cur, cur_gn = ins, None
+            normalisation pass (a read + write of all five levels) disappears.  The same holds for the
+            layers behind the tower (`consumers`: (weight key, Cout, flags) of the prediction convolution --
+            slab kernel, id 7 -- and, for the center tower, of the corners tower's first layer): when every one
+            of them takes F_GNIN the tower returns its last layer RAW together with (stats, gamma, beta)."""
+            cur, cur_gn = ins, in_gn
             for i in range(4):
                 wgt, bias = P["%s.%d" % (name, 3 * i)]
                 gamma, beta = P["%s.%d.gn" % (name, 3 * i + 1)]
@@ -346,12 +349,15 @@ class HeadPlan:
                     gsegs[k] = _lib.GnSeg(o.t.data_ptr(), o.h, o.w, t0, tpi)
                     t0 += tpi * n
                 assert t0 == nt == c.num_tiles()
-                fuse_next = False
-                if i < 3 and fuse_gn:
-                    wn, bn_ = P["%s.%d" % (name, 3 * (i + 1))]
-                    nxt = ConvCall(wn, bn_, C, C, 3, 1, 1, F_GNIN, seg_list(outs, outs), n,
+                nxt_specs = [("%s.%d" % (name, 3 * (i + 1)), C, 0)] if i < 3 else consumers
+                fuse_next = fuse_gn and len(nxt_specs) > 0
+                for key, cout, fl in (nxt_specs if fuse_next else ()):
+                    wn, bn_ = P[key]
+                    f32 = bool(fl & F_F32)
+                    dst = [torch.empty(1, dtype=torch.float32, device=device)] * len(outs) if f32 else outs
+                    nxt = ConvCall(wn, bn_, C, cout, 3, 1, 1, fl | F_GNIN, seg_list(outs, dst, f32=f32), n,
                                    gn_in=(stats, gamma, beta))
-                    fuse_next = nxt.kernel_id() == 6
+                    fuse_next = fuse_next and nxt.kernel_id() == (7 if f32 else 6)
                 if fuse_next:
                     calls.append(FnCall(L.dafne_groupnorm_finalize_hip,
                                         (gsegs, len(outs), n, C, _lib.ptr(partial), _lib.ptr(stats), ctypes.c_float(1e-5)),
@@ -367,27 +373,30 @@ class HeadPlan:
                     for a in cur:
                         pool.put(a)
                 cur, cur_gn = outs, nxt_gn
-            return cur
+            return cur, cur_gn
 
-        cls_t = tower("cls_tower", feats)
-        ctr_t = tower("center_tower", feats)
-        cor_t = tower("corners_tower", ctr_t)
+        fuse_pred = os.environ.get("DAFNE_FUSE_GN_PRED", "1") != "0"
+        cls_t, cls_gn = tower("cls_tower", feats, None, [("cls_logits", num_classes, F_F32)] if fuse_pred else [])
+        ctr_t, ctr_gn = tower("center_tower", feats, None,
+                              [("center_pred", 2, F_F32), ("corners_tower.0", C, 0)] if fuse_pred else [])
+        cor_t, cor_gn = tower("corners_tower", ctr_t, ctr_gn, [("corners_ctrness", 9, F_F32)] if fuse_pred else [])
 
-        def pred(key, ins, cout, name):
+        def pred(key, ins, cout, name, gn_in):
             wgt, bias = P[key]
             if outputs is not None:
                 outs = outputs[name]
                 assert all(o.is_contiguous() and tuple(o.shape) == (n, f.h, f.w, cout) for o, f in zip(outs, ins))
             else:
                 outs = [torch.empty(n, f.h, f.w, cout, dtype=torch.float32, device=device) for f in ins]
-            c = ConvCall(wgt, bias, C, cout, 3, 1, 1, F_F32, seg_list(ins, outs, f32=True), n)
+            c = ConvCall(wgt, bias, C, cout, 3, 1, 1, F_F32 | (F_GNIN if gn_in is not None else 0),
+                         seg_list(ins, outs, f32=True), n, gn_in=gn_in)
             calls.append(c)
             plan.flops += c.flops
             return outs
 
-        self.logits = pred("cls_logits", cls_t, num_classes, "logits")
-        self.center = pred("center_pred", ctr_t, 2, "center")
-        self.delta_ctr = pred("corners_ctrness", cor_t, 9, "delta_ctr")     # corners_pred (8) + ctrness (1) fused
+        self.logits = pred("cls_logits", cls_t, num_classes, "logits", cls_gn)
+        self.center = pred("center_pred", ctr_t, 2, "center", ctr_gn)
+        self.delta_ctr = pred("corners_ctrness", cor_t, 9, "delta_ctr", cor_gn)     # corners_pred (8) + ctrness (1) fused
         self.scales = P["scales"]
 
 

@@ -224,6 +224,74 @@ def test_patch_kernel_gn_stats_and_gn_input_chain():
         assert (got - ref).abs().max() < 0.06 * ref.abs().max()      # stats from fp32 conv vs bf16 map: noise floor
 
 
+@pytest.mark.parametrize("cout,cin", [(15, 256), (9, 256), (2, 256), (32, 128), (7, 64)])
+def test_slab_kernel_levels_and_gn_input(cout, cin):
+    """Prediction convolution over ragged levels on the slab kernel (id 7): fp32 output vs torch; then the
+    F_GNIN form (GroupNorm + ReLU of a raw tower output applied in LDS) against the same kernel run on the
+    output of the separate normalisation pass -- bit for bit."""
+    from dafne_amd import engine, _lib
+    d = dev()
+    L = _lib.load()
+    g = torch.Generator().manual_seed(100 + cout)
+    C, N = cin, 3
+    sizes = [(40, 72), (17, 33), (8, 8), (3, 5), (1, 1)]
+    xs = [bfr(torch.randn(N, C, h, w, generator=g)) for h, w in sizes]
+    w1 = bfr(torch.randn(C, C, 3, 3, generator=g) / (C * 9) ** 0.5)
+    b1 = torch.randn(C, generator=g) * 0.1
+    wq = bfr(torch.randn(cout, C, 3, 3, generator=g) / (C * 9) ** 0.5)
+    bq = torch.randn(cout, generator=g)
+    gamma = (1 + 0.2 * torch.randn(C, generator=g)).to(d)
+    beta = (0.3 * torch.randn(C, generator=g)).to(d)
+    st = _lib.current_stream()
+    wp1, bp1 = engine.pack_conv(w1, b1, d)
+    wpq, bpq = engine.pack_conv(wq, bq, d)
+    ins = [engine.Act.from_nchw(x.to(d)) for x in xs]
+
+    def pred(src, gn_in):
+        outs = [torch.full((N, h, w, cout), float("nan"), dtype=torch.float32, device=d) for h, w in sizes]
+        segs = [(i.t, o, None, i.h, i.w, i.h, i.w) for i, o in zip(src, outs)]
+        c = engine.ConvCall(wpq, bpq, C, cout, 3, 1, 1, engine.F_F32 | (engine.F_GNIN if gn_in else 0), segs, N, gn_in=gn_in)
+        assert c.kernel_name() == "conv3x3_slab"
+        c(st)
+        return outs
+
+    # plain: vs torch
+    for x, o in zip(xs, pred(ins, None)):
+        ref = F.conv2d(x, wq, bq, padding=1).permute(0, 2, 3, 1)
+        got = o.cpu()
+        assert torch.isfinite(got).all()
+        assert float((got - ref).abs().max()) < 2e-3 * max(float(ref.abs().max()), 1.0)
+
+    # raw tower layer + statistics
+    def layer1():
+        raw = [engine.Act(N, h, w, C, d) for h, w in sizes]
+        segs = [(i.t, o.t, None, i.h, i.w, i.h, i.w) for i, o in zip(ins, raw)]
+        probe = engine.ConvCall(wp1, bp1, C, C, 3, 1, 1, 0, segs, N)
+        partial = torch.zeros(probe.num_tiles(), C // 8, 2, dtype=torch.float32, device=d)
+        c = engine.ConvCall(wp1, bp1, C, C, 3, 1, 1, engine.F_GN, segs, N, gn_partial=partial)
+        c(st)
+        stats = torch.zeros(len(raw), N, C // 8, 2, dtype=torch.float32, device=d)
+        gsegs = (_lib.GnSeg * len(raw))()
+        t0 = 0
+        for k, (o, tpi) in enumerate(zip(raw, c.tiles_per_image())):
+            gsegs[k] = _lib.GnSeg(o.t.data_ptr(), o.h, o.w, t0, tpi)
+            t0 += tpi * N
+        return raw, partial, stats, gsegs
+
+    raw, partial, stats, gsegs = layer1()
+    _lib.check(L.dafne_groupnorm_finalize_hip(gsegs, len(raw), N, C, _lib.ptr(partial), _lib.ptr(stats),
+                                              ctypes.c_float(1e-5), st), "finalize")
+    fused = pred(raw, (stats, gamma, beta))
+    raw_u, partial_u, stats_u, gsegs_u = layer1()
+    _lib.check(L.dafne_groupnorm_relu_nhwc_bf16_hip(gsegs_u, len(raw_u), N, C, _lib.ptr(partial_u), _lib.ptr(stats_u),
+                                                    _lib.ptr(gamma), _lib.ptr(beta), ctypes.c_float(1e-5), st), "gn")
+    unfused = pred(raw_u, None)
+    torch.cuda.synchronize()
+    for a, b_ in zip(fused, unfused):
+        assert torch.isfinite(a).all()
+        assert torch.equal(a, b_)
+
+
 @pytest.mark.parametrize("cout", [15, 9, 2, 1, 16])
 def test_prediction_conv_f32_output(cout):
     g = torch.Generator().manual_seed(cout)
