@@ -132,7 +132,7 @@ def conv_kernel_profile(model, batch, splits, reps=3):
         for j in range(len(plans[0].calls)):
             for k, plan in enumerate(plans):
                 c = plan.calls[j]
-                if isinstance(c, engine.ConvCall):
+                if getattr(c, "flops", 0) > 0:        # ConvCall or a matrix FnCall (stem_pool)
                     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                     a.record(cs[k])
                     c(sp[k])
@@ -171,7 +171,7 @@ def conv_kernel_profile_isolated(model, batch, reps=3):
     for _ in range(reps):
         evs = []
         for c in plan.calls:
-            if isinstance(c, engine.ConvCall):
+            if getattr(c, "flops", 0) > 0:        # ConvCall or a matrix FnCall (stem_pool)
                 a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 a.record()
                 c(stream)

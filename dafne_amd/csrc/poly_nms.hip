@@ -791,7 +791,6 @@ __global__ void __launch_bounds__(256) nms_scan_kernel(const int* __restrict__ c
     int rb, cb;
     tile_rc(t, w.nblk, rb, cb);
     if (rb * kTile >= M || cb * kTile >= M) return;
-    const size_t ibase = (size_t)img * w.Mp;
     const int grow = rb * kTile + lane;
     w.mask[(size_t)img * w.mask_words + (size_t)t * kTile + lane] = 0ull;
     if (w.use_perm && w.cls) { // class-major layout: two blocks without a common class have no candidate pair

@@ -154,8 +154,12 @@ class ConvCall:
 
 
 class FnCall:
-    def __init__(self, fn, args, keep, name):
+    def __init__(self, fn, args, keep, name, flops=0, nbytes=0):
         self.fn, self.args, self.keep, self.name = fn, args, keep, name
+        self.flops, self.bytes = flops, nbytes      # > 0: a matrix kernel that bench.py attributes like a ConvCall
+
+    def kernel_name(self):
+        return self.name
 
     def __call__(self, stream):
         rc = self.fn(*self.args, stream)
@@ -198,16 +202,25 @@ class DensePlan:
         # stem: preprocess output [N, H+6, W+6, 4] -> conv7x7/s2 -> maxpool
         self.stem_in = torch.zeros(n, h + 6, w + 6, 4, dtype=BF16, device=device)
         wgt, bias = P["stem"]
-        stem_out = pool.get(n, h // 2, w // 2, 64)
-        c = ConvCall(wgt, bias, 4, 64, 7, 2, 3, F_RELU,
-                     [(self.stem_in, stem_out.t, None, h + 6, w + 6, h // 2, w // 2)], n)
-        self.calls.append(c)
-        self.flops += c.flops
         x = pool.get(n, h // 4, w // 4, 64)
-        self.calls.append(FnCall(L.dafne_maxpool3x3s2_nhwc_bf16_hip,
-                                 (_lib.ptr(stem_out.t), _lib.ptr(x.t), n, h // 2, w // 2, 64),
-                                 (stem_out, x), "maxpool"))
-        pool.put(stem_out)
+        stem_flops = 2 * n * (h // 2) * (w // 2) * 64 * 7 * 7 * 3
+        if os.environ.get("DAFNE_FUSE_STEM", "1") != "0":
+            # conv7x7/s2 + ReLU + max-pool in one kernel: the half-resolution map never reaches HBM
+            fc = FnCall(L.dafne_stem_pool_hip, (_lib.ptr(self.stem_in), _lib.ptr(wgt), _lib.ptr(bias), n, h, w, _lib.ptr(x.t)),
+                        (self.stem_in, wgt, bias, x), "stem_pool", flops=stem_flops,
+                        nbytes=n * ((h + 6) * (w + 6) * 8 + (h // 4) * (w // 4) * 128))
+            self.calls.append(fc)
+            self.flops += stem_flops
+        else:
+            stem_out = pool.get(n, h // 2, w // 2, 64)
+            c = ConvCall(wgt, bias, 4, 64, 7, 2, 3, F_RELU,
+                         [(self.stem_in, stem_out.t, None, h + 6, w + 6, h // 2, w // 2)], n)
+            self.calls.append(c)
+            self.flops += c.flops
+            self.calls.append(FnCall(L.dafne_maxpool3x3s2_nhwc_bf16_hip,
+                                     (_lib.ptr(stem_out.t), _lib.ptr(x.t), n, h // 2, w // 2, 64),
+                                     (stem_out, x), "maxpool"))
+            pool.put(stem_out)
 
         feats = {}
         for si, nb in enumerate(STAGE_BLOCKS[depth]):

@@ -182,7 +182,7 @@ int dafne_gather_detections_hip(const float* d_corners, const float* d_scores, c
 #define DAFNE_CONV_UPSAMPLE_ADD 4u /* += nearest-2x upsample of d_res [N,H/2+2,W/2+2,C] */
 #define DAFNE_CONV_OUT_F32 8u      /* fp32 un-haloed NHWC output [N,Hout,Wout,Cout]     */
 #define DAFNE_CONV_GN_STATS 16u    /* emit per-(M tile, group of 8 ch) sum and sum-sq   */
-#define DAFNE_CONV_GN_INPUT 32u    /* GroupNorm + ReLU of the INPUT applied on load (3x3 patch kernel only) */
+#define DAFNE_CONV_GN_INPUT 32u    /* GroupNorm + ReLU of the INPUT applied on load (3x3 patch / slab kernels) */
 
 typedef struct dafne_conv_seg {
     const void* d_in;   /* bf16 [N, Hin+2, Win+2, Cin]; stem: [N, Hin, Win, 4] pre-padded */
@@ -221,7 +221,8 @@ int dafne_conv2d_num_tiles(const dafne_conv_params* prm, const dafne_conv_seg* s
  * 0 conv_igemm_kernel<1,4,1,2> (32 cout x 256 px)   1 conv_igemm_kernel<1,4,2,2> (64 x 256)
  * 2 conv_igemm_kernel<2,2,2,2> (128 x 128)           3 conv_igemm_kernel<4,2,2,4> (256 x 256, 8 waves)
  * 4 conv_stream_kernel (persistent, 1x1, Cin 512)    5 conv_ws_kernel (persistent, weights in registers, 1x1, Cin <= 256)
- * 6 conv3x3_patch_kernel (3x3 s1, 256 cout x 8x32 px tiles, input patch staged once per 64-channel slab) */
+ * 6 conv3x3_patch_kernel (3x3 s1, 256 cout x 8x32 px tiles, input patch staged once per 64-channel slab)
+ * 7 conv3x3_slab_kernel (3x3 s1, Cout <= 32, fp32 output: whole 64-channel slabs of both operands in LDS) */
 int dafne_conv2d_kernel_id(const dafne_conv_params* prm, const dafne_conv_seg* segs);
 /* M tiles per image of every segment (out[n_segs]): where a segment's rows sit in d_gn_partial */
 int dafne_conv2d_tiles_per_image(const dafne_conv_params* prm, const dafne_conv_seg* segs, int32_t* out);
@@ -247,6 +248,17 @@ int dafne_preprocess_image_hip(const uint8_t* d_img, int layout_hwc, int n_image
 size_t dafne_resize_workspace_bytes(int C, int H, int new_w);
 int dafne_resize_bilinear_u8_hip(const uint8_t* d_in, int layout_hwc, int C, int H, int W, int new_h, int new_w,
                                  int hflip, int vflip, uint8_t* d_out, void* d_ws, size_t ws_bytes, void* stream);
+/*
+ * detectron2 BasicStem in one kernel [recalled; the backbone of backbone/fpn.py:58-91]: conv 7x7 / s2 / p3
+ * (FrozenBN folded into d_weight / d_bias) + ReLU + max-pool 3x3 / s2 / p1.  d_in: the layout
+ * dafne_preprocess_image_hip writes, bf16 [N, H+6, W+6, 4]; d_weight: bf16 [64, 256] with k = (kh 0..7, kw 0..7,
+ * c 0..3), zero where kh = 7, kw = 7 or c = 3 (the stem weight of dafne_conv2d_nhwc_bf16_hip); d_out: bf16
+ * [N, H/4+2, W/4+2, 64] (interior written, halo untouched).  H, W multiples of 4.  Bit-identical to the stem
+ * through dafne_conv2d_nhwc_bf16_hip followed by dafne_maxpool3x3s2_nhwc_bf16_hip; the half-resolution map
+ * never reaches HBM.
+ */
+int dafne_stem_pool_hip(const void* d_in, const void* d_weight, const float* d_bias, int n_images, int H, int W,
+                        void* d_out, void* stream);
 /* 3x3 stride-2 pad-1 max pool of a post-ReLU map: [N,Hin+2,Win+2,C] -> [N,Hin/2+2,Win/2+2,C] */
 int dafne_maxpool3x3s2_nhwc_bf16_hip(const void* d_in, void* d_out, int n_images, int Hin, int Win,
                                      int C, void* stream);

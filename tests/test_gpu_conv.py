@@ -398,9 +398,14 @@ def test_stem_preprocess_maxpool():
     po = engine.Act(N, H // 4, W // 4, 64, d)
     _lib.check(L.dafne_maxpool3x3s2_nhwc_bf16_hip(_lib.ptr(so.t), _lib.ptr(po.t), N, H // 2, W // 2, 64,
                                                   _lib.current_stream()))
+    # the fused stem (conv + ReLU + pool in one kernel) is bit-identical to the two launches
+    pf = engine.Act(N, H // 4, W // 4, 64, d)
+    _lib.check(L.dafne_stem_pool_hip(_lib.ptr(stem_in), _lib.ptr(wp), _lib.ptr(bp), N, H, W, _lib.ptr(pf.t),
+                                     _lib.current_stream()))
     torch.cuda.synchronize()
     assert torch.equal(stem_in[:, 3:-3, 3:-3, :3].float().cpu(), xn.permute(0, 2, 3, 1))
     close_bf16(po.nchw_float().cpu(), ref)
+    assert torch.equal(pf.t, po.t)
     # HWC input layout gives the same stem input
     stem2 = torch.zeros_like(stem_in)
     imh = img.permute(0, 2, 3, 1).contiguous().to(d)
@@ -408,3 +413,33 @@ def test_stem_preprocess_maxpool():
                                             _lib.current_stream()))
     torch.cuda.synchronize()
     assert torch.equal(stem2, stem_in)
+
+
+@pytest.mark.parametrize("N,H,W", [(1, 32, 32), (3, 160, 224), (2, 1024, 1024), (1, 480, 1216)])
+def test_stem_pool_fused_equals_conv_then_pool(N, H, W):
+    """dafne_stem_pool_hip against the stem through the generic kernel + max-pool launch: ragged tiles
+    (pooled width not a multiple of 32, height not a multiple of 4 rows), several tiles per workgroup,
+    top / left pool padding; bit for bit, halo untouched."""
+    from dafne_amd import engine, _lib
+    L = _lib.load()
+    d = dev()
+    g = torch.Generator().manual_seed(H + W)
+    stem_in = torch.zeros(N, H + 6, W + 6, 4, dtype=BF, device=d)
+    stem_in[:, 3:-3, 3:-3, :3] = (torch.randint(0, 256, (N, H, W, 3), generator=g).float() - 110.0).to(BF).to(d)
+    w = bfr(torch.randn(64, 3, 7, 7, generator=g) / 200.0)
+    b = torch.randn(64, generator=g) * 0.5
+    wp, bp = engine.pack_stem(w, b, d)
+    st = _lib.current_stream()
+    so = engine.Act(N, H // 2, W // 2, 64, d)
+    engine.ConvCall(wp, bp, 4, 64, 7, 2, 3, engine.F_RELU, [(stem_in, so.t, None, H + 6, W + 6, H // 2, W // 2)], N)(st)
+    po = engine.Act(N, H // 4, W // 4, 64, d)
+    _lib.check(L.dafne_maxpool3x3s2_nhwc_bf16_hip(_lib.ptr(so.t), _lib.ptr(po.t), N, H // 2, W // 2, 64, st))
+    pf = engine.Act(N, H // 4, W // 4, 64, d)
+    _lib.check(L.dafne_stem_pool_hip(_lib.ptr(stem_in), _lib.ptr(wp), _lib.ptr(bp), N, H, W, _lib.ptr(pf.t), st))
+    torch.cuda.synchronize()
+    assert float(po.t.float().abs().max()) > 0
+    assert torch.equal(pf.t, po.t)
+    if N * H * W <= 3 * 160 * 224:
+        ref = F.max_pool2d(bfr(F.relu(F.conv2d(stem_in[:, 3:-3, 3:-3, :3].float().cpu().permute(0, 3, 1, 2), w, b,
+                                               stride=2, padding=3))), 3, 2, 1)
+        close_bf16(pf.nchw_float().cpu(), ref)
