@@ -91,6 +91,16 @@ def pack_stem(weight, bias, device):
     return w.reshape(cout, 256).to(BF16).to(device).contiguous(), b.to(device).contiguous()
 
 
+def pack_b2b(w3, w1):
+    """Fragment-major weights of dafne_bottleneck_tail_head_hip from the packed 1x1 weights of conv3 ([1024, 256] bf16)
+    and the next block's conv1 ([256, 1024] bf16): bf16 [8 phases][8 waves][16 k16-steps][64 lanes][8], phase 2c =
+    conv3 rows c*256 .. +256 over K = 256, phase 2c+1 = conv1 over K-chunk c; lane = 32 * (k half) + row."""
+    assert tuple(w3.shape) == (1024, 256) and tuple(w1.shape) == (256, 1024) and w3.dtype == BF16 and w1.dtype == BF16
+    a1 = w3.reshape(4, 8, 32, 16, 2, 8).permute(0, 1, 3, 4, 2, 5)            # c, w, t, h, r, e
+    a2 = w1.reshape(8, 32, 4, 16, 2, 8).permute(2, 0, 3, 4, 1, 5)            # c, w, t, h, r, e
+    return torch.stack([a1, a2], dim=1).contiguous().reshape(8, 8, 16, 64, 8)
+
+
 def fold_frozen_bn(weight, bn_w, bn_b, bn_mean, bn_var, eps=1e-5):
     s = bn_w * torch.rsqrt(bn_var + eps)
     return weight * s[:, None, None, None], bn_b - bn_mean * s
@@ -223,7 +233,9 @@ class DensePlan:
             pool.put(stem_out)
 
         feats = {}
+        fuse_b2b = os.environ.get("DAFNE_FUSE_B2B", "1") != "0"
         for si, nb in enumerate(STAGE_BLOCKS[depth]):
+            y1_next = None
             for b in range(nb):
                 p = "res%d.%d." % (si + 2, b)
                 stride = 2 if (b == 0 and si > 0) else 1
@@ -231,10 +243,31 @@ class DensePlan:
                     sc = conv(p + "shortcut", x, 1, stride, 0, 0)
                 else:
                     sc = x
-                y1 = conv(p + "conv1", x, 1, stride, 0, F_RELU)       # STRIDE_IN_1X1
+                if y1_next is not None:
+                    y1, y1_next = y1_next, None                       # computed by the previous block's fused tail
+                else:
+                    y1 = conv(p + "conv1", x, 1, stride, 0, F_RELU)       # STRIDE_IN_1X1
                 y2 = conv(p + "conv2", y1, 3, 1, 1, F_RELU)
                 pool.put(y1)
-                y3 = conv(p + "conv3", y2, 1, 1, 0, F_RELU | F_RES, res=sc)
+                w3, b3 = P[p + "conv3"]
+                nxt = "res%d.%d.conv1" % (si + 2, b + 1)
+                if fuse_b2b and b + 1 < nb and tuple(w3.shape) == (1024, 256) and tuple(P[nxt][0].shape) == (256, 1024):
+                    # conv3 + residual + ReLU and the next block's conv1 + ReLU in one kernel (conv_b2b.hip)
+                    w1, b1 = P[nxt]
+                    key = p + "b2b"
+                    if key not in P:
+                        P[key] = pack_b2b(w3, w1)
+                    y3 = pool.get(n, y2.h, y2.w, 1024)
+                    y1_next = pool.get(n, y2.h, y2.w, 256)
+                    fl = 2 * n * y2.h * y2.w * (256 * 1024 + 1024 * 256)
+                    nb_ = n * y2.h * y2.w * (256 + 1024 + 1024 + 256) * 2 + 2 * 1024 * 256 * 2
+                    self.calls.append(FnCall(L.dafne_bottleneck_tail_head_hip,
+                                             (_lib.ptr(y2.t), _lib.ptr(sc.t), _lib.ptr(P[key]), _lib.ptr(b3), _lib.ptr(b1),
+                                              n, y2.h, y2.w, _lib.ptr(y3.t), _lib.ptr(y1_next.t)),
+                                             (y2, sc, P[key], b3, b1, y3, y1_next), "conv_b2b", flops=fl, nbytes=nb_))
+                    self.flops += fl
+                else:
+                    y3 = conv(p + "conv3", y2, 1, 1, 0, F_RELU | F_RES, res=sc)
                 pool.put(y2)
                 if b == 0:
                     pool.put(sc)

@@ -249,6 +249,20 @@ size_t dafne_resize_workspace_bytes(int C, int H, int new_w);
 int dafne_resize_bilinear_u8_hip(const uint8_t* d_in, int layout_hwc, int C, int H, int W, int new_h, int new_w,
                                  int hflip, int vflip, uint8_t* d_out, void* d_ws, size_t ws_bytes, void* stream);
 /*
+ * Tail of one res4 bottleneck + head of the next in one kernel [detectron2 BottleneckBlock, recalled; the ResNet of
+ * backbone/fpn.py:58-91]:  d_out = relu(conv3(d_in) + bias3 + d_res)  (1x1, 256 -> 1024, identity shortcut) and
+ * d_next = relu(conv1'(d_out) + bias1)  (1x1, 1024 -> 256, the NEXT block's first convolution, stride 1).
+ * All tensors bf16 NHWC with a 1-pixel halo: d_in / d_next [N,H+2,W+2,256], d_res / d_out [N,H+2,W+2,1024] (interior
+ * written).  d_wfrag: both weight matrices fragment-major, bf16 [8][8][16][64][8] = [phase][wave][k16 step][lane][8]:
+ * phase 2c = conv3 rows c*256 + wave*32 + (lane & 31), K columns 16*step + 8*(lane >> 5) .. +8;  phase 2c+1 =
+ * conv1' rows wave*32 + (lane & 31), K columns c*256 + 16*step + 8*(lane >> 5) .. +8  (engine.pack_b2b).
+ * Bit-identical to dafne_conv2d_nhwc_bf16_hip(conv3, RELU|RESIDUAL) followed by (conv1', RELU); d_out is written
+ * once and not read back.
+ */
+int dafne_bottleneck_tail_head_hip(const void* d_in, const void* d_res, const void* d_wfrag, const float* d_bias3,
+                                   const float* d_bias1, int n_images, int H, int W, void* d_out, void* d_next,
+                                   void* stream);
+/*
  * detectron2 BasicStem in one kernel [recalled; the backbone of backbone/fpn.py:58-91]: conv 7x7 / s2 / p3
  * (FrozenBN folded into d_weight / d_bias) + ReLU + max-pool 3x3 / s2 / p1.  d_in: the layout
  * dafne_preprocess_image_hip writes, bf16 [N, H+6, W+6, 4]; d_weight: bf16 [64, 256] with k = (kh 0..7, kw 0..7,

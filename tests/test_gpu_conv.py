@@ -443,3 +443,42 @@ def test_stem_pool_fused_equals_conv_then_pool(N, H, W):
         ref = F.max_pool2d(bfr(F.relu(F.conv2d(stem_in[:, 3:-3, 3:-3, :3].float().cpu().permute(0, 3, 1, 2), w, b,
                                                stride=2, padding=3))), 3, 2, 1)
         close_bf16(pf.nchw_float().cpu(), ref)
+
+
+@pytest.mark.parametrize("N,H,W", [(1, 8, 16), (2, 64, 64), (3, 13, 21), (1, 1, 1)])
+def test_bottleneck_tail_head_fused_equals_two_convs(N, H, W):
+    """dafne_bottleneck_tail_head_hip (conv3 + residual + ReLU, then the next block's conv1 + ReLU, one kernel)
+    against the two launches of the generic path: bit for bit on both outputs, ragged last tile, halo untouched;
+    and against torch within bf16 rounding."""
+    from dafne_amd import engine, _lib
+    L = _lib.load()
+    d = dev()
+    g = torch.Generator().manual_seed(1000 + H * W)
+    t = bfr(torch.randn(N, 256, H, W, generator=g))
+    x = bfr(torch.randn(N, 1024, H, W, generator=g))
+    w3 = bfr(torch.randn(1024, 256, 1, 1, generator=g) / 16.0)
+    b3 = torch.randn(1024, generator=g) * 0.2
+    w1 = bfr(torch.randn(256, 1024, 1, 1, generator=g) / 32.0)
+    b1 = torch.randn(256, generator=g) * 0.2
+    st = _lib.current_stream()
+    ta, xa = engine.Act.from_nchw(t.to(d)), engine.Act.from_nchw(x.to(d))
+    w3p, b3p = engine.pack_conv(w3, b3, d)
+    w1p, b1p = engine.pack_conv(w1, b1, d)
+    # separate launches
+    y_u, z_u = engine.Act(N, H, W, 1024, d), engine.Act(N, H, W, 256, d)
+    engine.ConvCall(w3p, b3p, 256, 1024, 1, 1, 0, engine.F_RELU | engine.F_RES, [(ta.t, y_u.t, xa.t, H, W, H, W)], N)(st)
+    engine.ConvCall(w1p, b1p, 1024, 256, 1, 1, 0, engine.F_RELU, [(y_u.t, z_u.t, None, H, W, H, W)], N)(st)
+    # fused
+    wf = engine.pack_b2b(w3p, w1p)
+    y_f, z_f = engine.Act(N, H, W, 1024, d), engine.Act(N, H, W, 256, d)
+    _lib.check(L.dafne_bottleneck_tail_head_hip(_lib.ptr(ta.t), _lib.ptr(xa.t), _lib.ptr(wf), _lib.ptr(b3p), _lib.ptr(b1p),
+                                                N, H, W, _lib.ptr(y_f.t), _lib.ptr(z_f.t), st), "b2b")
+    torch.cuda.synchronize()
+    assert torch.equal(y_f.t, y_u.t)
+    assert torch.equal(z_f.t, z_u.t)
+    assert float(z_f.t[:, 0].abs().max()) == 0 and float(y_f.t[:, :, -1].abs().max()) == 0
+    y_ref = bfr(F.relu(F.conv2d(t, w3, b3) + x))
+    close_bf16(y_f.nchw_float().cpu(), y_ref)
+    z_ref = bfr(F.relu(F.conv2d(y_ref, w1, b1)))
+    got = z_f.nchw_float().cpu()
+    assert float((got - z_ref).abs().max()) < 0.02 * float(z_ref.abs().max())
