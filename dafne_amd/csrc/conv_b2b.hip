@@ -6,17 +6,20 @@
 //
 // Unfused these are two small launches per block (17 GFLOP each at batch 8, 64x64 maps): one round of tiles whose
 // duration is prologue + epilogue + operand latency, and Y (67 MB) is written, then read straight back.  Here a
-// workgroup owns 128 pixels and ALL channels: for each 256-channel chunk of Y it runs GEMM1 (K = 256, operand T
+// workgroup owns 64 pixels and ALL channels: for each 256-channel chunk of Y it runs GEMM1 (K = 256, operand T
 // resident in LDS), adds bias + residual in place in LDS, stores the chunk to HBM and immediately uses the LDS copy
-// as the K-chunk of GEMM2, whose accumulators (128 px x 256 cout) live in registers across the four chunks.  Y is
+// as the K-chunk of GEMM2, whose accumulators (64 px x 256 cout) live in registers across the four chunks.  Y is
 // never read back; the second launch, its prologue and its epilogue disappear.
 //
-//   * LDS: T tile 64 KB + Y chunk 64 KB (both as four [128 px][128 B] slabs, 16-byte chunk ^ (px & 7)).  The residual
-//     chunk is DMA'd (global_load_lds) into the Y buffer under GEMM1 and updated in place by the epilogue.
+//   * 4 waves, 2 workgroups per CU: the phases that leave the matrix pipe idle (residual / epilogue / row stores,
+//     ~45 % of a workgroup's time) overlap with the other workgroup's GEMM phases.
+//   * LDS per workgroup: T tile 32 KB + Y chunk 32 KB (four [64 px][128 B] slabs each, 16-byte chunk ^ (px & 7)) +
+//     5 KB of biases.  The residual chunk is DMA'd (global_load_lds) into the Y buffer under GEMM1 and updated in
+//     place by the epilogue.
 //   * No LDS left for a weight ring, so the A operand streams L2 -> REGISTERS: the host packs both weight matrices
-//     fragment-major (dafne_b2b_pack layout: [phase][wave][k16 step][lane][8 bf16]), a wave's fragment is one coalesced
-//     1-KiB load, 8 fragments are in flight per wave while the previous 8 are consumed.  8 waves = 8 x 32 output
-//     channels, each over all 128 pixels (1 A + 4 B fragments per 4 MFMAs).
+//     fragment-major (engine.pack_b2b: [phase][wave][k16 step][fragment][lane][8 bf16]); a wave owns 64 output
+//     channels (2 fragments), one load group = 4 steps x 2 fragments = 8 coalesced 1-KiB loads, one group is in
+//     flight while the previous one is consumed (2 A + 2 B fragments per 4 MFMAs).
 //   * K is walked in ascending order in both GEMMs and the epilogue expressions are those of the separate kernels:
 //     results are bit-identical to conv3 (+residual) followed by conv1.
 #include "common.h"
@@ -30,18 +33,19 @@ typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
 typedef __attribute__((address_space(1))) void gvoid;
 typedef __attribute__((address_space(3))) void lvoid;
 
-constexpr int kPx = 128;                 // pixels per workgroup
-constexpr int kSlab = kPx * 128;         // one 64-channel slab of the tile: 16 KB
-constexpr int kBuf = 4 * kSlab;          // 256 channels: 64 KB
-constexpr int kSmem = 2 * kBuf;           // + 5 KB of biases behind it
+constexpr int kPx = 64;                  // pixels per workgroup
+constexpr int kSlab = kPx * 128;         // one 64-channel slab of the tile: 8 KB
+constexpr int kBuf = 4 * kSlab;          // 256 channels: 32 KB
+constexpr int kSmem = 2 * kBuf;          // + 5 KB of biases behind it
 constexpr int kSmemTotal = kSmem + (1024 + 256) * 4;
 constexpr int kCM = 256, kCB = 1024, kChunks = kCB / 256;
-constexpr int kPhaseBytes = 8 * 16 * 1024;    // one phase of the fragment-major weights: 8 waves x 16 steps x 1 KB
+constexpr int kNW = 4, kNT = 256;
+constexpr int kPhaseBytes = kNW * 16 * 2 * 1024;    // one phase of the fragment-major weights: 4 waves x 16 steps x 2 KB
 
 struct B2bDev {
     const char* in;      // bf16 [N, H+2, W+2, 256]
     const char* res;     // bf16 [N, H+2, W+2, 1024]
-    const char* wf;      // bf16 [8 phases][8 waves][16 steps][64 lanes][8]
+    const char* wf;      // bf16 [8 phases][4 waves][16 steps][2 fragments][64 lanes][8]
     const float* b3;     // [1024]
     const float* b1;     // [256]
     char* out;           // bf16 [N, H+2, W+2, 1024]
@@ -56,8 +60,6 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
     return start + idx;
 }
 
-__device__ __forceinline__ float bf2f(unsigned short h) { return __uint_as_float((unsigned)h << 16); }
-
 __device__ __forceinline__ unsigned pack_bf16(float a, float b) {
     typedef __attribute__((ext_vector_type(2))) float f32x2;
     typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
@@ -66,7 +68,28 @@ __device__ __forceinline__ unsigned pack_bf16(float a, float b) {
     return __builtin_bit_cast(unsigned, r);
 }
 
-__global__ void __launch_bounds__(512) conv_b2b_kernel(B2bDev P) {
+// Vector-memory program order of a workgroup (per lane): T tile DMA (8) | A(0) .. A(7) (2 loads each) | R(0), the first
+// residual chunk (8 DMA) | then for every k16 step j = 0 .. 127 (32 per chunk: 16 of GEMM1, 16 of GEMM2):
+//   [wait A(j)] MFMAs | 2 row stores of the Y chunk if (j & 31) in 16..19 | A(j + 8) if j + 8 < 128 |
+//   R(c + 1) (8 DMA) after the last step of chunk c < 3.
+// b2b_wait(j) = number of those instructions issued after A(j) and before the wait for it: vmcnt is in-order, so
+// `s_waitcnt vmcnt(b2b_wait(j))` is exactly "A(j) and everything older has landed".
+constexpr int b2b_st(int i) { return ((i & 31) >= 16 && (i & 31) <= 19) ? 2 : 0; }
+constexpr int b2b_res(int i) { return ((i & 31) == 31 && i < 127) ? 8 : 0; }
+constexpr int b2b_wait(int j) {
+    int n = 0;
+    if (j <= 7) {
+        n += 2 * (7 - j) + 8;                                  // A(j+1..7), R(0)
+        for (int i = 0; i < j; i++) n += b2b_st(i) + (i + 8 < 128 ? 2 : 0) + b2b_res(i);
+    } else {
+        n += b2b_res(j - 8);                                   // R right behind A(j) at the end of step j - 8
+        for (int i = j - 7; i < j; i++) n += b2b_st(i) + (i + 8 < 128 ? 2 : 0) + b2b_res(i);
+    }
+    return n;
+}
+static_assert(b2b_wait(0) == 22 && b2b_wait(8) == 14 && b2b_wait(127) == 0 && b2b_wait(39) == 22, "vmcnt bookkeeping");
+
+__global__ void __launch_bounds__(256, 2) conv_b2b_kernel(B2bDev P) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -88,11 +111,11 @@ __global__ void __launch_bounds__(512) conv_b2b_kernel(B2bDev P) {
         return (unsigned)((img * (P.H + 2) + ho + 1) * Wp + wo + 1);
     };
 
-    // ---- DMA maps: a slab is 16 pieces of 8 px x 128 B; wave w moves pieces w and w + 8 of every slab
+    // ---- DMA maps: a slab is 8 pieces of 8 px x 128 B; wave w moves pieces w and w + 4 of every slab
     unsigned dpix[2], dq[2];
 #pragma unroll
     for (int ii = 0; ii < 2; ii++) {
-        const int px = (wave + 8 * ii) * 8 + (lane >> 3);
+        const int px = (wave + kNW * ii) * 8 + (lane >> 3);
         dpix[ii] = halo_index(px);
         dq[ii] = (unsigned)(((lane & 7) ^ (px & 7)) * 16);
     }
@@ -102,180 +125,198 @@ __global__ void __launch_bounds__(512) conv_b2b_kernel(B2bDev P) {
 #pragma unroll
             for (int ii = 0; ii < 2; ii++)
                 __builtin_amdgcn_global_load_lds((gvoid*)(src + (size_t)dpix[ii] * pix_bytes + col0 + sl * 128 + dq[ii]),
-                                                 (lvoid*)(lds + buf * kBuf + sl * kSlab + (wave + 8 * ii) * 1024), 16, 0, 0);
+                                                 (lvoid*)(lds + buf * kBuf + sl * kSlab + (wave + kNW * ii) * 1024), 16, 0, 0);
     };
 
     // ---- fragment offsets
     unsigned bs[4];                          // B fragment of k16 step s inside a slab, pixel fragment 0
 #pragma unroll
     for (int s = 0; s < 4; s++) bs[s] = (unsigned)(frow * 128 + (((2 * s + half) ^ (frow & 7)) * 16));
-    unsigned eg[4];                          // epilogue: this lane's 4 channels of group g, pixel fragment 0 (Y buffer)
-#pragma unroll
-    for (int g = 0; g < 4; g++)
-        eg[g] = lds_base + (unsigned)(kBuf + (wave >> 1) * kSlab + frow * 128 + (((((wave & 1) * 4 + g) ^ (frow & 7))) * 16) + 8 * half);
+    // epilogue: the wave's 64 channels are slab `wave` of the Y buffer; this lane's row + half inside it
+    const unsigned ebase = lds_base + (unsigned)(kBuf + wave * kSlab + frow * 128 + 8 * half);
 
-    // ---- A operand: 8 fragments per load group, L2 -> registers through inline asm (the compiler would sink visible
-    // loads to their uses and wait for each); readiness is tracked by hand: vmcnt is in-order, every vector-memory
-    // instruction of this kernel is issued in a fixed program order, so the number of younger instructions at each
-    // wait is a constant (stores of a ragged tile are clamped, not predicated, to keep the count exact).
-    const unsigned voff = (unsigned)(wave * 16 * 1024 + lane * 16);
-    bf16x8 a0[8], a1[8];
-#define B2B_LOAD_A(dst, phase, t0)                                                                              \
+    // ---- A operand: L2 -> registers through inline asm (the compiler would sink visible loads to their uses and wait
+    // for each).  A ring of 8 k16 steps (2 fragments each): the loads of step j + 8 are issued as soon as step j's MFMAs
+    // are, so 7 steps (~1 us of matrix work for the two waves of a SIMD) cover the L2 latency.  Readiness is tracked by
+    // hand (b2b_wait); stores of a ragged tile are clamped, not predicated, to keep the instruction count exact.
+    const unsigned voff = (unsigned)(wave * 16 * 2048 + lane * 16);
+    bf16x8 ar[8][2];
+#define B2B_LOAD_STEP(j)                                                                                        \
     {                                                                                                           \
-        const char* sb0 = P.wf + (size_t)(phase) * kPhaseBytes + (t0) * 1024;                                   \
-        const char* sb1 = sb0 + 4096;                                                                           \
-        asm volatile("global_load_dwordx4 %0, %4, %5\n\tglobal_load_dwordx4 %1, %4, %5 offset:1024\n\t"         \
-                     "global_load_dwordx4 %2, %4, %5 offset:2048\n\tglobal_load_dwordx4 %3, %4, %5 offset:3072" \
-                     : "=&v"(dst[0]), "=&v"(dst[1]), "=&v"(dst[2]), "=&v"(dst[3])                               \
-                     : "v"(voff), "s"(sb0)                                                                      \
-                     : "memory");                                                                               \
-        asm volatile("global_load_dwordx4 %0, %4, %5\n\tglobal_load_dwordx4 %1, %4, %5 offset:1024\n\t"         \
-                     "global_load_dwordx4 %2, %4, %5 offset:2048\n\tglobal_load_dwordx4 %3, %4, %5 offset:3072" \
-                     : "=&v"(dst[4]), "=&v"(dst[5]), "=&v"(dst[6]), "=&v"(dst[7])                               \
-                     : "v"(voff), "s"(sb1)                                                                      \
+        const char* sb = P.wf + (size_t)((j) >> 4) * kPhaseBytes + ((j) & 15) * 2048;                           \
+        asm volatile("global_load_dwordx4 %0, %2, %3\n\tglobal_load_dwordx4 %1, %2, %3 offset:1024"           \
+                     : "=&v"(ar[(j) & 7][0]), "=&v"(ar[(j) & 7][1])                                             \
+                     : "v"(voff), "s"(sb)                                                                       \
                      : "memory");                                                                               \
     }
-#define B2B_WAIT_A(dst, n)                                                                                      \
-    asm volatile("s_waitcnt vmcnt(" #n ")"                                                                      \
-                 : "+v"(dst[0]), "+v"(dst[1]), "+v"(dst[2]), "+v"(dst[3]), "+v"(dst[4]), "+v"(dst[5]), "+v"(dst[6]), \
-                   "+v"(dst[7])                                                                                 \
-                 :                                                                                              \
-                 : "memory")
+#define B2B_WAIT_STEP(j)                                                                                        \
+    {                                                                                                           \
+        constexpr int kWaitN = b2b_wait(j);                                                                     \
+        asm volatile("s_waitcnt vmcnt(%2)" : "+v"(ar[(j) & 7][0]), "+v"(ar[(j) & 7][1]) : "n"(kWaitN) : "memory"); \
+    }
 
-    f32x16 acc1[4], acc2[4];
+    f32x16 acc1[2][2], acc2[2][2];
 #pragma unroll
-    for (int b = 0; b < 4; b++)
+    for (int f = 0; f < 2; f++)
 #pragma unroll
-        for (int k = 0; k < 16; k++) acc2[b][k] = 0.f;
+        for (int b = 0; b < 2; b++)
+#pragma unroll
+            for (int k = 0; k < 16; k++) acc2[f][b][k] = 0.f;
 
-    auto steps = [&](const bf16x8* a, int t0, int buf, f32x16* acc) {
-#pragma unroll
-        for (int k = 0; k < 8; k++) {
-            const int t = t0 + k, sl = t >> 2, s = t & 3;
-            bf16x8 bfr[4];
-#pragma unroll
-            for (int b = 0; b < 4; b++) bfr[b] = *(const bf16x8*)(lds + buf * kBuf + sl * kSlab + b * 4096 + bs[s]);
-#pragma unroll
-            for (int b = 0; b < 4; b++) acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[k], bfr[b], acc[b], 0, 0, 0);
-        }
-    };
     auto barrier = [&]() {
         __builtin_amdgcn_sched_barrier(0);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
     };
-    // acc + bias (+ residual already in the Y buffer) -> ReLU -> bf16, in place in the Y buffer
-    const unsigned lbias_off = lds_base + (unsigned)kSmem;      // [1024 conv3 | 256 conv1] fp32
-    auto epilogue = [&](const f32x16* acc, int bias0, bool with_res) {
-        const unsigned rmask = with_res ? 0xffffffffu : 0u;
-#pragma unroll
-        for (int g = 0; g < 4; g++) {
-            typedef __attribute__((ext_vector_type(4))) float f32x4;
-            f32x4 bv;
-            u32x2 rc[4];
-            const unsigned bad = lbias_off + (unsigned)((bias0 + wave * 32 + 8 * g + 4 * half) * 4);
-            // inline asm: a plain LDS read here makes the compiler drain vmcnt (it cannot tell the read from the
-            // residual DMA's destination).  The four pixel fragments sit 4096 B apart.
-            asm volatile("ds_read_b128 %4, %6\n\tds_read_b64 %0, %5\n\tds_read_b64 %1, %5 offset:4096\n\t"
-                         "ds_read_b64 %2, %5 offset:8192\n\tds_read_b64 %3, %5 offset:12288\n\ts_waitcnt lgkmcnt(0)"
-                         : "=&v"(rc[0]), "=&v"(rc[1]), "=&v"(rc[2]), "=&v"(rc[3]), "=&v"(bv)
-                         : "v"(eg[g]), "v"(bad)
-                         : "memory");
-#pragma unroll
-            for (int b = 0; b < 4; b++) {
-                u32x2 r = rc[b];
-                r.x &= rmask;
-                r.y &= rmask;
-                const float v0 = fmaxf(acc[b][4 * g] + bv.x + bf2f((unsigned short)(r.x & 0xffff)), 0.f);
-                const float v1 = fmaxf(acc[b][4 * g + 1] + bv.y + bf2f((unsigned short)(r.x >> 16)), 0.f);
-                const float v2 = fmaxf(acc[b][4 * g + 2] + bv.z + bf2f((unsigned short)(r.y & 0xffff)), 0.f);
-                const float v3 = fmaxf(acc[b][4 * g + 3] + bv.w + bf2f((unsigned short)(r.y >> 16)), 0.f);
-                rc[b].x = pack_bf16(v0, v1);
-                rc[b].y = pack_bf16(v2, v3);
-            }
-            asm volatile("ds_write_b64 %4, %0\n\tds_write_b64 %4, %1 offset:4096\n\tds_write_b64 %4, %2 offset:8192\n\t"
-                         "ds_write_b64 %4, %3 offset:12288"
-                         :
-                         : "v"(rc[0]), "v"(rc[1]), "v"(rc[2]), "v"(rc[3]), "v"(eg[g])
-                         : "memory");
-        }
-    };
-    // the Y buffer (256 channels of 128 px) -> global rows: 32 consecutive threads write one pixel's 512 B.
+    // the Y buffer (256 channels of 64 px) -> global rows: 32 consecutive threads write one pixel's 512 B, 8 passes.
     // EXACTLY 8 stores per lane (vmcnt bookkeeping): rows past the end of a ragged tile re-write the last valid row.
     const int plast = HW - 1 - m0;
-    auto store_rows = [&](char* dst, unsigned pix_bytes, unsigned col0) {
+    auto store_one = [&](int i, char* dst, unsigned pix_bytes, unsigned col0) {
+        int idx = tid + kNT * i;
+        asm volatile("" : "+v"(idx));                // recompute the row address at every pass: holding 8 of them spills
+        int px = idx >> 5;
+        px = px < plast ? px : plast;
+        const int j = idx & 31;
+        const int sl = j >> 3, q = j & 7;
+        const u32x4 v = *(const u32x4*)(lds + kBuf + sl * kSlab + px * 128 + ((q ^ (px & 7)) * 16));
+        *(u32x4*)(dst + (size_t)halo_index(px) * pix_bytes + col0 + j * 16) = v;
+    };
+    // k16 step: acc[f][b] += A[f] . B[b]  (slab q of buffer buf, step s inside the slab)
+    auto consume = [&](const bf16x8* a, int q, int st, int buf, f32x16 (*acc)[2]) {
+        bf16x8 bfr[2];
 #pragma unroll
-        for (int i = 0; i < 8; i++) {
-            int idx = tid + 512 * i;
-            asm volatile("" : "+v"(idx));            // recompute the row address at every pass: holding 8 of them spills
-            int px = idx >> 5;
-            px = px < plast ? px : plast;
-            const int j = idx & 31;
-            const int sl = j >> 3, q = j & 7;
-            u32x4 v;
-            const unsigned ad = lds_base + (unsigned)(kBuf + sl * kSlab + px * 128 + ((q ^ (px & 7)) * 16));
-            asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(v) : "v"(ad) : "memory");
-            char* gp = dst + (size_t)halo_index(px) * pix_bytes + col0 + j * 16;
-            *(u32x4*)gp = v;     // compiler-issued: it inserts the wait states a > 64-bit store needs before its data registers are reused
+        for (int b = 0; b < 2; b++) bfr[b] = *(const bf16x8*)(lds + buf * kBuf + q * kSlab + b * 4096 + bs[st]);
+#pragma unroll
+        for (int f = 0; f < 2; f++)
+#pragma unroll
+            for (int b = 0; b < 2; b++) acc[f][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[f], bfr[b], acc[f][b], 0, 0, 0);
+    };
+    // acc + bias (+ residual already in the Y buffer) -> ReLU -> bf16, in place in the Y buffer
+    const unsigned lbias_off = lds_base + (unsigned)kSmem;      // [1024 conv3 | 256 conv1] fp32
+    auto epilogue = [&](f32x16 (*acc)[2], int bias0, bool with_res) {
+        typedef __attribute__((ext_vector_type(4))) float f32x4;
+        typedef __attribute__((ext_vector_type(2))) float f32x2;
+        const unsigned rmask = with_res ? 0xffffffffu : 0u;
+#pragma unroll
+        for (int f = 0; f < 2; f++) {
+            f32x4 bv[4];
+            u32x2 rc[4][2];
+            unsigned ead[4];
+            // LDS reads of the fragment first, one wait.  Inline asm: a plain LDS read here makes the compiler drain
+            // vmcnt (it cannot tell the read from the residual DMA's destination).  Pixel fragments sit 4096 B apart.
+#pragma unroll
+            for (int g = 0; g < 4; g++) {
+                ead[g] = ebase + (unsigned)((((f * 4 + g) ^ (frow & 7))) * 16);
+                const unsigned bad = lbias_off + (unsigned)((bias0 + wave * 64 + f * 32 + 8 * g + 4 * half) * 4);
+                asm volatile("ds_read_b128 %2, %4\n\tds_read_b64 %0, %3\n\tds_read_b64 %1, %3 offset:4096"
+                             : "=&v"(rc[g][0]), "=&v"(rc[g][1]), "=&v"(bv[g])
+                             : "v"(ead[g]), "v"(bad)
+                             : "memory");
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)"
+                         : "+v"(rc[0][0]), "+v"(rc[0][1]), "+v"(rc[1][0]), "+v"(rc[1][1]), "+v"(rc[2][0]), "+v"(rc[2][1]),
+                           "+v"(rc[3][0]), "+v"(rc[3][1]), "+v"(bv[0]), "+v"(bv[1]), "+v"(bv[2]), "+v"(bv[3])
+                         :
+                         : "memory");
+#pragma unroll
+            for (int g = 0; g < 4; g++) {
+                const f32x2 blo = {bv[g][0], bv[g][1]}, bhi = {bv[g][2], bv[g][3]};
+#pragma unroll
+                for (int b = 0; b < 2; b++) {
+                    u32x2 r = rc[g][b];
+                    r.x &= rmask;
+                    r.y &= rmask;
+                    const f32x2 rlo = {__uint_as_float(r.x << 16), __uint_as_float(r.x & 0xffff0000u)};
+                    const f32x2 rhi = {__uint_as_float(r.y << 16), __uint_as_float(r.y & 0xffff0000u)};
+                    const f32x2 alo = {acc[f][b][4 * g], acc[f][b][4 * g + 1]}, ahi = {acc[f][b][4 * g + 2], acc[f][b][4 * g + 3]};
+                    const f32x2 vlo = alo + blo + rlo, vhi = ahi + bhi + rhi;          // (acc + bias) + residual
+                    rc[g][b].x = pack_bf16(fmaxf(vlo[0], 0.f), fmaxf(vlo[1], 0.f));
+                    rc[g][b].y = pack_bf16(fmaxf(vhi[0], 0.f), fmaxf(vhi[1], 0.f));
+                }
+                asm volatile("ds_write_b64 %2, %0\n\tds_write_b64 %2, %1 offset:4096" ::"v"(rc[g][0]), "v"(rc[g][1]), "v"(ead[g]) : "memory");
+            }
         }
     };
 
+#ifdef DAFNE_B2B_TIMING
+    unsigned long long stamp[12];
+    int nstamp = 0;
+#define B2B_STAMP() stamp[nstamp++] = __builtin_amdgcn_s_memtime()
+#else
+#define B2B_STAMP()
+#endif
+    B2B_STAMP();
     // ---- prologue: biases -> LDS (plain loads, before any hand-counted load is in flight)
     {
         float* lb = (float*)(lds + kSmem);
-        for (int k = tid; k < kCB; k += 512) lb[k] = P.b3[k];
+        for (int k = tid; k < kCB; k += kNT) lb[k] = P.b3[k];
         if (tid < kCM) lb[kCB + tid] = P.b1[tid];
     }
     __syncthreads();
-    dma_tile(P.in, kCM * 2, 0, 0);
-    dma_tile(P.res, kCB * 2, 0, 1);
-    B2B_LOAD_A(a0, 0, 0);
-    B2B_WAIT_A(a0, 0);
+    dma_tile(P.in, kCM * 2, 0, 0);                                     // T
+    B2B_LOAD_STEP(0) B2B_LOAD_STEP(1) B2B_LOAD_STEP(2) B2B_LOAD_STEP(3)
+    B2B_LOAD_STEP(4) B2B_LOAD_STEP(5) B2B_LOAD_STEP(6) B2B_LOAD_STEP(7)
+    dma_tile(P.res, kCB * 2, 0, 1);                                    // R(0): not awaited here
+    B2B_WAIT_STEP(0);                                                  // T and A(0)
     barrier();
+    B2B_STAMP();
 
-    // Vector-memory program order per chunk c (loads of 8, L = A fragments, R = residual DMA, ST = stores):
-    //   L1 a1<-(2c, 8..15) | L2 a0<-(2c+1, 0..7) | ST chunk c | L3 a1<-(2c+1, 8..15) | L4 a0<-(2c+2, 0..7) | R(c+1)
-#pragma unroll
-    for (int c = 0; c < kChunks; c++) {
-        // GEMM1: Y chunk c = W3[c] . T   (K = 256 over the four slabs of the T tile)
-#pragma unroll
-        for (int b = 0; b < 4; b++)
-#pragma unroll
-            for (int k = 0; k < 16; k++) acc1[b][k] = 0.f;
-        B2B_LOAD_A(a1, 2 * c, 8);                    // L1
-        B2B_WAIT_A(a0, 16);                          // a0 = L4 of the previous chunk; younger: R(c), L1
-        steps(a0, 0, 0, acc1);
-        __builtin_amdgcn_sched_barrier(0);
-        B2B_LOAD_A(a0, 2 * c + 1, 0);                // L2
-        B2B_WAIT_A(a1, 8);                           // L1 (and the older residual DMA R(c)) landed; younger: L2
-        steps(a1, 8, 0, acc1);
-        barrier();                                   // every wave's residual pieces are in the Y buffer
-        epilogue(acc1, c * 256, true);
-        barrier();
-        store_rows(P.out, kCB * 2, (unsigned)c * 512u);      // ST
-        __builtin_amdgcn_sched_barrier(0);
-        // GEMM2: Z += W1[:, chunk c] . Y chunk
-        B2B_LOAD_A(a1, 2 * c + 1, 8);                // L3
-        B2B_WAIT_A(a0, 16);                          // L2; younger: ST, L3
-        steps(a0, 0, 1, acc2);
-        __builtin_amdgcn_sched_barrier(0);
-        if (c + 1 < kChunks) {
-            B2B_LOAD_A(a0, 2 * c + 2, 0);            // L4
-            B2B_WAIT_A(a1, 8);                       // L3; younger: L4
-        } else {
-            B2B_WAIT_A(a1, 0);
-        }
-        steps(a1, 8, 1, acc2);
-        barrier();                                   // every wave is done reading the Y buffer
-        if (c + 1 < kChunks) dma_tile(P.res, kCB * 2, (unsigned)(c + 1) * 512u, 1);      // R(c+1)
-        __builtin_amdgcn_sched_barrier(0);
+#define B2B_STEP(j, ACC, STORES)                                                                                \
+    {                                                                                                           \
+        B2B_WAIT_STEP(j);                                                                                       \
+        consume(ar[(j) & 7], ((j) & 15) >> 2, (j) & 3, ((j) >> 4) & 1, ACC);                                    \
+        if (STORES) {                                                                                           \
+            store_one(2 * ((j) & 3), P.out, kCB * 2, (unsigned)((j) >> 5) * 512u);                              \
+            store_one(2 * ((j) & 3) + 1, P.out, kCB * 2, (unsigned)((j) >> 5) * 512u);                          \
+        }                                                                                                       \
+        __builtin_amdgcn_sched_barrier(0);                                                                      \
+        if ((j) + 8 < 128) B2B_LOAD_STEP((j) + 8)                                                               \
     }
+#define B2B_STEP4(j, ACC, STORES) B2B_STEP((j), ACC, STORES) B2B_STEP((j) + 1, ACC, STORES) B2B_STEP((j) + 2, ACC, STORES) B2B_STEP((j) + 3, ACC, STORES)
+#define B2B_CHUNK(C)                                                                                            \
+    {                                                                                                           \
+        /* GEMM1: Y chunk C = W3[C] . T  (K = 256 over the four slabs of the T tile) */                        \
+        _Pragma("unroll") for (int f = 0; f < 2; f++)                                                           \
+        _Pragma("unroll") for (int b = 0; b < 2; b++)                                                           \
+        _Pragma("unroll") for (int k = 0; k < 16; k++) acc1[f][b][k] = 0.f;                                     \
+        B2B_STEP4(32 * (C) + 0, acc1, false) B2B_STEP4(32 * (C) + 4, acc1, false)                               \
+        B2B_STEP4(32 * (C) + 8, acc1, false) B2B_STEP4(32 * (C) + 12, acc1, false)                              \
+        barrier(); /* every wave's residual pieces are in the Y buffer (older than A(32C+15)) */                \
+        if ((C) == 0) B2B_STAMP();                                                                              \
+        epilogue(acc1, (C) * 256, true);                                                                        \
+        barrier();                                                                                              \
+        if ((C) == 0) B2B_STAMP();                                                                              \
+        /* GEMM2: Z += W1[:, chunk C] . Y chunk; the chunk's row stores ride behind the first four steps */     \
+        B2B_STEP4(32 * (C) + 16, acc2, true) B2B_STEP4(32 * (C) + 20, acc2, false)                              \
+        B2B_STEP4(32 * (C) + 24, acc2, false) B2B_STEP4(32 * (C) + 28, acc2, false)                             \
+        barrier(); /* every wave is done reading the Y buffer */                                                \
+        if ((C) + 1 < kChunks) dma_tile(P.res, kCB * 2, (unsigned)((C) + 1) * 512u, 1);                         \
+        __builtin_amdgcn_sched_barrier(0);                                                                      \
+        B2B_STAMP();                                                                                            \
+    }
+    B2B_CHUNK(0)
+    B2B_CHUNK(1)
+    B2B_CHUNK(2)
+    B2B_CHUNK(3)
+#undef B2B_CHUNK
+#undef B2B_STEP4
+#undef B2B_STEP
     epilogue(acc2, kCB, false);
     barrier();
-    store_rows(P.next, kCM * 2, 0);
-#undef B2B_LOAD_A
-#undef B2B_WAIT_A
+    B2B_STAMP();
+#pragma unroll
+    for (int i = 0; i < 8; i++) store_one(i, P.next, kCM * 2, 0);
+#ifdef DAFNE_B2B_TIMING
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    B2B_STAMP();
+    if (tid == 0 && blockIdx.x < 64) {       // into the top halo row of image 0 of d_next (zeros otherwise)
+        unsigned long long* o = (unsigned long long*)P.next + blockIdx.x * 12;
+        for (int k = 0; k < nstamp; k++) o[k] = stamp[k] - stamp[0];
+    }
+#endif
+#undef B2B_LOAD_STEP
+#undef B2B_WAIT_STEP
 }
 
 }  // namespace
@@ -300,7 +341,7 @@ int dafne_bottleneck_tail_head_hip(const void* d_in, const void* d_res, const vo
         DAFNE_HIP_TRY(hipFuncSetAttribute((const void*)conv_b2b_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kSmemTotal));
         attr_done = true;
     }
-    hipLaunchKernelGGL(conv_b2b_kernel, dim3(D.tiles), dim3(512), kSmemTotal, (hipStream_t)stream, D);
+    hipLaunchKernelGGL(conv_b2b_kernel, dim3(D.tiles), dim3(kNT), kSmemTotal, (hipStream_t)stream, D);
     return dafne::check_launch("conv_b2b");
 }
 

@@ -253,9 +253,10 @@ int dafne_resize_bilinear_u8_hip(const uint8_t* d_in, int layout_hwc, int C, int
  * backbone/fpn.py:58-91]:  d_out = relu(conv3(d_in) + bias3 + d_res)  (1x1, 256 -> 1024, identity shortcut) and
  * d_next = relu(conv1'(d_out) + bias1)  (1x1, 1024 -> 256, the NEXT block's first convolution, stride 1).
  * All tensors bf16 NHWC with a 1-pixel halo: d_in / d_next [N,H+2,W+2,256], d_res / d_out [N,H+2,W+2,1024] (interior
- * written).  d_wfrag: both weight matrices fragment-major, bf16 [8][8][16][64][8] = [phase][wave][k16 step][lane][8]:
- * phase 2c = conv3 rows c*256 + wave*32 + (lane & 31), K columns 16*step + 8*(lane >> 5) .. +8;  phase 2c+1 =
- * conv1' rows wave*32 + (lane & 31), K columns c*256 + 16*step + 8*(lane >> 5) .. +8  (engine.pack_b2b).
+ * written).  d_wfrag: both weight matrices fragment-major, bf16 [8][4][16][2][64][8] = [phase][wave][k16 step]
+ * [fragment][lane][8]: phase 2c = conv3 rows c*256 + wave*64 + fragment*32 + (lane & 31), K columns 16*step +
+ * 8*(lane >> 5) .. +8;  phase 2c+1 = conv1' rows wave*64 + fragment*32 + (lane & 31), K columns c*256 + 16*step +
+ * 8*(lane >> 5) .. +8  (engine.pack_b2b).
  * Bit-identical to dafne_conv2d_nhwc_bf16_hip(conv3, RELU|RESIDUAL) followed by (conv1', RELU); d_out is written
  * once and not read back.
  */
