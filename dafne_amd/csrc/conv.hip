@@ -66,6 +66,8 @@ struct ConvDev {
     const float* in_stats;   // GN_INPUT: [n_segs][N][Cin/8][2] mean, rstd of the input
     const float* in_gamma;   //           [Cin]
     const float* in_beta;    //           [Cin]
+    const float* oscale;     // fp8 path: [Cout] output scale (weight scale / in_qscale)
+    float in_qscale;         // fp8 path: activations are multiplied by this before the e4m3 rounding
 };
 
 __device__ __forceinline__ unsigned short f2bf(float f) {
@@ -1670,6 +1672,389 @@ __global__ void __launch_bounds__(512) conv3x3_patch_kernel(ConvDev P) {
 }
 
 // ---------------------------------------------------------------------------------------
+// fp8 (OCP e4m3) twin of conv3x3_patch_kernel: BASELINE config 5 (fp8 weights, CDNA4 fp8 MFMA conv path).
+//
+// Weights are e4m3 bytes in the same [Cout][Cin/64][KH][KW][64] order (64 B per tap row) with one fp32
+// dequantisation scale per output channel; activations stay bf16 in HBM and are quantised ON LOAD: the bf16
+// input patch of a 64-channel slab is DMA'd into a staging buffer and converted (after the optional
+// GroupNorm + ReLU of GN_INPUT, in fp32: y * in_qscale, clamp to +-448, v_cvt_pk_fp8_f32 = round to nearest even)
+// into an fp8 patch (64 B per pixel, double-buffered across slabs) by the wave that loaded the piece.  The matrix
+// instruction is v_mfma_f32_32x32x64_f8f6f4 (both operands e4m3, no block scales): one instruction covers a whole
+// 64-channel tap, so a K step of this kernel moves exactly the bytes a HALF step of the bf16 kernel moves
+// (256 x 64 B of weights, 32 B per lane and fragment) and the schedule carries over unchanged -- two wave
+// groups one phase apart, 4 weight buffers, counted vmcnt -- with half as many steps per slab (9) and twice
+// the flops per phase.  fp32 accumulation; epilogue acc * oscale[cout] + bias (oscale = weight scale / in_qscale),
+// then exactly the bf16 kernel's epilogue (ReLU, GroupNorm partial sums, bf16 NHWC store).
+//   * fp8 patch pixel (py, px), 16-byte chunk c (16 channels): 128-byte row py*17 + (px>>1), chunk
+//     ((px&1)*4 + c) ^ ((px>>1)&7): the 2 x ds_read_b128 of a B fragment (32 consecutive px, 32 channels)
+//     are bank-conflict free;
+//   * the next slab's 6 bf16 patch pieces per wave are issued in both phases of steps 0..2, have landed by
+//     the wait that ends step 4, and are converted in the read phases of steps 5..7.
+typedef __attribute__((ext_vector_type(8))) int i32x8;
+constexpr int kQBuf = kPPieces * 512;               // fp8 patch: 344 px x 64 B
+constexpr int kQOffStage = 2 * kPAStage;            // bf16 staging of one slab's patch (single buffer)
+constexpr int kQOffPatch = kQOffStage + kPBuf;
+constexpr int kQOffTab = kQOffPatch + 2 * kQBuf;
+constexpr int kQSmem = kQOffTab + kPTabMaxC * 9;
+static_assert(kQSmem <= 160 * 1024, "LDS budget");
+
+template <bool GNIN>
+__global__ void __launch_bounds__(512) conv3x3_patch_fp8_kernel(ConvDev P) {
+    constexpr int NW = 8, WP = 2, TC = 2, TP = 4, BN = 256, BM = 256, NT = 512;
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wc = wave / WP, wp = wave % WP;
+    const int grp = wave >> 2;
+    const int frow = lane & 31, half = lane >> 5;
+
+    const int T = P.mtiles * P.ntiles;
+    const int bid = xcd_remap(blockIdx.x, T);
+    const int nt = bid % P.ntiles;
+    const int mt = bid / P.ntiles;
+    int si = 0;
+#pragma unroll
+    for (int k = 1; k < kMaxSegs; k++)
+        if (k < P.n_segs && mt >= P.seg[k].tile0) si = k;
+    const SegDev& S = P.seg[si];
+    const int tloc = mt - S.tile0;
+    const int img = tloc / S.tiles_per_img;
+    const int tt = tloc - img * S.tiles_per_img;
+    const int ty = tt / S.tiles_x, tx = tt - ty * S.tiles_x;
+    const int Y0 = ty * kPH, X0 = tx * kPW;
+    const int H = S.Hout, W = S.Wout, Hp = H + 2, Wp = W + 2;
+    const int nslab = P.Cin / kBK;
+    const int V = 9 * nslab;                // K steps: one 64-channel tap each
+
+    float* tab_stats = (float*)(lds + kQOffTab);
+    float* tab_gamma = tab_stats + P.Cin / 4;
+    float* tab_beta = tab_gamma + P.Cin;
+    if (GNIN) {
+        const float* st = P.in_stats + ((size_t)si * P.N + img) * (P.Cin / 8) * 2;
+        for (int k = tid; k < P.Cin / 4; k += NT) tab_stats[k] = st[k];
+        for (int k = tid; k < P.Cin; k += NT) {
+            tab_gamma[k] = P.in_gamma[k];
+            tab_beta[k] = P.in_beta[k];
+        }
+        __syncthreads();
+    }
+    const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) char*)lds;
+    const float qs = P.in_qscale;
+
+    // ---- per-lane source offsets ------------------------------------------------------------
+    unsigned hofs[2];                      // weight rows of this wave's two pieces per step
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+        const int r = (i * NW + wave) * 16 + (lane >> 2);
+        const int q = (lane & 3) ^ ((r >> 2) & 3);
+        hofs[i] = (unsigned)(nt * BN + r) * (unsigned)P.kbytes + (unsigned)q * 16u;
+    }
+    unsigned pofs[6];                      // bf16 patch pixels of this wave's six pieces per slab
+    int ppi[6];
+#pragma unroll
+    for (int i = 0; i < 6; i++) {
+        int pi = i * NW + wave;
+        if (pi >= kPPieces) pi -= NW;      // pieces 43..47: the wave re-fetches its previous piece
+        ppi[i] = pi;
+        int r = pi * 8 + (lane >> 3);
+        r = r < kPRows ? r : kPRows - 1;
+        const int py = r / kPCols, px = r - py * kPCols;
+        int gy = Y0 + py, gx = X0 + px;
+        gy = gy < Hp ? gy : Hp - 1;
+        gx = gx < Wp ? gx : Wp - 1;
+        const int q = (lane & 7) ^ ((px >> 1) & 7);
+        pofs[i] = ((unsigned)(img * Hp + gy) * (unsigned)Wp + (unsigned)gx) * (unsigned)(P.Cin * 2) + (unsigned)q * 16u;
+    }
+    // B-fragment offsets inside an fp8 patch line: pixel column frow+kw, 16-byte chunks 2*half, 2*half+1
+    unsigned boff[3][2];
+#pragma unroll
+    for (int kw = 0; kw < 3; kw++)
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+            const int px = frow + kw;
+            boff[kw][j] = (unsigned)(px >> 1) * 128u + (unsigned)(((((px & 1) << 2) | (2 * half + j)) ^ ((px >> 1) & 7)) * 16);
+        }
+    const int fsw4 = (frow >> 2) & 3;
+    unsigned hroff[2];
+#pragma unroll
+    for (int j = 0; j < 2; j++) hroff[j] = (unsigned)frow * 64u + (unsigned)(((2 * half + j) ^ fsw4) * 16);
+    const int arow0 = wc * TC * 32;
+
+    // Steps are walked in the order v = (slab*3 + kw)*3 + kh: the three kh taps of one kw are consecutive, so the
+    // B fragments of 6 patch lines are read once and serve all three.  4 weight buffers of 256 x 64 B.
+    auto piece_a = [&](int v, int i) {
+        if (v >= V) return;
+        const int kh = v % 3, g = v / 3;
+        const int kw = g % 3, sl = g / 3;
+        const unsigned koff = (unsigned)((sl * 9 + kh * 3 + kw) * 64);
+        char* dst = lds + (v & 3) * kPAHalf + (i * NW + wave) * 1024;
+        __builtin_amdgcn_global_load_lds((gvoid*)(P.w + hofs[i] + koff), (lvoid*)dst, 16, 0, 0);
+    };
+    auto piece_p = [&](int slab, int i) {
+        char* dst = lds + kQOffStage + ppi[i] * 1024;
+        __builtin_amdgcn_global_load_lds((gvoid*)(S.in + pofs[i] + (unsigned)slab * 128u), (lvoid*)dst, 16, 0, 0);
+    };
+    // bf16 staging -> (GroupNorm + ReLU) -> e4m3 patch of `slab`; a lane handles logical chunk lane&7 (8 channels)
+    // of pixel row lane>>3 of the piece and writes 8 bytes.
+    auto cvt_pieces = [&](int slab, int i0, int n) {
+        float gmean = 0.f, grstd = 1.f;
+        float gam[8], bet[8];
+        if (GNIN) {
+            const int ch = slab * kBK + (lane & 7) * 8;
+            const unsigned ts = lds_base + (unsigned)(kQOffTab + (ch >> 3) * 8);
+            const unsigned tg = lds_base + (unsigned)(kQOffTab + P.Cin + ch * 4);
+            const unsigned tb = tg + (unsigned)P.Cin * 4u;
+            u32x2 ms;
+            f32x4 g0, g1, b0, b1;
+            asm volatile("ds_read_b64 %0, %5\n\tds_read_b128 %1, %6\n\tds_read_b128 %2, %6 offset:16\n\t"
+                         "ds_read_b128 %3, %7\n\tds_read_b128 %4, %7 offset:16\n\ts_waitcnt lgkmcnt(0)"
+                         : "=&v"(ms), "=&v"(g0), "=&v"(g1), "=&v"(b0), "=&v"(b1)
+                         : "v"(ts), "v"(tg), "v"(tb)
+                         : "memory");
+            gmean = __uint_as_float(ms.x);
+            grstd = __uint_as_float(ms.y);
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                gam[k] = g0[k]; gam[4 + k] = g1[k];
+                bet[k] = b0[k]; bet[4 + k] = b1[k];
+            }
+        }
+        for (int i = i0; i < i0 + n; i++) {
+            if (i == 5 && 5 * NW + wave >= kPPieces) continue;        // duplicate of piece i = 4
+            const int pi = ppi[i];
+            const int r = pi * 8 + (lane >> 3);
+            const int py = r / kPCols, px = r - py * kPCols;
+            const int gy = Y0 + py, gx = X0 + px;
+            const bool inside = gy >= 1 && gy <= H && gx >= 1 && gx <= W && r < kPRows;
+            const int lc = lane & 7;
+            const int phys = lc ^ ((px >> 1) & 7);
+            const unsigned ad = lds_base + (unsigned)(kQOffStage + pi * 1024 + (lane >> 3) * 128 + phys * 16);
+            u32x4 v;
+            asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(v) : "v"(ad) : "memory");
+            const unsigned u[4] = {v.x, v.y, v.z, v.w};
+            float y[8];
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                const float x = bf2f((unsigned short)(k & 1 ? u[k >> 1] >> 16 : u[k >> 1] & 0xffff));
+                float t = x;
+                if (GNIN) t = fmaxf((x - gmean) * grstd * gam[k] + bet[k], 0.f);      // expression of gn_apply_kernel
+                t = t * qs;
+                y[k] = inside ? fminf(fmaxf(t, -448.f), 448.f) : 0.f;
+            }
+            unsigned o0 = 0u, o1 = 0u;
+            o0 = __builtin_amdgcn_cvt_pk_fp8_f32(y[0], y[1], o0, false);
+            o0 = __builtin_amdgcn_cvt_pk_fp8_f32(y[2], y[3], o0, true);
+            o1 = __builtin_amdgcn_cvt_pk_fp8_f32(y[4], y[5], o1, false);
+            o1 = __builtin_amdgcn_cvt_pk_fp8_f32(y[6], y[7], o1, true);
+            const u32x2 o = {o0, o1};
+            const unsigned qd = lds_base + (unsigned)(kQOffPatch + (slab & 1) * kQBuf + (py * 17 + (px >> 1)) * 128 +
+                                                       (((((px & 1) << 2) | (lc >> 1)) ^ ((px >> 1) & 7)) * 16) + (lc & 1) * 8);
+            if (r < kPRows) asm volatile("ds_write_b64 %0, %1" ::"v"(qd), "v"(o) : "memory");
+        }
+    };
+
+    f32x16 acc[TC][TP];
+#pragma unroll
+    for (int a = 0; a < TC; a++)
+#pragma unroll
+        for (int b = 0; b < TP; b++)
+#pragma unroll
+            for (int k = 0; k < 16; k++) acc[a][b][k] = 0.f;
+    i32x8 af[TC], bfr[TP + 2];
+    auto ld256 = [](const char* p0, const char* p1) {
+        typedef __attribute__((ext_vector_type(4))) int i32x4;
+        const i32x4 lo = *(const i32x4*)p0, hi = *(const i32x4*)p1;
+        return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+    };
+    auto read_a = [&](int v) {
+        const char* sb = lds + (v & 3) * kPAHalf;
+#pragma unroll
+        for (int a = 0; a < TC; a++) af[a] = ld256(sb + (arow0 + a * 32) * 64 + hroff[0], sb + (arow0 + a * 32) * 64 + hroff[1]);
+    };
+    auto read_b6 = [&](int slab, int kw) {      // patch lines wp*4 .. wp*4+5 at column offset kw
+        const char* pb = lds + kQOffPatch + (slab & 1) * kQBuf;
+#pragma unroll
+        for (int rr = 0; rr < TP + 2; rr++)
+            bfr[rr] = ld256(pb + ((wp * TP + rr) * 17) * 128 + boff[kw][0], pb + ((wp * TP + rr) * 17) * 128 + boff[kw][1]);
+    };
+    auto mma8 = [&](int kh) {
+#pragma unroll
+        for (int a = 0; a < TC; a++)
+#pragma unroll
+            for (int b = 0; b < TP; b++)
+                acc[a][b] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(af[a], bfr[b + kh], acc[a][b], 0, 0, 0, 0, 0, 0);
+    };
+    // odd phases wait: the 4 youngest weight pieces plus the patch pieces issued in this and the previous step
+    // (np = 0, 2 or 4) may stay in flight across the barrier
+    auto phase_end = [&](bool odd, int t, int np) {
+        if (odd) {
+            if (t <= 2 * V - 7) {
+                if (np == 4) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+                else if (np == 2) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            } else {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+    };
+
+    // ---- prologue: patch of slab 0 (DMA + conversion), weights of steps 0..2 -----------------------------
+#pragma unroll
+    for (int i = 0; i < 6; i++) piece_p(0, i);
+    piece_a(0, 0); piece_a(0, 1); piece_a(1, 0); piece_a(1, 1); piece_a(2, 0); piece_a(2, 1);
+    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");          // this wave's patch pieces have landed
+    cvt_pieces(0, 0, 6);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");          // step 0 is complete
+    phase_end(false, -1, 0);
+
+    // Global phase t = 2 v + p (p = 0: fragment reads of group 0 / MFMAs of group 1, p = 1: the reverse) issues
+    // weight piece p of step v + 3 and, in steps 0..2 of a slab, patch piece 2*UU + p of the next slab.
+#define NPATCH(UU) (more ? (((UU) <= 2 ? 2 : 0) + ((UU) >= 1 && (UU) <= 3 ? 2 : 0)) : 0)
+#define QPATCH_G0(UU, KW_, KH_)                                                                              \
+    {                                                                                                        \
+        const int v = slab * 9 + (UU);                                                                       \
+        piece_a(v + 3, 0);                                                                                   \
+        if (more && (UU) <= 2) piece_p(slab + 1, 2 * (UU));                                                  \
+        if (more && (UU) >= 5 && (UU) <= 7) cvt_pieces(slab + 1, 2 * ((UU) - 5), 2);                         \
+        read_a(v);                                                                                           \
+        if ((KH_) == 0) read_b6(slab, KW_);                                                                  \
+        phase_end(false, 2 * v, 0);                                                                          \
+        piece_a(v + 3, 1);                                                                                   \
+        if (more && (UU) <= 2) piece_p(slab + 1, 2 * (UU) + 1);                                              \
+        mma8(KH_);                                                                                           \
+        phase_end(true, 2 * v + 1, NPATCH(UU));                                                              \
+    }
+    // group 1 runs one phase behind: reads in p = 1 of step v, MFMAs in p = 0 of step v + 1
+#define QPATCH_G1(UU, KW_, KH_)                                                                              \
+    {                                                                                                        \
+        const int v = slab * 9 + (UU);                                                                       \
+        piece_a(v + 3, 1);                                                                                   \
+        if (more && (UU) <= 2) piece_p(slab + 1, 2 * (UU) + 1);                                              \
+        if (more && (UU) >= 5 && (UU) <= 7) cvt_pieces(slab + 1, 2 * ((UU) - 5), 2);                         \
+        read_a(v);                                                                                           \
+        if ((KH_) == 0) read_b6(slab, KW_);                                                                  \
+        phase_end(true, 2 * v + 1, NPATCH(UU));                                                              \
+        piece_a(v + 4, 0);                                                                                   \
+        if ((UU) < 8) {                                                                                      \
+            if (more && (UU) + 1 <= 2) piece_p(slab + 1, 2 * ((UU) + 1));                                    \
+        } else if (slab + 2 < nslab) {                                                                       \
+            piece_p(slab + 2, 0);                                                                            \
+        }                                                                                                    \
+        mma8(KH_);                                                                                           \
+        if (v + 1 < V) phase_end(false, 2 * v + 2, 0);                                                       \
+    }
+#define QPATCH_SLAB(M)                                                                                       \
+    M(0, 0, 0) M(1, 0, 1) M(2, 0, 2) M(3, 1, 0) M(4, 1, 1) M(5, 1, 2) M(6, 2, 0) M(7, 2, 1) M(8, 2, 2)
+    if (grp == 0) {
+        for (int slab = 0; slab < nslab; slab++) {
+            const bool more = slab + 1 < nslab;
+            QPATCH_SLAB(QPATCH_G0)
+        }
+    } else {
+        // phase 0 of the whole loop: this group idles one phase (issues its share of the loads only)
+        piece_a(3, 0);
+        if (nslab > 1) piece_p(1, 0);
+        phase_end(false, 0, 0);
+        for (int slab = 0; slab < nslab; slab++) {
+            const bool more = slab + 1 < nslab;
+            QPATCH_SLAB(QPATCH_G1)
+        }
+    }
+#undef QPATCH_SLAB
+#undef QPATCH_G0
+#undef QPATCH_G1
+#undef NPATCH
+
+    // ------------------------------------------------------------ epilogue (scale, bias, ReLU, GN sums, bf16)
+    const bool relu = P.flags & DAFNE_CONV_RELU;
+    const bool gn = P.flags & DAFNE_CONV_GN_STATS;
+    constexpr int ROWB = BN * 2 + 16;
+    constexpr int CHB = BN / 8;
+    char* stg = lds;
+    float gsum[TC][4], gsq[TC][4];
+#pragma unroll
+    for (int a = 0; a < TC; a++)
+#pragma unroll
+        for (int g = 0; g < 4; g++) gsum[a][g] = gsq[a][g] = 0.f;
+    __syncthreads();   // every wave is done with the weight stages and the patch
+#pragma unroll
+    for (int a = 0; a < TC; a++)
+#pragma unroll
+        for (int g = 0; g < 4; g++) {
+            const int co = nt * BN + (wc * TC + a) * 32 + 8 * g + 4 * half;
+            const float4 bia = P.bias ? *(const float4*)(P.bias + co) : make_float4(0.f, 0.f, 0.f, 0.f);
+            const float4 osc = *(const float4*)(P.oscale + co);
+#pragma unroll
+            for (int b = 0; b < TP; b++) {
+                const int px = (wp * TP + b) * 32 + frow;
+                const bool valid = (Y0 + wp * TP + b) < H && (X0 + frow) < W;
+                float v0 = acc[a][b][4 * g] * osc.x + bia.x, v1 = acc[a][b][4 * g + 1] * osc.y + bia.y;
+                float v2 = acc[a][b][4 * g + 2] * osc.z + bia.z, v3 = acc[a][b][4 * g + 3] * osc.w + bia.w;
+                if (relu) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f); }
+                if (gn && valid) {
+                    gsum[a][g] += (v0 + v1) + (v2 + v3);
+                    gsq[a][g] += (v0 * v0 + v1 * v1) + (v2 * v2 + v3 * v3);
+                }
+                uint2 pk;
+                pk.x = pack_bf16(v0, v1);
+                pk.y = pack_bf16(v2, v3);
+                *(uint2*)(stg + px * ROWB + ((wc * TC + a) * 32 + 8 * g + 4 * half) * 2) = pk;
+            }
+        }
+    float* redb = (float*)(lds + BM * ROWB);   // [NW][TC*4][2]
+    if (gn) {
+#pragma unroll
+        for (int a = 0; a < TC; a++)
+#pragma unroll
+            for (int g = 0; g < 4; g++) {
+                float sv = gsum[a][g], qv = gsq[a][g];
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) {
+                    sv += __shfl_xor(sv, o, 64);
+                    qv += __shfl_xor(qv, o, 64);
+                }
+                if (lane == 0) {
+                    redb[(wave * TC * 4 + a * 4 + g) * 2 + 0] = sv;
+                    redb[(wave * TC * 4 + a * 4 + g) * 2 + 1] = qv;
+                }
+            }
+    }
+    __syncthreads();
+    if (gn && tid < BN / 8) {
+        const int wcc = tid / (TC * 4), ag = tid % (TC * 4);
+        float sv = 0.f, qv = 0.f;
+#pragma unroll
+        for (int p2 = 0; p2 < WP; p2++) {
+            sv += redb[((wcc * WP + p2) * TC * 4 + ag) * 2 + 0];
+            qv += redb[((wcc * WP + p2) * TC * 4 + ag) * 2 + 1];
+        }
+        const int group = (nt * BN) / 8 + tid;
+        if (group < P.Cout / 8) {
+            float* o = P.gn_partial + ((size_t)mt * (P.Cout / 8) + group) * 2;
+            o[0] = sv;
+            o[1] = qv;
+        }
+    }
+    constexpr int CPT = BM * CHB / NT;       // 16-byte chunks per thread
+#pragma unroll
+    for (int i = 0; i < CPT; i++) {
+        const int idx = tid + i * NT;
+        const int p = idx / CHB, cc = idx - p * CHB;
+        const int gy = Y0 + (p >> 5), gx = X0 + (p & 31);
+        if (gy < H && gx < W) {
+            const size_t opix = (size_t)(img * Hp + gy + 1) * Wp + gx + 1;
+            const uint4 v = *(const uint4*)(stg + p * ROWB + cc * 16);
+            *(uint4*)(S.out + (opix * P.Cout + nt * BN + cc * 8) * 2) = v;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------
 // 3x3 stride-1 convolution with <= 32 output channels and fp32 NHWC output: the prediction convolutions of
 // the head (cls_logits 15, center_pred 2, corners_pred+ctrness 9; dafne.py:318-344).  1/8 of a tower layer's
 // MFMA work on the same input bytes: these layers are bound by operand staging and barriers, not by the matrix
@@ -1915,18 +2300,24 @@ Cfg pick_cfg(int Cout, long long blocks256 = 0, unsigned flags = 0) {
 
 // 3x3 / stride 1 / pad 1 layers with Cout % 256 == 0 and a plain bf16 output go to the patch kernel when
 // the launch has enough 8x32 tiles to fill the chip (the head towers, the FPN output convolutions).
-bool patch_eligible(const dafne_conv_params* p, const dafne_conv_seg* segs) {
-    static const int mode = getenv("DAFNE_CONV_PATCH") ? atoi(getenv("DAFNE_CONV_PATCH")) : 1;
-    if (!mode) return false;
+// shape conditions of the patch kernels (bf16 and fp8), without the occupancy heuristic
+bool patch_shape_ok(const dafne_conv_params* p, const dafne_conv_seg* segs) {
     if (p->KH != 3 || p->KW != 3 || p->stride != 1 || p->pad != 1) return false;
     if (p->Cin % kBK || p->Cout % 256 || !p->d_bias) return false;
     if (p->flags & (DAFNE_CONV_RESIDUAL | DAFNE_CONV_UPSAMPLE_ADD | DAFNE_CONV_OUT_F32)) return false;
     if ((p->flags & DAFNE_CONV_GN_INPUT) && p->Cin > kPTabMaxC) return false;
-    long long tiles = 0;
-    for (int s = 0; s < p->n_segs; s++) {
+    for (int s = 0; s < p->n_segs; s++)
         if (segs[s].Hin != segs[s].Hout || segs[s].Win != segs[s].Wout) return false;
+    return true;
+}
+
+bool patch_eligible(const dafne_conv_params* p, const dafne_conv_seg* segs) {
+    static const int mode = getenv("DAFNE_CONV_PATCH") ? atoi(getenv("DAFNE_CONV_PATCH")) : 1;
+    if (!mode) return false;
+    if (!patch_shape_ok(p, segs)) return false;
+    long long tiles = 0;
+    for (int s = 0; s < p->n_segs; s++)
         tiles += (long long)((segs[s].Hout + kPH - 1) / kPH) * ((segs[s].Wout + kPW - 1) / kPW) * p->n_images;
-    }
     static const long long min_tiles = getenv("DAFNE_CONV_PATCH_MIN_TILES") ? atoll(getenv("DAFNE_CONV_PATCH_MIN_TILES")) : 200;
     return (p->flags & DAFNE_CONV_GN_INPUT) || tiles * (p->Cout / 256) >= min_tiles;
 }
@@ -1944,8 +2335,10 @@ bool slab_eligible(const dafne_conv_params* p, const dafne_conv_seg* segs) {
     return true;
 }
 
-int build(ConvDev& D, const dafne_conv_params* p, const dafne_conv_seg* segs) {
+int build(ConvDev& D, const dafne_conv_params* p, const dafne_conv_seg* segs, bool fp8 = false) {
     if (!p || !segs) return dafne::fail(DAFNE_E_INVALID, "conv: null params");
+    D.oscale = nullptr;
+    D.in_qscale = 1.f;
     if (p->n_segs < 1 || p->n_segs > kMaxSegs || p->n_images < 1) return dafne::fail(DAFNE_E_INVALID, "conv: bad segment/image count");
     const bool stem = p->Cin == 4 && p->KH == 7 && p->KW == 7 && p->stride == 2;
     if (!stem) {
@@ -1976,6 +2369,14 @@ int build(ConvDev& D, const dafne_conv_params* p, const dafne_conv_seg* segs) {
     D.kbytes = D.ksteps * kRowBytes;
     D.in_stats = p->d_in_gn_stats; D.in_gamma = p->d_in_gn_gamma; D.in_beta = p->d_in_gn_beta;
     D.patch = patch_eligible(p, segs) ? 1 : 0;
+    if (fp8) {
+        // e4m3 weights: the fp8 patch kernel is the only fp8 kernel (64-byte tap rows)
+        if (stem || !patch_shape_ok(p, segs))
+            return dafne::fail(DAFNE_E_UNSUPPORTED, "conv fp8w: needs 3x3 s1 p1, Cin %% 64 == 0, Cout %% 256 == 0, bias, bf16 output, "
+                                                    "no residual / top-down add (GN_INPUT: Cin <= 512)");
+        D.patch = 1;
+        D.kbytes = D.ksteps * kBK;
+    }
     D.slab = !D.patch && slab_eligible(p, segs) ? 1 : 0;
     if ((p->flags & DAFNE_CONV_GN_INPUT) && !D.patch && !D.slab)
         return dafne::fail(DAFNE_E_UNSUPPORTED, "conv: GN_INPUT needs the 3x3 patch kernel (3x3 s1 p1, Cout %% 256 == 0, Cin <= 512, bias, "
@@ -2066,6 +2467,19 @@ int launch_patch(const ConvDev& D, hipStream_t st) {
     if (D.flags & DAFNE_CONV_GN_INPUT) hipLaunchKernelGGL(conv3x3_patch_kernel<true>, grid, block, kPSmem, st, D);
     else hipLaunchKernelGGL(conv3x3_patch_kernel<false>, grid, block, kPSmem, st, D);
     return dafne::check_launch("conv3x3_patch");
+}
+
+int launch_patch_fp8(const ConvDev& D, hipStream_t st) {
+    static bool attr_done = false;
+    if (!attr_done) {
+        DAFNE_HIP_TRY(hipFuncSetAttribute((const void*)conv3x3_patch_fp8_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, kQSmem));
+        DAFNE_HIP_TRY(hipFuncSetAttribute((const void*)conv3x3_patch_fp8_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, kQSmem));
+        attr_done = true;
+    }
+    const dim3 grid(D.mtiles * D.ntiles), block(512);
+    if (D.flags & DAFNE_CONV_GN_INPUT) hipLaunchKernelGGL(conv3x3_patch_fp8_kernel<true>, grid, block, kQSmem, st, D);
+    else hipLaunchKernelGGL(conv3x3_patch_fp8_kernel<false>, grid, block, kQSmem, st, D);
+    return dafne::check_launch("conv3x3_patch_fp8");
 }
 
 int launch_slab(const ConvDev& D, hipStream_t st) {
@@ -2204,6 +2618,18 @@ int dafne_conv2d_nhwc_bf16_hip(const dafne_conv_params* prm, const dafne_conv_se
     if (D.bn == 128) return launch<2, 2, 2, 2>(D, st);
     if (D.bn == 64) return launch<1, 4, 2, 2>(D, st);
     return launch<1, 4, 1, 2>(D, st);
+}
+
+int dafne_conv2d_nhwc_fp8w_hip(const dafne_conv_params* prm, const dafne_conv_seg* segs, const float* d_oscale,
+                               float in_qscale, void* stream) {
+    ConvDev D;
+    int rc = build(D, prm, segs, true);
+    if (rc) return rc;
+    if (!d_oscale) return dafne::fail(DAFNE_E_INVALID, "conv fp8w: null output scale");
+    if (!(in_qscale > 0.f)) return dafne::fail(DAFNE_E_INVALID, "conv fp8w: in_qscale must be positive");
+    D.oscale = d_oscale;
+    D.in_qscale = in_qscale;
+    return launch_patch_fp8(D, (hipStream_t)stream);
 }
 
 }  // extern "C"

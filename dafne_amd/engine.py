@@ -80,6 +80,34 @@ def pack_conv(weight, bias, device):
     return w.to(BF16).to(device).contiguous(), b.to(device).contiguous()
 
 
+E4M3_MAX = 448.0
+
+
+def quantize_weight_e4m3(weight):
+    """[Cout, ...] fp32 -> (q, scale, deq): OCP e4m3 values (torch.float8_e4m3fn, round to nearest even) of
+    weight / scale with ONE POWER-OF-TWO scale per output channel (the smallest 2^k with amax / 2^k <= 448), and the
+    dequantised weight q * scale.  Power-of-two scales make q * scale exact in fp32 AND in bf16 (an e4m3 value has
+    <= 4 significant bits), so the layers that stay on the bf16 kernels compute with exactly the fp8 model's weights.
+    This is the definition of BASELINE config 5's "fp8 weights" (the reference has no fp8 path)."""
+    w = weight.detach().float().cpu()
+    amax = w.reshape(w.shape[0], -1).abs().amax(dim=1)
+    k = torch.ceil(torch.log2(torch.clamp(amax, min=1e-30) / E4M3_MAX))
+    scale = torch.where(amax > 0, torch.exp2(k), torch.ones_like(amax))
+    scale = torch.where(amax / scale > E4M3_MAX, scale * 2, scale)          # log2 rounding guard
+    q = (w / scale.reshape(-1, *([1] * (w.dim() - 1)))).to(torch.float8_e4m3fn)
+    deq = q.float() * scale.reshape(-1, *([1] * (w.dim() - 1)))
+    return q, scale, deq
+
+
+def pack_conv_fp8(weight, device):
+    """[Cout,Cin,3,3] fp32 -> (e4m3 bytes [Cout, (Cin/64)*9*64] in the kernel's K order (slab, kh, kw, channel),
+    fp32 scale [Cout]) for dafne_conv2d_nhwc_fp8w_hip."""
+    cout, cin, kh, kw = weight.shape
+    q, scale, _ = quantize_weight_e4m3(weight)
+    qb = q.view(torch.uint8).reshape(cout, cin // 64, 64, kh, kw).permute(0, 1, 3, 4, 2).reshape(cout, -1)
+    return qb.contiguous().to(device), scale.to(device).contiguous()
+
+
 def pack_stem(weight, bias, device):
     """[64,3,7,7] -> bf16 [64, 256]: k = (kh 0..7, kw 0..7, c 0..3), zero where kh=7, kw=7 or c=3."""
     cout = weight.shape[0]
@@ -111,11 +139,14 @@ def fold_frozen_bn(weight, bn_w, bn_b, bn_mean, bn_var, eps=1e-5):
 class ConvCall:
     """One dafne_conv2d_nhwc_bf16_hip launch with its argument structs kept alive."""
 
-    def __init__(self, w, b, cin, cout, k, stride, pad, flags, segs, n_images, gn_partial=None, gn_in=None):
+    def __init__(self, w, b, cin, cout, k, stride, pad, flags, segs, n_images, gn_partial=None, gn_in=None, fp8=None):
         """gn_in: (stats [n_segs,N,Cin/8,2], gamma [Cin], beta [Cin]) of the INPUT maps when they hold the raw
-        output of the previous tower convolution (flag F_GNIN: GroupNorm + ReLU applied on load)."""
+        output of the previous tower convolution (flag F_GNIN: GroupNorm + ReLU applied on load).
+        fp8: (oscale fp32 [Cout], in_qscale) -> `w` holds e4m3 bytes (pack_conv_fp8) and the call goes to
+        dafne_conv2d_nhwc_fp8w_hip (fp8 MFMA, activations quantised on load)."""
         L = _lib.load()
-        self.keep = (w, b, gn_partial, [s for s in segs], gn_in)
+        self.fp8 = fp8
+        self.keep = (w, b, gn_partial, [s for s in segs], gn_in, fp8)
         gi = [t.data_ptr() for t in gn_in] if gn_in is not None else [None, None, None]
         self.prm = _lib.ConvParams(n_images, len(segs), cin, cout, k, k, stride, pad, flags,
                                    w.data_ptr(), b.data_ptr() if b is not None else None,
@@ -150,6 +181,8 @@ class ConvCall:
 
     def kernel_name(self):
         """The HIP kernel this call dispatches to (conv.hip), for per-kernel attribution in bench.py."""
+        if self.fp8 is not None:
+            return "conv3x3_patch_fp8"
         return self.KERNEL_NAMES[self.kernel_id()]
 
     def tiles_per_image(self):
@@ -159,6 +192,12 @@ class ConvCall:
         return list(out)
 
     def __call__(self, stream):
+        if self.fp8 is not None:
+            rc = _lib.load().dafne_conv2d_nhwc_fp8w_hip(ctypes.byref(self.prm), self.segs, _lib.ptr(self.fp8[0]),
+                                                        ctypes.c_float(self.fp8[1]), stream)
+            if rc:
+                _lib.check(rc, "dafne_conv2d_nhwc_fp8w_hip")
+            return
         rc = self.fn(ctypes.byref(self.prm), self.segs, stream)
         if rc:
             _lib.check(rc, "dafne_conv2d_nhwc_bf16_hip")
@@ -386,7 +425,14 @@ class HeadPlan:
                 probe = ConvCall(wgt, bias, C, C, 3, 1, 1, flags & ~F_GN, seg_list(cur, outs), n, gn_in=cur_gn)
                 nt = probe.num_tiles()
                 partial = torch.empty(nt, C // 8, 2, dtype=torch.float32, device=device)
-                c = ConvCall(wgt, bias, C, C, 3, 1, 1, flags, seg_list(cur, outs), n, gn_partial=partial, gn_in=cur_gn)
+                q8 = P.get("%s.%d.fp8" % (name, 3 * i)) if cur_gn is not None else None
+                if q8 is not None and probe.kernel_id() == 6:
+                    # fp8 model: e4m3 weights on the fp8 MFMA kernel, the GroupNorm + ReLU output quantised on load
+                    # (in_qscale 1: a normalised, rectified map sits well inside e4m3's range)
+                    c = ConvCall(q8[0], bias, C, C, 3, 1, 1, flags, seg_list(cur, outs), n, gn_partial=partial,
+                                 gn_in=cur_gn, fp8=(q8[1], 1.0))
+                else:
+                    c = ConvCall(wgt, bias, C, C, 3, 1, 1, flags, seg_list(cur, outs), n, gn_partial=partial, gn_in=cur_gn)
                 calls.append(c)
                 plan.flops += c.flops
                 stats = torch.empty(len(outs), n, C // 8, 2, dtype=torch.float32, device=device)
@@ -448,16 +494,23 @@ class HeadPlan:
 
 
 # ---------------------------------------------------------- weights from a state dict
-def pack_backbone_weights(sd, depth, device, prefix="backbone."):
+def _wq(w, fp8):
+    """fp8 model (ENGINE.WEIGHT_DTYPE fp8_e4m3): the weight every kernel sees is the dequantised e4m3 weight."""
+    return quantize_weight_e4m3(w)[2] if fp8 else w
+
+
+def pack_backbone_weights(sd, depth, device, prefix="backbone.", fp8=False):
     """state dict with the reference checkpoint's names -> packed
-    backbone weights; FrozenBN folded into weight scale + bias."""
+    backbone weights; FrozenBN folded into weight scale + bias.  fp8: the folded weights are quantised to e4m3 with
+    power-of-two per-channel scales (quantize_weight_e4m3) and run, exactly dequantised, on the bf16 kernels."""
     P = {}
     bu = prefix + "bottom_up."
 
     def cb(k):
-        return fold_frozen_bn(sd[k + ".weight"].float(), sd[k + ".norm.weight"].float(),
+        w, b = fold_frozen_bn(sd[k + ".weight"].float(), sd[k + ".norm.weight"].float(),
                               sd[k + ".norm.bias"].float(), sd[k + ".norm.running_mean"].float(),
                               sd[k + ".norm.running_var"].float())
+        return _wq(w, fp8), b
 
     w, b = cb(bu + "stem.conv1")
     P["stem"] = pack_stem(w, b, device)
@@ -469,35 +522,43 @@ def pack_backbone_weights(sd, depth, device, prefix="backbone."):
     for lvl in (3, 4, 5):
         for kind in ("lateral", "output"):
             k = "%sfpn_%s%d" % (prefix, kind, lvl)
-            P["fpn_%s%d" % (kind, lvl)] = pack_conv(sd[k + ".weight"], sd[k + ".bias"], device)
+            P["fpn_%s%d" % (kind, lvl)] = pack_conv(_wq(sd[k + ".weight"], fp8), sd[k + ".bias"], device)
     for nme in ("p6", "p7"):
         k = prefix + "top_block." + nme
-        P[nme] = pack_conv(sd[k + ".weight"], sd[k + ".bias"], device)
+        P[nme] = pack_conv(_wq(sd[k + ".weight"], fp8), sd[k + ".bias"], device)
     return P
 
 
-def pack_head_weights(sd, device, prefix="proposal_generator.dafne_head."):
+def pack_head_weights(sd, device, prefix="proposal_generator.dafne_head.", fp8=False):
     """DAFNeHead parameters -> packed weights.  corners_pred and ctrness both read
-    the corners tower (dafne.py:403,467-468) and are fused into one 9-channel conv."""
+    the corners tower (dafne.py:403,467-468) and are fused into one 9-channel conv.
+    fp8: every weight is the dequantised e4m3 weight; the tower layers additionally get key + ".fp8" =
+    (e4m3 bytes, scale) for the fp8 MFMA kernel (HeadPlan uses it where the input is normalised on load)."""
     P = {}
     hp = prefix
     for tower in ("cls_tower", "center_tower", "corners_tower"):
         for i in range(4):
             k = "%s%s.%d" % (hp, tower, 3 * i)
-            P["%s.%d" % (tower, 3 * i)] = pack_conv(sd[k + ".weight"], sd[k + ".bias"], device)
+            P["%s.%d" % (tower, 3 * i)] = pack_conv(_wq(sd[k + ".weight"], fp8), sd[k + ".bias"], device)
+            if fp8:
+                P["%s.%d.fp8" % (tower, 3 * i)] = pack_conv_fp8(sd[k + ".weight"], device)
             g = "%s%s.%d" % (hp, tower, 3 * i + 1)
             P["%s.%d.gn" % (tower, 3 * i + 1)] = (sd[g + ".weight"].float().to(device).contiguous(),
                                                   sd[g + ".bias"].float().to(device).contiguous())
-    P["cls_logits"] = pack_conv(sd[hp + "cls_logits.weight"], sd[hp + "cls_logits.bias"], device)
-    P["center_pred"] = pack_conv(sd[hp + "center_pred.weight"], sd[hp + "center_pred.bias"], device)
+    P["cls_logits"] = pack_conv(_wq(sd[hp + "cls_logits.weight"], fp8), sd[hp + "cls_logits.bias"], device)
+    P["center_pred"] = pack_conv(_wq(sd[hp + "center_pred.weight"], fp8), sd[hp + "center_pred.bias"], device)
     wcc = torch.cat([sd[hp + "corners_pred.weight"].float(), sd[hp + "ctrness.weight"].float()], 0)
     bcc = torch.cat([sd[hp + "corners_pred.bias"].float(), sd[hp + "ctrness.bias"].float()], 0)
-    P["corners_ctrness"] = pack_conv(wcc, bcc, device)
+    P["corners_ctrness"] = pack_conv(_wq(wcc, fp8), bcc, device)
     P["scales"] = [float(sd["%sscales.%d.scale" % (hp, l)].reshape(-1)[0]) for l in range(5)]
     return P
 
 
-def pack_model_weights(sd, depth, device):
-    P = pack_backbone_weights(sd, depth, device)
-    P.update(pack_head_weights(sd, device))
+def pack_model_weights(sd, depth, device, weight_dtype="bf16"):
+    """weight_dtype: "bf16" or "fp8_e4m3" (cfg.ENGINE.WEIGHT_DTYPE; BASELINE config 5)."""
+    if weight_dtype not in ("bf16", "fp8_e4m3"):
+        raise NotImplementedError("ENGINE.WEIGHT_DTYPE %r (bf16 or fp8_e4m3)" % (weight_dtype,))
+    fp8 = weight_dtype == "fp8_e4m3"
+    P = pack_backbone_weights(sd, depth, device, fp8=fp8)
+    P.update(pack_head_weights(sd, device, fp8=fp8))
     return P

@@ -16,7 +16,7 @@ from ..params import ConvParams, ResNetParams, TopBlockParams
 
 
 class ResNetFPNBackbone(nn.Module):
-    def __init__(self, depth, out_channels=256):
+    def __init__(self, depth, out_channels=256, weight_dtype="bf16"):
         super().__init__()
         self.depth = depth
         self.bottom_up = ResNetParams(depth)
@@ -25,6 +25,7 @@ class ResNetFPNBackbone(nn.Module):
             setattr(self, "fpn_output%d" % lvl, ConvParams(out_channels, out_channels, 3))
         self.top_block = TopBlockParams(out_channels)
         self._out_channels = out_channels
+        self.weight_dtype = weight_dtype          # cfg.ENGINE.WEIGHT_DTYPE: bf16 | fp8_e4m3
         self._packed = None
         self._plans = {}
 
@@ -37,7 +38,8 @@ class ResNetFPNBackbone(nn.Module):
 
     def _weights(self, device):
         if self._packed is None:
-            self._packed = engine.pack_backbone_weights(self.state_dict(), self.depth, device, prefix="")
+            self._packed = engine.pack_backbone_weights(self.state_dict(), self.depth, device, prefix="",
+                                                               fp8=self.weight_dtype == "fp8_e4m3")
         return self._packed
 
     def invalidate(self):
@@ -77,4 +79,6 @@ def build_dafne_resnet_fpn_backbone(cfg, input_shape=None):
         raise NotImplementedError("engine supports FPN without norm, fuse type 'sum'")
     if cfg.MODEL.DAFNE.TOP_LEVELS != 2:
         raise NotImplementedError("engine supports TOP_LEVELS == 2 (P6 and P7)")
-    return ResNetFPNBackbone(r.DEPTH, cfg.MODEL.FPN.OUT_CHANNELS)
+    if cfg.ENGINE.WEIGHT_DTYPE not in ("bf16", "fp8_e4m3"):
+        raise NotImplementedError("ENGINE.WEIGHT_DTYPE %r (bf16 or fp8_e4m3)" % (cfg.ENGINE.WEIGHT_DTYPE,))
+    return ResNetFPNBackbone(r.DEPTH, cfg.MODEL.FPN.OUT_CHANNELS, weight_dtype=cfg.ENGINE.WEIGHT_DTYPE)

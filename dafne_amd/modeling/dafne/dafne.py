@@ -38,6 +38,7 @@ class DAFNeHead(nn.Module):
         assert len(chans) == 1, "Each level must have the same channel!"
         c = chans.pop()
         self.num_classes = d.NUM_CLASSES
+        self.weight_dtype = cfg.ENGINE.WEIGHT_DTYPE       # bf16 | fp8_e4m3
         self.fpn_strides = d.FPN_STRIDES
         self.num_levels = len(input_shape)
         self.in_channels_to_top_module = c
@@ -68,7 +69,8 @@ class DAFNeHead(nn.Module):
 
     def _weights(self, device):
         if self._packed is None:
-            self._packed = engine.pack_head_weights(self.state_dict(), device, prefix="")
+            self._packed = engine.pack_head_weights(self.state_dict(), device, prefix="",
+                                                           fp8=self.weight_dtype == "fp8_e4m3")
         return self._packed
 
     def run_raw(self, feats):

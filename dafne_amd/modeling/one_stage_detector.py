@@ -77,7 +77,8 @@ class OneStageDetector(nn.Module):
 
     def _weights(self):
         if self._packed is None:
-            self._packed = engine.pack_model_weights(self.state_dict(), self.depth, self.device)
+            self._packed = engine.pack_model_weights(self.state_dict(), self.depth, self.device,
+                                                     weight_dtype=self.cfg.ENGINE.WEIGHT_DTYPE)
         return self._packed
 
     def _dev_const(self, values, dtype, shape):

@@ -212,6 +212,23 @@ typedef struct dafne_conv_params {
  * the padding taps; weight rows are 256 bf16).
  */
 int dafne_conv2d_nhwc_bf16_hip(const dafne_conv_params* prm, const dafne_conv_seg* segs, void* stream);
+/*
+ * fp8-weight twin (BASELINE config 5: "fp8 weights, CDNA4 fp8 MFMA conv path"; SURVEY 8(b) item 5
+ * dafne_conv2d_nhwc_{bf16,fp8w}_hip).  The reference has no fp8 path: this entry DEFINES it.
+ *   d_weight   OCP e4m3 bytes [Cout][Cin/64][KH][KW][64] (same K order as the bf16 layout, 1 byte per element)
+ *   d_oscale   fp32 [Cout]: weight dequantisation scale of the output channel divided by in_qscale
+ *   in_qscale  > 0: activations (bf16 in HBM, after the optional GN_INPUT GroupNorm + ReLU, in fp32) are multiplied
+ *              by it, clamped to +-448 and rounded to e4m3 (round to nearest even) while they are loaded
+ * out = epilogue(oscale[c] * sum_k e4m3(w)[c][k] * e4m3(x)[k] + bias[c]) with fp32 accumulation on
+ * v_mfma_f32_32x32x64_f8f6f4; flags / GroupNorm statistics / output layout as dafne_conv2d_nhwc_bf16_hip.
+ * Shapes: 3x3, stride 1, pad 1, Cin % 64 == 0, Cout % 256 == 0, bias, bf16 output, no residual / top-down add
+ * (the head towers and FPN output convolutions: the layers the bf16 patch kernel takes); anything else returns
+ * DAFNE_E_UNSUPPORTED -- the other layers of a config-5 model run dafne_conv2d_nhwc_bf16_hip on weights that the
+ * host dequantised exactly (power-of-two scales).  Tile geometry (d_gn_partial rows) = the bf16 call's when that
+ * call's kernel id is 6.
+ */
+int dafne_conv2d_nhwc_fp8w_hip(const dafne_conv_params* prm, const dafne_conv_seg* segs, const float* d_oscale,
+                               float in_qscale, void* stream);
 int dafne_conv2d_cout_pad(int Cout);
 /* output pixels per M tile the call would use (geometry of d_gn_partial rows), -1 on error */
 int dafne_conv2d_tile_pixels(const dafne_conv_params* prm, const dafne_conv_seg* segs);
