@@ -125,6 +125,31 @@ def _bf(x, on):
     return x.to(torch.bfloat16).to(torch.float32) if on else x
 
 
+E4M3_MAX = 448.0
+
+
+def quantize_weight_e4m3(w):
+    """BASELINE config 5 ("fp8 weights"): the reference has no fp8 path, so this restatement DEFINES it.
+    One power-of-two scale per output channel (smallest 2^k with amax / 2^k <= 448), values rounded to OCP e4m3
+    (round to nearest even).  Returns the dequantised weight (exact in fp32 and in bf16)."""
+    amax = w.reshape(w.shape[0], -1).abs().amax(dim=1)
+    scale = torch.ones_like(amax)
+    nz = amax > 0
+    scale[nz] = torch.exp2(torch.ceil(torch.log2(amax[nz] / E4M3_MAX)))
+    scale = torch.where(amax / scale > E4M3_MAX, scale * 2, scale)
+    sh = (-1,) + (1,) * (w.dim() - 1)
+    return (w / scale.reshape(sh)).to(torch.float8_e4m3fn).to(torch.float32) * scale.reshape(sh)
+
+
+def quantize_act_e4m3(x):
+    """Activation rounding of the fp8 MFMA layers: fp32 value clamped to +-448, rounded to e4m3 (in_qscale 1)."""
+    return x.clamp(-E4M3_MAX, E4M3_MAX).to(torch.float8_e4m3fn).to(torch.float32)
+
+
+def _wt(w, E, fp8):
+    return _bf(quantize_weight_e4m3(w) if fp8 else w, E)
+
+
 def fold_bn(P, prefix, eps=1e-5):
     """FrozenBatchNorm2d folded into the conv: y = conv(x, w*s) + (b - mean*s)."""
     s = P[prefix + ".norm.weight"] * torch.rsqrt(P[prefix + ".norm.running_var"] + eps)
@@ -132,15 +157,16 @@ def fold_bn(P, prefix, eps=1e-5):
     return P[prefix + ".weight"] * s[:, None, None, None], b
 
 
-def backbone_forward(P, x, depth=50, emulate_bf16=False, taps=None):
+def backbone_forward(P, x, depth=50, emulate_bf16=False, taps=None, fp8=False):
     """x: [N,3,H,W] fp32, already normalised (and padded to /32).
-    Returns {"p3".."p7"}.  ``taps`` (dict) collects intermediate tensors."""
+    Returns {"p3".."p7"}.  ``taps`` (dict) collects intermediate tensors.
+    fp8: every (BN-folded) weight is the dequantised e4m3 weight (quantize_weight_e4m3)."""
     E = emulate_bf16
     bu = "backbone.bottom_up."
 
     def cbr(x, prefix, stride, pad, relu=True, res=None):
         w, b = fold_bn(P, prefix)
-        y = F.conv2d(x, _bf(w, E), b, stride=stride, padding=pad)
+        y = F.conv2d(x, _wt(w, E, fp8), b, stride=stride, padding=pad)
         if res is not None:
             y = y + res
         if relu:
@@ -167,30 +193,37 @@ def backbone_forward(P, x, depth=50, emulate_bf16=False, taps=None):
     out = {}
     prev = None
     for lvl in (5, 4, 3):
-        lat = F.conv2d(feats["res%d" % lvl], _bf(P["backbone.fpn_lateral%d.weight" % lvl], E),
+        lat = F.conv2d(feats["res%d" % lvl], _wt(P["backbone.fpn_lateral%d.weight" % lvl], E, fp8),
                        P["backbone.fpn_lateral%d.bias" % lvl])
         if prev is not None:
             lat = lat + F.interpolate(prev, scale_factor=2, mode="nearest")
         prev = _bf(lat, E)
-        out["p%d" % lvl] = _bf(F.conv2d(prev, _bf(P["backbone.fpn_output%d.weight" % lvl], E),
+        out["p%d" % lvl] = _bf(F.conv2d(prev, _wt(P["backbone.fpn_output%d.weight" % lvl], E, fp8),
                                         P["backbone.fpn_output%d.bias" % lvl], padding=1), E)
-    p6 = _bf(F.conv2d(out["p5"], _bf(P["backbone.top_block.p6.weight"], E),
+    p6 = _bf(F.conv2d(out["p5"], _wt(P["backbone.top_block.p6.weight"], E, fp8),
                       P["backbone.top_block.p6.bias"], stride=2, padding=1), E)
-    p7 = _bf(F.conv2d(F.relu(p6), _bf(P["backbone.top_block.p7.weight"], E),
+    p7 = _bf(F.conv2d(F.relu(p6), _wt(P["backbone.top_block.p7.weight"], E, fp8),
                       P["backbone.top_block.p7.bias"], stride=2, padding=1), E)
     out["p6"], out["p7"] = p6, p7
     return {k: out[k] for k in ("p3", "p4", "p5", "p6", "p7")}
 
 
-def head_forward(P, feats, prefix="proposal_generator.dafne_head.", emulate_bf16=False):
+def head_forward(P, feats, prefix="proposal_generator.dafne_head.", emulate_bf16=False, fp8=False):
     """DAFNeHead.forward, center-to-corner branch with CORNER_TOWER_ON_CENTER_TOWER,
     CTR_ON_REG, USE_SCALE (dafne.py:350-370,388-414,459-494).  feats: list of 5
-    [N,256,H,W].  Returns per-level lists (logits, reg, center, ctrness)."""
+    [N,256,H,W].  Returns per-level lists (logits, reg, center, ctrness).
+    fp8 (needs emulate_bf16): config 5 -- every weight is the dequantised e4m3 weight, and the tower layers whose
+    input is a GroupNorm + ReLU output (layers 1..3 of each tower, layer 0 of the corners tower) see that input rounded
+    to e4m3 from its fp32 value (the engine's fp8 MFMA layers quantise on load); all other activations are bf16."""
     E = emulate_bf16
+    assert E or not fp8
 
-    def tower(x, name):
+    def tower(x, name, first_q8=False):
+        """x: fp32 activation (rounded at the consumer); returns the last layer's fp32 GroupNorm + ReLU output."""
         for i in range(4):
-            y = F.conv2d(x, _bf(P["%s%s.%d.weight" % (prefix, name, 3 * i)], E),
+            q8 = fp8 and (i > 0 or first_q8)
+            xin = quantize_act_e4m3(x) if q8 else _bf(x, E)
+            y = F.conv2d(xin, _wt(P["%s%s.%d.weight" % (prefix, name, 3 * i)], E, fp8),
                          P["%s%s.%d.bias" % (prefix, name, 3 * i)], padding=1)
             if E:
                 # engine: statistics from the fp32 accumulator, value stored as bf16
@@ -203,7 +236,7 @@ def head_forward(P, feats, prefix="proposal_generator.dafne_head.", emulate_bf16
                 yn = ((y16 - mean) * rstd).reshape(n, c, h, w)
                 yn = yn * P["%s%s.%d.weight" % (prefix, name, 3 * i + 1)][None, :, None, None] \
                     + P["%s%s.%d.bias" % (prefix, name, 3 * i + 1)][None, :, None, None]
-                x = _bf(F.relu(yn), True)
+                x = F.relu(yn)
             else:
                 y = F.group_norm(y, y.shape[1] // 8, P["%s%s.%d.weight" % (prefix, name, 3 * i + 1)],
                                  P["%s%s.%d.bias" % (prefix, name, 3 * i + 1)], eps=1e-5)
@@ -211,14 +244,14 @@ def head_forward(P, feats, prefix="proposal_generator.dafne_head.", emulate_bf16
         return x
 
     def pred(x, name):
-        return F.conv2d(x, _bf(P[prefix + name + ".weight"], E), P[prefix + name + ".bias"], padding=1)
+        return F.conv2d(_bf(x, E), _wt(P[prefix + name + ".weight"], E, fp8), P[prefix + name + ".bias"], padding=1)
 
     logits, regs, centers, ctrs = [], [], [], []
     for l, f in enumerate(feats):
         f = _bf(f, E)
         cls_t = tower(f, "cls_tower")
         ctr_t = tower(f, "center_tower")
-        cor_t = tower(ctr_t, "corners_tower")
+        cor_t = tower(ctr_t, "corners_tower", first_q8=True)
         center = pred(ctr_t, "center_pred")
         delta = pred(cor_t, "corners_pred")
         reg = center.repeat(1, 4, 1, 1) + delta

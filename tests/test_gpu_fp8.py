@@ -154,3 +154,81 @@ def test_fp8w_rejects_unsupported_shapes():
     c = engine.ConvCall(w, b, 64, 128, 3, 1, 1, 0, [(x.t, o.t, None, 16, 16, 16, 16)], 1, fp8=(sc, 1.0))
     with pytest.raises(_lib.DafneHipError, match="fp8w"):
         c(_lib.current_stream())
+
+
+# ---------------------------------------------------------------------------------- config 5 model (fp8 weights)
+def _build(cfgname, seed):
+    import os
+    import dafne_amd.modeling  # noqa: F401
+    from dafne_amd.config import load_cfg
+    from dafne_amd.registry import build_model
+    from oracle import model as om
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cfg = load_cfg(os.path.join(root, "configs", cfgname))
+    m = build_model(cfg)
+    P = om.make_params(cfg.MODEL.RESNETS.DEPTH, cfg.MODEL.DAFNE.NUM_CLASSES, seed=seed)
+    m.load_state_dict(P)
+    m.to(dev())
+    m.invalidate()
+    return cfg, m, P
+
+
+def _rel(a, b):
+    return float((a - b).norm() / b.norm().clamp_min(1e-12))
+
+
+def test_fp8_model_backbone_and_head_vs_oracle():
+    """ucas_aod_r101_fp8.yaml (ENGINE.WEIGHT_DTYPE fp8_e4m3) vs oracle/model.py with fp8=True: the backbone runs the
+    bf16 kernels on exactly dequantised e4m3 weights (same tolerance as the bf16 model, tests/test_gpu_model.py), the
+    head's GroupNorm-fed tower layers run the fp8 MFMA kernel.
+
+    Head tolerance: an e4m3 rounding step is 2^-3 relative, so a pipeline of up to 7 quantise-on-load layers amplifies
+    any fp32 summation-order difference far more than the bf16 pipeline does (a perturbation eps flips a rounding with
+    probability eps / ulp and then costs a whole ulp).  The bound is therefore MEASURED on the oracle itself: the
+    oracle's outputs for the same features with 5 % of the elements moved by one bf16 ulp ("twin").  The engine must be
+    no further from the oracle than that twin (or 2.5e-2, the bf16 model's bound, where the twin is closer), and closer
+    to the fp8 definition than to the bf16 model (the quantisation is really applied)."""
+    from oracle import model as om
+    cfg, m, P = _build("ucas_aod_r101_fp8.yaml", seed=3)
+    assert cfg.ENGINE.WEIGHT_DTYPE == "fp8_e4m3"
+    g = torch.Generator().manual_seed(0)
+    img = torch.randint(0, 256, (2, 3, 128, 160), generator=g, dtype=torch.uint8)
+    x, _ = om.preprocess([img[0], img[1]], cfg.MODEL.PIXEL_MEAN, cfg.MODEL.PIXEL_STD)
+    keys = ("p3", "p4", "p5", "p6", "p7")
+    with torch.no_grad():
+        f_q = om.backbone_forward(P, x, 101, emulate_bf16=True, fp8=True)
+        f_b = om.backbone_forward(P, x, 101, emulate_bf16=True)
+        fq = [f_q[k] for k in keys]
+        h_q = om.head_forward(P, fq, emulate_bf16=True, fp8=True)
+        h_b = om.head_forward(P, fq, emulate_bf16=True)
+        gt = torch.Generator().manual_seed(1)
+        twin = [(f * (1 + (torch.rand(f.shape, generator=gt) < 0.05).float() * 2.0 ** -8)).to(torch.bfloat16).float() for f in fq]
+        h_t = om.head_forward(P, twin, emulate_bf16=True, fp8=True)
+    feats = m.backbone(x.to(dev()))
+    for k in keys:
+        e_q, e_b = _rel(feats[k].cpu(), f_q[k]), _rel(feats[k].cpu(), f_b[k])
+        assert e_q < 2.5e-2 and e_b > 2 * e_q, (k, e_q, e_b)
+    head = m.proposal_generator.dafne_head
+    logits, regs, centers, _, ctrs, _, _ = head(None, [f.to(dev()) for f in fq])
+    for l in range(5):
+        for i, (name, got) in enumerate((("logits", logits[l]), ("reg", regs[l]), ("center", centers[l]), ("ctr", ctrs[l]))):
+            e_q, e_b, e_t = _rel(got.cpu(), h_q[i][l]), _rel(got.cpu(), h_b[i][l]), _rel(h_t[i][l], h_q[i][l])
+            assert e_q < max(2.5e-2, e_t), (name, l, e_q, e_t)
+            assert e_b > e_q, (name, l, e_q, e_b)
+
+
+def test_fp8_model_uses_the_fp8_kernel_and_runs_end_to_end():
+    """Config 5 end to end at a small size: nine tower layers go to conv3x3_patch_fp8, detections are well formed."""
+    import numpy as np
+    cfg, m, P = _build("ucas_aod_r101_fp8.yaml", seed=17)
+    g = torch.Generator().manual_seed(3)
+    h, w = 256, 320
+    img = torch.randint(0, 256, (3, h, w), generator=g, dtype=torch.uint8)
+    out = m([{"image": img, "height": h, "width": w}])[0]["instances"]
+    plan = m.plan(1, h, w)
+    names = [c.kernel_name() for c in plan.calls if hasattr(c, "kernel_name")]
+    assert names.count("conv3x3_patch_fp8") == 10, names      # layers 1..3 of three towers + corners_tower.0
+    assert 0 < len(out) <= cfg.MODEL.DAFNE.POST_NMS_TOPK_TEST + 8
+    s = out.scores.cpu().numpy()
+    assert np.all(np.diff(s) <= 0) and s.min() > 0 and s.max() <= 1
+    assert torch.isfinite(out.pred_corners).all() and int(out.pred_classes.max()) < 2
