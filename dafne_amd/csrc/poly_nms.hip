@@ -495,10 +495,20 @@ __global__ void __launch_bounds__(256) nms_prep_kernel(const float* __restrict__
 }
 
 // Same result as nms_prep_kernel for M <= 16384 rows, without the O(M^2) rank-by-counting: one workgroup per
-// image sorts 64-bit keys (order-preserving score bits << 32 | row index) in LDS with a bitonic network --
-// descending keys = score descending, larger index first on ties = argsort(kind="stable")[::-1] -- and then
-// gathers the rows into sorted order.  (10 000 rows: 8 x 10^8 compares -> 1.2 x 10^6 compare-exchanges.)
+// image sorts 64-bit keys (inverted order-preserving score bits << 32 | row index) in LDS with a stable LSD radix
+// sort (4 passes of 8 bits over the score word), and then gathers the rows into sorted order.  The initial
+// sequence is the rows in DESCENDING index order, so equal scores keep that order: score descending, larger
+// index first on ties = argsort(kind="stable")[::-1].
+//   * sequence positions are wave-striped: wave w owns positions [w*64*E, (w+1)*64*E), round r of the wave covers
+//     w*64*E + r*64 + lane (E = ceil(M / 1024) <= 16 rounds); a thread keeps its E keys in registers across a
+//     pass, so the scatter goes back into the same LDS array (no ping-pong buffer: 16384 keys = 128 KB);
+//   * rank of a key = (keys with a smaller digit) + (keys with the same digit earlier in the sequence): per round
+//     the lanes holding the same digit find each other with 8 ballots, the lowest one bumps the wave's counter of
+//     that digit, the others take the old value by readlane; an exclusive scan over (digit, wave) turns the
+//     per-wave counters into scatter bases.
+// (A bitonic network needed 105 barrier-separated LDS stages for 16384 keys: 230 us per image; this: 4 passes.)
 constexpr int kSortMax = 16384;
+constexpr int kSortHistBytes = 16 * 256 * 4;
 __global__ void __launch_bounds__(1024) nms_sort_prep_kernel(const float* __restrict__ dets9, int row_cap,
                                                              const int* __restrict__ counts, int m_cap, NmsWs w) {
     extern __shared__ u64 skey[];
@@ -506,32 +516,89 @@ __global__ void __launch_bounds__(1024) nms_sort_prep_kernel(const float* __rest
     const int M = img_count(counts, img, m_cap);
     if (M == 0) return;
     const float* d = dets9 + (size_t)img * row_cap * 9;
-    int n = 64;
-    while (n < M) n <<= 1;
-    for (int i = threadIdx.x; i < n; i += 1024) {
-        u64 key = 0ull;                                    // padding sorts to the end
-        if (i < M) {
-            unsigned u = __float_as_uint(d[(size_t)i * 9 + 8]);
-            u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);    // float order -> unsigned order
-            key = ((u64)u << 32) | (u64)(unsigned)i;
-            if (key == 0ull) key = 1ull;                   // keep real rows above the padding (score = -NaN pattern only)
+    const int E = (M + 1023) >> 10;                        // rounds per wave (uniform)
+    const int n = E << 10;                                 // padded sequence length
+    unsigned* hist = reinterpret_cast<unsigned*>(skey + n);      // [16 waves][256 digits]; re-used below as the class bytes
+    __shared__ unsigned wsum[16];
+    {
+        const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+        const int wbase = wv * 64 * E;
+        const u64 lt = (1ull << lane) - 1ull;
+        u64 key[16];
+        unsigned lrank[16];
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            key[r] = ~0ull;                                // padding: largest key, after every real row (stable)
+            if (r < E) {
+                const int sp = wbase + r * 64 + lane;      // sequence position: row M-1-sp
+                if (sp < M) {
+                    const int i = M - 1 - sp;
+                    unsigned u = __float_as_uint(d[(size_t)i * 9 + 8]);
+                    u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);    // float order -> unsigned order
+                    key[r] = ((u64)(~u) << 32) | (u64)(unsigned)i;     // ascending ~u = descending score
+                }
+            }
         }
-        skey[i] = key;
-    }
-    __syncthreads();
-    for (int k = 2; k <= n; k <<= 1) {
-        for (int j = k >> 1; j > 0; j >>= 1) {
-            for (int t = threadIdx.x; t < (n >> 1); t += 1024) {
-                const int lo = ((t & ~(j - 1)) << 1) | (t & (j - 1));      // index with bit j clear
-                const int hi = lo | j;
-                const u64 a = skey[lo], b = skey[hi];
-                const bool desc = (lo & k) == 0;           // overall descending order
-                if (desc ? a < b : a > b) {
-                    skey[lo] = b;
-                    skey[hi] = a;
+        for (int pass = 0; pass < 4; pass++) {
+            const int sh = 32 + 8 * pass;
+            for (int k = threadIdx.x; k < 16 * 256; k += 1024) hist[k] = 0u;
+            __syncthreads();
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                if (r < E) {
+                    const unsigned dg = (unsigned)(key[r] >> sh) & 255u;
+                    u64 peers = ~0ull;
+#pragma unroll
+                    for (int b = 0; b < 8; b++) {
+                        const bool bit = (dg >> b) & 1u;
+                        const u64 m = __ballot(bit);
+                        peers &= bit ? m : ~m;
+                    }
+                    const int leader = __ffsll((long long)peers) - 1;
+                    unsigned old = 0u;
+                    if (lane == leader) {
+                        old = hist[wv * 256 + dg];
+                        hist[wv * 256 + dg] = old + (unsigned)__popcll(peers);
+                    }
+                    old = __shfl(old, leader, 64);
+                    lrank[r] = old + (unsigned)__popcll(peers & lt);
                 }
             }
             __syncthreads();
+            {   // exclusive scan over (digit major, wave minor): thread t owns digit t>>2, waves 4*(t&3) .. +3
+                const int dgt = threadIdx.x >> 2, w0 = (threadIdx.x & 3) * 4;
+                unsigned c[4];
+#pragma unroll
+                for (int q = 0; q < 4; q++) c[q] = hist[(w0 + q) * 256 + dgt];
+                const unsigned tsum = c[0] + c[1] + c[2] + c[3];
+                unsigned x = tsum;
+#pragma unroll
+                for (int o = 1; o < 64; o <<= 1) {
+                    const unsigned y = __shfl_up(x, o, 64);
+                    if (lane >= o) x += y;
+                }
+                if (lane == 63) wsum[wv] = x;
+                __syncthreads();
+                unsigned base = 0u;
+                for (int w2 = 0; w2 < wv; w2++) base += wsum[w2];
+                unsigned e = base + x - tsum;
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    hist[(w0 + q) * 256 + dgt] = e;
+                    e += c[q];
+                }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int r = 0; r < 16; r++)
+                if (r < E) skey[hist[wv * 256 + ((unsigned)(key[r] >> sh) & 255u)] + lrank[r]] = key[r];
+            __syncthreads();
+            if (pass < 3) {
+#pragma unroll
+                for (int r = 0; r < 16; r++)
+                    if (r < E) key[r] = skey[wbase + r * 64 + lane];
+                __syncthreads();
+            }
         }
     }
     // ---- class-major tile order -------------------------------------------------------------------
@@ -546,7 +613,7 @@ __global__ void __launch_bounds__(1024) nms_sort_prep_kernel(const float* __rest
     __shared__ int ccnt[kMaxCls], cbase[kMaxCls + 1], crun[kMaxCls];
     __shared__ int wcnt[16][kMaxCls];
     __shared__ int nzero, badcls, ncls_s;
-    unsigned char* scls = reinterpret_cast<unsigned char*>(skey + n);      // class per sorted position (after the keys)
+    unsigned char* scls = reinterpret_cast<unsigned char*>(skey + n);      // class per sorted position (after the keys: the histogram's space)
     const bool have_cls = w.cls != nullptr && w.use_perm;
     if (threadIdx.x < kMaxCls) { ccnt[threadIdx.x] = 0; crun[threadIdx.x] = 0; }
     if (threadIdx.x == 0) { nzero = 0; badcls = 0; ncls_s = 1; }
@@ -1322,15 +1389,14 @@ int run_nms(const float* d_dets9, int row_cap, const int* d_counts, int N, int m
         static bool attr_done = false;
         if (!attr_done) {
             DAFNE_HIP_TRY(hipFuncSetAttribute((const void*)nms_sort_prep_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                              kSortMax * ((int)sizeof(u64) + 1)));
+                                              kSortMax * (int)sizeof(u64) + kSortHistBytes));
             attr_done = true;
         }
-        int n = 64;
-        while (n < m_cap) n <<= 1;
+        const int n = ((m_cap + 1023) >> 10) << 10;                   // padded sequence of the largest image
         w.use_perm = 1;
         if (getenv("DAFNE_NMS_NO_CLASS_ORDER")) w.cls = nullptr;      // experiments: score order is the tile order
-        hipLaunchKernelGGL(nms_sort_prep_kernel, dim3(N), dim3(1024), (size_t)n * (sizeof(u64) + 1), st, d_dets9, row_cap, d_counts,
-                           m_cap, w);
+        hipLaunchKernelGGL(nms_sort_prep_kernel, dim3(N), dim3(1024), (size_t)n * sizeof(u64) + kSortHistBytes, st, d_dets9, row_cap,
+                           d_counts, m_cap, w);
     } else {
         w.use_perm = 1;
         if (getenv("DAFNE_NMS_NO_CLASS_ORDER")) w.cls = nullptr;
