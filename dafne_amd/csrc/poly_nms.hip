@@ -332,10 +332,23 @@ __global__ void __launch_bounds__(1024) nms_minmax_kernel(const float* __restric
     const int M = img_count(counts, img, m_cap);
     const float* b = boxes + (size_t)img * m_cap * 8;
     float mx = -INFINITY, mn = INFINITY;
-    for (int i = threadIdx.x; i < M * 8; i += blockDim.x) {
-        float v = b[i];
-        mx = fmaxf(mx, v);
-        mn = fminf(mn, v);
+    // rows are 32 B: float4 loads, four in flight per thread (one workgroup per image: latency, not bandwidth, is the cost)
+    const float4* b4 = reinterpret_cast<const float4*>(b);
+    const int n4 = M * 2;
+    for (int i0 = threadIdx.x; i0 < n4; i0 += 4 * (int)blockDim.x) {
+        float4 v[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int i = i0 + k * (int)blockDim.x;
+            v[k] = i < n4 ? b4[i] : make_float4(mx, mx, mx, mx);
+        }
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            if (i0 + k * (int)blockDim.x < n4) {
+                mx = fmaxf(mx, fmaxf(fmaxf(v[k].x, v[k].y), fmaxf(v[k].z, v[k].w)));
+                mn = fminf(mn, fminf(fminf(v[k].x, v[k].y), fminf(v[k].z, v[k].w)));
+            }
+        }
     }
     for (int o = 32; o > 0; o >>= 1) {
         mx = fmaxf(mx, __shfl_xor(mx, o, 64));
@@ -1509,6 +1522,7 @@ int dafne_select_over_all_levels_hip(const float* d_boxes8, const float* d_score
     }
     if (!d_boxes8 || !d_scores || !d_classes || !d_keep || !d_ws)
         return dafne::fail(DAFNE_E_INVALID, "select: null pointer");
+    if ((uintptr_t)d_boxes8 & 15) return dafne::fail(DAFNE_E_INVALID, "select: d_boxes8 must be 16-byte aligned");
     if (!(nms_thresh > 0)) return dafne::fail(DAFNE_E_UNSUPPORTED, "select: nms_thresh <= 0 bypasses NMS in the reference; handle on the caller side");
     NmsWs w;
     size_t need = carve(w, d_ws, n_images, m_cap);

@@ -102,7 +102,7 @@ int dafne_poly_nms_batched_hip(const float* d_dets9, const int32_t* d_counts, in
  * ml_nms + the post-NMS cap for a batch (nms.py:10-92, dafne_outputs.py:907-925):
  * class 5 -> 4, offset = float(class) * (max(boxes) - min(boxes) + 1) in fp32 per
  * image, NMS at nms_thresh, then the post_topk cap.
- *   d_boxes8 [n_images, m_cap, 8] f32, d_scores [n_images, m_cap] f32,
+ *   d_boxes8 [n_images, m_cap, 8] f32 (16-byte aligned), d_scores [n_images, m_cap] f32,
  *   d_classes [n_images, m_cap] int32, d_counts [n_images] int32 (device).
  */
 int dafne_select_over_all_levels_hip(const float* d_boxes8, const float* d_scores,
