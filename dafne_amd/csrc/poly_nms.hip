@@ -262,6 +262,7 @@ struct NmsWs {
     u64* mask;       // [N][ntiles][64]  tile-major
     u64* rowflag;    // [N][nblk]  bit r of word b: row 64b+r suppresses something
     unsigned* meta;  // [N][4]     0: max|coord| (float bits) 1: span+1 (float bits)
+    unsigned* nzero; // [N]        rows with exactly zero area (census of nms_offset_kernel: select path)
     float* dets9;    // [N][Mp][9] (select path only)
     unsigned* pair_cnt;        // [N][nblk]  pairs appended per row block (may exceed pair_cap)
     u64* pairs;                // [N][nblk][pair_cap]  (row | col << 32), sorted positions
@@ -291,6 +292,7 @@ size_t carve(NmsWs& w, void* base, int N, int m_cap, bool f64 = false) {
     // list nearly every tile overflowed into the slower in-place path
     w.pair_cap = Mp <= 12288 ? kPairCap : 4 * kPairCap;
     w.meta = c.take<unsigned>(n * 4);
+    w.nzero = c.take<unsigned>(n);
     w.pair_cnt = c.take<unsigned>(n * nblk);
     w.rowflag = c.take<u64>(n * nblk);
     w.tile_flag = c.take<unsigned char>(n * ntiles);   // meta .. tile_flag are zeroed per call (contiguous)
@@ -376,7 +378,8 @@ __global__ void __launch_bounds__(256) nms_offset_kernel(const float* __restrict
                                                          const int* __restrict__ classes,
                                                          const int* __restrict__ counts, int m_cap,
                                                          int Mp, const unsigned* __restrict__ meta,
-                                                         float* __restrict__ dets9, unsigned char* __restrict__ cls) {
+                                                         float* __restrict__ dets9, unsigned char* __restrict__ cls,
+                                                         unsigned* __restrict__ nzero) {
     const int img = blockIdx.y;
     const int M = img_count(counts, img, m_cap);
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -387,9 +390,15 @@ __global__ void __launch_bounds__(256) nms_offset_kernel(const float* __restrict
     const float off = (float)c * span1;                      // nms.py:81
     const float* b = boxes + ((size_t)img * m_cap + i) * 8;
     float* d = dets9 + ((size_t)img * Mp + i) * 9;
+    float v[8];
 #pragma unroll
-    for (int k = 0; k < 8; k++) d[k] = b[k] + off;           // nms.py:83
+    for (int k = 0; k < 8; k++) v[k] = b[k] + off;           // nms.py:83
+#pragma unroll
+    for (int k = 0; k < 8; k++) d[k] = v[k];
     d[8] = scores[(size_t)img * m_cap + i];
+    // census of exactly-zero-area rows (of the OFFSET boxes, as the clip sees them): two of them can suppress each
+    // other across classes (union == 0 -> IoU 1), which rules out the class-major tile order for the image
+    if (quad_area(load_quad_f32(v)) == 0.0) atomicAdd(&nzero[img], 1u);
     cls[(size_t)img * Mp + i] = (unsigned char)(c < 0 ? 255 : (c > 255 ? 255 : c));
 }
 
@@ -531,177 +540,139 @@ __global__ void __launch_bounds__(1024) nms_sort_prep_kernel(const float* __rest
     const float* d = dets9 + (size_t)img * row_cap * 9;
     const int E = (M + 1023) >> 10;                        // rounds per wave (uniform)
     const int n = E << 10;                                 // padded sequence length
-    unsigned* hist = reinterpret_cast<unsigned*>(skey + n);      // [16 waves][256 digits]; re-used below as the class bytes
+    unsigned* hist = reinterpret_cast<unsigned*>(skey + n);      // [16 waves][256 digits]
     __shared__ unsigned wsum[16];
-    {
-        const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-        const int wbase = wv * 64 * E;
-        const u64 lt = (1ull << lane) - 1ull;
-        u64 key[16];
-        unsigned lrank[16];
+    constexpr int kMaxCls = 64;
+    __shared__ int cbase[kMaxCls + 1];
+    __shared__ int badcls, ncls_s;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int wbase = wv * 64 * E;
+    const u64 lt = (1ull << lane) - 1ull;
+    u64 key[16];
+    unsigned dg[16], lrank[16];
+    // One stable ranking pass over the digits dg[r] of the sequence: afterwards lrank[r] = keys with the same digit
+    // earlier in this wave's range, hist[wave][digit] = first output position of that (digit, wave) group.
+    auto rank_pass = [&]() {
+        for (int k = threadIdx.x; k < 16 * 256; k += 1024) hist[k] = 0u;
+        __syncthreads();
 #pragma unroll
         for (int r = 0; r < 16; r++) {
-            key[r] = ~0ull;                                // padding: largest key, after every real row (stable)
             if (r < E) {
-                const int sp = wbase + r * 64 + lane;      // sequence position: row M-1-sp
-                if (sp < M) {
-                    const int i = M - 1 - sp;
-                    unsigned u = __float_as_uint(d[(size_t)i * 9 + 8]);
-                    u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);    // float order -> unsigned order
-                    key[r] = ((u64)(~u) << 32) | (u64)(unsigned)i;     // ascending ~u = descending score
+                u64 peers = ~0ull;
+#pragma unroll
+                for (int b = 0; b < 8; b++) {
+                    const bool bit = (dg[r] >> b) & 1u;
+                    const u64 m = __ballot(bit);
+                    peers &= bit ? m : ~m;
                 }
+                const int leader = __ffsll((long long)peers) - 1;
+                unsigned old = 0u;
+                if (lane == leader) {
+                    old = hist[wv * 256 + dg[r]];
+                    hist[wv * 256 + dg[r]] = old + (unsigned)__popcll(peers);
+                }
+                old = __shfl(old, leader, 64);
+                lrank[r] = old + (unsigned)__popcll(peers & lt);
             }
         }
-        for (int pass = 0; pass < 4; pass++) {
-            const int sh = 32 + 8 * pass;
-            for (int k = threadIdx.x; k < 16 * 256; k += 1024) hist[k] = 0u;
-            __syncthreads();
+        __syncthreads();
+        // exclusive scan over (digit major, wave minor): thread t owns digit t>>2, waves 4*(t&3) .. +3
+        const int dgt = threadIdx.x >> 2, w0 = (threadIdx.x & 3) * 4;
+        unsigned c[4];
 #pragma unroll
-            for (int r = 0; r < 16; r++) {
-                if (r < E) {
-                    const unsigned dg = (unsigned)(key[r] >> sh) & 255u;
-                    u64 peers = ~0ull;
+        for (int q = 0; q < 4; q++) c[q] = hist[(w0 + q) * 256 + dgt];
+        const unsigned tsum = c[0] + c[1] + c[2] + c[3];
+        unsigned x = tsum;
 #pragma unroll
-                    for (int b = 0; b < 8; b++) {
-                        const bool bit = (dg >> b) & 1u;
-                        const u64 m = __ballot(bit);
-                        peers &= bit ? m : ~m;
-                    }
-                    const int leader = __ffsll((long long)peers) - 1;
-                    unsigned old = 0u;
-                    if (lane == leader) {
-                        old = hist[wv * 256 + dg];
-                        hist[wv * 256 + dg] = old + (unsigned)__popcll(peers);
-                    }
-                    old = __shfl(old, leader, 64);
-                    lrank[r] = old + (unsigned)__popcll(peers & lt);
-                }
-            }
-            __syncthreads();
-            {   // exclusive scan over (digit major, wave minor): thread t owns digit t>>2, waves 4*(t&3) .. +3
-                const int dgt = threadIdx.x >> 2, w0 = (threadIdx.x & 3) * 4;
-                unsigned c[4];
+        for (int o = 1; o < 64; o <<= 1) {
+            const unsigned y = __shfl_up(x, o, 64);
+            if (lane >= o) x += y;
+        }
+        if (lane == 63) wsum[wv] = x;
+        __syncthreads();
+        unsigned base = 0u;
+        for (int w2 = 0; w2 < wv; w2++) base += wsum[w2];
+        unsigned e = base + x - tsum;
 #pragma unroll
-                for (int q = 0; q < 4; q++) c[q] = hist[(w0 + q) * 256 + dgt];
-                const unsigned tsum = c[0] + c[1] + c[2] + c[3];
-                unsigned x = tsum;
+        for (int q = 0; q < 4; q++) {
+            hist[(w0 + q) * 256 + dgt] = e;
+            e += c[q];
+        }
+        __syncthreads();
+    };
 #pragma unroll
-                for (int o = 1; o < 64; o <<= 1) {
-                    const unsigned y = __shfl_up(x, o, 64);
-                    if (lane >= o) x += y;
-                }
-                if (lane == 63) wsum[wv] = x;
-                __syncthreads();
-                unsigned base = 0u;
-                for (int w2 = 0; w2 < wv; w2++) base += wsum[w2];
-                unsigned e = base + x - tsum;
-#pragma unroll
-                for (int q = 0; q < 4; q++) {
-                    hist[(w0 + q) * 256 + dgt] = e;
-                    e += c[q];
-                }
-            }
-            __syncthreads();
-#pragma unroll
-            for (int r = 0; r < 16; r++)
-                if (r < E) skey[hist[wv * 256 + ((unsigned)(key[r] >> sh) & 255u)] + lrank[r]] = key[r];
-            __syncthreads();
-            if (pass < 3) {
-#pragma unroll
-                for (int r = 0; r < 16; r++)
-                    if (r < E) key[r] = skey[wbase + r * 64 + lane];
-                __syncthreads();
+    for (int r = 0; r < 16; r++) {
+        key[r] = ~0ull;                                    // padding: largest key, after every real row (stable)
+        if (r < E) {
+            const int sp = wbase + r * 64 + lane;          // sequence position: row M-1-sp
+            if (sp < M) {
+                const int i = M - 1 - sp;
+                unsigned u = __float_as_uint(d[(size_t)i * 9 + 8]);
+                u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);        // float order -> unsigned order
+                key[r] = ((u64)(~u) << 32) | (u64)(unsigned)i;         // ascending ~u = descending score
             }
         }
+    }
+    for (int pass = 0; pass < 4; pass++) {
+        const int sh = 32 + 8 * pass;
+#pragma unroll
+        for (int r = 0; r < 16; r++) dg[r] = (unsigned)(key[r] >> sh) & 255u;
+        rank_pass();
+#pragma unroll
+        for (int r = 0; r < 16; r++)
+            if (r < E) skey[hist[wv * 256 + dg[r]] + lrank[r]] = key[r];
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < 16; r++)
+            if (r < E) key[r] = skey[wbase + r * 64 + lane];            // key at sequence position wbase + r*64 + lane
+        __syncthreads();
     }
     // ---- class-major tile order -------------------------------------------------------------------
     // Boxes of different classes sit >= 1 px apart after the class offsets (nms.py:81-83), so they never
     // suppress each other -- unless BOTH have exactly zero area (the reference's union == 0 -> IoU 1 quirk).
-    // With at most one zero-area box in the image the greedy result is the same whether the rows are walked
-    // in global score order or class by class (score order inside a class); laid out class by class, a
-    // 64x64 tile of two blocks without a common class has no candidates and nms_scan skips it (1/15 of the
-    // tiles remain for 15 classes).  perm maps the global score order to that layout; the keep list is
-    // still emitted in global score order (nms_reduce walks perm).
-    constexpr int kMaxCls = 64;
-    __shared__ int ccnt[kMaxCls], cbase[kMaxCls + 1], crun[kMaxCls];
-    __shared__ int wcnt[16][kMaxCls];
-    __shared__ int nzero, badcls, ncls_s;
-    unsigned char* scls = reinterpret_cast<unsigned char*>(skey + n);      // class per sorted position (after the keys: the histogram's space)
+    // With at most one zero-area box in the image (census taken by nms_offset_kernel) the greedy result is the same
+    // whether the rows are walked in global score order or class by class (score order inside a class); laid out
+    // class by class, a 64x64 tile of two blocks without a common class has no candidates and nms_scan skips it
+    // (1/15 of the tiles remain for 15 classes).  The layout is one more stable ranking pass with the class as the
+    // digit; perm maps the global score order to it and the keep list is still emitted in global score order
+    // (nms_reduce walks perm).
     const bool have_cls = w.cls != nullptr && w.use_perm;
-    if (threadIdx.x < kMaxCls) { ccnt[threadIdx.x] = 0; crun[threadIdx.x] = 0; }
-    if (threadIdx.x == 0) { nzero = 0; badcls = 0; ncls_s = 1; }
+    if (threadIdx.x == 0) { badcls = 0; ncls_s = 1; }
     __syncthreads();
+    bool cm = false;
     if (have_cls) {
-        for (int p = threadIdx.x; p < M; p += 1024) {
-            const int i = (int)(unsigned)skey[p];
-            float v[8];
+        int cmaxl = 0;
 #pragma unroll
-            for (int k = 0; k < 8; k++) v[k] = d[(size_t)i * 9 + k];
-            Quad q = load_quad_f32(v);
-            if (quad_area(q) == 0.0) atomicAdd(&nzero, 1);
-            const int c = w.cls[(size_t)img * w.Mp + i];
-            scls[p] = (unsigned char)c;
-            if (c >= kMaxCls) badcls = 1;
-            else { atomicAdd(&ccnt[c], 1); atomicMax(&ncls_s, c + 1); }
+        for (int r = 0; r < 16; r++) {
+            dg[r] = 255u;                                  // padding ranks behind every class
+            if (r < E && wbase + r * 64 + lane < M) {
+                const int c = w.cls[(size_t)img * w.Mp + (int)(unsigned)key[r]];
+                dg[r] = (unsigned)c;
+                if (c >= kMaxCls) badcls = 1;
+                else cmaxl = max(cmaxl, c + 1);
+            }
         }
+        for (int o = 32; o > 0; o >>= 1) cmaxl = max(cmaxl, __shfl_xor(cmaxl, o, 64));
+        if (lane == 0) atomicMax(&ncls_s, cmaxl);
+        rank_pass();                                       // (its barriers also publish badcls / ncls_s)
+        cm = w.nzero[img] < 2u && !badcls;
     }
-    __syncthreads();
-    const bool cm = have_cls && nzero < 2 && !badcls;
     const int ncls = cm ? ncls_s : 1;
-    if (threadIdx.x == 0) {
-        int run = 0;
-        for (int c = 0; c < kMaxCls; c++) { cbase[c] = run; run += cm ? ccnt[c] : 0; }
-        cbase[kMaxCls] = run;
-    }
+    if (threadIdx.x <= kMaxCls)
+        cbase[threadIdx.x] = !cm ? 0 : (threadIdx.x < kMaxCls ? (int)hist[threadIdx.x] : M);      // hist[0][c]: first row of class c
     __syncthreads();
-    float amax = 0.f;
-    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    for (int p0 = 0; p0 < M; p0 += 1024) {
-        const int p = p0 + threadIdx.x;
-        const bool live = p < M;
-        int pos = p;
-        if (cm) {                                  // stable partition by class: rank among equal classes before p
-            const int myc = live ? scls[p] : -1;
-            int myrank = 0;
-            for (int c = 0; c < ncls; c++) {
-                const u64 m = __ballot(myc == c);
-                if (myc == c) myrank = __popcll(m & ((1ull << lane) - 1ull));
-                if (lane == 0) wcnt[wv][c] = __popcll(m);
-            }
-            __syncthreads();
-            if (live) {
-                int off = crun[myc];
-                for (int w2 = 0; w2 < wv; w2++) off += wcnt[w2][myc];
-                pos = cbase[myc] + off + myrank;
-            }
-            __syncthreads();
-            if (threadIdx.x < ncls) {
-                int t = 0;
-                for (int w2 = 0; w2 < 16; w2++) t += wcnt[w2][threadIdx.x];
-                crun[threadIdx.x] += t;
-            }
-            __syncthreads();
-        }
-        if (live) {
-            const int i = (int)(unsigned)skey[p];
-            const size_t gbase = (size_t)img * w.Mp + p;       // score order
-            const size_t base = (size_t)img * w.Mp + pos;      // tile order
-            float v[8];
 #pragma unroll
-            for (int k = 0; k < 8; k++) v[k] = d[(size_t)i * 9 + k];
+    for (int r = 0; r < 16; r++) {
+        const int sp = wbase + r * 64 + lane;
+        if (r < E && sp < M) {
+            const int pos = cm ? (int)(hist[wv * 256 + dg[r]] + lrank[r]) : sp;
+            const unsigned nu = (unsigned)(key[r] >> 32);              // ~u
+            const unsigned u = ~nu;
+            const unsigned bits = (u & 0x80000000u) ? (u & 0x7fffffffu) : ~u;
+            const size_t gbase = (size_t)img * w.Mp + sp;              // score order
             w.perm[gbase] = pos;
-            w.sscore[gbase] = d[(size_t)i * 9 + 8];
-            w.order[base] = i;
-            float4* sb = reinterpret_cast<float4*>(w.sbox + base * 8);
-            sb[0] = make_float4(v[0], v[1], v[2], v[3]);
-            sb[1] = make_float4(v[4], v[5], v[6], v[7]);
-            const float xmin = fminf(fminf(v[0], v[2]), fminf(v[4], v[6])), xmax = fmaxf(fmaxf(v[0], v[2]), fmaxf(v[4], v[6]));
-            const float ymin = fminf(fminf(v[1], v[3]), fminf(v[5], v[7])), ymax = fmaxf(fmaxf(v[1], v[3]), fmaxf(v[5], v[7]));
-            w.hull[base] = make_float4(xmin, ymin, xmax, ymax);
-            Quad q = load_quad_f32(v);
-            w.area[base] = fabs(quad_area(q));
-#pragma unroll
-            for (int k = 0; k < 8; k++) amax = fmaxf(amax, fabsf(v[k]));
+            w.sscore[gbase] = __uint_as_float(bits);
+            w.order[(size_t)img * w.Mp + pos] = (int)(unsigned)key[r]; // tile order -> original row
         }
     }
     if (threadIdx.x <= kMaxCls) w.cbase[(size_t)img * 65 + threadIdx.x] = cbase[threadIdx.x];
@@ -718,6 +689,34 @@ __global__ void __launch_bounds__(1024) nms_sort_prep_kernel(const float* __rest
         }
         w.bcls[((size_t)img * w.nblk + b) * 2 + 0] = (unsigned char)cmin;
         w.bcls[((size_t)img * w.nblk + b) * 2 + 1] = (unsigned char)cmax;
+    }
+}
+
+// Second half of the sort path: rows gathered into tile order (order[pos] -> sbox / hull / area), chip-wide.
+__global__ void __launch_bounds__(256) nms_gather_kernel(const float* __restrict__ dets9, int row_cap,
+                                                         const int* __restrict__ counts, int m_cap, NmsWs w) {
+    const int img = blockIdx.y;
+    const int M = img_count(counts, img, m_cap);
+    if ((int)(blockIdx.x * blockDim.x) >= M) return;
+    const int pos = blockIdx.x * blockDim.x + threadIdx.x;
+    const float* d = dets9 + (size_t)img * row_cap * 9;
+    float amax = 0.f;
+    if (pos < M) {
+        const size_t base = (size_t)img * w.Mp + pos;
+        const int i = w.order[base];
+        float v[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) v[k] = d[(size_t)i * 9 + k];
+        float4* sb = reinterpret_cast<float4*>(w.sbox + base * 8);
+        sb[0] = make_float4(v[0], v[1], v[2], v[3]);
+        sb[1] = make_float4(v[4], v[5], v[6], v[7]);
+        const float xmin = fminf(fminf(v[0], v[2]), fminf(v[4], v[6])), xmax = fmaxf(fmaxf(v[0], v[2]), fmaxf(v[4], v[6]));
+        const float ymin = fminf(fminf(v[1], v[3]), fminf(v[5], v[7])), ymax = fmaxf(fmaxf(v[1], v[3]), fmaxf(v[5], v[7]));
+        w.hull[base] = make_float4(xmin, ymin, xmax, ymax);
+        Quad q = load_quad_f32(v);
+        w.area[base] = fabs(quad_area(q));
+#pragma unroll
+        for (int k = 0; k < 8; k++) amax = fmaxf(amax, fabsf(v[k]));
     }
     for (int o = 32; o > 0; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o, 64));
     if ((threadIdx.x & 63) == 0 && amax > 0.f) atomicMax(&w.meta[img * 4 + 0], __float_as_uint(amax));
@@ -1410,6 +1409,7 @@ int run_nms(const float* d_dets9, int row_cap, const int* d_counts, int N, int m
         if (getenv("DAFNE_NMS_NO_CLASS_ORDER")) w.cls = nullptr;      // experiments: score order is the tile order
         hipLaunchKernelGGL(nms_sort_prep_kernel, dim3(N), dim3(1024), (size_t)n * sizeof(u64) + kSortHistBytes, st, d_dets9, row_cap,
                            d_counts, m_cap, w);
+        hipLaunchKernelGGL(nms_gather_kernel, gp, dim3(256), 0, st, d_dets9, row_cap, d_counts, m_cap, w);
     } else {
         w.use_perm = 1;
         if (getenv("DAFNE_NMS_NO_CLASS_ORDER")) w.cls = nullptr;
@@ -1533,7 +1533,7 @@ int dafne_select_over_all_levels_hip(const float* d_boxes8, const float* d_score
     int rc = dafne::check_launch("nms_minmax");
     if (rc) return rc;
     hipLaunchKernelGGL(nms_offset_kernel, dim3((m_cap + 255) / 256, n_images), dim3(256), 0, st, d_boxes8,
-                       d_scores, d_classes, d_counts, m_cap, w.Mp, w.meta, w.dets9, w.cls);
+                       d_scores, d_classes, d_counts, m_cap, w.Mp, w.meta, w.dets9, w.cls, w.nzero);
     rc = dafne::check_launch("nms_offset");
     if (rc) return rc;
     return run_nms(w.dets9, w.Mp, d_counts, n_images, m_cap, nms_thresh, post_topk, d_keep, d_num_keep, w, st, true);
