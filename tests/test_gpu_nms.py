@@ -266,3 +266,31 @@ def test_class_major_order_on_the_counting_path(n_zero):
         kth = np.sort(scores[0][exp_keep])[len(exp_keep) - 1000]
         exp_keep = exp_keep[scores[0][exp_keep] >= kth]
     assert keep[0, :int(nk[0])].cpu().tolist() == exp_keep.tolist()
+
+
+def test_chunked_sort_path_with_ragged_counts():
+    """m_cap above 16384 with per-image counts on both sides of the chunk size: image 0 is sorted in two chunks and
+    merged by binary search, image 1 (9 000 rows) in one; many equal scores (ties go to the larger row index)."""
+    from dafne_amd import _lib
+    L = _lib.load()
+    rng = np.random.default_rng(77)
+    m_cap, counts = 20000, [20000, 9000]
+    boxes = np.stack([rrects(m_cap, rng, extent=1800.0) for _ in counts])
+    scores = np.round(rng.uniform(0.05, 1, (2, m_cap)), 2).astype(np.float32)        # ~95 distinct values: ties everywhere
+    classes = rng.integers(0, 15, (2, m_cap)).astype(np.int32)
+    d = dev()
+    tb, ts, tc = (torch.from_numpy(a).to(d) for a in (boxes, scores, classes))
+    tn = torch.tensor(counts, dtype=torch.int32, device=d)
+    keep = torch.full((2, m_cap), -1, dtype=torch.int64, device=d)
+    nk = torch.zeros(2, dtype=torch.int32, device=d)
+    nbytes = L.dafne_poly_nms_workspace_bytes(2, m_cap)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=d)
+    _lib.check(L.dafne_select_over_all_levels_hip(_lib.ptr(tb), _lib.ptr(ts), _lib.ptr(tc), _lib.ptr(tn), 2, m_cap, 0.1, 1000,
+                                                  _lib.ptr(keep), _lib.ptr(nk), _lib.ptr(ws), nbytes, _lib.current_stream()))
+    torch.cuda.synchronize()
+    for i, m in enumerate(counts):
+        exp_keep = pp.batched_nms_poly(boxes[i, :m], scores[i, :m], classes[i, :m].astype(np.int64), 0.1, fast=True)
+        if len(exp_keep) > 1000:
+            kth = np.sort(scores[i][exp_keep])[len(exp_keep) - 1000]
+            exp_keep = exp_keep[scores[i][exp_keep] >= kth]
+        assert keep[i, :int(nk[i])].cpu().tolist() == exp_keep.tolist(), i
