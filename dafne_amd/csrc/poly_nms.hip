@@ -418,11 +418,29 @@ __global__ void __launch_bounds__(1024) nms_cls_layout_kernel(const float* __res
     if (threadIdx.x < kMaxCls) ccnt[threadIdx.x] = 0;
     if (threadIdx.x == 0) { badcls = 0; ncls_s = 1; }
     __syncthreads();
-    for (int i = threadIdx.x; i < M; i += 1024) {      // (zero-area census: nms_offset_kernel, w.nzero)
-        const int c = w.cls[(size_t)img * w.Mp + i];
+    // class histogram (zero-area census: nms_offset_kernel, w.nzero).  Lanes with the same class find each other with
+    // 6 ballots and the lowest one adds their count: one LDS atomic per distinct class and wave round instead of 64
+    // colliding ones.
+    int cmaxl = 0;
+    for (int i0 = 0; i0 < M; i0 += 1024) {
+        const int i = i0 + threadIdx.x;
+        const int c = i < M ? (int)w.cls[(size_t)img * w.Mp + i] : -1;
+        const bool ok = c >= 0 && c < kMaxCls;
         if (c >= kMaxCls) badcls = 1;
-        else { atomicAdd(&ccnt[c], 1); atomicMax(&ncls_s, c + 1); }
+        u64 peers = __ballot(ok);
+#pragma unroll
+        for (int b = 0; b < 6; b++) {
+            const bool bit = (c >> b) & 1;
+            const u64 m = __ballot(bit);
+            peers &= bit ? m : ~m;
+        }
+        if (ok) {
+            if ((int)(threadIdx.x & 63) == __ffsll((long long)peers) - 1) atomicAdd(&ccnt[c], __popcll(peers));
+            cmaxl = max(cmaxl, c + 1);
+        }
     }
+    for (int o = 32; o > 0; o >>= 1) cmaxl = max(cmaxl, __shfl_xor(cmaxl, o, 64));
+    if ((threadIdx.x & 63) == 0) atomicMax(&ncls_s, cmaxl);
     __syncthreads();
     const bool cm = M > 0 && w.nzero[img] < 2u && !badcls;
     if (threadIdx.x == 0) {
