@@ -104,7 +104,7 @@ class OneStageDetector(nn.Module):
 
     # ------------------------------------------------------------ fused path
     def detect_packed(self, images_u8, valid_hw=None, out_hw=None, layout_hwc=False, do_postprocess=True,
-                      pipelined=False, splits=1):
+                      pipelined=False, splits=1, stream_offset=0):
         """images_u8: device uint8 [N,3,H,W] (or [N,H,W,3] with layout_hwc) BGR.
         valid_hw: optional per-image (h, w) true sizes; out_hw: optional per-image
         requested output (height, width).  Returns (rows [N,k_cap,18], counts [N])
@@ -116,7 +116,8 @@ class OneStageDetector(nn.Module):
         gather run once on the whole batch on a side stream, overlapping the next call's
         convolutions (two plan sets / head-output buffers alternate).
         The returned tensors are then produced on `self.side_stream`: wait on it (or
-        torch.cuda.synchronize()) before reading them."""
+        torch.cuda.synchronize()) before reading them.  stream_offset rotates the compute streams the
+        sub-batches use: consecutive calls with different offsets (the TTA wrapper's chunks) run concurrently."""
         if not images_u8.is_cuda or images_u8.dtype != torch.uint8:
             raise RuntimeError("detect_packed needs a uint8 CUDA tensor (the MI355X engine has no CPU path)")
         L = _lib.load()
@@ -180,6 +181,8 @@ class OneStageDetector(nn.Module):
             slot = st["i"] & 1
             st["i"] += 1
             cs, plans, bounds = st["cs"], st["plans"][slot], st["bounds"]
+            if stream_offset:
+                cs = [_shared_stream(images_u8.device, "compute", (int(stream_offset) + k) % 3) for k in range(splits)]
             inputs_ready = torch.cuda.Event()
             inputs_ready.record(main)
             vts = []
