@@ -232,3 +232,21 @@ def test_fp8_model_uses_the_fp8_kernel_and_runs_end_to_end():
     s = out.scores.cpu().numpy()
     assert np.all(np.diff(s) <= 0) and s.min() > 0 and s.max() <= 1
     assert torch.isfinite(out.pred_corners).all() and int(out.pred_classes.max()) < 2
+
+
+def test_fp8_model_pipelined_equals_serial():
+    """The fp8 model through the pipelined path (sub-batches on concurrent streams, post-process on the side stream)
+    gives the detections of the serial path (same kernels on the same sub-batch composition: splits=1)."""
+    cfg, m, P = _build("ucas_aod_r101_fp8.yaml", seed=13)
+    g = torch.Generator().manual_seed(6)
+    batches = [torch.randint(0, 256, (3, 3, 128, 160), generator=g, dtype=torch.uint8).to(dev()) for _ in range(3)]
+    serial = [m.detect_packed(b) for b in batches]
+    torch.cuda.synchronize()
+    serial = [(r.clone(), c.clone()) for r, c in serial]
+    piped = [m.detect_packed(b, pipelined=True, splits=1) for b in batches]
+    torch.cuda.synchronize()
+    for (r0, c0), (r1, c1) in zip(serial, piped):
+        assert torch.equal(c0, c1)
+        for i in range(3):
+            k = int(c0[i])
+            assert torch.equal(r0[i, :k], r1[i, :k])

@@ -172,6 +172,28 @@ def test_tta_merge_vs_oracle():
     assert np.abs(out.pred_corners.cpu().numpy() - exp["pred_corners"]).max() < 1e-3
 
 
+def test_tta_packed_chunks_equal_the_reference_style_loop():
+    """OneStageRCNNWithTTA._batch_inference_packed (chunks of views on the pipelined path, one host wait) returns the
+    detections of _batch_inference (tta.py:170-179: one model.inference call per chunk)."""
+    from dafne_amd.modeling.tta import OneStageRCNNWithTTA
+    cfg, m, P = build("dota-1.5_r101.yaml", seed=21)
+    cfg.TEST.AUG.MIN_SIZES = [96, 128, 160, 224]
+    cfg.TEST.AUG.MAX_SIZE = 256
+    tta = OneStageRCNNWithTTA(cfg, m)
+    g = torch.Generator().manual_seed(9)
+    img = torch.randint(0, 256, (3, 128, 160), generator=g, dtype=torch.uint8).to(dev())
+    aug, _ = tta._get_augmented_inputs({"image": img, "height": 128, "width": 160})
+    assert len(aug) == 12
+    a = tta._batch_inference(aug)
+    b = tta._batch_inference_packed(aug)
+    assert len(a) == len(b) == 12
+    for x, y in zip(a, b):
+        ix, iy = x["instances"], y["instances"]
+        assert len(ix) == len(iy) and ix.image_size == iy.image_size
+        assert torch.equal(ix.pred_corners, iy.pred_corners) and torch.equal(ix.scores, iy.scores)
+        assert torch.equal(ix.pred_classes, iy.pred_classes)
+
+
 def test_pipelined_side_stream_equals_serial():
     cfg, m, P = build("dota-1.0_r50.yaml", seed=13)
     g = torch.Generator().manual_seed(6)
