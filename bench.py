@@ -79,13 +79,19 @@ def seeded_state_dict(model, seed):
     return sd
 
 
-def build_model(depth, device, seed=0, cfgname=None):
+def build_model(depth, device, seed=0, cfgname=None, cls_prior=None):
+    """cls_prior: class-logit bias instead of the reference's -4.595.  The configs that threshold the RAW class score
+    (THRESH_WITH_CTR false: DOTA-1.5, UCAS-AOD, HRSC) yield no candidates at -4.595 with random weights; the side
+    metrics on those configs raise it so that decode / NMS see full candidate sets."""
     import dafne_amd.modeling  # noqa: F401
     from dafne_amd.config import load_cfg
     from dafne_amd.registry import build_model as bm
     cfg = load_cfg(os.path.join(ROOT, "configs", cfgname or "dota-1.0_r%d.yaml" % depth))
     m = bm(cfg)
     sd = seeded_state_dict(m, seed)
+    if cls_prior is not None:
+        kb = "proposal_generator.dafne_head.cls_logits.bias"
+        sd[kb] = torch.full_like(sd[kb], float(cls_prior))
     m.load_state_dict(sd)
     m.to(device)
     m.invalidate()
@@ -371,13 +377,15 @@ def main():
             del m50
             # configs[4]: R101-FPN, 2 classes, fp8 (e4m3) weights, 16 images per GPU -- reported beside the bf16 metric,
             # never as `value` (reduced precision); the ten GroupNorm-fed tower layers run the fp8 MFMA kernel
-            cfg8, m8, _ = build_model(101, device, seed=0, cfgname="ucas_aod_r101_fp8.yaml")
+            cfg8, m8, _ = build_model(101, device, seed=0, cfgname="ucas_aod_r101_fp8.yaml", cls_prior=-1.5)
             b16 = torch.cat([batch, batch.flip(0)])[:16]
             n8 = max(args.steps // 4, 3)
             dt8 = time_steps(lambda: m8.detect_packed(b16, pipelined=True, splits=args.splits), n8, 2, False)
-            out["configs4_fp8w_r101_b16"] = {"images_per_sec": b16.shape[0] * n8 / dt8, "dtype": "fp8 e4m3 weights (head towers on fp8 MFMA) / bf16",
+            r8, c8 = m8.detect_packed(b16, pipelined=True, splits=args.splits)
+            torch.cuda.synchronize()
+            out["configs4_fp8w_r101_b16"] = {"images_per_sec": b16.shape[0] * n8 / dt8, "detections_per_image_mean": float(c8.float().mean().item()), "dtype": "fp8 e4m3 weights (head towers on fp8 MFMA) / bf16",
                                              "workload": "UCAS-AOD head (2 classes) 1024x1024 R101-FPN, batch 16, 1 GPU"}
-            m8b = build_model(101, device, seed=0, cfgname="ucas_aod_r101.yaml")[1]
+            m8b = build_model(101, device, seed=0, cfgname="ucas_aod_r101.yaml", cls_prior=-1.5)[1]
             dt8b = time_steps(lambda: m8b.detect_packed(b16, pipelined=True, splits=args.splits), n8, 2, False)
             out["configs4_fp8w_r101_b16"]["bf16_same_workload_images_per_sec"] = b16.shape[0] * n8 / dt8b
             del m8, m8b
@@ -386,12 +394,7 @@ def main():
             # its 1000 post-NMS slots (this config thresholds the raw class score; the bench weights keep the
             # reference's -4.6 prior and would yield no candidates), i.e. the merge sees its worst case.
             from dafne_amd.modeling.tta import OneStageRCNNWithTTA
-            cfg15, m15, sd15 = build_model(101, device, seed=0, cfgname="dota-1.5_r101.yaml")
-            kb = "proposal_generator.dafne_head.cls_logits.bias"
-            sd15[kb] = torch.full_like(sd15[kb], -1.5)
-            m15.load_state_dict(sd15)
-            m15.to(device)
-            m15.invalidate()
+            cfg15, m15, sd15 = build_model(101, device, seed=0, cfgname="dota-1.5_r101.yaml", cls_prior=-1.5)
             tta = OneStageRCNNWithTTA(cfg15, m15)
             one = lambda k: tta([{"image": batch[k], "height": args.size, "width": args.size}])[0]["instances"]
             one(0)

@@ -5,12 +5,8 @@ R = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert
 import torch, bench
 from dafne_amd.modeling.tta import OneStageRCNNWithTTA
 dev = torch.device("cuda", 0)
-cfg, model, sd = bench.build_model(101, dev, cfgname="dota-1.5_r101.yaml")
+cfg, model, sd = bench.build_model(101, dev, cfgname="dota-1.5_r101.yaml", cls_prior=-1.5)
 cfg.TEST.AUG.ENABLED = True
-# class prior raised so that every view fills its 1000 post-NMS slots (THRESH_WITH_CTR is false in this config and the
-# bench weights keep the reference's -4.6 prior): the merge then sees the full 27 000 boxes
-sd["proposal_generator.dafne_head.cls_logits.bias"] = torch.full_like(sd["proposal_generator.dafne_head.cls_logits.bias"], -1.5)
-model.load_state_dict(sd); model.to(dev); model.invalidate()
 tta = OneStageRCNNWithTTA(cfg, model)
 print("TTA sizes", cfg.TEST.AUG.MIN_SIZES, "max", cfg.TEST.AUG.MAX_SIZE)
 g = torch.Generator().manual_seed(0)
