@@ -1493,12 +1493,13 @@ __global__ void __launch_bounds__(512) conv3x3_patch_kernel(ConvDev P) {
                 for (int b = 0; b < TP; b++)
                     acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[k2][a], bfr[k2][b + kh], acc[a][b], 0, 0, 0);
     };
-    // one weight piece per wave and phase; odd phases wait: the 4 youngest weight pieces (+1 patch piece
-    // when one was issued within the last 4 phases) may stay in flight across the barrier
-    auto phase_end = [&](bool odd, int t, bool patch_in_window) {
+    // one weight piece per wave and phase; odd phases wait: the 4 youngest weight pieces plus the patch pieces
+    // issued in this and the previous half-step (np = 0, 1, 2) may stay in flight across the barrier
+    auto phase_end = [&](bool odd, int t, int np) {
         if (odd) {
             if (t <= 4 * K - 7) {
-                if (patch_in_window) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+                if (np == 2) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+                else if (np == 1) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
                 else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
             } else {
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1519,45 +1520,48 @@ __global__ void __launch_bounds__(512) conv3x3_patch_kernel(ConvDev P) {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }
     asm volatile("s_waitcnt vmcnt(4)" ::: "memory");          // half-step 0 is complete
-    phase_end(false, -1, false);
+    phase_end(false, -1, 0);
 
     // Global phase t = 2 u + p (u = half-step, p = 0: fragment reads of group 0 / MFMAs of group 1,
-    // p = 1: the reverse) issues weight piece p of half-step u + 3.  Patch pieces of slab+1: one at p = 0
-    // of half-steps 0, 2, .., 10 of the slab (all landed by the wait that ends half-step 12); their
-    // GroupNorm runs in the read phases of half-steps 13, 14, 15.
+    // p = 1: the reverse) issues weight piece p of half-step u + 3.  Patch pieces of slab+1: piece i at p = 0 of
+    // half-step i of the slab (i = 0..5); a piece has landed three half-steps later (the waits let the pieces of
+    // the current and the previous half-step stay in flight).  Their GroupNorm runs ONE piece per read phase, in
+    // the read phases that carry no B-fragment reads (kh = 1, 2: half-steps 7, 8, 10, 11, 13, 14): two pieces in
+    // one phase made that phase twice as long as the other group's MFMA phase and idled the matrix pipe.
     // G = (kw, half): half-steps 3G .. 3G+2 = kh 0..2; UU = 3G is the half-step index inside the slab.
+#define PATCH_NP(UU) (more ? (((UU) <= 5 ? 1 : 0) + (((UU) >= 1 && (UU) <= 6) ? 1 : 0)) : 0)
+#define PATCH_GN(UU)                                                                                         \
+    if (GNIN && more && (UU) >= 7 && (UU) <= 14 && (UU) % 3 != 0) gn_pieces(slab + 1, ((UU) - 7) - ((UU) - 6) / 3, 1);
 #define PATCH_HS_G0(UU, KW_, H_, KH_)                                                                        \
     {                                                                                                        \
         const int u = slab * 18 + (UU);                                                                      \
-        const bool pw = more && (UU) <= 11;                                                                  \
         piece_a(u + 3, 0);                                                                                   \
-        if (more && (UU) <= 10 && ((UU) & 1) == 0) piece_p(slab + 1, (UU) / 2 <= 5 ? (UU) / 2 : 0);          \
-        if (GNIN && more && (UU) >= 13 && (UU) <= 15) gn_pieces(slab + 1, 2 * ((UU) - 13), 2);               \
+        if (more && (UU) <= 5) piece_p(slab + 1, (UU));                                                      \
+        PATCH_GN(UU)                                                                                         \
         read_a(u);                                                                                           \
         if ((KH_) == 0) read_b6(slab, KW_, H_);                                                              \
-        phase_end(false, 2 * u, pw);                                                                         \
+        phase_end(false, 2 * u, 0);                                                                          \
         piece_a(u + 3, 1);                                                                                   \
         mma16(KH_);                                                                                          \
-        phase_end(true, 2 * u + 1, pw);                                                                      \
+        phase_end(true, 2 * u + 1, PATCH_NP(UU));                                                            \
     }
     // group 1 runs one phase behind: reads in p = 1 of half-step u, MFMAs in p = 0 of half-step u + 1
 #define PATCH_HS_G1(UU, KW_, H_, KH_)                                                                        \
     {                                                                                                        \
         const int u = slab * 18 + (UU);                                                                      \
-        const bool pw = more && (UU) <= 11;                                                                  \
         piece_a(u + 3, 1);                                                                                   \
-        if (GNIN && more && (UU) >= 13 && (UU) <= 15) gn_pieces(slab + 1, 2 * ((UU) - 13), 2);               \
+        PATCH_GN(UU)                                                                                         \
         read_a(u);                                                                                           \
         if ((KH_) == 0) read_b6(slab, KW_, H_);                                                              \
-        phase_end(true, 2 * u + 1, pw);                                                                      \
+        phase_end(true, 2 * u + 1, PATCH_NP(UU));                                                            \
         piece_a(u + 4, 0);                                                                                   \
-        {                                                                                                    \
-            const bool nxt_patch = (UU) < 17 ? (more && (UU) + 1 <= 10 && (((UU) + 1) & 1) == 0) : (slab + 2 < nslab); \
-            if (nxt_patch) piece_p((UU) < 17 ? slab + 1 : slab + 2, (UU) < 17 ? (((UU) + 1) / 2 <= 5 ? ((UU) + 1) / 2 : 0) : 0); \
-            const bool pwn = (UU) < 17 ? (more && (UU) + 1 <= 11) : (slab + 2 < nslab);                      \
-            mma16(KH_);                                                                                      \
-            if (u + 1 < U) phase_end(false, 2 * u + 2, pwn);                                                 \
+        if ((UU) < 17) {                                                                                     \
+            if (more && (UU) + 1 <= 5) piece_p(slab + 1, (UU) + 1);                                          \
+        } else if (slab + 2 < nslab) {                                                                       \
+            piece_p(slab + 2, 0);                                                                            \
         }                                                                                                    \
+        mma16(KH_);                                                                                          \
+        if (u + 1 < U) phase_end(false, 2 * u + 2, 0);                                                       \
     }
 #define PATCH_SLAB(M)                                                                                        \
     M(0, 0, 0, 0) M(1, 0, 0, 1) M(2, 0, 0, 2) M(3, 0, 1, 0) M(4, 0, 1, 1) M(5, 0, 1, 2)                      \
@@ -1572,7 +1576,7 @@ __global__ void __launch_bounds__(512) conv3x3_patch_kernel(ConvDev P) {
         // phase 0 of the whole loop: this group idles one phase (issues its share of the loads only)
         piece_a(3, 0);
         if (nslab > 1) piece_p(1, 0);
-        phase_end(false, 0, nslab > 1);
+        phase_end(false, 0, 0);
         for (int slab = 0; slab < nslab; slab++) {
             const bool more = slab + 1 < nslab;
             PATCH_SLAB(PATCH_HS_G1)
@@ -1581,6 +1585,8 @@ __global__ void __launch_bounds__(512) conv3x3_patch_kernel(ConvDev P) {
 #undef PATCH_SLAB
 #undef PATCH_HS_G0
 #undef PATCH_HS_G1
+#undef PATCH_GN
+#undef PATCH_NP
 
     // ------------------------------------------------------------ epilogue (bias, ReLU, GN sums, bf16)
     const bool relu = P.flags & DAFNE_CONV_RELU;

@@ -27,10 +27,11 @@ for k in range(NI):
     fl = engine.F_GN | engine.F_GNIN
     cb = engine.ConvCall(wp, bp, C, C, 3, 1, 1, fl, segs, B, gn_partial=partial, gn_in=(stats, gamma, beta))
     cq = engine.ConvCall(wq, bp, C, C, 3, 1, 1, fl, segs, B, gn_partial=partial, gn_in=(stats, gamma, beta), fp8=(ws, 1.0))
-    sets.append((cb, cq, ins, outs))
+    cn = engine.ConvCall(wp, bp, C, C, 3, 1, 1, engine.F_GN, segs, B, gn_partial=partial)
+    sets.append((cb, cq, cn, ins, outs))
 st = _lib.current_stream()
 flops = sets[0][0].flops
-for name, idx in (("bf16 conv3x3_patch<GNIN>", 0), ("fp8 conv3x3_patch_fp8<GNIN>", 1)):
+for name, idx in (("bf16 conv3x3_patch<GNIN>", 0), ("fp8 conv3x3_patch_fp8<GNIN>", 1), ("bf16 conv3x3_patch (no GN input)", 2)):
     for s in sets: s[idx](st)
     torch.cuda.synchronize()
     reps = 12
