@@ -1461,6 +1461,55 @@ __global__ void __launch_bounds__(512) conv3x3_patch_kernel(ConvDev P) {
         }
     };
 
+    // The same conversion for ONE piece with a single LDS round trip: the piece and the constants are read together
+    // and waited for once (gn_pieces pays the latency twice: constants, then piece).
+    auto gn_skip = [&](int i) { return i == 5 && 5 * NW + wave >= kPPieces; };      // duplicate of piece i = 4
+    auto gn_one = [&](int slab, int i) {
+        if (gn_skip(i)) return;
+        const int ch = slab * kBK + (lane & 7) * 8;
+        const unsigned ts = lds_base + (unsigned)(kPOffTab + (ch >> 3) * 8);
+        const unsigned tg = lds_base + (unsigned)(kPOffTab + P.Cin + ch * 4);
+        const unsigned tb = tg + (unsigned)P.Cin * 4u;
+        u32x4 gq_v;
+        u32x2 gq_ms;
+        f32x4 gq_g0, gq_g1, gq_b0, gq_b1;
+        {
+            const int pi = ppi[i];
+            const int r = pi * 8 + (lane >> 3);
+            const int py = r / kPCols, px = r - py * kPCols;
+            const int phys = (lane & 7) ^ ((px >> 1) & 7);
+            const unsigned ad = lds_base + (unsigned)(kPOffPatch + (slab & 1) * kPBuf + pi * 1024 + (lane >> 3) * 128 + phys * 16);
+            asm volatile("ds_read_b128 %0, %6\n\tds_read_b64 %1, %7\n\tds_read_b128 %2, %8\n\tds_read_b128 %3, %8 offset:16\n\t"
+                         "ds_read_b128 %4, %9\n\tds_read_b128 %5, %9 offset:16\n\ts_waitcnt lgkmcnt(0)"
+                         : "=&v"(gq_v), "=&v"(gq_ms), "=&v"(gq_g0), "=&v"(gq_g1), "=&v"(gq_b0), "=&v"(gq_b1)
+                         : "v"(ad), "v"(ts), "v"(tg), "v"(tb)
+                         : "memory");
+        }
+        const float gmean = __uint_as_float(gq_ms.x), grstd = __uint_as_float(gq_ms.y);
+        const float gam[8] = {gq_g0[0], gq_g0[1], gq_g0[2], gq_g0[3], gq_g1[0], gq_g1[1], gq_g1[2], gq_g1[3]};
+        const float bet[8] = {gq_b0[0], gq_b0[1], gq_b0[2], gq_b0[3], gq_b1[0], gq_b1[1], gq_b1[2], gq_b1[3]};
+        const int pi = ppi[i];
+        const int r = pi * 8 + (lane >> 3);
+        const int py = r / kPCols, px = r - py * kPCols;
+        const int gy = Y0 + py, gx = X0 + px;
+        const bool inside = gy >= 1 && gy <= H && gx >= 1 && gx <= W && r < kPRows;
+        const int phys = (lane & 7) ^ ((px >> 1) & 7);
+        const unsigned ad = lds_base + (unsigned)(kPOffPatch + (slab & 1) * kPBuf + pi * 1024 + (lane >> 3) * 128 + phys * 16);
+        const unsigned u[4] = {gq_v.x, gq_v.y, gq_v.z, gq_v.w};
+        float y[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const float x = bf2f((unsigned short)(k & 1 ? u[k >> 1] >> 16 : u[k >> 1] & 0xffff));
+            y[k] = fmaxf((x - gmean) * grstd * gam[k] + bet[k], 0.f);      // expression of gn_apply_kernel
+        }
+        u32x4 o;
+        o.x = inside ? pack_bf16(y[0], y[1]) : 0u;
+        o.y = inside ? pack_bf16(y[2], y[3]) : 0u;
+        o.z = inside ? pack_bf16(y[4], y[5]) : 0u;
+        o.w = inside ? pack_bf16(y[6], y[7]) : 0u;
+        asm volatile("ds_write_b128 %0, %1" ::"v"(ad), "v"(o) : "memory");
+    };
+
     f32x16 acc[TC][TP];
 #pragma unroll
     for (int a = 0; a < TC; a++)
@@ -1530,14 +1579,14 @@ __global__ void __launch_bounds__(512) conv3x3_patch_kernel(ConvDev P) {
     // one phase made that phase twice as long as the other group's MFMA phase and idled the matrix pipe.
     // G = (kw, half): half-steps 3G .. 3G+2 = kh 0..2; UU = 3G is the half-step index inside the slab.
 #define PATCH_NP(UU) (more ? (((UU) <= 5 ? 1 : 0) + (((UU) >= 1 && (UU) <= 6) ? 1 : 0)) : 0)
-#define PATCH_GN(UU)                                                                                         \
-    if (GNIN && more && (UU) >= 7 && (UU) <= 14 && (UU) % 3 != 0) gn_pieces(slab + 1, ((UU) - 7) - ((UU) - 6) / 3, 1);
+#define PATCH_GN_ON(UU) (GNIN && more && (UU) >= 7 && (UU) <= 14 && (UU) % 3 != 0)
+#define PATCH_GN_PIECE(UU) (((UU) - 7) - ((UU) - 6) / 3)
 #define PATCH_HS_G0(UU, KW_, H_, KH_)                                                                        \
     {                                                                                                        \
         const int u = slab * 18 + (UU);                                                                      \
         piece_a(u + 3, 0);                                                                                   \
         if (more && (UU) <= 5) piece_p(slab + 1, (UU));                                                      \
-        PATCH_GN(UU)                                                                                         \
+        if (PATCH_GN_ON(UU)) gn_one(slab + 1, PATCH_GN_PIECE(UU));                                           \
         read_a(u);                                                                                           \
         if ((KH_) == 0) read_b6(slab, KW_, H_);                                                              \
         phase_end(false, 2 * u, 0);                                                                          \
@@ -1550,7 +1599,7 @@ __global__ void __launch_bounds__(512) conv3x3_patch_kernel(ConvDev P) {
     {                                                                                                        \
         const int u = slab * 18 + (UU);                                                                      \
         piece_a(u + 3, 1);                                                                                   \
-        PATCH_GN(UU)                                                                                         \
+        if (PATCH_GN_ON(UU)) gn_one(slab + 1, PATCH_GN_PIECE(UU));                                           \
         read_a(u);                                                                                           \
         if ((KH_) == 0) read_b6(slab, KW_, H_);                                                              \
         phase_end(true, 2 * u + 1, PATCH_NP(UU));                                                            \
@@ -1585,7 +1634,8 @@ __global__ void __launch_bounds__(512) conv3x3_patch_kernel(ConvDev P) {
 #undef PATCH_SLAB
 #undef PATCH_HS_G0
 #undef PATCH_HS_G1
-#undef PATCH_GN
+#undef PATCH_GN_ON
+#undef PATCH_GN_PIECE
 #undef PATCH_NP
 
     // ------------------------------------------------------------ epilogue (bias, ReLU, GN sums, bf16)
