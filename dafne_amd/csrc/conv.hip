@@ -1744,8 +1744,9 @@ __global__ void __launch_bounds__(512) conv3x3_patch_kernel(ConvDev P) {
 //   * fp8 patch pixel (py, px), 16-byte chunk c (16 channels): 128-byte row py*17 + (px>>1), chunk
 //     ((px&1)*4 + c) ^ ((px>>1)&7): the 2 x ds_read_b128 of a B fragment (32 consecutive px, 32 channels)
 //     are bank-conflict free;
-//   * the next slab's 6 bf16 patch pieces per wave are issued in both phases of steps 0..2, have landed by
-//     the wait that ends step 4, and are converted in the read phases of steps 5..7.
+//   * the next slab's 6 bf16 patch pieces per wave are issued in both phases of steps 0..2; a piece has landed
+//     three steps after its issue and piece i is converted in the read phase of step 3 + i (one piece per phase:
+//     two made that phase longer than the other group's MFMA phase).
 typedef __attribute__((ext_vector_type(8))) int i32x8;
 constexpr int kQBuf = kPPieces * 512;               // fp8 patch: 344 px x 64 B
 constexpr int kQOffStage = 2 * kPAStage;            // bf16 staging of one slab's patch (single buffer)
@@ -1908,6 +1909,9 @@ __global__ void __launch_bounds__(512) conv3x3_patch_fp8_kernel(ConvDev P) {
                                                        (((((px & 1) << 2) | (lc >> 1)) ^ ((px >> 1) & 7)) * 16) + (lc & 1) * 8);
             if (r < kPRows) asm volatile("ds_write_b64 %0, %1" ::"v"(qd), "v"(o) : "memory");
         }
+        // the last piece of a slab is converted in the slab's last step: its write must have landed before the barrier
+        // that lets the other group read the patch
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     };
 
     f32x16 acc[TC][TP];
@@ -1976,7 +1980,7 @@ __global__ void __launch_bounds__(512) conv3x3_patch_fp8_kernel(ConvDev P) {
         const int v = slab * 9 + (UU);                                                                       \
         piece_a(v + 3, 0);                                                                                   \
         if (more && (UU) <= 2) piece_p(slab + 1, 2 * (UU));                                                  \
-        if (more && (UU) >= 5 && (UU) <= 7) cvt_pieces(slab + 1, 2 * ((UU) - 5), 2);                         \
+        if (more && (UU) >= 3) cvt_pieces(slab + 1, (UU) - 3, 1);                                       \
         read_a(v);                                                                                           \
         if ((KH_) == 0) read_b6(slab, KW_);                                                                  \
         phase_end(false, 2 * v, 0);                                                                          \
@@ -1991,7 +1995,7 @@ __global__ void __launch_bounds__(512) conv3x3_patch_fp8_kernel(ConvDev P) {
         const int v = slab * 9 + (UU);                                                                       \
         piece_a(v + 3, 1);                                                                                   \
         if (more && (UU) <= 2) piece_p(slab + 1, 2 * (UU) + 1);                                              \
-        if (more && (UU) >= 5 && (UU) <= 7) cvt_pieces(slab + 1, 2 * ((UU) - 5), 2);                         \
+        if (more && (UU) >= 3) cvt_pieces(slab + 1, (UU) - 3, 1);                                       \
         read_a(v);                                                                                           \
         if ((KH_) == 0) read_b6(slab, KW_);                                                                  \
         phase_end(true, 2 * v + 1, NPATCH(UU));                                                              \
