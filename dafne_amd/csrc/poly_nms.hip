@@ -1107,44 +1107,68 @@ __device__ __forceinline__ bool quad_fast_ok(Quad& q, double& area) {
 }
 
 // returns 0: IoU < thresh - margin, 1: IoU > thresh + margin, 2: undecided (use the exact path)
+//
+// Geometric intersection area of two strictly convex CCW quads WITHOUT building the intersection polygon: its boundary
+// consists of the parts of A's edges that lie inside B and of B's edges that lie inside A, and by Green's theorem the
+// area is half the sum of cross(start, end) over those parts.  The part of an edge inside the other quad is a parameter
+// interval [t0, t1] clipped by the other quad's four half-planes (Cyrus-Beck), so everything stays in registers: 32
+// signed distances g = cross(edge, vertex - edge origin), 32 interval updates, 8 cross products -- no LDS scratch, no
+// data-dependent indexing, no divergent loop (a Sutherland-Hodgman clip through LDS took ~14 000 cycles per pair).
+// Robustness: a vertex closer than 1e-6 px to the other quad's edge line could be classified on either side (and two
+// coincident edges would then be counted twice or not at all), so any |g| <= 1e-6 * |edge| sends the pair to the exact
+// path; otherwise all inside/outside decisions are certain in fp64 and the area is accurate to ~1e-9 px^2 (coordinates
+// are taken relative to A's first vertex).  The decision margins are those of the comment above.
+__device__ __forceinline__ void boundary_part(const Quad& Pq, const Quad& Qq, double& area2, bool& shaky) {
+    double g[4][4];                          // g[i][j]: vertex i of P against edge j of Q (>= 0: inside)
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const P2 c = Qq.v[j], d = Qq.v[(j + 1) & 3];
+        const double ex = d.x - c.x, ey = d.y - c.y;
+        const double tol = 1e-12 * (ex * ex + ey * ey);
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const double v = ex * (Pq.v[i].y - c.y) - ey * (Pq.v[i].x - c.x);
+            g[i][j] = v;
+            shaky |= v * v <= tol;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const P2 a = Pq.v[i], b = Pq.v[(i + 1) & 3];
+        double t0 = 0.0, t1 = 1.0;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const double ga = g[i][j], gb = g[(i + 1) & 3][j];
+            const double tc = ga / (ga - gb);            // only used when the signs differ (ga != gb then)
+            const bool na = ga < 0.0, nb = gb < 0.0;
+            t0 = (na && !nb) ? fmax(t0, tc) : t0;        // entering the half-plane
+            t1 = (!na && nb) ? fmin(t1, tc) : t1;        // leaving it
+            t1 = (na && nb) ? -1.0 : t1;                 // wholly outside
+        }
+        if (t1 > t0) {
+            const double dx = b.x - a.x, dy = b.y - a.y;
+            const double sx = a.x + t0 * dx, sy = a.y + t0 * dy, ex2 = a.x + t1 * dx, ey2 = a.y + t1 * dy;
+            area2 += sx * ey2 - sy * ex2;
+        }
+    }
+}
+
 __device__ __forceinline__ int fast_decision(Scratch s, Quad A, Quad B, double thresh) {
     double aa, ab;
-    const bool oka = quad_fast_ok(A, aa), okb = quad_fast_ok(B, ab);
+    const bool oka = quad_fast_ok(A, aa), okb = quad_fast_ok(B, ab);       // both counter-clockwise afterwards
     if (!(oka && okb)) return 2;
-    P2* cur = s.p;      // <= 8 of the kCapP slots
-    P2* out = s.pp;
-    int n = 4;
+    const P2 o = A.v[0];
 #pragma unroll
-    for (int k = 0; k < 4; k++) cur[k * kTile] = A.v[k];
-    for (int e = 0; e < 4 && n > 0; e++) {
-        const P2 a = B.v[e], b = B.v[(e + 1) & 3];
-        const double ex = b.x - a.x, ey = b.y - a.y;
-        int m = 0;
-        P2 P = cur[0];
-        double dP = ex * (P.y - a.y) - ey * (P.x - a.x);
-        for (int i = 0; i < n; i++) {
-            const P2 Q = cur[((i + 1 == n) ? 0 : i + 1) * kTile];
-            const double dQ = ex * (Q.y - a.y) - ey * (Q.x - a.x);
-            if (dP >= 0) out[(m++) * kTile] = P;
-            if ((dP > 0 && dQ < 0) || (dP < 0 && dQ > 0)) {
-                const double t = dP / (dP - dQ);
-                P2 X;
-                X.x = P.x + (Q.x - P.x) * t;
-                X.y = P.y + (Q.y - P.y) * t;
-                out[(m++) * kTile] = X;
-            }
-            P = Q;
-            dP = dQ;
-        }
-        P2* tmp = cur; cur = out; out = tmp;
-        n = m < 9 ? m : 9;
+    for (int k = 0; k < 4; k++) {
+        A.v[k].x -= o.x; A.v[k].y -= o.y;
+        B.v[k].x -= o.x; B.v[k].y -= o.y;
     }
-    double inter = 0;
-    for (int i = 0; i < n; i++) {
-        const P2 a = cur[i * kTile], b = cur[((i + 1 == n) ? 0 : i + 1) * kTile];
-        inter += a.x * b.y - a.y * b.x;
-    }
-    inter = fabs(inter) * 0.5;
+    double area2 = 0.0;
+    bool shaky = false;
+    boundary_part(A, B, area2, shaky);
+    boundary_part(B, A, area2, shaky);
+    if (shaky) return 2;
+    const double inter = fmax(0.5 * area2, 0.0);
     const double uni = aa + ab - inter;
     if (!(uni >= 16.0)) return 2;
     const double iou = inter / uni;
