@@ -1200,17 +1200,43 @@ __global__ void __launch_bounds__(64) nms_iou_kernel(const int* __restrict__ cou
     const int nbu = (M + kTile - 1) / kTile;
     // Phase A per 64-pair chunk: one lane per pair takes the convex fast path; the undecided pairs are
     // queued and clipped 4 at a time (16 lanes each) in polyiou.cpp's own operation order.
-    __shared__ u64 exq[kTile];
+    // The undecided pairs are POOLED across chunks (a stack in LDS): a chunk leaves 1-2 of them on average, and the
+    // exact path costs the same for 1 as for 4 pairs, so it only runs on full groups of 4 (and once at the end).
+    __shared__ u64 exq[2 * kTile];
     const int chunks = w.pair_cap / kTile;
     auto record = [&](int r, int c) {
         atomicOr(&w.mask[(size_t)img * w.mask_words + tile_id(r >> 6, c >> 6, nb) * kTile + (r & 63)], 1ull << (c & 63));
         atomicOr(&w.rowflag[(size_t)img * nb + (r >> 6)], 1ull << (r & 63));
     };
-    for (long long item = gw; item < (long long)nbu * chunks; item += nw) {
+    int nq = 0;                                                  // wave-uniform stack height
+    auto exact4 = [&](int n_live) {                              // pops min(4, nq) pairs
+        const int k = nq - 1 - (lane >> 4);
+        const bool live = (lane >> 4) < n_live;
+        const u64 e2 = exq[live ? k : nq - 1];
+        const int r = (int)(unsigned)e2, c = (int)(e2 >> 32);
+        Quad A = w.dbox ? load_quad_f64(w.dbox + (ibase + r) * 8) : load_quad_f32(w.sbox + (ibase + r) * 8);
+        Quad B = w.dbox ? load_quad_f64(w.dbox + (ibase + c) * 8) : load_quad_f32(w.sbox + (ibase + c) * 8);
+        const double iou = iou_group16(s, A, B, lane);
+        if (live && (lane & 15) == 0 && iou > thresh && (!w.strict || hulls_overlap_strict(A, B))) record(r, c);
+        nq -= n_live;
+        __builtin_amdgcn_wave_barrier();
+    };
+    // Items (row block, 64-pair chunk) are dealt round-robin to the waves; most chunk slots of a row block are empty,
+    // so a wave first fetches the pair counts of its next 64 items with ONE load (lane l: item base + l*nw) and then
+    // walks only the non-empty ones -- instead of one dependent global load per item.
+    const long long total = (long long)nbu * chunks;
+    for (long long base = gw; base < total; base += 64LL * nw) {
+      const long long myit = base + (long long)lane * nw;
+      unsigned mycnt = 0u;
+      if (myit < total) mycnt = min(w.pair_cnt[(size_t)img * nb + (int)(myit / chunks)], (unsigned)w.pair_cap);
+      u64 todo = __ballot(myit < total && (unsigned)(myit % chunks) * (unsigned)kTile < mycnt);
+      while (todo) {
+        const int il = __ffsll((long long)todo) - 1;
+        todo &= todo - 1;
+        const long long item = base + (long long)il * nw;
         const int lrb = (int)(item / chunks);
         const unsigned p0 = (unsigned)(item % chunks) * (unsigned)kTile;
-        const unsigned n_pairs = min(w.pair_cnt[(size_t)img * nb + lrb], (unsigned)w.pair_cap);
-        if (p0 >= n_pairs) continue;
+        const unsigned n_pairs = (unsigned)__shfl((int)mycnt, il, 64);
         const u64* list = w.pairs + ((size_t)img * nb + lrb) * w.pair_cap;
         int dec = 0;
         u64 en = 0ull;
@@ -1229,21 +1255,13 @@ __global__ void __launch_bounds__(64) nms_iou_kernel(const int* __restrict__ cou
         }
         const u64 need = __ballot(dec == 2);
         if (need == 0ull) continue;
-        if (dec == 2) exq[__popcll(need & ((1ull << lane) - 1ull))] = en;
+        if (dec == 2) exq[nq + __popcll(need & ((1ull << lane) - 1ull))] = en;
+        nq += __popcll(need);
         __builtin_amdgcn_wave_barrier();
-        const int nq = __popcll(need);
-        for (int q0 = 0; q0 < nq; q0 += 4) {
-            const int k = q0 + (lane >> 4);
-            const bool live = k < nq;
-            const u64 e2 = exq[live ? k : nq - 1];
-            const int r = (int)(unsigned)e2, c = (int)(e2 >> 32);
-            Quad A = w.dbox ? load_quad_f64(w.dbox + (ibase + r) * 8) : load_quad_f32(w.sbox + (ibase + r) * 8);
-            Quad B = w.dbox ? load_quad_f64(w.dbox + (ibase + c) * 8) : load_quad_f32(w.sbox + (ibase + c) * 8);
-            const double iou = iou_group16(s, A, B, lane);
-            if (live && (lane & 15) == 0 && iou > thresh && (!w.strict || hulls_overlap_strict(A, B))) record(r, c);
-        }
-        __builtin_amdgcn_wave_barrier();
+        while (nq >= 4) exact4(4);
+      }
     }
+    if (nq > 0) exact4(nq);
     if (w.meta[img * 4 + 3] == 0u) return;
     // overflow phase: tiles whose pairs did not fit the list are clipped in place
     for (long long t = gw; t < ntiles; t += nw) {
