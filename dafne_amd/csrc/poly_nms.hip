@@ -1356,10 +1356,19 @@ __global__ void __launch_bounds__(kReduceThreads) nms_reduce_kernel(
             const int r0 = cb[c], r1 = cb[c + 1];
             if (r1 <= r0) continue;
             const int b0 = r0 >> 6, b1 = (r1 - 1) >> 6;
+            // the diagonal word and the row flags of block b+1 are fetched while block b is scanned (they do not depend
+            // on the scan): two global-load latencies leave the serial chain of every block
+            u64 dw_nx = mask[tile_id(b0, b0, nb) * kTile + lane];
+            u64 rf_nx = rowflag[b0];
             for (int b = b0; b <= b1; b++) {
                 const int lo = max(r0, b * kTile) - b * kTile, hi = min(r1, (b + 1) * kTile) - b * kTile;
                 const u64 rowmask = (hi >= 64 ? ~0ull : ((1ull << hi) - 1ull)) & ~((1ull << lo) - 1ull);
-                const u64 dw = ((rowmask >> lane) & 1ull) ? mask[tile_id(b, b, nb) * kTile + lane] : 0ull;
+                const u64 dw = ((rowmask >> lane) & 1ull) ? dw_nx : 0ull;
+                const u64 rf = rf_nx;
+                if (b < b1) {
+                    dw_nx = mask[tile_id(b + 1, b + 1, nb) * kTile + lane];
+                    rf_nx = rowflag[b + 1];
+                }
                 u64 bits = __ballot(dw != 0ull);
                 const unsigned dlo = (unsigned)dw, dhi = (unsigned)(dw >> 32);
                 u64 rem = remv[b];
@@ -1377,15 +1386,23 @@ __global__ void __launch_bounds__(kReduceThreads) nms_reduce_kernel(
                 }
                 const u64 K = ~rem;                         // kept rows of this class in block b
                 if (lane == 0 && K) atomicOr(&kept[b], K);
-                const u64 K2 = K & rowflag[b];
+                const u64 K2 = K & rf;
                 if (K2) {
                     for (int wd = b + 1 + lane; wd <= b1; wd += 64) {
+                        const u64* trow = mask + tile_id(b, wd, nb) * kTile;
                         u64 acc = 0ull;
                         u64 kb = K2;
-                        while (kb) {
-                            const int r = __ffsll((long long)kb) - 1;
-                            kb &= kb - 1;
-                            acc |= mask[tile_id(b, wd, nb) * kTile + r];
+                        while (kb) {                              // four independent loads in flight per step
+                            int rr[4];
+#pragma unroll
+                            for (int q = 0; q < 4; q++) {
+                                rr[q] = kb ? __ffsll((long long)kb) - 1 : -1;
+                                kb &= kb - 1;                     // (0 stays 0)
+                            }
+                            u64 v[4];
+#pragma unroll
+                            for (int q = 0; q < 4; q++) v[q] = rr[q] >= 0 ? trow[rr[q]] : 0ull;
+                            acc |= (v[0] | v[1]) | (v[2] | v[3]);
                         }
                         if (acc) atomicOr(&remv[wd], acc);
                     }
