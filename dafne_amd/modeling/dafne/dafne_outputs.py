@@ -7,9 +7,10 @@ Training (target assignment, losses; :44-731) is out of scope for this engine.
 import torch
 from torch import nn
 
+from ... import _lib
 from ... import postprocess as pp
 from ...structures import Instances
-from ..nms.nms import ml_nms
+from ..nms.nms import ml_nms  # noqa: F401  (re-exported: the reference module imports it here)
 
 
 class DAFNeOutputs(nn.Module):
@@ -84,16 +85,36 @@ class DAFNeOutputs(nn.Module):
         return pp.rows_to_instances(rows, counts, sizes)
 
     def select_over_all_levels(self, boxlists):
-        """:907-925, Instances in / Instances out (used by the TTA merge, tta.py:265)."""
+        """:907-925, Instances in / Instances out (used by the TTA merge, tta.py:265): ml_nms, then the kthvalue cap
+        with ties.  Both steps are one device call (dafne_select_over_all_levels_hip) and one host wait per image."""
         results = []
         for bl in boxlists:
-            result = ml_nms(bl, self.nms_thresh)
-            n = len(result)
-            if n > self.post_nms_topk > 0:
-                s = result.scores
-                thr = torch.kthvalue(s, n - self.post_nms_topk + 1).values
-                result = result[torch.nonzero(s >= thr).squeeze(1)]
-            results.append(result)
+            n = len(bl)
+            if self.nms_thresh <= 0 or n == 0:          # ml_nms returns its input unchanged (nms.py:22-25)
+                result = bl
+                if n > self.post_nms_topk > 0:
+                    s = result.scores
+                    thr = torch.kthvalue(s, n - self.post_nms_topk + 1).values
+                    result = result[torch.nonzero(s >= thr).squeeze(1)]
+                results.append(result)
+                continue
+            if not bl.pred_corners.is_cuda:
+                raise _lib.DafneHipError("select_over_all_levels: the MI355X engine has no CPU path (got CPU tensors)")
+            L = _lib.load()
+            dev = bl.pred_corners.device
+            with torch.cuda.device(dev):
+                b = bl.pred_corners.detach().to(torch.float32).contiguous()
+                sc = bl.scores.detach().to(torch.float32).contiguous()
+                c = bl.pred_classes.detach().to(torch.int32).contiguous()
+                keep = torch.empty(n, dtype=torch.int64, device=dev)
+                nk = torch.zeros(1, dtype=torch.int32, device=dev)
+                nbytes = L.dafne_poly_nms_workspace_bytes(1, n)
+                ws = torch.empty(max(nbytes, 256), dtype=torch.uint8, device=dev)
+                _lib.check(L.dafne_select_over_all_levels_hip(
+                    _lib.ptr(b), _lib.ptr(sc), _lib.ptr(c), None, 1, n, float(self.nms_thresh),
+                    int(max(self.post_nms_topk, 0)), _lib.ptr(keep), _lib.ptr(nk), _lib.ptr(ws), nbytes,
+                    _lib.current_stream()), "dafne_select_over_all_levels_hip")
+                results.append(bl[keep[: int(nk.item())]])
         return results
 
 
