@@ -13,7 +13,8 @@
 //
 //   * 4 waves, 2 workgroups per CU: the phases that leave the matrix pipe idle (residual / epilogue / row stores,
 //     ~45 % of a workgroup's time) overlap with the other workgroup's GEMM phases.
-//   * LDS per workgroup: T tile 32 KB + Y chunk 32 KB (four [64 px][128 B] slabs each, 16-byte chunk ^ (px & 7)) +
+//   * LDS per workgroup: T tile 32 KB + Y chunk 32 KB (four [64 px][128 B] slabs each, 16-byte chunk ^ ((px >> 1) & 7): conflict-free for the
+//     16-lane groups ds_read_b128 is serviced in over a 256-byte bank row; chunk ^ (px & 7) was 2-way conflicted) +
 //     5 KB of biases.  The residual chunk is DMA'd (global_load_lds) into the Y buffer under GEMM1 and updated in
 //     place by the epilogue.
 //   * No LDS left for a weight ring, so the A operand streams L2 -> REGISTERS: the host packs both weight matrices
@@ -117,7 +118,7 @@ __global__ void __launch_bounds__(256, 2) conv_b2b_kernel(B2bDev P) {
     for (int ii = 0; ii < 2; ii++) {
         const int px = (wave + kNW * ii) * 8 + (lane >> 3);
         dpix[ii] = halo_index(px);
-        dq[ii] = (unsigned)(((lane & 7) ^ (px & 7)) * 16);
+        dq[ii] = (unsigned)(((lane & 7) ^ ((px >> 1) & 7)) * 16);
     }
     auto dma_tile = [&](const char* src, unsigned pix_bytes, unsigned col0, int buf) {
 #pragma unroll
@@ -131,7 +132,7 @@ __global__ void __launch_bounds__(256, 2) conv_b2b_kernel(B2bDev P) {
     // ---- fragment offsets
     unsigned bs[4];                          // B fragment of k16 step s inside a slab, pixel fragment 0
 #pragma unroll
-    for (int s = 0; s < 4; s++) bs[s] = (unsigned)(frow * 128 + (((2 * s + half) ^ (frow & 7)) * 16));
+    for (int s = 0; s < 4; s++) bs[s] = (unsigned)(frow * 128 + (((2 * s + half) ^ ((frow >> 1) & 7)) * 16));
     // epilogue: the wave's 64 channels are slab `wave` of the Y buffer; this lane's row + half inside it
     const unsigned ebase = lds_base + (unsigned)(kBuf + wave * kSlab + frow * 128 + 8 * half);
 
@@ -179,7 +180,7 @@ __global__ void __launch_bounds__(256, 2) conv_b2b_kernel(B2bDev P) {
         px = px < plast ? px : plast;
         const int j = idx & 31;
         const int sl = j >> 3, q = j & 7;
-        const u32x4 v = *(const u32x4*)(lds + kBuf + sl * kSlab + px * 128 + ((q ^ (px & 7)) * 16));
+        const u32x4 v = *(const u32x4*)(lds + kBuf + sl * kSlab + px * 128 + ((q ^ ((px >> 1) & 7)) * 16));
         *(u32x4*)(dst + (size_t)halo_index(px) * pix_bytes + col0 + j * 16) = v;
     };
     // k16 step: acc[f][b] += A[f] . B[b]  (slab q of buffer buf, step s inside the slab)
@@ -207,7 +208,7 @@ __global__ void __launch_bounds__(256, 2) conv_b2b_kernel(B2bDev P) {
             // vmcnt (it cannot tell the read from the residual DMA's destination).  Pixel fragments sit 4096 B apart.
 #pragma unroll
             for (int g = 0; g < 4; g++) {
-                ead[g] = ebase + (unsigned)((((f * 4 + g) ^ (frow & 7))) * 16);
+                ead[g] = ebase + (unsigned)((((f * 4 + g) ^ ((frow >> 1) & 7))) * 16);
                 const unsigned bad = lbias_off + (unsigned)((bias0 + wave * 64 + f * 32 + 8 * g + 4 * half) * 4);
                 asm volatile("ds_read_b128 %2, %4\n\tds_read_b64 %0, %3\n\tds_read_b64 %1, %3 offset:4096"
                              : "=&v"(rc[g][0]), "=&v"(rc[g][1]), "=&v"(bv[g])
