@@ -279,8 +279,8 @@ def cpu_baseline(cfg, sd, depth, budget_s=25.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=8, help="images per GPU per step")
     ap.add_argument("--depth", type=int, default=101, choices=[50, 101])
     ap.add_argument("--size", type=int, default=1024)
