@@ -271,7 +271,19 @@ def cpu_baseline(cfg, sd, depth, budget_s=25.0):
         opp.detector_postprocess(det, (1024, 1024), (1024, 1024), (1024, 1024))
         t_total += time.perf_counter() - t0
         n_done += 1
-    return {"value": n_done / t_total, "unit": "images/sec", "cores": cores, "kind": "port",
+    # rotated NMS alone on the CPU (SURVEY 8(d) "CPU baseline beside it"): the C oracle, one thread, one image of the
+    # M = 10 000 synthetic candidate set of nms_ms_per_image (hull pre-filter on)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from conftest import rrects
+    rng = np.random.default_rng(1234)
+    bq = rrects(10000, rng, extent=1024.0)
+    sq = rng.uniform(0.05, 1, 10000).astype(np.float32)
+    cq = rng.integers(0, 15, 10000).astype(np.int64)
+    t0 = time.perf_counter()
+    kq = opp.batched_nms_poly(bq, sq, cq, 0.1, fast=True)
+    nms_cpu_ms = 1e3 * (time.perf_counter() - t0)
+    return {"rotated_nms_ms_per_img_m10000": nms_cpu_ms, "rotated_nms_cores": 1, "rotated_nms_kept": int(len(kq)),
+            "value": n_done / t_total, "unit": "images/sec", "cores": cores, "kind": "port",
             "sample": "%d x 1024x1024 image(s), R%d-FPN fp32 torch-CPU + C/numpy post-process, batch 1, %.1f s"
                       % (n_done, depth, t_total)}
 
