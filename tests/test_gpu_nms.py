@@ -294,3 +294,33 @@ def test_chunked_sort_path_with_ragged_counts():
             kth = np.sort(scores[i][exp_keep])[len(exp_keep) - 1000]
             exp_keep = exp_keep[scores[i][exp_keep] >= kth]
         assert keep[i, :int(nk[i])].cpu().tolist() == exp_keep.tolist(), i
+
+
+def test_coincident_edges_duplicates_and_nesting():
+    """Axis-parallel and 45-degree boxes on an integer grid: exact duplicates, boxes sharing whole edges or single
+    vertices, nested boxes, vertices lying on another box's edge.  These are the cases where a sign test of the
+    register-only fast path (boundary integral of clipped edge intervals) could go either way; they must be detected
+    (|signed distance| <= 1e-6 |edge|) and take the exact reference-order path.  Keep lists vs the oracle."""
+    from dafne_amd.modeling.nms import batched_nms_poly, poly_gpu_nms
+    rng = np.random.default_rng(99)
+    rows = []
+    for _ in range(1500):                       # axis-parallel, integer corners: edges coincide / touch all the time
+        x0, y0 = rng.integers(0, 40, 2) * 4.0
+        w, h = rng.integers(1, 6, 2) * 4.0
+        rows.append([x0, y0, x0 + w, y0, x0 + w, y0 + h, x0, y0 + h])
+    for _ in range(700):                        # diamonds on the same grid (vertices land on the rectangles' edges)
+        cx, cy = rng.integers(2, 40, 2) * 4.0
+        r = rng.integers(1, 4) * 4.0
+        rows.append([cx - r, cy, cx, cy - r, cx + r, cy, cx, cy + r])
+    b = np.asarray(rows, np.float32)
+    b = np.concatenate([b, b[rng.integers(0, len(b), 400)]])          # exact duplicates
+    cw = b[rng.integers(0, len(b), 200)].reshape(-1, 4, 2)[:, ::-1].reshape(-1, 8)      # clockwise twins
+    b = np.concatenate([b, cw])
+    for thr in (0.1, 0.3, 1.0 / 3.0, 0.5):
+        s = np.round(rng.uniform(0.05, 1, len(b)), 2).astype(np.float32)        # many equal scores
+        d9 = np.concatenate([b, s[:, None]], 1).astype(np.float32)
+        assert poly_gpu_nms(d9, thr, 0) == oracle.poly_nms(d9, thr)
+        # class-aware select path (class offsets, class-major tile order, IoU upper bound in the tile pre-filter)
+        c = rng.integers(0, 6, len(b))
+        got = batched_nms_poly(torch.from_numpy(b).to(dev()), torch.from_numpy(s).to(dev()), torch.from_numpy(c).to(dev()), thr)
+        assert got.cpu().tolist() == pp.batched_nms_poly(b, s, c.astype(np.int64), thr).tolist()
