@@ -135,10 +135,16 @@ def _defaults():
         VERSION=2, EXPERIMENT_NAME="dafne", OUTPUT_DIR="./output", SEED=-1,
         MODEL=model,
         INPUT=dict(FORMAT="BGR", MIN_SIZE_TEST=1024, MAX_SIZE_TEST=1024, MIN_SIZE_TRAIN=[1024],
-                   MAX_SIZE_TRAIN=1024, RESIZE_TYPE="shortest-edge"),
-        DATASETS=dict(TRAIN=[], TEST=[]),
+                   MAX_SIZE_TRAIN=1024, RESIZE_TYPE="shortest-edge",
+                   # dafne/config/defaults.py:10,26-27,121-134 (data-loader keys; kept so cfg reads never fail)
+                   HFLIP_TRAIN=True, MIN_AREA=10, MIN_SIDE=2, ROTATION_AUG_ANGLES=[0.0, 90.0, 180.0, 270.0],
+                   RESIZE_HEIGHT_TRAIN=0, RESIZE_WIDTH_TRAIN=0, RESIZE_HEIGHT_TEST=0, RESIZE_WIDTH_TEST=0,
+                   ROTATION_AUG_SAMPLE_STYLE="choice", USE_COLOR_AUGMENTATIONS=False),
+        # DOTA_REMOVE_CONTAINER_CRANE: dafne/config/defaults.py:148, read by dota_evaluation.py:120,312
+        DATASETS=dict(TRAIN=[], TEST=[], DOTA_REMOVE_CONTAINER_CRANE=False),
         DATALOADER=dict(NUM_WORKERS=4),
-        SOLVER=dict(IMS_PER_BATCH=8),
+        DEBUG=dict(OVERFIT_NUM_IMAGES=-1),
+        SOLVER=dict(IMS_PER_BATCH=8, AMP=dict(ENABLED=False), OPTIMIZER="sgd"),
         TEST=dict(DETECTIONS_PER_IMAGE=2000, IOU_TH=0.5, NUM_PRED_VIS=20, EXPECTED_RESULTS=[],
                   AUG=dict(ENABLED=False, MIN_SIZES=[1024], MAX_SIZE=1200, FLIP=True,
                            HFLIP=True, VFLIP=True, ROTATION_ANGLES=[])),

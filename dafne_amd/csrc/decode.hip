@@ -531,9 +531,13 @@ int setup(DecodeDev& D, const dafne_decode_params* prm, const dafne_level_desc* 
     D.n_images = prm->n_images; D.n_levels = prm->n_levels; D.C = prm->n_classes;
     D.topk = prm->pre_nms_topk; D.twc = prm->thresh_with_ctr; D.sortc = prm->sort_corners;
     D.m_cap = prm->m_cap; D.thresh = prm->pre_nms_thresh;
-    // scores lie in (max(thresh,0), 1]; key = bits - key_lo, top bin index < 2048
+    // key = bits - key_lo, top bin index < 2048.  THRESH_WITH_CTR: the ranked score IS the thresholded one, so
+    // scores lie in (max(thresh,0), 1] and the key range starts at the threshold.  Otherwise the candidate test is
+    // cls > thresh while the ranked score is sqrt(cls * ctr), anywhere in (0, 1] (dafne_outputs.py:812-829): the
+    // key range must start at 0, or every score below the threshold would collapse into one key and top-k would
+    // pick among them by flat index instead of by score.
     union { float f; unsigned u; } t, one;
-    t.f = prm->pre_nms_thresh > 0.f ? prm->pre_nms_thresh : 0.f;
+    t.f = (prm->thresh_with_ctr && prm->pre_nms_thresh > 0.f) ? prm->pre_nms_thresh : 0.f;
     one.f = 1.0f;
     D.key_lo = t.u < one.u ? t.u : 0u;
     unsigned range = one.u - D.key_lo;

@@ -265,6 +265,8 @@ struct NmsWs {
     u64* rowflag;    // [N][nblk]  bit r of word b: row 64b+r suppresses something
     unsigned* meta;  // [N][4]     0: max|coord| (float bits) 1: span+1 (float bits)
     unsigned* nzero; // [N]        rows with exactly zero area (census of nms_offset_kernel: select path)
+    unsigned* stats; // [N][4]     pairs decided by nms_iou: 0 fast path "suppress", 1 fast path "keep", 2 exact
+                     //            (reference-order) path from the pair lists, 3 exact path of overflowed tiles
     float* dets9;    // [N][Mp][9] (select path only)
     unsigned* pair_cnt;        // [N][nblk]  pairs appended per row block (may exceed pair_cap)
     u64* pairs;                // [N][nblk][pair_cap]  (row | col << 32), sorted positions
@@ -283,6 +285,11 @@ struct NmsWs {
     size_t mask_words;         // per image
 };
 
+// dafne_poly_nms_set_exact_only(): parity runs can switch the three analytic shortcuts off -- the guarded hull
+// pre-filter and the IoU upper bound of nms_scan, the convex decision fast path of nms_iou -- so that every pair of a
+// live tile is clipped in polyiou.cpp's own operation order.  Process-wide, read per call.
+int g_exact_only = 0;
+
 size_t carve(NmsWs& w, void* base, int N, int m_cap, bool f64 = false) {
     int Mp = (m_cap + kTile - 1) / kTile * kTile;
     if (Mp == 0) Mp = kTile;
@@ -297,6 +304,7 @@ size_t carve(NmsWs& w, void* base, int N, int m_cap, bool f64 = false) {
     w.pair_cap = Mp <= 12288 ? kPairCap : 4 * kPairCap;
     w.meta = c.take<unsigned>(n * 4);
     w.nzero = c.take<unsigned>(n);
+    w.stats = c.take<unsigned>(n * 4);
     w.pair_cnt = c.take<unsigned>(n * nblk);
     w.rowflag = c.take<u64>(n * nblk);
     w.tile_flag = c.take<unsigned char>(n * ntiles);   // meta .. tile_flag are zeroed per call (contiguous)
@@ -317,7 +325,7 @@ size_t carve(NmsWs& w, void* base, int N, int m_cap, bool f64 = false) {
     w.posidx = c.take<int>(n * Mp);
     w.use_perm = 0;
     w.strict = 0;
-    w.fast = getenv("DAFNE_NMS_NO_FAST") == nullptr ? 1 : 0;
+    w.fast = (g_exact_only || getenv("DAFNE_NMS_NO_FAST") != nullptr) ? 0 : 1;
     w.mask_words = ntiles * kTile;
     w.mask = c.take<u64>(n * w.mask_words);
     return dafne::align_up(c.off, 256);
@@ -986,7 +994,7 @@ __device__ __forceinline__ u64 tile_candidates(const NmsWs& w, int img, int M, i
     const bool colv = gcol < M;
     const float4 ch = colv ? w.hull[ibase + gcol] : make_float4(0, 0, 0, 0);
     const float R = __uint_as_float(w.meta[img * 4 + 0]);
-    const bool prefilter = thresh >= 1e-6;
+    const bool prefilter = thresh >= 1e-6 && w.fast;        // exact-only runs clip every pair of a live tile
     const bool strict = w.strict != 0;
     const double guard = 256.0 * (2e-13 * (double)R * (double)R + 1e-6) / (prefilter ? thresh : 1.0);
     // area_r + area_c > guard is implied by either area alone exceeding it (areas >= 0);
@@ -998,7 +1006,7 @@ __device__ __forceinline__ u64 tile_candidates(const NmsWs& w, int img, int M, i
     // branch-free tests, so the unrolled loop keeps 8 reads in flight)
     rhull[lane] = grow < M ? w.hull[ibase + grow] : make_float4(0, 0, 0, 0);
     const float tb = (float)thresh - 2e-3f;
-    const bool bound_on = !strict && w.dbox == nullptr && tb > 1e-3f;
+    const bool bound_on = !strict && w.dbox == nullptr && tb > 1e-3f && w.fast;
     const float k1 = (1.f + tb) * (1.f + 1e-5f), k2 = tb * (1.f - 1e-5f);
     const float ac = (bound_on && colv) ? w.farea[ibase + gcol] : -1.f;
     rarea[lane] = (bound_on && grow < M) ? w.farea[ibase + grow] : -1.f;
@@ -1209,6 +1217,7 @@ __global__ void __launch_bounds__(64) nms_iou_kernel(const int* __restrict__ cou
         atomicOr(&w.rowflag[(size_t)img * nb + (r >> 6)], 1ull << (r & 63));
     };
     int nq = 0;                                                  // wave-uniform stack height
+    unsigned n_yes = 0u, n_no = 0u, n_exact = 0u, n_ovf = 0u;    // wave-uniform path counters (w.stats)
     auto exact4 = [&](int n_live) {                              // pops min(4, nq) pairs
         const int k = nq - 1 - (lane >> 4);
         const bool live = (lane >> 4) < n_live;
@@ -1254,6 +1263,9 @@ __global__ void __launch_bounds__(64) nms_iou_kernel(const int* __restrict__ cou
             }
         }
         const u64 need = __ballot(dec == 2);
+        n_yes += (unsigned)__popcll(__ballot(dec == 1));
+        n_no += (unsigned)__popcll(__ballot(dec == 0 && en != 0ull && en != ~0ull));
+        n_exact += (unsigned)__popcll(need);
         if (need == 0ull) continue;
         if (dec == 2) exq[nq + __popcll(need & ((1ull << lane) - 1ull))] = en;
         nq += __popcll(need);
@@ -1262,7 +1274,15 @@ __global__ void __launch_bounds__(64) nms_iou_kernel(const int* __restrict__ cou
       }
     }
     if (nq > 0) exact4(nq);
-    if (w.meta[img * 4 + 3] == 0u) return;
+    auto flush_stats = [&]() {
+        if (lane == 0) {
+            if (n_yes) atomicAdd(&w.stats[img * 4 + 0], n_yes);
+            if (n_no) atomicAdd(&w.stats[img * 4 + 1], n_no);
+            if (n_exact) atomicAdd(&w.stats[img * 4 + 2], n_exact);
+            if (n_ovf) atomicAdd(&w.stats[img * 4 + 3], n_ovf);
+        }
+    };
+    if (w.meta[img * 4 + 3] == 0u) { flush_stats(); return; }
     // overflow phase: tiles whose pairs did not fit the list are clipped in place
     for (long long t = gw; t < ntiles; t += nw) {
         if (!w.tile_flag[(size_t)img * ntiles + t]) continue;
@@ -1276,6 +1296,7 @@ __global__ void __launch_bounds__(64) nms_iou_kernel(const int* __restrict__ cou
             if (lane >= o) incl += v;
         }
         const int total = __shfl(incl, 63, 64);
+        n_ovf += (unsigned)total;
         cand_s[wv][lane] = mycand;
         pre_s[wv][lane] = incl - cnt;
         __builtin_amdgcn_wave_barrier();
@@ -1301,6 +1322,7 @@ __global__ void __launch_bounds__(64) nms_iou_kernel(const int* __restrict__ cou
         }
         __builtin_amdgcn_wave_barrier();
     }
+    flush_stats();
 }
 
 // ---------------------------------------------------------------- nms_reduce
@@ -1698,6 +1720,15 @@ int dafne_poly_iou_pairs_hip(const double* d_p, const double* d_q, int64_t n, do
     hipLaunchKernelGGL(iou_pairs_kernel, dim3((unsigned)blocks), dim3(64), 0, (hipStream_t)stream, d_p,
                        d_q, (long long)n, d_out);
     return dafne::check_launch("iou_pairs");
+}
+
+void dafne_poly_nms_set_exact_only(int on) { g_exact_only = on ? 1 : 0; }
+
+size_t dafne_poly_nms_stats_offset(int n_images, int m_cap, int f64_rows) {
+    if (n_images <= 0 || m_cap < 0) return 0;
+    NmsWs w;
+    carve(w, nullptr, n_images, m_cap, f64_rows != 0);
+    return (size_t)reinterpret_cast<uintptr_t>(w.stats);
 }
 
 size_t dafne_poly_nms_workspace_bytes(int n_images, int m_cap) {

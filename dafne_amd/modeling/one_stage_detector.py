@@ -191,6 +191,9 @@ class OneStageDetector(nn.Module):
                 cs[k].wait_event(inputs_ready)
                 if st["done"][slot] is not None:
                     cs[k].wait_event(st["done"][slot])    # side stream finished with plan set `slot` (2 calls ago)
+                # the batch was allocated on the caller's stream but is read on cs[k], possibly long after the caller
+                # dropped it (the read queues behind the previous call's network): tell the caching allocator
+                images_u8.record_stream(cs[k])
                 with torch.cuda.stream(cs[k]):
                     vt = None if all_full else self._dev_const(valid_hw[lo:hi], torch.int32, (hi - lo, 2))
                     vts.append(vt)
@@ -216,6 +219,8 @@ class OneStageDetector(nn.Module):
                 done = torch.cuda.Event()
                 done.record(self.side_stream)
             st["done"][slot] = done
+            for t in res:                     # allocated on the side stream, consumed on the caller's
+                t.record_stream(main)
             return res
 
     def forward(self, batched_inputs, do_postprocess=True):

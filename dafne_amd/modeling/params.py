@@ -27,12 +27,17 @@ class ConvParams(nn.Module):
 
 
 class FrozenBNParams(nn.Module):
+    """detectron2 FrozenBatchNorm2d buffers [recalled, SURVEY App. B]: eps 1e-5 and running_var initialised to
+    1 - eps, so that a trunk that ships affine-only BN (MSRA R-50.pkl / R-101.pkl: `*_bn_s`, `*_bn_b`, no running
+    statistics) gets scale = weight * rsqrt(running_var + eps) = weight exactly."""
+    EPS = 1e-5
+
     def __init__(self, c):
         super().__init__()
         self.register_buffer("weight", torch.ones(c))
         self.register_buffer("bias", torch.zeros(c))
         self.register_buffer("running_mean", torch.zeros(c))
-        self.register_buffer("running_var", torch.ones(c))
+        self.register_buffer("running_var", torch.ones(c) - self.EPS)
 
 
 class AffineParams(nn.Module):

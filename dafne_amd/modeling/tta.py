@@ -5,8 +5,9 @@ contract as the reference's dafne/modeling/tta.py (`DotaDatasetMapperTTA` :29-13
 For every TEST.AUG.MIN_SIZES entry the image is resized (shortest edge, capped by
 MAX_SIZE) and additionally flipped horizontally / vertically; the detector runs on
 chunks of 3 views with do_postprocess=False; corners are mapped back through the
-inverse transforms (un-flip, then un-resize; float64 like detectron2's
-apply_coords on the numpy copy, :244-259) and all views are merged by ONE rotated
+inverse transforms (un-flip, then un-resize; float32 like fvcore / detectron2's
+in-place apply_coords on the float32 numpy copy, :244-259 -- python-scalar operands are weak, so the
+scale is rounded to float32 and `width - x` stays float32) and all views are merged by ONE rotated
 NMS + cap (`select_over_all_levels`, :264-268) -- up to 27 x 1000 quads, on the GPU.
 
 The pixel resampling (detectron2's ResizeTransform is PIL bilinear on uint8 [recalled]) and the flips run on
@@ -35,10 +36,10 @@ class ResizeT:
     def apply_image(self, img, hflip=False, vflip=False):            # uint8 CHW on the GPU
         return resize_u8(img, self.new_h, self.new_w, hflip, vflip)
 
-    def apply_coords(self, c):             # [n,2] float64
+    def apply_coords(self, c):             # [n,2] float32: x * float32(python double ratio), one fp32 multiply
         c = c.clone()
-        c[:, 0] = c[:, 0] * (self.new_w * 1.0 / self.w)
-        c[:, 1] = c[:, 1] * (self.new_h * 1.0 / self.h)
+        c[:, 0] = c[:, 0] * torch.tensor(self.new_w * 1.0 / self.w, dtype=c.dtype)
+        c[:, 1] = c[:, 1] * torch.tensor(self.new_h * 1.0 / self.h, dtype=c.dtype)
         return c
 
     def inverse(self):
@@ -240,13 +241,16 @@ class OneStageRCNNWithTTA(nn.Module):
         return augmented_inputs, tfms
 
     def _get_augmented_corners(self, augmented_inputs, tfms):
-        outputs = self._batch_inference_packed(augmented_inputs)
+        return self._invert_and_concat(self._batch_inference_packed(augmented_inputs), tfms)
+
+    def _invert_and_concat(self, outputs, tfms):
+        """tta.py:237-262: every view's corners back through the inverse of its transform list, then one Instances."""
         lst = []
         for output, tfm in zip(outputs, tfms):
             inst = output["instances"]
             pc = inst.pred_corners
             n = pc.shape[0]
-            orig = tfm.inverse().apply_coords(pc.reshape(-1, 2).to(torch.float64)).reshape(n, 8).to(pc.dtype)
+            orig = tfm.inverse().apply_coords(pc.reshape(-1, 2)).reshape(n, 8)      # float32 throughout (:247-259)
             r = Instances(inst.image_size)
             r.scores = inst.scores
             r.centerness = inst.centerness

@@ -85,6 +85,21 @@ int dafne_poly_nms_f64_batched_hip(const double* d_dets9, const int32_t* d_count
  * IoU: fp64 triangle-fan clip of polyiou.cpp on the float32 inputs.
  */
 size_t dafne_poly_nms_workspace_bytes(int n_images, int m_cap);
+/*
+ * Parity switch.  The in-model NMS decides `iou_poly > thresh` (polyiou.cpp:112-133 in fp64) and takes three analytic
+ * shortcuts on the way, each with a proven margin: a guarded hull-separation pre-filter, an IoU
+ * upper bound for convex pairs, and a one-lane geometric clip for convex pairs far from the threshold.
+ * dafne_poly_nms_set_exact_only(1) turns all three off for every later NMS call of the process (every pair of every
+ * live tile then runs the reference-order clip; same results, slower): what tests/test_gpu_nms.py uses to show the
+ * shortcuts change nothing.  Also set by the environment variable DAFNE_NMS_NO_FAST.
+ *
+ * dafne_poly_nms_stats_offset: byte offset inside the NMS workspace of uint32 stats[n_images][4], valid after a
+ * call has completed: pairs decided by (0) the fast path as "suppress", (1) the fast path as "keep", (2) the
+ * reference-order path, (3) the reference-order path of tiles that overflowed the pair lists.  f64_rows: 1 for the
+ * dafne_poly_nms_f64_* workspace layout.
+ */
+void dafne_poly_nms_set_exact_only(int on);
+size_t dafne_poly_nms_stats_offset(int n_images, int m_cap, int f64_rows);
 int dafne_poly_nms_hip(const float* d_dets9, int M, double thresh, int64_t* d_keep,
                        int32_t* d_num_keep, void* d_ws, size_t ws_bytes, void* stream);
 /*

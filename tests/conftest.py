@@ -38,3 +38,34 @@ def rrects(n, rng, extent=1024.0, lo=8.0, hi=256.0, jitter=0.5):
     p[:, 0::2] = c[:, :1] + ux
     p[:, 1::2] = c[:, 1:] + uy
     return (p + rng.normal(0, jitter, p.shape)).astype(np.float32)
+
+
+NMS_SET_KINDS = ("uniform", "dense", "skewed")
+
+
+def nms_candidate_set(kind, m, rng, extent=1024.0):
+    """SURVEY 8(d) synthetic candidate sets for the rotated NMS -> (boxes [m,8] f32, scores [m] f32, classes [m] i64).
+      uniform  centres U(0, extent)^2, classes uniform over 15 (the DOTA-1.0 head)
+      dense    70 % of the boxes packed into one 256 x 256 window (long suppression chains), classes uniform over 15
+      skewed   the DOTA-1.5 histogram: 16 classes, 60 % of the boxes in {4, 5, 6} (small-vehicle / large-vehicle /
+               ship; nms.py:77-79 then merges 5 into 4), the rest uniform over the other 13
+    Quads: rotated rectangles, long side log-U(8,256), aspect U(1,6), angle U(0,pi), N(0,0.5) corner jitter;
+    scores U(0.05,1)."""
+    b = rrects(m, rng, extent=extent)
+    s = rng.uniform(0.05, 1, m).astype(np.float32)
+    if kind == "uniform":
+        c = rng.integers(0, 15, m)
+    elif kind == "dense":
+        c = rng.integers(0, 15, m)
+        nd = int(0.7 * m)
+        win = rrects(nd, rng, extent=256.0)
+        win += np.float32(extent / 2 - 128.0)
+        idx = rng.permutation(m)[:nd]
+        b[idx] = win
+    elif kind == "skewed":
+        hot = rng.random(m) < 0.6
+        others = np.array([k for k in range(16) if k not in (4, 5, 6)])
+        c = np.where(hot, rng.choice([4, 5, 6], m), rng.choice(others, m))
+    else:
+        raise ValueError(kind)
+    return b.astype(np.float32), s, c.astype(np.int64)

@@ -108,6 +108,56 @@ def test_decode_candidates_vs_oracle_all_levels():
             assert np.abs(cand.hbox[im, :n].cpu().numpy() - exp["pred_boxes"]).max() < TOL
 
 
+def test_topk_ranks_below_threshold_scores_without_ctr_threshold():
+    """THRESH_WITH_CTR false (hrsc / dota-1.5 / ucas configs): the candidate test is cls > thresh but the ranked score
+    is sqrt(cls * ctr), which may lie far below the threshold (dafne_outputs.py:812-829).  With more candidates than
+    PRE_NMS_TOPK and the k-th best score BELOW the threshold the cut must still be taken by score (then lowest flat
+    index among equal scores), exactly as the oracle's topk."""
+    from dafne_amd import postprocess as pp
+    rng = np.random.default_rng(77)
+    N, C, topk = 2, 3, 200
+    sizes = [(24, 32), (12, 16)]
+    strides = [8, 16]
+    lv, raw = [], []
+    for (h, w), s in zip(sizes, strides):
+        lg = rng.normal(1.0, 1.0, (N, h, w, C)).astype(np.float32)          # cls > 0.05 almost everywhere
+        dl = rng.normal(0, 1.0, (N, h, w, 8)).astype(np.float32)
+        ce = rng.normal(0, 1.0, (N, h, w, 2)).astype(np.float32)
+        ct = rng.normal(-9.0, 1.5, (N, h, w, 1)).astype(np.float32)         # ctr ~ 1e-4: scores ~ 1e-2 < thresh
+        ct[0, : h // 2] = np.round(ct[0, : h // 2])                         # ties below the threshold too
+        lg[0, : h // 2] = np.round(lg[0, : h // 2])
+        raw.append((lg, dl, ce, ct))
+        lv.append(pp.LevelInput(*(torch.from_numpy(a).to(dev()) for a in (lg, dl, ce, ct)), s, 1.0))
+    cand = pp.decode_levels(lv, num_classes=C, pre_nms_thresh=0.05, pre_nms_topk=topk, thresh_with_ctr=False,
+                            sort_corners=False)
+    torch.cuda.synchronize()
+    for im in range(N):
+        per = []
+        for l, ((lg, dl, ce, ct), s) in enumerate(zip(raw, strides)):
+            reg = (np.tile(ce[im], (1, 1, 4)) + dl[im]).astype(np.float32)
+            per.append(opp.decode_level(np.transpose(lg[im], (2, 0, 1)), np.transpose(reg, (2, 0, 1)),
+                                        np.transpose(ct[im], (2, 0, 1)), s, thresh=0.05, topk=topk,
+                                        thresh_with_ctr=False, sort_corners=False, level=l))
+            assert per[-1]["scores"].shape[0] == topk and np.sort(per[-1]["scores"])[0] < 0.05   # the regime under test
+        exp = opp.cat(per)
+        n = int(cand.counts[im])
+        assert n == exp["scores"].shape[0]
+        gk = _key(cand.levels[im, :n].cpu().numpy(), cand.locs[im, :n].cpu().numpy(), cand.classes[im, :n].cpu().numpy())
+        ek = _key(exp["fpn_levels"], exp["locations"], exp["pred_classes"])
+        gs, es = cand.scores[im, :n].cpu().numpy(), exp["scores"]
+        if not np.array_equal(gk, ek):
+            # expf vs numpy exp may move a score by an ulp across the cut: the symmetric difference must be a handful of
+            # entries whose scores sit at the cut value
+            diff = np.setxor1d(gk, ek)
+            assert len(diff) <= 4, len(diff)
+            cut = np.sort(es)[0]
+            for k_ in diff:
+                sc = gs[gk == k_] if k_ in gk else es[ek == k_]
+                assert abs(float(sc[0]) - cut) <= 2e-7 * max(cut, 1e-30) + 1e-12
+            continue
+        assert np.abs(gs - es).max() < 1e-6
+
+
 def test_gather_postprocess_vs_oracle():
     from dafne_amd import postprocess as pp
     rng = np.random.default_rng(22)

@@ -127,6 +127,66 @@ def test_end_to_end_detections_vs_oracle_postprocess(cfgname):
         assert all(abs(gs[j] - exp["scores"][j]) < 1e-6 for j in moved)
 
 
+def test_checkpoint_file_to_engine_vs_oracle(tmp_path):
+    """F1 (tools/plain_train_net.py:576-578): a detectron2-style `.pth` ({"model": state_dict}) and an MSRA-style
+    Caffe2-named `.pkl` trunk go file -> load_weights -> packed engine weights -> features, and match the oracle run on
+    the same tensors (pkl: the running statistics the trunk does not ship keep d2's defaults, mean 0 / var 1 - eps)."""
+    import pickle
+    import dafne_amd.modeling  # noqa: F401
+    from test_model_cpu import _d2_to_c2
+    from dafne_amd.checkpoint import load_weights
+    from dafne_amd.config import load_cfg
+    from dafne_amd.registry import build_model
+    cfg = load_cfg(os.path.join(ROOT, "configs", "dota-1.0_r50.yaml"))
+    P = om.make_params(50, 15, seed=31)
+    g = torch.Generator().manual_seed(8)
+    img = torch.randint(0, 256, (1, 3, 96, 128), generator=g, dtype=torch.uint8)
+    x, _ = om.preprocess([img[0]], cfg.MODEL.PIXEL_MEAN, cfg.MODEL.PIXEL_STD)
+    # ---- .pth
+    pth = str(tmp_path / "model_final.pth")
+    torch.save({"model": P, "iteration": 90000}, pth)
+    m = build_model(cfg)
+    m.to(dev())
+    missing, unexpected = load_weights(m, pth, strict=True)
+    assert not missing and not unexpected
+    with torch.no_grad():
+        f_e = om.backbone_forward(P, x, 50, emulate_bf16=True)
+        f_32 = om.backbone_forward(P, x, 50)
+    feats = m.backbone(x.to(dev()))
+    for k in ("p3", "p4", "p5", "p6", "p7"):
+        e_emu, e_32, floor = rel(feats[k].cpu(), f_e[k]), rel(feats[k].cpu(), f_32[k]), rel(f_e[k], f_32[k])
+        assert e_emu < 2.5e-2 and e_32 < 2.5e-2 and e_32 < 1.5 * floor, (k, e_emu, e_32, floor)
+    out = m([{"image": img[0], "height": 96, "width": 128}])[0]["instances"]
+    assert len(out) > 0
+    # ---- Caffe2-named .pkl trunk over the same head / FPN
+    bu = "backbone.bottom_up."
+    c2 = {_d2_to_c2(k[len(bu):]): v.numpy() for k, v in P.items()
+          if k.startswith(bu) and not k.endswith(("running_mean", "running_var"))}
+    c2["fc1000_w"] = np.zeros((1000, 2048), np.float32)
+    pkl = str(tmp_path / "R-50.pkl")
+    with open(pkl, "wb") as f:
+        pickle.dump({"model": c2, "matching_heuristics": True}, f)
+    m2 = build_model(cfg)
+    m2.to(dev())
+    load_weights(m2, {k: v for k, v in P.items() if not k.startswith(bu)})
+    missing, unexpected = load_weights(m2, pkl)
+    assert not unexpected and all(k.endswith(("running_mean", "running_var")) for k in missing)
+    P2 = dict(P)
+    for k in P:
+        if k.startswith(bu) and k.endswith("running_mean"):
+            P2[k] = torch.zeros_like(P[k])
+        if k.startswith(bu) and k.endswith("running_var"):
+            P2[k] = torch.ones_like(P[k]) - 1e-5
+    with torch.no_grad():
+        f2_e = om.backbone_forward(P2, x, 50, emulate_bf16=True)
+        f2_32 = om.backbone_forward(P2, x, 50)
+    feats2 = m2.backbone(x.to(dev()))
+    for k in ("p3", "p4", "p5", "p6", "p7"):
+        e_emu, e_32, floor = rel(feats2[k].cpu(), f2_e[k]), rel(feats2[k].cpu(), f2_32[k]), rel(f2_e[k], f2_32[k])
+        assert e_emu < 2.5e-2 and e_32 < 2.5e-2 and e_32 < 1.5 * floor, (k, e_emu, e_32, floor)
+        assert rel(f2_32[k], f_32[k]) > 1e-3       # the two trunks really differ (statistics vs defaults)
+
+
 def test_batch_invariance_and_determinism():
     cfg, m, P = build("dota-1.0_r50.yaml", seed=7)
     g = torch.Generator().manual_seed(2)
@@ -170,6 +230,37 @@ def test_tta_merge_vs_oracle():
     assert np.array_equal(out.pred_classes.cpu().numpy(), exp["pred_classes"])
     assert np.abs(out.scores.cpu().numpy() - exp["scores"]).max() == 0
     assert np.abs(out.pred_corners.cpu().numpy() - exp["pred_corners"]).max() < 1e-3
+
+
+@pytest.mark.parametrize("name", ["d15", "d10_pre", "d15_cap"])
+def test_tta_merge_vs_reference_fixture(golden, name):
+    """The TTA stage downstream of the detector -- views built by the resize kernel, inverse coordinate maps, merged
+    rotated NMS + cap -- against tests/golden/tta_merge.npz = the reference's own tta.py
+    (_get_augmented_inputs / _get_augmented_corners / _merge_detections, :232-268) run under stubs on canned per-view
+    detections: views pixel-identical, inverse-mapped corners and the merged detections bit-equal, same order."""
+    from test_model_cpu import _tta_fixture_outputs
+    from dafne_amd.modeling.tta import DotaDatasetMapperTTA, OneStageRCNNWithTTA
+    g = golden("tta_merge")
+    cfg, m, P = build("dota-1.5_r101.yaml" if name != "d10_pre" else "dota-1.0_r101.yaml", seed=9)
+    C, post = [int(v) for v in g[name + "_cfg"]]
+    assert cfg.MODEL.DAFNE.NUM_CLASSES == C
+    cfg.TEST.AUG.MIN_SIZES = [int(v) for v in g[name + "_min_sizes"]]
+    cfg.TEST.AUG.MAX_SIZE = int(g[name + "_max_size"])
+    m.proposal_generator.dafne_outputs.post_nms_topk = m.proposal_generator.dafne_outputs.post_nms_topk_test = post
+    oh, ow = [int(v) for v in g[name + "_orig_hw"]]
+    tta = OneStageRCNNWithTTA(cfg, m)
+    aug, tfms = tta._get_augmented_inputs({"image": torch.from_numpy(g[name + "_image"]), "height": oh, "width": ow})
+    want = g[name + "_views"]
+    assert len(aug) == want.shape[0]
+    for k, v in enumerate(aug):
+        assert tuple(v["image"].shape[1:]) == (int(want[k, 0]), int(want[k, 1]))
+        if "%s_view%d_image" % (name, k) in g:
+            assert np.array_equal(v["image"].cpu().numpy(), g["%s_view%d_image" % (name, k)])
+    inst = tta._invert_and_concat(_tta_fixture_outputs(g, name, dev()), tfms)
+    assert np.array_equal(inst.pred_corners.cpu().numpy(), g[name + "_inv_corners"])
+    merged = tta._merge_detections(inst)
+    for key in ("pred_corners", "scores", "centerness", "pred_classes"):
+        assert np.array_equal(getattr(merged, key).cpu().numpy(), g["%s_merged_%s" % (name, key)]), key
 
 
 def test_tta_packed_chunks_equal_the_reference_style_loop():

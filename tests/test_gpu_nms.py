@@ -6,7 +6,7 @@ import torch
 
 import oracle
 from oracle import postprocess as pp
-from conftest import rrects
+from conftest import NMS_SET_KINDS, nms_candidate_set, rrects
 
 pytestmark = pytest.mark.gpu
 
@@ -129,6 +129,7 @@ def test_full_size_properties():
         c = rng.integers(0, 16, m)
         d9 = oracle.build_dets9(b, s, c)          # nms.py:74-90 on the host
         k = np.asarray(poly_gpu_nms(d9, 0.1, 0))
+        assert k.tolist() == oracle.poly_nms(d9, 0.1, fast=True)            # the full-size list itself, bit-exact
         # the fused device path (offsets computed on the GPU) gives the same list
         fused = batched_nms_poly(torch.from_numpy(b).to(dev()), torch.from_numpy(s).to(dev()),
                                  torch.from_numpy(c).to(dev()), 0.1)
@@ -324,3 +325,113 @@ def test_coincident_edges_duplicates_and_nesting():
         c = rng.integers(0, 6, len(b))
         got = batched_nms_poly(torch.from_numpy(b).to(dev()), torch.from_numpy(s).to(dev()), torch.from_numpy(c).to(dev()), thr)
         assert got.cpu().tolist() == pp.batched_nms_poly(b, s, c.astype(np.int64), thr).tolist()
+
+
+def _select(boxes, scores, classes, thr, post, counts=None):
+    """dafne_select_over_all_levels_hip on [N,M,*] arrays -> (list of keep lists, stats [N,4])."""
+    from dafne_amd import _lib
+    L = _lib.load()
+    N, m = scores.shape
+    d = dev()
+    tb, ts, tc = (torch.from_numpy(np.ascontiguousarray(a)).to(d) for a in (boxes, scores, classes.astype(np.int32)))
+    tn = None if counts is None else torch.tensor(counts, dtype=torch.int32, device=d)
+    keep = torch.full((N, m), -1, dtype=torch.int64, device=d)
+    nk = torch.zeros(N, dtype=torch.int32, device=d)
+    nbytes = L.dafne_poly_nms_workspace_bytes(N, m)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=d)
+    _lib.check(L.dafne_select_over_all_levels_hip(_lib.ptr(tb), _lib.ptr(ts), _lib.ptr(tc), _lib.ptr(tn), N, m, thr, post,
+                                                  _lib.ptr(keep), _lib.ptr(nk), _lib.ptr(ws), nbytes, _lib.current_stream()))
+    torch.cuda.synchronize()
+    off = L.dafne_poly_nms_stats_offset(N, m, 0)
+    stats = ws[off:off + 16 * N].view(torch.int32).reshape(N, 4).cpu().numpy()
+    return [keep[i, :int(nk[i])].cpu().tolist() for i in range(N)], stats
+
+
+def _oracle_select(b, s, c, thr, post):
+    k = pp.batched_nms_poly(b, s, c, thr, fast=True)
+    if post > 0 and len(k) > post:
+        kth = np.sort(s[k])[len(k) - post]
+        k = k[s[k] >= kth]
+    return k.tolist()
+
+
+@pytest.mark.parametrize("m", [10000, 27000])
+@pytest.mark.parametrize("kind", NMS_SET_KINDS)
+def test_full_size_sets_exact_vs_oracle(kind, m):
+    """SURVEY 8(d) candidate sets at the two full sizes -- M = 10 000 (5 levels x PRE_NMS_TOPK: configs 2/3/5) and
+    27 000 (the 27-view TTA merge: config 4) -- uniform, DENSE (70 % of the boxes in one 256^2 window) and the DOTA-1.5
+    SKEWED class histogram (60 % in {4,5,6}, 16 classes, incl. the 5 -> 4 merge): the keep lists of the class-aware
+    path (with and without the post-NMS cap) and of the plain [M,9] entry point equal the oracle's, bit for bit."""
+    from dafne_amd.modeling.nms import poly_gpu_nms
+    rng = np.random.default_rng(1234)
+    b, s, c = nms_candidate_set(kind, m, rng)
+    for post in (0, 1000):
+        got, stats = _select(b[None], s[None], c[None], 0.1, post)
+        assert got[0] == _oracle_select(b, s, c, 0.1, post), (kind, m, post)
+    assert stats[0].sum() > 0
+    d9 = oracle.build_dets9(b, s, c)
+    assert poly_gpu_nms(d9, 0.1, 0) == oracle.poly_nms(d9, 0.1, fast=True)
+    print("NMS_PATHS %s M=%d fast-suppress %d fast-keep %d exact %d exact(overflow tiles) %d" % ((kind, m) + tuple(stats[0])))
+
+
+def test_exact_only_mode_changes_nothing():
+    """dafne_poly_nms_set_exact_only(1) switches off the hull pre-filter, the IoU upper bound and the convex decision
+    fast path: every pair of every live tile goes through polyiou.cpp's operation order.  Same keep lists as the
+    default mode and as the UNFILTERED oracle, on dense / skewed sets and a batch with ragged counts."""
+    from dafne_amd import _lib
+    L = _lib.load()
+    rng = np.random.default_rng(4321)
+    sets = [nms_candidate_set(kind, 3000, rng, extent=400.0) for kind in NMS_SET_KINDS]
+    B = np.stack([x[0] for x in sets]); S = np.stack([x[1] for x in sets]); C = np.stack([x[2] for x in sets])
+    counts = [3000, 2500, 1777]
+    fast, st_fast = _select(B, S, C, 0.1, 300, counts)
+    try:
+        L.dafne_poly_nms_set_exact_only(1)
+        exact, st_exact = _select(B, S, C, 0.1, 300, counts)
+    finally:
+        L.dafne_poly_nms_set_exact_only(0)
+    assert st_exact[:, :2].sum() == 0 and st_exact[:, 2:].sum() > st_fast[:, 2:].sum()
+    assert st_fast[:, :2].sum() > 0
+    for i, n in enumerate(counts):
+        k = pp.batched_nms_poly(B[i, :n], S[i, :n], C[i, :n], 0.1, fast=False)          # unfiltered oracle
+        if len(k) > 300:
+            k = k[S[i][k] >= np.sort(S[i][k])[len(k) - 300]]
+        assert exact[i] == k.tolist() and fast[i] == k.tolist(), i
+
+
+@pytest.mark.parametrize("thr", [0.05, 0.1, 0.3, 0.5])
+def test_decision_fuzz_one_million_pairs(thr):
+    """>= 10^6 two-box images in total (250 000 per threshold) whose reference IoU lies within +-5e-3 of the threshold:
+    shifted / rotated copies with sides from 1 to 2000 px and aspect up to 1:50, fp32 class-offset magnitudes up to
+    16 x (span + 1), near-convex quads with a 1e-3 px reflex vertex, pairs sitting on the decision edge of the hull
+    IoU upper bound (tests/nms_fuzz.py).  The keep count of every image must equal the oracle's decision
+    iou_poly(fp64) > thr; the path counters say how many pairs each path decided."""
+    import nms_fuzz
+    from dafne_amd import _lib
+    L = _lib.load()
+    n, chunk = 250000, 50000
+    paths = np.zeros(4, np.int64)
+    near = 0
+    for c0 in range(0, n, chunk):
+        dets, fam = nms_fuzz.make_pairs(chunk, thr, seed=int(thr * 1000) * 100 + c0 // chunk)
+        want, iou = nms_fuzz.expected_keep_counts(dets, thr)
+        near += int((np.abs(iou - thr) <= 5.5e-3).sum())
+        d = torch.from_numpy(dets).to(dev())
+        keep = torch.empty((chunk, 2), dtype=torch.int64, device=dev())
+        nk = torch.zeros(chunk, dtype=torch.int32, device=dev())
+        nbytes = L.dafne_poly_nms_workspace_bytes(chunk, 2)
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=dev())
+        _lib.check(L.dafne_poly_nms_batched_hip(_lib.ptr(d), None, chunk, 2, thr, 0, _lib.ptr(keep), _lib.ptr(nk), _lib.ptr(ws),
+                                                nbytes, _lib.current_stream()), "nms")
+        got = nk.cpu().numpy()
+        bad = np.nonzero(got != want)[0]
+        assert len(bad) == 0, (thr, c0, bad[:10], fam[bad[:10]], iou[bad[:10]])
+        off = L.dafne_poly_nms_stats_offset(chunk, 2, 0)
+        paths += ws[off:off + 16 * chunk].view(torch.int32).reshape(chunk, 4).sum(0).cpu().numpy()
+        del ws, d, keep, nk
+    listed = int(paths.sum())
+    print("NMS_FUZZ thr=%.2f pairs=%d within5e-3=%d listed=%d fast-suppress=%d fast-keep=%d exact=%d dropped-by-scan=%d"
+          % (thr, n, near, listed, paths[0], paths[1], paths[2] + paths[3], n - listed))
+    assert near >= 0.75 * n                      # the set really hugs the threshold
+    assert paths[2] + paths[3] >= 0.3 * n        # ... so most pairs need the reference-order path,
+    assert paths[0] + paths[1] > 0               # and the fast path still decided some

@@ -83,9 +83,48 @@ def test_tta_mapper_geometry_and_inverse_transforms(monkeypatch):
     rng = np.random.default_rng(0)
     c = rng.uniform(0, 400, (5, 8)).astype(np.float32)
     for v, hf, vf in ((v_plain, False, False), (v_h, True, False), (v_v, False, True)):
-        got = v["transforms"].inverse().apply_coords(torch.from_numpy(c).reshape(-1, 2).double()).reshape(5, 8).float()
+        got = v["transforms"].inverse().apply_coords(torch.from_numpy(c).reshape(-1, 2)).reshape(5, 8)
+        assert got.dtype == torch.float32
         exp = opp.tta_invert_corners(c, (128 / nw, 96 / nh), hf, vf, (nh, nw))
         assert np.array_equal(got.numpy(), exp)
+
+
+def _tta_fixture_outputs(g, name, device="cpu"):
+    from dafne_amd.structures import Instances
+    outs = []
+    for k, (nh, nw, _, _) in enumerate(g[name + "_views"]):
+        r = Instances((int(nh), int(nw)))
+        for key in ("pred_corners", "scores", "centerness", "pred_classes"):
+            setattr(r, key, torch.from_numpy(g["%s_view%d_%s" % (name, k, key)]).to(device))
+        outs.append({"instances": r})
+    return outs
+
+
+@pytest.mark.parametrize("name", ["d15", "d10_pre", "d15_cap"])
+def test_tta_views_and_inverse_maps_vs_reference_fixture(monkeypatch, golden, name):
+    """DotaDatasetMapperTTA + OneStageRCNNWithTTA._invert_and_concat against tests/golden/tta_merge.npz (the
+    reference's tta.py run under stubs): same view order / sizes / pixels, inverse-mapped corners bit-equal.  Host
+    logic only: the oracle's Pillow-exact resampler stands in for the device kernel."""
+    import numpy as np
+    import dafne_amd.modeling.tta as tta_mod
+    from oracle import resize as orz
+    monkeypatch.setattr(tta_mod, "resize_u8", lambda im, nh, nw, hf=False, vf=False: torch.from_numpy(
+        orz.resize_bilinear_u8(im.numpy(), nh, nw, hf, vf)))
+    g = golden("tta_merge")
+    cfg = _cfg("dota-1.5_r101.yaml")
+    cfg.TEST.AUG.MIN_SIZES = [int(v) for v in g[name + "_min_sizes"]]
+    cfg.TEST.AUG.MAX_SIZE = int(g[name + "_max_size"])
+    oh, ow = [int(v) for v in g[name + "_orig_hw"]]
+    views = tta_mod.DotaDatasetMapperTTA(cfg)({"image": torch.from_numpy(g[name + "_image"]), "height": oh, "width": ow})
+    want = g[name + "_views"]
+    assert len(views) == want.shape[0]
+    for k, v in enumerate(views):
+        assert tuple(v["image"].shape[1:]) == (int(want[k, 0]), int(want[k, 1]))
+        if "%s_view%d_image" % (name, k) in g:
+            assert np.array_equal(v["image"].numpy(), g["%s_view%d_image" % (name, k)])
+    inst = tta_mod.OneStageRCNNWithTTA._invert_and_concat(None, _tta_fixture_outputs(g, name), [v["transforms"] for v in views])
+    assert inst.pred_corners.dtype == torch.float32
+    assert np.array_equal(inst.pred_corners.numpy(), g[name + "_inv_corners"])
 
 
 def test_checkpoint_loading_pth_and_c2_pkl(tmp_path):
@@ -121,3 +160,64 @@ def test_checkpoint_loading_pth_and_c2_pkl(tmp_path):
     sd2 = m2.state_dict()
     assert float(sd2["backbone.bottom_up.stem.conv1.weight"].mean()) == 0.5
     assert float(sd2["backbone.bottom_up.stem.conv1.norm.weight"][0]) == 2.0
+
+
+def _d2_to_c2(name):
+    """Test-side inverse of the Caffe2 naming (MSRA R-50.pkl / R-101.pkl keys), written independently of
+    checkpoint._c2_to_d2: `backbone.bottom_up.` stripped d2 name -> Caffe2 blob name."""
+    parts = name.split(".")
+    leaf = {"weight": "w"}
+    if parts[0] == "stem":
+        if parts[2] == "weight":
+            return "conv1_w"
+        return "res_conv1_bn_" + {"weight": "s", "bias": "b"}[parts[3]]
+    stage, blk, conv = parts[0], parts[1], parts[2]
+    br = {"shortcut": "branch1", "conv1": "branch2a", "conv2": "branch2b", "conv3": "branch2c"}[conv]
+    if parts[3] == "weight":
+        return "%s_%s_%s_w" % (stage, blk, br)
+    return "%s_%s_%s_bn_%s" % (stage, blk, br, {"weight": "s", "bias": "b"}[parts[4]])
+
+
+@pytest.mark.parametrize("depth", [50, 101])
+def test_c2_trunk_covers_every_bottom_up_key(tmp_path, depth):
+    """A complete MSRA-style trunk (every conv weight + affine BN scale / shift of R-50 / R-101 under its Caffe2 name,
+    plus the fc1000 blobs) maps onto EVERY backbone.bottom_up.* parameter; the running statistics it does not ship keep
+    d2's defaults (mean 0, var 1 - eps), for which FrozenBN folds to scale = weight exactly
+    (tools/plain_train_net.py:576-578 -> DetectionCheckpointer -> c2_model_loading [recalled])."""
+    import pickle
+    import numpy as np
+    import dafne_amd.modeling  # noqa: F401
+    from dafne_amd import engine
+    from dafne_amd.checkpoint import load_weights
+    from dafne_amd.registry import build_model
+    cfg = _cfg("dota-1.0_r%d.yaml" % depth)
+    m = build_model(cfg)
+    own = m.state_dict()
+    bu = [k for k in own if k.startswith("backbone.bottom_up.")]
+    stats = [k for k in bu if k.endswith(("running_mean", "running_var"))]
+    rng = np.random.default_rng(depth)
+    c2 = {}
+    for k in bu:
+        if k in stats:
+            continue
+        c2[_d2_to_c2(k[len("backbone.bottom_up."):])] = rng.normal(0, 1, tuple(own[k].shape)).astype(np.float32)
+    n_convs = {50: 53, 101: 104}[depth]
+    assert len(c2) == 3 * n_convs                                    # w, bn_s, bn_b per convolution
+    c2["fc1000_w"] = np.zeros((1000, 2048), np.float32)
+    c2["fc1000_b"] = np.zeros((1000,), np.float32)
+    pkl = str(tmp_path / ("R-%d.pkl" % depth))
+    with open(pkl, "wb") as f:
+        pickle.dump({"model": c2, "matching_heuristics": True}, f)
+    missing, unexpected = load_weights(m, pkl)
+    assert not unexpected
+    assert sorted(k for k in missing if k.startswith("backbone.bottom_up.")) == sorted(stats)
+    sd = m.state_dict()
+    for k in bu:
+        if k not in stats:
+            assert np.array_equal(sd[k].numpy(), c2[_d2_to_c2(k[len("backbone.bottom_up."):])]), k
+    k0 = "backbone.bottom_up.res4.5.conv2"
+    assert float(sd[k0 + ".norm.running_var"][0]) == np.float32(1.0) - np.float32(1e-5)
+    w, b = engine.fold_frozen_bn(sd[k0 + ".weight"], sd[k0 + ".norm.weight"], sd[k0 + ".norm.bias"],
+                                 sd[k0 + ".norm.running_mean"], sd[k0 + ".norm.running_var"])
+    assert torch.allclose(w, sd[k0 + ".weight"] * sd[k0 + ".norm.weight"][:, None, None, None], rtol=1e-6, atol=0)
+    assert torch.equal(b, sd[k0 + ".norm.bias"])

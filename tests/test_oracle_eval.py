@@ -83,3 +83,27 @@ def test_task1_writer_format(tmp_path):
     gt.write_text("imagesource:GoogleEarth\ngsd:0.1\n1 2 3 4 5 6 7 8 plane 1\n1 2 3 4 5 6 7 8 ship\n")
     objs = de.parse_gt(str(gt))
     assert [o["difficult"] for o in objs] == [1, 0] and objs[1]["name"] == "ship" and objs[0]["bbox"][7] == 8.0
+
+
+def test_task1_writer_with_loaded_configs(tmp_path):
+    """_generate_task_1_files / do_dota_evaluation read cfg.DATASETS.DOTA_REMOVE_CONTAINER_CRANE and cfg.TEST.IOU_TH
+    (dota_evaluation.py:120,312; default False: dafne/config/defaults.py:148): every shipped config must carry them."""
+    import glob
+    import os
+    from dafne_amd.config import get_cfg, load_cfg
+    from dafne_amd.evaluation import dota_evaluation as de
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cfgs = [get_cfg()] + [load_cfg(p) for p in sorted(glob.glob(os.path.join(root, "configs", "*.yaml")))]
+    assert len(cfgs) > 3
+    corners = np.arange(16, dtype=np.float32).reshape(2, 8)
+    preds = [{"file_name": "x/P0001__1__0___0.png", "height": 1024, "width": 1024, "corners": corners,
+              "labels": np.array([15, 0]), "scores": np.array([0.5, 0.25], np.float32),
+              "centerness": np.array([0.5, 0.5], np.float32)}]
+    names = de.CLASSNAMES_DOTA_1_0 + ["container-crane"]
+    for i, cfg in enumerate(cfgs):
+        assert cfg.DATASETS.DOTA_REMOVE_CONTAINER_CRANE is False and cfg.TEST.IOU_TH == 0.5
+        out = tmp_path / ("o%d" % i)
+        (out / "Task1").mkdir(parents=True)
+        de._generate_task_1_files(None, preds, str(out), str(out / "Task1"), names, cfg)
+        assert len((out / "Task1" / "Task1_container-crane.txt").read_text().splitlines()) == 1   # not skipped by default
+        assert len((out / "Task1" / "Task1_plane.txt").read_text().splitlines()) == 1

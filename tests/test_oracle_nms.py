@@ -68,3 +68,18 @@ def test_idempotent():
     d = oracle.build_dets9(b, s, np.zeros(800, np.int64))
     k = oracle.poly_nms(d, 0.1)
     assert oracle.poly_nms(d[k], 0.1) == list(range(len(k)))
+
+
+def test_fuzz_pair_generator_hugs_the_threshold():
+    """tests/nms_fuzz.py (the GPU decision fuzz's input): nine of ten families put the reference IoU within 5.5e-3 of the
+    threshold, on both sides of it."""
+    import nms_fuzz
+    for thr in (0.05, 0.5):
+        dets, fam = nms_fuzz.make_pairs(20000, thr, seed=3)
+        want, iou = nms_fuzz.expected_keep_counts(dets, thr)
+        assert dets.dtype == np.float32 and dets.shape == (20000, 2, 9)
+        for f in range(8):
+            k = fam == f
+            assert (np.abs(iou[k] - thr) <= 5.5e-3).mean() > 0.95, (thr, f)
+            assert 0.3 < (want[k] == 1).mean() < 0.7, (thr, f)
+        assert (np.abs(iou[fam == 8] - thr) <= 5.5e-3).mean() > 0.4      # the axis-aligned half

@@ -59,3 +59,57 @@ def test_detector_postprocess_drops_empty_and_scales():
     assert out["scores"].tolist() == pytest.approx([.9, .7])
     assert out["pred_boxes"].tolist() == [[5, 20, 10, 40], [45, 180, 50, 200]]
     assert out["pred_corners"][0].tolist() == [0, 2, 1, 6, 2, 10, 3, 14]
+
+
+TTA_CASES = ["d15", "d10_pre", "d15_cap"]
+
+
+def _tta_fixture_views(g, name):
+    """Per view: (detections in the view's frame, (h, w, hflip, vflip))."""
+    views = g[name + "_views"]
+    dets = []
+    for k in range(views.shape[0]):
+        dets.append({key: g["%s_view%d_%s" % (name, k, key)] for key in ("pred_corners", "scores", "centerness", "pred_classes")})
+    return views, dets
+
+
+@pytest.mark.parametrize("name", TTA_CASES)
+def test_tta_inverse_and_merge_golden(golden, name):
+    """oracle tta_invert_corners + select_over_all_levels vs the reference's tta.py (_get_augmented_corners /
+    _merge_detections run under stubs, tests/golden/make_golden_tta.py): the inverse-mapped corners are bit-equal
+    (float32 arithmetic, un-flip -> un-resize -> un-pre-resize) and the merged detections are the same rows in the
+    same order."""
+    g = golden("tta_merge")
+    views, dets = _tta_fixture_views(g, name)
+    h, w = g[name + "_image"].shape[1:]
+    oh, ow = [int(v) for v in g[name + "_orig_hw"]]
+    pre = None if (oh, ow) == (h, w) else (ow * 1.0 / w, oh * 1.0 / h)
+    inv = []
+    for (nh, nw, hf, vf), d in zip(views, dets):
+        c = pp.tta_invert_corners(d["pred_corners"], (w * 1.0 / nw, h * 1.0 / nh), bool(hf), bool(vf), (int(nh), int(nw)),
+                                  pre_scale_xy=pre)
+        inv.append({**d, "pred_corners": c})
+    allv = pp.cat(inv)
+    assert allv["pred_corners"].dtype == np.float32
+    assert np.array_equal(allv["pred_corners"], g[name + "_inv_corners"])
+    C, post = [int(v) for v in g[name + "_cfg"]]
+    out = pp.select_over_all_levels(allv, float(g[name + "_nms_th"]), post)
+    for key in ("pred_corners", "scores", "centerness", "pred_classes"):
+        assert np.array_equal(out[key], g["%s_merged_%s" % (name, key)]), key
+    # the fast (hull pre-filtered) oracle NMS gives the same merge
+    out2 = pp.select_over_all_levels(allv, float(g[name + "_nms_th"]), post, fast=True)
+    assert np.array_equal(out2["pred_corners"], out["pred_corners"])
+
+
+def test_tta_view_list_golden(golden):
+    """DotaDatasetMapperTTA's view order and sizes (reference tta.py:71-135 over a d2 ResizeShortestEdge stand-in):
+    per MIN_SIZES entry [resize, resize+hflip, resize+vflip]; sizes by the shortest-edge rule with the MAX_SIZE cap."""
+    from dafne_amd.modeling.tta import shortest_edge_size
+    g = golden("tta_merge")
+    for name in TTA_CASES:
+        h, w = g[name + "_image"].shape[1:]
+        want = []
+        for s in g[name + "_min_sizes"]:
+            nh, nw = shortest_edge_size(h, w, int(s), int(g[name + "_max_size"]))
+            want += [(nh, nw, 0, 0), (nh, nw, 1, 0), (nh, nw, 0, 1)]
+        assert [tuple(int(x) for x in v) for v in g[name + "_views"]] == want
