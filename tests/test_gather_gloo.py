@@ -75,3 +75,85 @@ def test_shard_range_covers_everything_once():
             lo, hi = shard_range(n, r, w)
             seen += list(range(lo, hi))
         assert seen == list(range(n))
+
+
+def _driver_worker(rank, world, port, q):
+    """The evaluation driver's shard / batch / pad / gather / order logic with the detector stubbed out
+    (tools/eval_net.py's multi-process mode minus the GPU)."""
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from dafne_amd.evaluation.driver import inference_on_images, instances_to_rows
+    from dafne_amd.evaluation.gather import to_predictions
+    from dafne_amd.structures import Boxes, Instances
+    k_cap = 16
+    results = {}
+    for n_total, batch in ((7, 3), (1, 4), (4, 1)):
+        calls = []
+
+        def detect_batch(lo, hi):                      # stub detector: image g yields g % 5 + 1 detections tagged with g
+            calls.append((lo, hi))
+            insts = []
+            for g in range(lo, hi):
+                k = g % 5 + 1
+                inst = Instances((64, 64))
+                inst.pred_corners = torch.full((k, 8), float(g))
+                inst.scores = torch.arange(k, 0, -1).float() / 10
+                inst.centerness = torch.ones(k)
+                inst.pred_classes = torch.full((k,), g, dtype=torch.int64)
+                inst.pred_boxes = Boxes(torch.zeros(k, 4))
+                insts.append(inst)
+            return instances_to_rows(insts, k_cap)
+        out = inference_on_images(detect_batch, n_total, k_cap, batch_size=batch, rank=rank, world=world)
+        per = (n_total + world - 1) // world
+        lo, hi = min(rank * per, n_total), min((rank + 1) * per, n_total)
+        ok_calls = [c for c in calls] == [(b, min(b + batch, hi)) for b in range(lo, hi, batch)]
+        if rank == 0:
+            rows, counts = out
+            preds = to_predictions(rows, counts, image_ids=list(range(n_total)))
+            ok = counts.tolist() == [g % 5 + 1 for g in range(n_total)] and rows.shape == (n_total, k_cap, 18) and all(
+                p["image_id"] == g and p["labels"].tolist() == [g] * (g % 5 + 1) and float(p["corners"][0, 0]) == g
+                for g, p in enumerate(preds))
+            results[(n_total, batch)] = ok and ok_calls
+        else:
+            results[(n_total, batch)] = out is None and ok_calls
+    q.put((rank, all(results.values()), sorted(results)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_evaluation_driver_with_stub_detector():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_driver_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(2)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(r[1] for r in res), res
+
+
+def test_single_process_driver_and_instances_roundtrip():
+    from dafne_amd import postprocess as pp
+    from dafne_amd.evaluation.driver import inference_on_images, instances_to_rows
+    from dafne_amd.structures import Boxes, Instances
+    inst = Instances((10, 20))
+    inst.pred_corners = torch.arange(24.0).reshape(3, 8)
+    inst.scores = torch.tensor([0.9, 0.5, 0.1])
+    inst.centerness = torch.tensor([0.3, 0.2, 0.1])
+    inst.pred_classes = torch.tensor([2, 0, 7])
+    inst.pred_boxes = Boxes(torch.arange(12.0).reshape(3, 4))
+    rows, counts = instances_to_rows([inst, Instances((10, 20), pred_corners=torch.zeros(0, 8), scores=torch.zeros(0),
+                                                       centerness=torch.zeros(0), pred_classes=torch.zeros(0, dtype=torch.int64))], 8)
+    assert counts.tolist() == [3, 0]
+    back = pp.rows_to_instances(rows, counts, [(10, 20), (10, 20)])
+    assert torch.equal(back[0].pred_corners, inst.pred_corners) and torch.equal(back[0].pred_classes, inst.pred_classes)
+    assert torch.equal(back[0].pred_boxes.tensor, inst.pred_boxes.tensor) and len(back[1]) == 0
+    out = inference_on_images(lambda lo, hi: (rows[lo:hi], counts[lo:hi]), 2, 8, batch_size=1)
+    assert torch.equal(out[0], rows) and out[1].tolist() == [3, 0]
+    with pytest.raises(Exception):
+        instances_to_rows([inst], 2)                     # more detections than the gather capacity

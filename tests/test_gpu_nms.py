@@ -435,3 +435,39 @@ def test_decision_fuzz_one_million_pairs(thr):
     assert near >= 0.75 * n                      # the set really hugs the threshold
     assert paths[2] + paths[3] >= 0.3 * n        # ... so most pairs need the reference-order path,
     assert paths[0] + paths[1] > 0               # and the fast path still decided some
+
+
+def test_shims_import_by_the_reference_names(golden):
+    """shims/poly_nms.py and shims/polyiou.py are what a maintainer puts on PYTHONPATH in place of the external
+    `poly_nms` CUDA extension (nms.py:6,91) and the SWIG `polyiou` module (voc_eval.py:184, ResultMerge:38-43): import
+    them by those names, call them with the reference's argument forms, compare with the golden fixtures."""
+    import importlib
+    import os
+    import sys
+    shim_dir = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "shims")
+    sys.path.insert(0, shim_dir)
+    try:
+        for name in ("poly_nms", "polyiou", "_dafne_amd_lib"):
+            sys.modules.pop(name, None)
+        poly_nms = importlib.import_module("poly_nms")
+        polyiou = importlib.import_module("polyiou")
+        assert os.path.dirname(poly_nms.__file__) == shim_dir and os.path.dirname(polyiou.__file__) == shim_dir
+        g = golden("nms_cases")
+        for name in ("rand300", "ties45", "degenerate", "kat_resultmerge"):
+            d9 = oracle.build_dets9(g[name + "_boxes"], g[name + "_scores"], g[name + "_classes"])     # nms.py:74-90
+            keep = poly_nms.poly_gpu_nms(d9, float(g[name + "_thr"]), 0)
+            assert isinstance(keep, list) and keep == g[name + "_keep"].tolist()
+        assert poly_nms.poly_gpu_nms(np.zeros((0, 9), np.float32), 0.1, 0) == []
+        gi = golden("iou_pairs")
+        for k in (0, 7, 1500, 3005, len(gi["iou"]) - 1):
+            v = polyiou.iou_poly(polyiou.VectorDouble(gi["p"][k]), polyiou.VectorDouble(gi["q"][k].tolist()))
+            assert isinstance(v, float) and v == gi["iou"][k]
+        assert np.array_equal(polyiou.iou_poly_pairs(gi["p"], gi["q"]), gi["iou"])
+        v = polyiou.VectorDouble()
+        for x in (0, 0, 1, 0, 1, 1, 0, 1):
+            v.push_back(x)
+        assert v.size() == 8 and polyiou.iou_poly(v, polyiou.VectorDouble([0.5, 0, 1.5, 0, 1.5, 1, 0.5, 1])) == 1.0 / 3.0
+    finally:
+        sys.path.remove(shim_dir)
+        for name in ("poly_nms", "polyiou", "_dafne_amd_lib"):
+            sys.modules.pop(name, None)

@@ -7,6 +7,14 @@ synthetic uint8 BGR images with seeded random weights -- config #1 of BASELINE.j
 `--config-file configs/hrsc_r50.yaml --height 800 --width 1216 --num-images 1`.
 
     python tools/eval_net.py --config-file configs/hrsc_r50.yaml [--weights model.pth] [KEY VALUE ...]
+
+Multi-GPU (plain_train_net.py:660-671 `launch(main, num_gpus, ...)`; dafne_evaluator.py:60-64): one process per GPU,
+contiguous image shards, one RCCL gather of the packed detections to rank 0, rank 0 writes the outputs.  Either
+
+    python tools/eval_net.py --num-gpus 8 --config-file ... --num-images 64 --batch 8
+    python -m torch.distributed.run --nproc-per-node 8 --master-addr 127.0.0.1 tools/eval_net.py --config-file ...
+
+(the first form spawns the workers itself, like detectron2's launch; the second reads RANK / LOCAL_RANK / WORLD_SIZE).
 """
 import argparse
 import json
@@ -19,11 +27,13 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--config-file", required=True)
     ap.add_argument("--weights", default="")
     ap.add_argument("--num-images", type=int, default=1)
+    ap.add_argument("--batch", type=int, default=1, help="images per detector call (detectron2's inference_on_dataset uses 1)")
+    ap.add_argument("--num-gpus", type=int, default=1, help="spawn this many worker processes, one per GPU")
     ap.add_argument("--height", type=int, default=0, help="synthetic image height (default INPUT.MIN_SIZE_TEST)")
     ap.add_argument("--width", type=int, default=0)
     ap.add_argument("--seed", type=int, default=0)
@@ -32,23 +42,38 @@ def main():
     ap.add_argument("--task1-dir", default="", help="DOTA configs: write Task1_<class>.txt files here and merge the tiles "
                                                     "(Task1_merged/) with the device NMS (dota_evaluation.py:110-184)")
     ap.add_argument("opts", nargs=argparse.REMAINDER, help="KEY VALUE config overrides")
-    args = ap.parse_args()
+    return ap.parse_args(argv)
 
+
+def synthetic_inputs(n, h, w, seed):
+    """Image i is a pure function of (seed, i): every rank can build exactly its own shard."""
+    out = []
+    for i in range(n):
+        g = torch.Generator().manual_seed(seed * 1000003 + i)
+        out.append({"image": torch.randint(0, 256, (3, h, w), generator=g, dtype=torch.uint8), "height": h, "width": w,
+                    "image_id": i, "file_name": "P%04d__1__0___%d.png" % (i // 4, 824 * (i % 4))})
+    return out
+
+
+def run(args, rank=0, world=1, local_rank=0):
     import dafne_amd.modeling  # noqa: F401  (registers the classes)
     from dafne_amd.checkpoint import load_weights
     from dafne_amd.config import load_cfg
-    from dafne_amd.evaluation.gather import to_predictions
+    from dafne_amd.evaluation.driver import inference_on_images, instances_to_rows
+    from dafne_amd.evaluation.gather import shard_range, to_predictions
     from dafne_amd.modeling.tta import OneStageRCNNWithTTA
     from dafne_amd.registry import build_model
 
     cfg = load_cfg(args.config_file, args.opts)
     if not torch.cuda.is_available():
         raise SystemExit("eval_net.py needs an MI355X: the HIP path has no CPU fallback")
-    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
     model = build_model(cfg)
     if args.weights or cfg.MODEL.WEIGHTS:
         missing, unexpected = load_weights(model, args.weights or cfg.MODEL.WEIGHTS)
-        print("loaded weights: %d missing, %d unexpected keys" % (len(missing), len(unexpected)))
+        if rank == 0:
+            print("loaded weights: %d missing, %d unexpected keys" % (len(missing), len(unexpected)))
     else:
         import bench
         model.load_state_dict(bench.seeded_state_dict(model, args.seed))
@@ -56,21 +81,33 @@ def main():
     model.invalidate()
     h = args.height or cfg.INPUT.MIN_SIZE_TEST
     w = args.width or cfg.INPUT.MIN_SIZE_TEST
-    g = torch.Generator().manual_seed(args.seed)
-    inputs = [{"image": torch.randint(0, 256, (3, h, w), generator=g, dtype=torch.uint8), "height": h, "width": w,
-               "image_id": i, "file_name": "P%04d__1__0___%d.png" % (i // 4, 824 * (i % 4))} for i in range(args.num_images)]
-    runner = OneStageRCNNWithTTA(cfg, model) if args.tta else model
-    outputs = []
-    for inp in inputs:                       # batch size 1 like detectron2's inference_on_dataset
-        outputs += runner([inp])
-    preds = []
-    for inp, out in zip(inputs, outputs):
-        inst = out["instances"].to("cpu")
-        preds.append({"image_id": inp["image_id"], "file_name": inp["file_name"], "height": inp["height"],
-                      "width": inp["width"], "labels": inst.pred_classes, "scores": inst.scores,
-                      "corners": inst.pred_corners, "centerness": inst.centerness})
-        print("image %d: %d detections, best score %.4f" % (inp["image_id"], len(inst),
-                                                             float(inst.scores.max()) if len(inst) else 0.0))
+    n = args.num_images
+    lo, hi = shard_range(n, rank, world)
+    all_meta = synthetic_inputs(n, h, w, args.seed) if rank == 0 and world == 1 else None
+    mine = all_meta[lo:hi] if all_meta is not None else synthetic_inputs(n, h, w, args.seed)[lo:hi]
+    k_cap = max(cfg.MODEL.DAFNE.POST_NMS_TOPK_TEST, 1) + 256
+    tta = OneStageRCNNWithTTA(cfg, model) if args.tta else None
+
+    def detect_batch(b0, b1):
+        chunk = mine[b0 - lo:b1 - lo]
+        if tta is not None:                  # one merged Instances per image -> packed rows for the gather
+            insts = [o["instances"] for o in tta(chunk)]
+            return instances_to_rows(insts, k_cap, dev)
+        batch = torch.stack([x["image"] for x in chunk]).to(dev)
+        rows, counts = model.detect_packed(batch, out_hw=[(x["height"], x["width"]) for x in chunk])
+        return rows, counts
+
+    out = inference_on_images(detect_batch, n, k_cap, batch_size=args.batch, rank=rank, world=world, device=dev)
+    torch.cuda.synchronize()
+    if rank != 0:
+        return None
+    rows_all, counts_all = out
+    meta = all_meta if all_meta is not None else synthetic_inputs(n, h, w, args.seed)
+    preds = to_predictions(rows_all, counts_all, image_ids=[m["image_id"] for m in meta])
+    for p, m in zip(preds, meta):
+        p.update(file_name=m["file_name"], height=m["height"], width=m["width"])
+        print("image %d: %d detections, best score %.4f" % (m["image_id"], len(p["scores"]),
+                                                             float(p["scores"].max()) if len(p["scores"]) else 0.0))
     if args.output:
         torch.save(preds, args.output)
     if args.task1_dir:
@@ -86,6 +123,42 @@ def main():
         n_out = sum(len(open(os.path.join(merged, f)).readlines()) for f in os.listdir(merged))
         print("Task1: %d tile detections -> %d after the tile merge (%s)" % (n_in, n_out, merged))
     return preds
+
+
+def _worker(local_rank, world, port, args):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(local_rank), LOCAL_RANK=str(local_rank),
+                      WORLD_SIZE=str(world))
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    _distributed_main(args)
+
+
+def _distributed_main(args):
+    import torch.distributed as dist
+    rank, world, local_rank = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"]), int(os.environ.get("LOCAL_RANK", "0"))
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    torch.cuda.set_device(local_rank)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    try:
+        return run(args, rank, world, local_rank)
+    finally:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def main(argv=None):
+    args = parse_args(argv)
+    if int(os.environ.get("WORLD_SIZE", "1")) > 1:            # under torch.distributed.run
+        return _distributed_main(args)
+    if args.num_gpus > 1:                                      # plain_train_net.py:660-671: launch one process per GPU
+        import socket
+        import torch.multiprocessing as mp
+        s = socket.socket()
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+        s.close()
+        mp.spawn(_worker, args=(args.num_gpus, port, args), nprocs=args.num_gpus, join=True)
+        return None
+    return run(args)
 
 
 if __name__ == "__main__":
