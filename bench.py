@@ -18,11 +18,14 @@ batch 8, one GPU) is measured in the same run at N=1 and reported under
 "configs1_r50_b8".  Random-init weights (seeded), synthetic images.
 
 Extra objects on the JSON line:
-  roofline      dominant kernel = the conv kernel (conv.hip: conv3x3_patch_kernel, conv_igemm_kernel<...> tile
-                instantiations, conv_ws_kernel, conv_stream_kernel, ...) with the most algorithmic FLOPs per step:
-                algorithmic FLOPs of its launches / their HIP-event time, vs the
-                dense bf16 MFMA peak (2.5 PFLOP/s); every instantiation is listed
-                under "kernels"
+  roofline      dominant kernel = the kernel with the most GPU time per step (whole batch on one stream: every launch
+                has the GPU to itself, the layout `--mode serial` runs and profiles/r02_kernel_stats_isolated.txt
+                profiles with rocprofv3): algorithmic FLOPs of its launches / their HIP-event time vs the dense bf16
+                MFMA peak (2.5 PFLOP/s).  "shared_stream" inside it repeats the bookkeeping for the timed region's
+                layout (3 sub-batches on concurrent streams, where a launch's duration includes sharing the GPU);
+                every instantiation is listed under "kernels" (timed layout) and "roofline_isolated"
+  roofline_nms  the rotated NMS on the SURVEY 8(d) candidate sets: class-filtered pairs per second and algorithmic bytes
+                per second against HBM
   cpu_baseline  the torch fp32 oracle (oracle/model.py + oracle/postprocess.py, a
                 port) timed on the host cores on a bounded sample, rank 0, N=1 only
 """
@@ -213,20 +216,23 @@ def conv_kernel_profile_isolated(model, batch, reps=3):
     return {k: {"tflops": v["flops"] / (v["ms"] * 1e-3) / 1e12, "frac": v["flops"] / (v["ms"] * 1e-3) / 1e12 / PEAK_BF16_TFLOPS,
                 "hbm_gbps_algorithmic": v["bytes"] / (v["ms"] * 1e-3) / 1e9,
                 "hbm_frac": v["bytes"] / (v["ms"] * 1e-3) / 1e9 / PEAK_HBM_GBPS,
-                "ms_per_step": v["ms"], "launches": v["launches"] // reps} for k, v in stats.items()}
+                "ms_per_step": v["ms"], "launches": v["launches"] // reps, "flops": v["flops"], "bytes": v["bytes"]}
+            for k, v in stats.items()}
 
 
-def nms_ms_per_image(device, m=10000, n_images=8, reps=5):
-    """Rotated-NMS ms/img (A10+A11 only) on the synthetic candidate set of SURVEY
-    8(d): M = 5 x PRE_NMS_TOPK rotated rectangles per image, seed 1234."""
+def nms_ms_per_image(device, m=10000, n_images=8, reps=5, kind="uniform", stats=None):
+    """Rotated-NMS ms/img (A10+A11 only) on the synthetic candidate sets of SURVEY
+    8(d) (tests/conftest.py nms_candidate_set: uniform / dense / skewed), seed 1234.  stats (dict): filled with the
+    algorithmic work of the set and the path counters of the last call."""
     from dafne_amd import _lib
     sys.path.insert(0, os.path.join(ROOT, "tests"))
-    from conftest import rrects
+    from conftest import nms_candidate_set
     L = _lib.load()
     rng = np.random.default_rng(1234)
-    b = np.stack([rrects(m, rng, extent=1024.0) for _ in range(n_images)])
-    s = rng.uniform(0.05, 1, (n_images, m)).astype(np.float32)
-    c = rng.integers(0, 15, (n_images, m)).astype(np.int32)
+    sets = [nms_candidate_set(kind, m, rng) for _ in range(n_images)]
+    b = np.stack([x[0] for x in sets])
+    s = np.stack([x[1] for x in sets])
+    c = np.stack([x[2] for x in sets]).astype(np.int32)
     tb, ts, tc = (torch.from_numpy(a).to(device) for a in (b, s, c))
     tn = torch.full((n_images,), m, dtype=torch.int32, device=device)
     keep = torch.empty((n_images, m), dtype=torch.int64, device=device)
@@ -244,48 +250,89 @@ def nms_ms_per_image(device, m=10000, n_images=8, reps=5):
     for _ in range(reps):
         run()
     torch.cuda.synchronize()
-    return 1e3 * (time.perf_counter() - t0) / reps / n_images
+    ms = 1e3 * (time.perf_counter() - t0) / reps / n_images
+    if stats is not None:
+        cm = np.where(c == 5, 4, c)                                 # nms.py:77-79
+        pairs_cls = sum(int(n) * (int(n) - 1) // 2 for img in cm for n in np.bincount(img))
+        off = L.dafne_poly_nms_stats_offset(n_images, m, 0)
+        st = ws[off:off + 16 * n_images].view(torch.int32).reshape(n_images, 4).sum(0).cpu().tolist()
+        nblk = (m + 63) // 64
+        stats.update({"pairs_all": n_images * m * (m - 1) // 2, "pairs_same_class": pairs_cls,
+                      "algorithmic_bytes": n_images * (36 * m + 2 * 8 * m * nblk),        # rows in, mask write + read
+                      "pairs_listed_after_hull_and_bound": int(sum(st)), "pairs_decided_fast_path": int(st[0] + st[1]),
+                      "pairs_decided_reference_order_path": int(st[2] + st[3]),
+                      "kept_mean": float(nk.float().mean().item()), "ms_per_call": ms * n_images})
+    return ms
 
 
-def cpu_baseline(cfg, sd, depth, budget_s=25.0):
-    """Oracle (port) on the host cores: full path for single 1024^2 images until
-    ~budget_s of CPU work is spent (at least one image)."""
+def _nms_one(args):
+    from oracle import postprocess as opp
+    b, s_, c = args
+    return len(opp.batched_nms_poly(b, s_, c, 0.1, fast=True))
+
+
+def cpu_baseline(cfg, sd, depth, budget_s=12.0):
+    """Oracle (port) on the host cores, bounded (~30 s of CPU work in total): the full path for single 1024^2 images
+    (batch 1, ~budget_s) and for ONE batch of 8 ("batch 1 and batch 8"); the rotated NMS alone on the
+    M = 10 000 set, one thread and all cores (8 images over a process pool: the C oracle is single-threaded)."""
     from oracle import model as om
     from oracle import postprocess as opp
     d = cfg.MODEL.DAFNE
     P = {k: v.float() for k, v in sd.items()}
     g = torch.Generator().manual_seed(0)
     cores = torch.get_num_threads()
+
+    def full_path(imgs):
+        with torch.no_grad():
+            x, sizes = om.preprocess(imgs, cfg.MODEL.PIXEL_MEAN, cfg.MODEL.PIXEL_STD)
+            f = om.backbone_forward(P, x, depth)
+            lg, rg, ce, ct = om.head_forward(P, [f[k] for k in ("p3", "p4", "p5", "p6", "p7")])
+        for i in range(len(imgs)):
+            levels = [(lg[l][i].numpy(), rg[l][i].numpy(), ct[l][i].numpy()) for l in range(5)]
+            det = opp.predict_proposals(levels, d.FPN_STRIDES, thresh=d.INFERENCE_TH_TEST, topk=d.PRE_NMS_TOPK_TEST,
+                                        nms_thresh=d.NMS_TH, post_topk=d.POST_NMS_TOPK_TEST,
+                                        thresh_with_ctr=d.THRESH_WITH_CTR, sort_corners=d.SORT_CORNERS, fast=True)
+            opp.detector_postprocess(det, (1024, 1024), (1024, 1024), (1024, 1024))
+
     n_done, t_total = 0, 0.0
     while n_done < 1 or (t_total < budget_s and n_done < 8):
         img = torch.randint(0, 256, (3, 1024, 1024), generator=g, dtype=torch.uint8)
         t0 = time.perf_counter()
-        with torch.no_grad():
-            x, sizes = om.preprocess([img], cfg.MODEL.PIXEL_MEAN, cfg.MODEL.PIXEL_STD)
-            f = om.backbone_forward(P, x, depth)
-            lg, rg, ce, ct = om.head_forward(P, [f[k] for k in ("p3", "p4", "p5", "p6", "p7")])
-        levels = [(lg[l][0].numpy(), rg[l][0].numpy(), ct[l][0].numpy()) for l in range(5)]
-        det = opp.predict_proposals(levels, d.FPN_STRIDES, thresh=d.INFERENCE_TH_TEST, topk=d.PRE_NMS_TOPK_TEST,
-                                    nms_thresh=d.NMS_TH, post_topk=d.POST_NMS_TOPK_TEST,
-                                    thresh_with_ctr=d.THRESH_WITH_CTR, sort_corners=d.SORT_CORNERS, fast=True)
-        opp.detector_postprocess(det, (1024, 1024), (1024, 1024), (1024, 1024))
+        full_path([img])
         t_total += time.perf_counter() - t0
         n_done += 1
-    # rotated NMS alone on the CPU (SURVEY 8(d) "CPU baseline beside it"): the C oracle, one thread, one image of the
-    # M = 10 000 synthetic candidate set of nms_ms_per_image (hull pre-filter on)
-    sys.path.insert(0, os.path.join(ROOT, "tests"))
-    from conftest import rrects
-    rng = np.random.default_rng(1234)
-    bq = rrects(10000, rng, extent=1024.0)
-    sq = rng.uniform(0.05, 1, 10000).astype(np.float32)
-    cq = rng.integers(0, 15, 10000).astype(np.int64)
+    imgs8 = [torch.randint(0, 256, (3, 1024, 1024), generator=g, dtype=torch.uint8) for _ in range(8)]
     t0 = time.perf_counter()
-    kq = opp.batched_nms_poly(bq, sq, cq, 0.1, fast=True)
+    full_path(imgs8)
+    t_b8 = time.perf_counter() - t0
+    # rotated NMS alone on the CPU (SURVEY 8(d) "CPU baseline beside it"): the C oracle (hull pre-filter on) on the
+    # M = 10 000 uniform candidate set of nms_ms_per_image -- one thread, then all cores
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from conftest import nms_candidate_set
+    rng = np.random.default_rng(1234)
+    sets = [nms_candidate_set("uniform", 10000, rng) for _ in range(8)]
+    t0 = time.perf_counter()
+    kq = opp.batched_nms_poly(*sets[0], 0.1, fast=True)
     nms_cpu_ms = 1e3 * (time.perf_counter() - t0)
-    return {"rotated_nms_ms_per_img_m10000": nms_cpu_ms, "rotated_nms_cores": 1, "rotated_nms_kept": int(len(kq)),
-            "value": n_done / t_total, "unit": "images/sec", "cores": cores, "kind": "port",
-            "sample": "%d x 1024x1024 image(s), R%d-FPN fp32 torch-CPU + C/numpy post-process, batch 1, %.1f s"
-                      % (n_done, depth, t_total)}
+    nms_all = {}
+    try:
+        import multiprocessing as mp
+        nproc = max(1, min(8, os.cpu_count() or 1))
+        with mp.get_context("spawn").Pool(nproc) as pool:      # spawn: never fork a process that holds a HIP context
+            pool.map(_nms_one, sets[:nproc])                    # warm (imports, page-in)
+            t0 = time.perf_counter()
+            pool.map(_nms_one, sets)
+            nms_all = {"rotated_nms_ms_per_img_m10000_all_cores": 1e3 * (time.perf_counter() - t0) / len(sets),
+                       "rotated_nms_all_cores_processes": nproc}
+    except Exception as e:      # noqa: BLE001
+        nms_all = {"rotated_nms_all_cores_error": "%s: %s" % (type(e).__name__, e)}
+    out = {"rotated_nms_ms_per_img_m10000": nms_cpu_ms, "rotated_nms_cores": 1, "rotated_nms_kept": int(len(kq)),
+           "value": n_done / t_total, "unit": "images/sec", "cores": cores, "kind": "port",
+           "batch8_images_per_sec": 8 / t_b8,
+           "sample": "%d x 1024x1024 image(s) at batch 1 (%.1f s) + one batch of 8 (%.1f s), R%d-FPN fp32 torch-CPU + "
+                     "C/numpy post-process" % (n_done, t_total, t_b8, depth)}
+    out.update(nms_all)
+    return out
 
 
 def main():
@@ -298,6 +345,10 @@ def main():
     ap.add_argument("--size", type=int, default=1024)
     ap.add_argument("--splits", type=int, default=3,
                     help="dense part runs as this many sub-batches on concurrent HIP streams")
+    ap.add_argument("--mode", choices=["pipelined", "serial"], default="pipelined",
+                    help="pipelined (default, the timed configuration): sub-batches on concurrent streams, post-process of step i "
+                         "under the convolutions of step i+1.  serial: the whole batch, every kernel alone on ONE stream -- the "
+                         "layout the isolated roofline is quoted on (profiles/r02_kernel_stats_isolated.txt)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip roofline profile pass, R50 and NMS side metrics")
     args = ap.parse_args()
@@ -326,6 +377,11 @@ def main():
         # decode + NMS + gather (+ the RCCL detection gather) ride a side stream and overlap the
         # next step's convolutions; the dense part runs as --splits sub-batches on concurrent
         # streams; every step still runs the whole path on its own batch.
+        if args.mode == "serial":
+            rows, counts = model.detect_packed(batch)
+            if distributed:
+                gather_detections(rows, counts, dst=0)
+            return rows, counts
         rows, counts = model.detect_packed(batch, pipelined=True, splits=args.splits)
         if distributed:
             with torch.cuda.stream(model.side_stream):
@@ -350,60 +406,95 @@ def main():
                    "parallelism": "dp%d (independent images, RCCL gather of detections)" % world,
                    "detections_per_image_mean": float(counts.float().mean().item())},
     }
-    if rank == 0 and not args.no_extras:
+    out["config"]["mode"] = args.mode
+    # extras only at N=1: at N>1 the other ranks would sit in the final barrier while rank 0 measures side metrics
+    if rank == 0 and world == 1 and not args.no_extras:
       try:
+        if args.mode == "serial":
+            model.detect_packed(batch, pipelined=True, splits=args.splits)     # builds the timed layout's plans for the profile
+            torch.cuda.synchronize()
         prof = conv_kernel_profile(model, batch, args.splits)
-        # dominant kernel = the one carrying the most algorithmic FLOPs of a step (the head towers' patch kernel:
-        # 45 % of the model's FLOPs; by time it is level with the 128x128 tile kernel and the pick would flip run to run)
-        domname = max(prof, key=lambda k: (prof[k]["flops"], prof[k]["ms"]))
-        dom = prof.get(domname)
-        if dom:
-            out["roofline"] = {"bound": "mfma", "achieved": dom["tflops"], "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                               "frac": dom["tflops"] / PEAK_BF16_TFLOPS, "traffic": None,
-                               "kernel": domname.replace("conv_igemm", "conv_igemm_kernel") if "igemm" in domname else domname + "_kernel",
-                               "algorithmic_bytes_per_step": dom.get("bytes"), "launches_per_step": dom["launches"],
-                               "avg_launch_us": dom["avg_launch_us"],
-                               "algorithmic_gflop_per_step": dom["flops"] / 1e9}
-            # HBM bytes per launch of that kernel from the PMC passes committed under profiles/ (rocprofv3
-            # --pmc FETCH_SIZE / WRITE_SIZE in separate runs of this same command; counters cannot be read
-            # from inside the process).  null when no PMC summary is present for the kernel.
+        iso = conv_kernel_profile_isolated(model, batch)
+        # dominant kernel = the one with the most GPU time per step when every launch has the GPU to itself (whole batch,
+        # one stream): the layout rocprofv3 profiles in profiles/r02_kernel_stats_isolated.txt (`--mode serial`)
+        domname = max(iso, key=lambda k: iso[k]["ms_per_step"])
+        di, ds = iso[domname], prof.get(domname)
+        kname = domname.replace("conv_igemm", "conv_igemm_kernel") if "igemm" in domname else domname + "_kernel"
+        out["roofline"] = {"bound": "mfma", "achieved": di["tflops"], "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                           "frac": di["frac"], "traffic": None, "kernel": kname,
+                           "layout": "isolated: whole batch of %d on one stream, launches do not overlap (bench.py --mode serial)" % args.batch,
+                           "launches_per_step": di["launches"], "avg_launch_us": 1e3 * di["ms_per_step"] / max(di["launches"], 1),
+                           "algorithmic_gflop_per_step": di["flops"] / 1e9, "algorithmic_bytes_per_step": di["bytes"],
+                           "share_of_gpu_time_per_step": di["ms_per_step"] / sum(v["ms_per_step"] for v in iso.values())}
+        # HBM bytes per launch of that kernel from the PMC passes committed under profiles/ (rocprofv3 --pmc FETCH_SIZE /
+        # WRITE_SIZE in separate runs of `bench.py --mode serial`; counters cannot be read from inside the process).
+        # null when no PMC summary is present for the kernel.
+        def pmc_traffic(fname):
             try:
-                pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
-                key = out["roofline"]["kernel"].replace(" ", "")
-                cands = [v for k, v in pmc["kernels"].items() if k == key or k.startswith(key + "<")]
+                pmc = json.load(open(os.path.join(ROOT, "profiles", fname)))
+                cands = [v for k, v in pmc["kernels"].items() if k == kname or k.startswith(kname + "<")]
                 if cands:
-                    out["roofline"]["traffic"] = 1e6 * sum(c["hbm_mb_per_launch"] for c in cands) / len(cands)
-                    out["roofline"]["traffic_unit"] = "bytes per launch (2 x FETCH_SIZE + WRITE_SIZE), " + pmc["source"]
+                    return 1e6 * sum(c["hbm_mb_per_launch"] for c in cands) / len(cands), pmc["source"]
             except (OSError, KeyError, ValueError):
                 pass
-            out["roofline"]["concurrent_streams"] = args.splits
-            # the same launches, counted over the wall time during which at least one of them runs (they overlap on the
-            # three streams; launches of OTHER kernels still share the GPU in that window)
-            if dom.get("union_ms", 0) > 0:
-                out["roofline"]["achieved_over_union_of_launches"] = dom["flops"] / (dom["union_ms"] * 1e-3) / 1e12
-                out["roofline"]["frac_over_union_of_launches"] = out["roofline"]["achieved_over_union_of_launches"] / PEAK_BF16_TFLOPS
-            out["roofline"]["note"] = ("launches of %d sub-batches share the GPU on concurrent streams: a launch's "
-                                       "duration includes that sharing (as rocprofv3 reports it); see "
-                                       "roofline_isolated for the same kernels with the GPU to themselves" % args.splits)
+            return None, None
+        tr, src = pmc_traffic("pmc_traffic_isolated.json")
+        if tr is not None:
+            out["roofline"]["traffic"] = tr
+            out["roofline"]["traffic_unit"] = "bytes per launch (2 x FETCH_SIZE + WRITE_SIZE), " + src
+        if ds:
+            out["roofline"]["shared_stream"] = {
+                "achieved": ds["tflops"], "frac": ds["tflops"] / PEAK_BF16_TFLOPS, "launches_per_step": ds["launches"],
+                "avg_launch_us": ds["avg_launch_us"], "concurrent_streams": args.splits,
+                "achieved_over_union_of_launches": ds["flops"] / (ds["union_ms"] * 1e-3) / 1e12 if ds.get("union_ms", 0) > 0 else None,
+                "note": "the timed region's layout: launches of %d sub-batches share the GPU on concurrent streams, so a "
+                        "launch's duration includes that sharing (as rocprofv3 reports it for the default command)" % args.splits}
+            tr2, src2 = pmc_traffic("pmc_traffic.json")
+            if tr2 is not None:
+                out["roofline"]["shared_stream"]["traffic"] = tr2
+                out["roofline"]["shared_stream"]["traffic_unit"] = "bytes per launch at sub-batch size, " + src2
         out["kernels"] = {k: {"tflops": v["tflops"], "ms_per_step": v["ms"], "launches": v["launches"],
                               "hbm_gbps_algorithmic": v["bytes"] / (v["ms"] * 1e-3) / 1e9} for k, v in prof.items()}
         # the HBM-bound kernel family next to the MFMA-bound dominant one: persistent weight-stationary 1x1 layers
-        if "conv_ws" in prof:
-            wsk = prof["conv_ws"]
-            out["roofline_hbm"] = {"bound": "hbm", "kernel": "conv_ws_kernel", "achieved": wsk["bytes"] / (wsk["ms"] * 1e-3) / 1e9,
-                                   "peak": PEAK_HBM_GBPS, "unit": "GB/s", "frac": wsk["bytes"] / (wsk["ms"] * 1e-3) / 1e9 / PEAK_HBM_GBPS,
-                                   "launches_per_step": wsk["launches"], "avg_launch_us": wsk["avg_launch_us"],
-                                   "algorithmic_bytes_per_step": wsk["bytes"],
-                                   "note": "in the timed stream layout (3 sub-batches share the GPU); roofline_isolated has the same kernels alone"}
-        out["roofline_isolated"] = conv_kernel_profile_isolated(model, batch)
+        if "conv_ws" in iso:
+            wi, wsk = iso["conv_ws"], prof.get("conv_ws")
+            out["roofline_hbm"] = {"bound": "hbm", "kernel": "conv_ws_kernel", "achieved": wi["hbm_gbps_algorithmic"],
+                                   "peak": PEAK_HBM_GBPS, "unit": "GB/s", "frac": wi["hbm_frac"], "layout": "isolated (as roofline)",
+                                   "launches_per_step": wi["launches"], "avg_launch_us": 1e3 * wi["ms_per_step"] / max(wi["launches"], 1),
+                                   "algorithmic_bytes_per_step": wi["bytes"]}
+            if wsk:
+                out["roofline_hbm"]["shared_stream"] = {"achieved": wsk["bytes"] / (wsk["ms"] * 1e-3) / 1e9,
+                                                        "frac": wsk["bytes"] / (wsk["ms"] * 1e-3) / 1e9 / PEAK_HBM_GBPS,
+                                                        "launches_per_step": wsk["launches"], "avg_launch_us": wsk["avg_launch_us"]}
+        out["roofline_isolated"] = {k: {kk: vv for kk, vv in v.items() if kk not in ("flops", "bytes")} for k, v in iso.items()}
         tot_flops = sum(v["flops"] for v in prof.values())
         out["model_tflops_end_to_end"] = tot_flops / (dt / args.steps) / 1e12
         out["mfma_frac_end_to_end"] = out["model_tflops_end_to_end"] / PEAK_BF16_TFLOPS
-        out["rotated_nms_ms_per_img"] = nms_ms_per_image(device)
-        # SURVEY 8(d) candidate-set sizes: per-level / per-image worst cases and the 27-view TTA merge (one image)
-        out["rotated_nms_ms_per_img_by_m"] = {"500x8": nms_ms_per_image(device, m=500), "2000x8": nms_ms_per_image(device, m=2000),
-                                              "10000x8": out["rotated_nms_ms_per_img"],
-                                              "27000x1": nms_ms_per_image(device, m=27000, n_images=1)}
+        # rotated NMS (A10 + A11), SURVEY 8(d) candidate sets: sizes 500 / 2000 / 10 000 per image (batch of 8) and the
+        # 27 000-row TTA merge (one image); uniform, DENSE (70 % of the boxes in one 256^2 window) and the DOTA-1.5
+        # SKEWED class histogram (60 % in {4,5,6})
+        nms_stats = {}
+        by_m = {}
+        for kind in ("uniform", "dense", "skewed"):
+            for m, n_img in ((500, 8), (2000, 8), (10000, 8), (27000, 1)):
+                if kind != "uniform" and m < 10000:
+                    continue
+                st = {}
+                key = "%dx%d" % (m, n_img) + ("" if kind == "uniform" else "_" + kind)
+                by_m[key] = nms_ms_per_image(device, m=m, n_images=n_img, kind=kind, stats=st)
+                nms_stats[key] = st
+        out["rotated_nms_ms_per_img"] = by_m["10000x8"]
+        out["rotated_nms_ms_per_img_by_m"] = by_m
+        # NMS roofline on the hardest full-size set: the unit of work is a pair of same-class boxes (the class offsets of
+        # nms.py:81-83 make every other pair a certain "no"); bytes = rows in + suppression mask written and read
+        hard = max((k for k in by_m if k.startswith("10000x8")), key=lambda k: by_m[k])
+        hs = nms_stats[hard]
+        sec = hs["ms_per_call"] * 1e-3
+        out["roofline_nms"] = {"set": hard, "bound": "latency / fp64 vector ALU (not MFMA, not HBM)", "ms_per_img": by_m[hard],
+                               "same_class_pairs_per_sec": hs["pairs_same_class"] / sec, "all_pairs_per_sec": hs["pairs_all"] / sec,
+                               "algorithmic_bytes_per_call": hs["algorithmic_bytes"],
+                               "achieved": hs["algorithmic_bytes"] / sec / 1e9, "peak": PEAK_HBM_GBPS, "unit": "GB/s",
+                               "frac": hs["algorithmic_bytes"] / sec / 1e9 / PEAK_HBM_GBPS, "per_set": nms_stats}
         if world == 1 and args.depth == 101:
             # side metrics on the other BASELINE configs: each one is guarded -- a failure there must never cost the
             # headline line

@@ -9,7 +9,7 @@ ROOT=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$ROOT/gpurun_out/pmc_$TAG
 mkdir -p $OUT
 cd /tmp; export TMPDIR=/tmp
-CMD="python $ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extras"
+CMD="python $ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extras ${BENCH_FLAGS:-}"
 for c in FETCH_SIZE WRITE_SIZE "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE"; do
   d=$OUT/$(echo $c | cut -d' ' -f1)
   timeout 600 rocprofv3 --kernel-trace --pmc $c -d $d -o p --output-format csv -- $CMD > $d.log 2>&1

@@ -79,8 +79,8 @@ def main():
                 traffic[k]["mfma_util_at_nominal_clock"] = round(u_nom, 4)
     txt = "\n".join(lines) + "\n"
     open(os.path.join(root, "summary.txt"), "w").write(txt)
-    src = ("profiles/r01_pmc_%s.txt (rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE / SQ_VALU_MFMA_BUSY_CYCLES, "
-           "separate passes; hbm = 2 x FETCH_SIZE + WRITE_SIZE, the gfx950 correction of MI355X_MICROARCH.md)" % tag)
+    src = ("profiles/%s_pmc_%s.txt (rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE / SQ_VALU_MFMA_BUSY_CYCLES, "
+           "separate passes; hbm = 2 x FETCH_SIZE + WRITE_SIZE, the gfx950 correction of MI355X_MICROARCH.md)" % (os.environ.get("PMC_ROUND", "r02"), tag))
     json.dump({"source": src, "kernels": traffic}, open(os.path.join(root, "pmc_traffic.json"), "w"), indent=1)
     print(txt)
 
