@@ -121,13 +121,13 @@ def pack_stem(weight, bias, device):
 
 def pack_b2b(w3, w1):
     """Fragment-major weights of dafne_bottleneck_tail_head_hip from the packed 1x1 weights of conv3 ([1024, 256] bf16)
-    and the next block's conv1 ([256, 1024] bf16): bf16 [8 phases][4 waves][16 k16-steps][2 fragments][64 lanes][8];
-    phase 2c = conv3 rows c*256 + wave*64 + frag*32 + (lane & 31) over K = 256, phase 2c+1 = conv1 rows wave*64 +
-    frag*32 + (lane & 31) over K-chunk c; K columns 16*step + 8*(lane >> 5) .. +8."""
+    and the next block's conv1 ([256, 1024] bf16): bf16 [8 phases][8 waves][16 k16-steps][64 lanes][8];
+    phase 2c = conv3 rows c*256 + wave*32 + (lane & 31) over K = 256, phase 2c+1 = conv1 rows wave*32 + (lane & 31)
+    over K-chunk c; K columns 16*step + 8*(lane >> 5) .. +8."""
     assert tuple(w3.shape) == (1024, 256) and tuple(w1.shape) == (256, 1024) and w3.dtype == BF16 and w1.dtype == BF16
-    a1 = w3.reshape(4, 4, 2, 32, 16, 2, 8).permute(0, 1, 4, 2, 5, 3, 6)      # c, w, t, f, h, r, e
-    a2 = w1.reshape(4, 2, 32, 4, 16, 2, 8).permute(3, 0, 4, 1, 5, 2, 6)      # c, w, t, f, h, r, e
-    return torch.stack([a1, a2], dim=1).contiguous().reshape(8, 4, 16, 2, 64, 8)
+    a1 = w3.reshape(4, 8, 32, 16, 2, 8).permute(0, 1, 3, 4, 2, 5)          # c, w, t, h, r, e
+    a2 = w1.reshape(8, 32, 4, 16, 2, 8).permute(2, 0, 3, 4, 1, 5)          # c, w, t, h, r, e
+    return torch.stack([a1, a2], dim=1).contiguous().reshape(8, 8, 16, 64, 8)
 
 
 def fold_frozen_bn(weight, bn_w, bn_b, bn_mean, bn_var, eps=1e-5):
