@@ -140,8 +140,10 @@ def conv_kernel_profile(model, batch, splits, reps=3):
         ref = torch.cuda.Event(enable_timing=True)
         ref.record(cs[0])
         # same enqueue order as the timed region: launch j of every sub-batch, each on its stream
-        for j in range(len(plans[0].calls)):
+        for j in range(max(len(p.calls) for p in plans)):
             for k, plan in enumerate(plans):
+                if j >= len(plan.calls):
+                    continue
                 c = plan.calls[j]
                 if getattr(c, "flops", 0) > 0:        # ConvCall or a matrix FnCall (stem_pool)
                     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

@@ -43,7 +43,8 @@ class ConvParams(ctypes.Structure):
                 ("KH", c_i32), ("KW", c_i32), ("stride", c_i32), ("pad", c_i32),
                 ("flags", c_u32), ("d_weight", c_void_p), ("d_bias", c_void_p),
                 ("d_gn_partial", c_void_p), ("d_in_gn_stats", c_void_p), ("d_in_gn_gamma", c_void_p),
-                ("d_in_gn_beta", c_void_p)]
+                ("d_in_gn_beta", c_void_p), ("d_gn_stats_out", c_void_p), ("d_gn_counters", c_void_p),
+                ("gn_eps", c_float)]
 
 
 class GnSeg(ctypes.Structure):

@@ -9,6 +9,6 @@ char* err_buf() {
 }  // namespace dafne
 
 extern "C" {
-int dafne_abi_version(void) { return 100; }  // 0.1.0
+int dafne_abi_version(void) { return 110; }  // 0.1.1: dafne_conv_params grew (GN_FINALIZE), b2b weight layout
 const char* dafne_last_error(void) { return dafne::err_buf(); }
 }

@@ -68,6 +68,9 @@ struct ConvDev {
     const float* in_beta;    //           [Cin]
     const float* oscale;     // fp8 path: [Cout] output scale (weight scale / in_qscale)
     float in_qscale;         // fp8 path: activations are multiplied by this before the e4m3 rounding
+    float* gn_stats_out;     // GN_FINALIZE: [n_segs][N][Cout/8][2] mean, rstd (written by the last tile of every image)
+    int* gn_counters;        // GN_FINALIZE: [n_segs][N] arrival tickets, zero between launches
+    float gn_eps;
 };
 
 __device__ __forceinline__ unsigned short f2bf(float f) {
@@ -1284,6 +1287,73 @@ __global__ void __launch_bounds__(256, 2) conv_ws_kernel(ConvDev P) {
     }
 }
 
+
+// ---------------------------------------------------------------------------------------
+// GN_FINALIZE (patch kernels): the GroupNorm statistics of the output are finalised by the LAST tile of every
+// (segment, image) to finish, instead of by a separate launch (gn_finalize_kernel, dense_ops.hip: 36 launches per
+// step of the R101 head, each a serialisation point between two tower convolutions).
+//   * every tile publishes its 32 (sum, sum-sq) pairs as 8-byte agent-scope atomic stores (write-through, never left
+//     in an L2 another XCD cannot see), wave 0 drains them (`s_waitcnt vmcnt(0)`: the stores are its own) and takes a
+//     ticket on the image's counter with a relaxed agent-scope fetch-add;
+//   * the tile that draws tiles_per_img - 1 reads all partials of the image back with 8-byte agent-scope atomic
+//     loads (both sides of the hand-off are device-scope atomics: valid for any placement of the tiles on XCDs /
+//     CUs, cdna_hip_programming.md G16) and reduces them IN gn_finalize_kernel's ORDER -- 32 slices of tiles
+//     sl, sl + 32, .., then the slices in order -- so mean / rstd are bit-identical to the separate kernel and do not
+//     depend on which tile came last; it then resets the counter for the next launch.
+// `scratch`: >= 32 * 32 * 2 floats of LDS nobody else touches any more; `flag`: one LDS int.  All 512 threads call.
+__device__ __forceinline__ void gn_fused_finalize(const ConvDev& P, const SegDev& S, int si, int img, int mt,
+                                                  const float (&sq)[2], bool writer, int group, float* scratch, int* flag) {
+    const int tid = threadIdx.x;
+    const int G = P.Cout / 8;
+    typedef unsigned long long u64a;
+    if (writer) {
+        const u64a v = ((u64a)__float_as_uint(sq[1]) << 32) | (u64a)__float_as_uint(sq[0]);
+        __hip_atomic_store((u64a*)(P.gn_partial + ((size_t)mt * G + group) * 2), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (tid < 64) {                                    // wave 0 holds every writer lane
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (tid == 0) {
+            const int old = __hip_atomic_fetch_add(P.gn_counters + si * P.N + img, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            *flag = old == S.tiles_per_img - 1;
+        }
+    }
+    __syncthreads();
+    if (!*flag) return;
+    const int t0 = S.tile0 + img * S.tiles_per_img;
+    const int g = tid & 31;
+#pragma unroll
+    for (int k = 0; k < 2; k++) {
+        const int sl = (tid >> 5) + 16 * k;            // 512 threads cover gn_finalize_kernel's 32 slices in two rounds
+        float sum = 0.f, sqs = 0.f;
+        if (g < G)
+            for (int t = sl; t < S.tiles_per_img; t += 32) {
+                const u64a v = __hip_atomic_load((const u64a*)(P.gn_partial + ((size_t)(t0 + t) * G + g) * 2), __ATOMIC_RELAXED,
+                                                 __HIP_MEMORY_SCOPE_AGENT);
+                sum += __uint_as_float((unsigned)v);
+                sqs += __uint_as_float((unsigned)(v >> 32));
+            }
+        scratch[(sl * 32 + g) * 2 + 0] = sum;
+        scratch[(sl * 32 + g) * 2 + 1] = sqs;
+    }
+    __syncthreads();
+    if (tid < 32 && tid < G) {
+        float a = 0.f, b = 0.f;
+#pragma unroll
+        for (int k = 0; k < 32; k++) {
+            a += scratch[(k * 32 + tid) * 2 + 0];
+            b += scratch[(k * 32 + tid) * 2 + 1];
+        }
+        const float cnt = (float)(S.Hout * S.Wout * 8);
+        const float mean = a / cnt;
+        float var = b / cnt - mean * mean;
+        var = var > 0.f ? var : 0.f;
+        float* o = P.gn_stats_out + (((size_t)si * P.N + img) * G + tid) * 2;
+        o[0] = mean;
+        o[1] = rsqrtf(var + P.gn_eps);
+    }
+    if (tid == 0) __hip_atomic_store(P.gn_counters + si * P.N + img, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 // ---------------------------------------------------------------------------------------
 // 3x3 stride-1 convolution fed from an LDS-staged input PATCH (im2col inside LDS).
 //
@@ -1641,6 +1711,9 @@ __global__ void __launch_bounds__(512) conv3x3_patch_kernel(ConvDev P) {
     // ------------------------------------------------------------ epilogue (bias, ReLU, GN sums, bf16)
     const bool relu = P.flags & DAFNE_CONV_RELU;
     const bool gn = P.flags & DAFNE_CONV_GN_STATS;
+    const bool fin = gn && (P.flags & DAFNE_CONV_GN_FINALIZE);     // wave-uniform
+    float fin_sq[2] = {0.f, 0.f};
+    bool fin_writer = false;
     constexpr int ROWB = BN * 2 + 16;
     constexpr int CHB = BN / 8;
     char* stg = lds;
@@ -1708,9 +1781,15 @@ __global__ void __launch_bounds__(512) conv3x3_patch_kernel(ConvDev P) {
         }
         const int group = (nt * BN) / 8 + tid;
         if (group < P.Cout / 8) {
-            float* o = P.gn_partial + ((size_t)mt * (P.Cout / 8) + group) * 2;
-            o[0] = sv;
-            o[1] = qv;
+            if (fin) {
+                fin_sq[0] = sv;
+                fin_sq[1] = qv;
+                fin_writer = true;
+            } else {
+                float* o = P.gn_partial + ((size_t)mt * (P.Cout / 8) + group) * 2;
+                o[0] = sv;
+                o[1] = qv;
+            }
         }
     }
     constexpr int CPT = BM * CHB / NT;       // 16-byte chunks per thread
@@ -1724,6 +1803,10 @@ __global__ void __launch_bounds__(512) conv3x3_patch_kernel(ConvDev P) {
             const uint4 v = *(const uint4*)(stg + p * ROWB + cc * 16);
             *(uint4*)(S.out + (opix * P.Cout + nt * BN + cc * 8) * 2) = v;
         }
+    }
+    if (fin) {
+        __syncthreads();                     // the staging tile has been read: its LDS is free for the reduction
+        gn_fused_finalize(P, S, si, img, mt, fin_sq, fin_writer, tid, (float*)lds, (int*)(lds + 32 * 32 * 2 * 4));
     }
 }
 
@@ -2037,6 +2120,9 @@ __global__ void __launch_bounds__(512) conv3x3_patch_fp8_kernel(ConvDev P) {
     // ------------------------------------------------------------ epilogue (scale, bias, ReLU, GN sums, bf16)
     const bool relu = P.flags & DAFNE_CONV_RELU;
     const bool gn = P.flags & DAFNE_CONV_GN_STATS;
+    const bool fin = gn && (P.flags & DAFNE_CONV_GN_FINALIZE);     // wave-uniform
+    float fin_sq[2] = {0.f, 0.f};
+    bool fin_writer = false;
     constexpr int ROWB = BN * 2 + 16;
     constexpr int CHB = BN / 8;
     char* stg = lds;
@@ -2099,9 +2185,15 @@ __global__ void __launch_bounds__(512) conv3x3_patch_fp8_kernel(ConvDev P) {
         }
         const int group = (nt * BN) / 8 + tid;
         if (group < P.Cout / 8) {
-            float* o = P.gn_partial + ((size_t)mt * (P.Cout / 8) + group) * 2;
-            o[0] = sv;
-            o[1] = qv;
+            if (fin) {
+                fin_sq[0] = sv;
+                fin_sq[1] = qv;
+                fin_writer = true;
+            } else {
+                float* o = P.gn_partial + ((size_t)mt * (P.Cout / 8) + group) * 2;
+                o[0] = sv;
+                o[1] = qv;
+            }
         }
     }
     constexpr int CPT = BM * CHB / NT;       // 16-byte chunks per thread
@@ -2115,6 +2207,10 @@ __global__ void __launch_bounds__(512) conv3x3_patch_fp8_kernel(ConvDev P) {
             const uint4 v = *(const uint4*)(stg + p * ROWB + cc * 16);
             *(uint4*)(S.out + (opix * P.Cout + nt * BN + cc * 8) * 2) = v;
         }
+    }
+    if (fin) {
+        __syncthreads();                     // the staging tile has been read: its LDS is free for the reduction
+        gn_fused_finalize(P, S, si, img, mt, fin_sq, fin_writer, tid, (float*)lds, (int*)(lds + 32 * 32 * 2 * 4));
     }
 }
 
@@ -2447,6 +2543,14 @@ int build(ConvDev& D, const dafne_conv_params* p, const dafne_conv_seg* segs, bo
                                                 "no residual / fp32 output) or the slab kernel (3x3 s1 p1, Cout <= 32, fp32 output, Cin <= 256)");
     if ((p->flags & DAFNE_CONV_GN_INPUT) && (!p->d_in_gn_stats || !p->d_in_gn_gamma || !p->d_in_gn_beta))
         return dafne::fail(DAFNE_E_INVALID, "conv: GN_INPUT without statistics / affine pointers");
+    D.gn_stats_out = nullptr; D.gn_counters = nullptr; D.gn_eps = 0.f;
+    if (p->flags & DAFNE_CONV_GN_FINALIZE) {
+        if (!(p->flags & DAFNE_CONV_GN_STATS) || !D.patch || p->Cout != 256)
+            return dafne::fail(DAFNE_E_UNSUPPORTED, "conv: GN_FINALIZE needs GN_STATS on a 3x3 patch-kernel layer with Cout == 256");
+        if (!p->d_gn_stats_out || !p->d_gn_counters || !(p->gn_eps > 0.f))
+            return dafne::fail(DAFNE_E_INVALID, "conv: GN_FINALIZE without statistics / counter buffers or eps");
+        D.gn_stats_out = p->d_gn_stats_out; D.gn_counters = p->d_gn_counters; D.gn_eps = p->gn_eps;
+    }
     if (D.patch) {
         D.bn = 256; D.bm = 256;
         D.Cout_pad = p->Cout;

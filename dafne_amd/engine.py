@@ -20,7 +20,7 @@ from . import _lib
 BF16 = torch.bfloat16
 STAGE_BLOCKS = {50: (3, 4, 6, 3), 101: (3, 4, 23, 3)}
 
-F_RELU, F_RES, F_UP, F_F32, F_GN, F_GNIN = 1, 2, 4, 8, 16, 32
+F_RELU, F_RES, F_UP, F_F32, F_GN, F_GNIN, F_GNFIN = 1, 2, 4, 8, 16, 32, 64
 
 
 # ------------------------------------------------------------------ activations
@@ -125,6 +125,10 @@ def pack_b2b(w3, w1):
     phase 2c = conv3 rows c*256 + wave*32 + (lane & 31) over K = 256, phase 2c+1 = conv1 rows wave*32 + (lane & 31)
     over K-chunk c; K columns 16*step + 8*(lane >> 5) .. +8."""
     assert tuple(w3.shape) == (1024, 256) and tuple(w1.shape) == (256, 1024) and w3.dtype == BF16 and w1.dtype == BF16
+    if os.environ.get("DAFNE_B2B_V0"):      # A/B only: the 64-pixel kernel's packing (scratch/variants/libb2b_v0.so)
+        a1 = w3.reshape(4, 4, 2, 32, 16, 2, 8).permute(0, 1, 4, 2, 5, 3, 6)
+        a2 = w1.reshape(4, 2, 32, 4, 16, 2, 8).permute(3, 0, 4, 1, 5, 2, 6)
+        return torch.stack([a1, a2], dim=1).contiguous().reshape(8, 4, 16, 2, 64, 8)
     a1 = w3.reshape(4, 8, 32, 16, 2, 8).permute(0, 1, 3, 4, 2, 5)          # c, w, t, h, r, e
     a2 = w1.reshape(8, 32, 4, 16, 2, 8).permute(2, 0, 3, 4, 1, 5)          # c, w, t, h, r, e
     return torch.stack([a1, a2], dim=1).contiguous().reshape(8, 8, 16, 64, 8)
@@ -139,18 +143,23 @@ def fold_frozen_bn(weight, bn_w, bn_b, bn_mean, bn_var, eps=1e-5):
 class ConvCall:
     """One dafne_conv2d_nhwc_bf16_hip launch with its argument structs kept alive."""
 
-    def __init__(self, w, b, cin, cout, k, stride, pad, flags, segs, n_images, gn_partial=None, gn_in=None, fp8=None):
+    def __init__(self, w, b, cin, cout, k, stride, pad, flags, segs, n_images, gn_partial=None, gn_in=None, fp8=None,
+                 gn_fin=None):
         """gn_in: (stats [n_segs,N,Cin/8,2], gamma [Cin], beta [Cin]) of the INPUT maps when they hold the raw
         output of the previous tower convolution (flag F_GNIN: GroupNorm + ReLU applied on load).
         fp8: (oscale fp32 [Cout], in_qscale) -> `w` holds e4m3 bytes (pack_conv_fp8) and the call goes to
-        dafne_conv2d_nhwc_fp8w_hip (fp8 MFMA, activations quantised on load)."""
+        dafne_conv2d_nhwc_fp8w_hip (fp8 MFMA, activations quantised on load).
+        gn_fin: (stats out [n_segs,N,Cout/8,2] fp32, counters [n_segs,N] int32 zeros, eps) with flag F_GNFIN: the last
+        tile of every image finalises the GroupNorm statistics of the OUTPUT (no dafne_groupnorm_finalize_hip launch)."""
         L = _lib.load()
         self.fp8 = fp8
-        self.keep = (w, b, gn_partial, [s for s in segs], gn_in, fp8)
+        self.keep = (w, b, gn_partial, [s for s in segs], gn_in, fp8, gn_fin)
         gi = [t.data_ptr() for t in gn_in] if gn_in is not None else [None, None, None]
+        gf = (gn_fin[0].data_ptr(), gn_fin[1].data_ptr(), float(gn_fin[2])) if gn_fin is not None else (None, None, 0.0)
         self.prm = _lib.ConvParams(n_images, len(segs), cin, cout, k, k, stride, pad, flags,
                                    w.data_ptr(), b.data_ptr() if b is not None else None,
-                                   gn_partial.data_ptr() if gn_partial is not None else None, gi[0], gi[1], gi[2])
+                                   gn_partial.data_ptr() if gn_partial is not None else None, gi[0], gi[1], gi[2],
+                                   gf[0], gf[1], gf[2])
         arr = (_lib.ConvSeg * len(segs))()
         for i, (tin, tout, tres, hin, win, hout, wout) in enumerate(segs):
             arr[i] = _lib.ConvSeg(tin.data_ptr(), tout.data_ptr(), tres.data_ptr() if tres is not None else None,
@@ -403,6 +412,7 @@ class HeadPlan:
         self.num_classes = num_classes
         calls = plan.calls
         fuse_gn = os.environ.get("DAFNE_FUSE_GN", "1") != "0"
+        fuse_gnfin = os.environ.get("DAFNE_FUSE_GNFIN", "1") != "0"
 
         def seg_list(ins, outs, f32=False):
             return [(i.t, (o if f32 else o.t), None, i.h, i.w, i.h, i.w) for i, o in zip(ins, outs)]
@@ -425,23 +435,9 @@ class HeadPlan:
                 probe = ConvCall(wgt, bias, C, C, 3, 1, 1, flags & ~F_GN, seg_list(cur, outs), n, gn_in=cur_gn)
                 nt = probe.num_tiles()
                 partial = torch.empty(nt, C // 8, 2, dtype=torch.float32, device=device)
-                q8 = P.get("%s.%d.fp8" % (name, 3 * i)) if cur_gn is not None else None
-                if q8 is not None and probe.kernel_id() == 6:
-                    # fp8 model: e4m3 weights on the fp8 MFMA kernel, the GroupNorm + ReLU output quantised on load
-                    # (in_qscale 1: a normalised, rectified map sits well inside e4m3's range)
-                    c = ConvCall(q8[0], bias, C, C, 3, 1, 1, flags, seg_list(cur, outs), n, gn_partial=partial,
-                                 gn_in=cur_gn, fp8=(q8[1], 1.0))
-                else:
-                    c = ConvCall(wgt, bias, C, C, 3, 1, 1, flags, seg_list(cur, outs), n, gn_partial=partial, gn_in=cur_gn)
-                calls.append(c)
-                plan.flops += c.flops
                 stats = torch.empty(len(outs), n, C // 8, 2, dtype=torch.float32, device=device)
-                gsegs = (_lib.GnSeg * len(outs))()
-                t0 = 0
-                for k, (o, tpi) in enumerate(zip(outs, c.tiles_per_image())):
-                    gsegs[k] = _lib.GnSeg(o.t.data_ptr(), o.h, o.w, t0, tpi)
-                    t0 += tpi * n
-                assert t0 == nt == c.num_tiles()
+                # does every consumer of this layer normalise on load?  (decided before the producer is built: the
+                # producer then finalises the statistics itself, flag F_GNFIN, and no launch sits between the two convs)
                 nxt_specs = [("%s.%d" % (name, 3 * (i + 1)), C, 0)] if i < 3 else consumers
                 fuse_next = fuse_gn and len(nxt_specs) > 0
                 for key, cout, fl in (nxt_specs if fuse_next else ()):
@@ -451,7 +447,30 @@ class HeadPlan:
                     nxt = ConvCall(wn, bn_, C, cout, 3, 1, 1, fl | F_GNIN, seg_list(outs, dst, f32=f32), n,
                                    gn_in=(stats, gamma, beta))
                     fuse_next = fuse_next and nxt.kernel_id() == (7 if f32 else 6)
-                if fuse_next:
+                fuse_fin = fuse_next and fuse_gnfin and probe.kernel_id() == 6 and C == 256
+                fin = (stats, torch.zeros(len(outs), n, dtype=torch.int32, device=device), 1e-5) if fuse_fin else None
+                if fuse_fin:
+                    flags |= F_GNFIN
+                q8 = P.get("%s.%d.fp8" % (name, 3 * i)) if cur_gn is not None else None
+                if q8 is not None and probe.kernel_id() == 6:
+                    # fp8 model: e4m3 weights on the fp8 MFMA kernel, the GroupNorm + ReLU output quantised on load
+                    # (in_qscale 1: a normalised, rectified map sits well inside e4m3's range)
+                    c = ConvCall(q8[0], bias, C, C, 3, 1, 1, flags, seg_list(cur, outs), n, gn_partial=partial,
+                                 gn_in=cur_gn, fp8=(q8[1], 1.0), gn_fin=fin)
+                else:
+                    c = ConvCall(wgt, bias, C, C, 3, 1, 1, flags, seg_list(cur, outs), n, gn_partial=partial, gn_in=cur_gn,
+                                 gn_fin=fin)
+                calls.append(c)
+                plan.flops += c.flops
+                gsegs = (_lib.GnSeg * len(outs))()
+                t0 = 0
+                for k, (o, tpi) in enumerate(zip(outs, c.tiles_per_image())):
+                    gsegs[k] = _lib.GnSeg(o.t.data_ptr(), o.h, o.w, t0, tpi)
+                    t0 += tpi * n
+                assert t0 == nt == c.num_tiles()
+                if fuse_fin:
+                    nxt_gn = (stats, gamma, beta)
+                elif fuse_next:
                     calls.append(FnCall(L.dafne_groupnorm_finalize_hip,
                                         (gsegs, len(outs), n, C, _lib.ptr(partial), _lib.ptr(stats), ctypes.c_float(1e-5)),
                                         (outs, partial, stats), "groupnorm_finalize"))

@@ -204,10 +204,12 @@ class OneStageDetector(nn.Module):
             # layer-interleaved enqueue: launch j of every sub-batch before launch j+1, so that the
             # prologue / epilogue bubbles of one sub-batch's kernel are filled by another's
             sp = [ctypes.c_void_p(s.cuda_stream) for s in cs]
-            ncalls = len(plans[0].calls)
+            # (sub-batches of different sizes may differ by a launch: the library picks kernels by tile count)
+            ncalls = max(len(p.calls) for p in plans)
             for j in range(ncalls):
                 for k in range(splits):
-                    plans[k].calls[j](sp[k])
+                    if j < len(plans[k].calls):
+                        plans[k].calls[j](sp[k])
             with torch.cuda.stream(self.side_stream):
                 for k in range(splits):
                     ev = torch.cuda.Event()

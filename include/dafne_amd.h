@@ -198,6 +198,9 @@ int dafne_gather_detections_hip(const float* d_corners, const float* d_scores, c
 #define DAFNE_CONV_OUT_F32 8u      /* fp32 un-haloed NHWC output [N,Hout,Wout,Cout]     */
 #define DAFNE_CONV_GN_STATS 16u    /* emit per-(M tile, group of 8 ch) sum and sum-sq   */
 #define DAFNE_CONV_GN_INPUT 32u    /* GroupNorm + ReLU of the INPUT applied on load (3x3 patch / slab kernels) */
+#define DAFNE_CONV_GN_FINALIZE 64u /* with GN_STATS, 3x3 patch-kernel layers with Cout == 256 (kernel id 6): the last tile
+                                    * of every image finalises mean / rstd into d_gn_stats_out -- same values, bit for bit, as
+                                    * dafne_groupnorm_finalize_hip on d_gn_partial, without the extra launch */
 
 typedef struct dafne_conv_seg {
     const void* d_in;   /* bf16 [N, Hin+2, Win+2, Cin]; stem: [N, Hin, Win, 4] pre-padded */
@@ -218,6 +221,10 @@ typedef struct dafne_conv_params {
     const float* d_in_gn_stats; /* [n_segs][n_images][Cin/8][2] mean, rstd */
     const float* d_in_gn_gamma; /* [Cin] */
     const float* d_in_gn_beta;  /* [Cin] */
+    /* GN_FINALIZE: */
+    float* d_gn_stats_out;      /* [n_segs][n_images][Cout/8][2] mean, rstd of the OUTPUT maps */
+    int32_t* d_gn_counters;     /* [n_segs][n_images] int32, zero before the first launch (the kernel resets them) */
+    float gn_eps;
 } dafne_conv_params;
 
 /*
@@ -285,10 +292,9 @@ int dafne_resize_bilinear_u8_hip(const uint8_t* d_in, int layout_hwc, int C, int
  * backbone/fpn.py:58-91]:  d_out = relu(conv3(d_in) + bias3 + d_res)  (1x1, 256 -> 1024, identity shortcut) and
  * d_next = relu(conv1'(d_out) + bias1)  (1x1, 1024 -> 256, the NEXT block's first convolution, stride 1).
  * All tensors bf16 NHWC with a 1-pixel halo: d_in / d_next [N,H+2,W+2,256], d_res / d_out [N,H+2,W+2,1024] (interior
- * written).  d_wfrag: both weight matrices fragment-major, bf16 [8][4][16][2][64][8] = [phase][wave][k16 step]
- * [fragment][lane][8]: phase 2c = conv3 rows c*256 + wave*64 + fragment*32 + (lane & 31), K columns 16*step +
- * 8*(lane >> 5) .. +8;  phase 2c+1 = conv1' rows wave*64 + fragment*32 + (lane & 31), K columns c*256 + 16*step +
- * 8*(lane >> 5) .. +8  (engine.pack_b2b).
+ * written).  d_wfrag: both weight matrices fragment-major, bf16 [8][8][16][64][8] = [phase][wave][k16 step]
+ * [lane][8]: phase 2c = conv3 rows c*256 + wave*32 + (lane & 31), K columns 16*step + 8*(lane >> 5) .. +8;
+ * phase 2c+1 = conv1' rows wave*32 + (lane & 31), K columns c*256 + 16*step + 8*(lane >> 5) .. +8  (engine.pack_b2b).
  * Bit-identical to dafne_conv2d_nhwc_bf16_hip(conv3, RELU|RESIDUAL) followed by (conv1', RELU); d_out is written
  * once and not read back.
  */
