@@ -263,6 +263,7 @@ struct NmsWs {
                      //            (the IoU upper bound of the tile pre-filter)
     u64* mask;       // [N][ntiles][64]  tile-major
     u64* rowflag;    // [N][nblk]  bit r of word b: row 64b+r suppresses something
+    u64* keptw;      // [N][nblk]  kept rows in tile order (nms_class_reduce -> nms_compact)
     unsigned* meta;  // [N][4]     0: max|coord| (float bits) 1: span+1 (float bits)
     unsigned* nzero; // [N]        rows with exactly zero area (census of nms_offset_kernel: select path)
     unsigned* stats; // [N][4]     pairs decided by nms_iou: 0 fast path "suppress", 1 fast path "keep", 2 exact
@@ -301,12 +302,13 @@ size_t carve(NmsWs& w, void* base, int N, int m_cap, bool f64 = false) {
     const size_t ntiles = (size_t)nblk * (nblk + 1) / 2;
     // a 64-row block of a TTA-merge-sized set (27 000 boxes in one tile) has ~10^4 candidate pairs: with the small
     // list nearly every tile overflowed into the slower in-place path
-    w.pair_cap = Mp <= 12288 ? kPairCap : 4 * kPairCap;
+    w.pair_cap = Mp <= 12288 ? 2 * kPairCap : 4 * kPairCap;
     w.meta = c.take<unsigned>(n * 4);
     w.nzero = c.take<unsigned>(n);
     w.stats = c.take<unsigned>(n * 4);
     w.pair_cnt = c.take<unsigned>(n * nblk);
     w.rowflag = c.take<u64>(n * nblk);
+    w.keptw = c.take<u64>(n * nblk);
     w.tile_flag = c.take<unsigned char>(n * ntiles);   // meta .. tile_flag are zeroed per call (contiguous)
     w.pairs = c.take<u64>(n * nblk * (size_t)w.pair_cap);
     w.order = c.take<int>(n * Mp);
@@ -1049,11 +1051,12 @@ __global__ void __launch_bounds__(256) nms_scan_kernel(const int* __restrict__ c
     tile_rc(t, w.nblk, rb, cb);
     if (rb * kTile >= M || cb * kTile >= M) return;
     const int grow = rb * kTile + lane;
-    w.mask[(size_t)img * w.mask_words + (size_t)t * kTile + lane] = 0ull;
-    if (w.use_perm && w.cls) { // class-major layout: two blocks without a common class have no candidate pair
+    if (w.use_perm && w.cls) { // class-major layout: two blocks without a common class have no candidate pair --
+        // and nobody ever reads such a tile (nms_class_reduce walks tiles inside a class only): not even zeroed
         const unsigned char* bc = w.bcls + (size_t)img * w.nblk * 2;
         if (bc[rb * 2] > bc[cb * 2 + 1] || bc[cb * 2] > bc[rb * 2 + 1]) return;
     }
+    w.mask[(size_t)img * w.mask_words + (size_t)t * kTile + lane] = 0ull;
     const u64 mycand = tile_candidates(w, img, M, rb, cb, thresh, rhull_s[wv], rarea_s[wv]);
     const int cnt = __popcll(mycand);
     int incl = cnt;
@@ -1213,6 +1216,9 @@ __global__ void __launch_bounds__(64) nms_iou_kernel(const int* __restrict__ cou
     __shared__ u64 exq[2 * kTile];
     const int chunks = w.pair_cap / kTile;
     auto record = [&](int r, int c) {
+#ifdef DAFNE_NMS_ABL_NOATOMIC
+        return;
+#endif
         atomicOr(&w.mask[(size_t)img * w.mask_words + tile_id(r >> 6, c >> 6, nb) * kTile + (r & 63)], 1ull << (c & 63));
         atomicOr(&w.rowflag[(size_t)img * nb + (r >> 6)], 1ull << (r & 63));
     };
@@ -1257,7 +1263,14 @@ __global__ void __launch_bounds__(64) nms_iou_kernel(const int* __restrict__ cou
                     const int r = (int)(unsigned)en, c = (int)(en >> 32);
                     const Quad A = w.dbox ? load_quad_f64(w.dbox + (ibase + r) * 8) : load_quad_f32(w.sbox + (ibase + r) * 8);
                     const Quad B = w.dbox ? load_quad_f64(w.dbox + (ibase + c) * 8) : load_quad_f32(w.sbox + (ibase + c) * 8);
+#ifdef DAFNE_NMS_ABL_NOFAST
+                    dec = (A.v[0].x > 1e30) ? 1 : 0;
+#else
                     dec = fast_decision(s, A, B, thresh);
+#endif
+#ifdef DAFNE_NMS_ABL_NOEXACT
+                    if (dec == 2) dec = 0;
+#endif
                     if (dec == 1 && (!w.strict || hulls_overlap_strict(A, B))) record(r, c);
                 }
             }
@@ -1273,7 +1286,6 @@ __global__ void __launch_bounds__(64) nms_iou_kernel(const int* __restrict__ cou
         while (nq >= 4) exact4(4);
       }
     }
-    if (nq > 0) exact4(nq);
     auto flush_stats = [&]() {
         if (lane == 0) {
             if (n_yes) atomicAdd(&w.stats[img * 4 + 0], n_yes);
@@ -1282,46 +1294,64 @@ __global__ void __launch_bounds__(64) nms_iou_kernel(const int* __restrict__ cou
             if (n_ovf) atomicAdd(&w.stats[img * 4 + 3], n_ovf);
         }
     };
-    if (w.meta[img * 4 + 3] == 0u) { flush_stats(); return; }
-    // overflow phase: tiles whose pairs did not fit the list are clipped in place
-    for (long long t = gw; t < ntiles; t += nw) {
-        if (!w.tile_flag[(size_t)img * ntiles + t]) continue;
-        int rb, cb;
-        tile_rc(t, nb, rb, cb);
-        const u64 mycand = tile_candidates(w, img, M, rb, cb, thresh, rhull_s[wv], rarea_s[wv]);
-        const int cnt = __popcll(mycand);
-        int incl = cnt;
-        for (int o = 1; o < 64; o <<= 1) {
-            const int v = __shfl_up(incl, o, 64);
-            if (lane >= o) incl += v;
-        }
-        const int total = __shfl(incl, 63, 64);
-        n_ovf += (unsigned)total;
-        cand_s[wv][lane] = mycand;
-        pre_s[wv][lane] = incl - cnt;
-        __builtin_amdgcn_wave_barrier();
-        for (int base = 0; base < total; base += 4) {
-            const int k = base + (lane >> 4);
-            const bool live = k < total;
-            const int kk = live ? k : total - 1;
-            int lo = 0, hi = 63;       // largest row with pre[row] <= kk
-            while (lo < hi) {
-                const int mid = (lo + hi + 1) >> 1;
-                if (pre_s[wv][mid] <= kk) lo = mid; else hi = mid - 1;
+    if (w.meta[img * 4 + 3] != 0u) {
+        // overflow phase: tiles whose pairs did not fit the row block's list are clipped in place -- same two paths as
+        // above (one lane per pair on the decision fast path, the undecided ones pooled for the reference-order clip).
+        // A wave reads the flags of 64 tiles with one load.  (The first version walked the tiles one dependent load at a
+        // time and sent EVERY pair of a flagged tile through the 16-lane exact path: one such tile cost its wave ~1 ms,
+        // the dense set's nms_iou went from 70 us to 576 us.)
+        for (long long tb = (long long)gw * 64; tb < ntiles; tb += (long long)nw * 64) {
+            const long long myt = tb + lane;
+            u64 todo = __ballot(myt < ntiles && w.tile_flag[(size_t)img * ntiles + myt] != 0);
+            while (todo) {
+                const int il = __ffsll((long long)todo) - 1;
+                todo &= todo - 1;
+                const long long t = tb + il;
+                int rb, cb;
+                tile_rc(t, nb, rb, cb);
+                const u64 mycand = tile_candidates(w, img, M, rb, cb, thresh, rhull_s[wv], rarea_s[wv]);
+                const int cnt = __popcll(mycand);
+                int incl = cnt;
+                for (int o = 1; o < 64; o <<= 1) {
+                    const int v = __shfl_up(incl, o, 64);
+                    if (lane >= o) incl += v;
+                }
+                const int total = __shfl(incl, 63, 64);
+                n_ovf += (unsigned)total;
+                cand_s[wv][lane] = mycand;
+                pre_s[wv][lane] = incl - cnt;
+                __builtin_amdgcn_wave_barrier();
+                for (int base = 0; base < total; base += 64) {
+                    const int k = base + lane;
+                    const bool live = k < total;
+                    const int kk = live ? k : total - 1;
+                    int lo = 0, hi = 63;       // largest row with pre[row] <= kk
+                    while (lo < hi) {
+                        const int mid = (lo + hi + 1) >> 1;
+                        if (pre_s[wv][mid] <= kk) lo = mid; else hi = mid - 1;
+                    }
+                    const int row = lo;
+                    const int col = kth_set_bit(cand_s[wv][row], kk - pre_s[wv][row]);
+                    const int r = rb * kTile + row, c = cb * kTile + col;
+                    int dec = live ? 2 : 0;
+                    if (live && w.fast) {
+                        const Quad A = w.dbox ? load_quad_f64(w.dbox + (ibase + r) * 8) : load_quad_f32(w.sbox + (ibase + r) * 8);
+                        const Quad B = w.dbox ? load_quad_f64(w.dbox + (ibase + c) * 8) : load_quad_f32(w.sbox + (ibase + c) * 8);
+                        dec = fast_decision(s, A, B, thresh);
+                        if (dec == 1 && (!w.strict || hulls_overlap_strict(A, B))) record(r, c);
+                    }
+                    const u64 need = __ballot(dec == 2);
+                    if (need == 0ull) continue;
+                    if (dec == 2) exq[nq + __popcll(need & ((1ull << lane) - 1ull))] = (u64)(unsigned)r | ((u64)(unsigned)c << 32);
+                    nq += __popcll(need);
+                    __builtin_amdgcn_wave_barrier();
+                    while (nq >= 4) exact4(4);
+                }
+                __builtin_amdgcn_wave_barrier();
             }
-            const int row = lo;
-            const int col = kth_set_bit(cand_s[wv][row], kk - pre_s[wv][row]);
-            const int r = rb * kTile + row, c = cb * kTile + col;
-            Quad A = w.dbox ? load_quad_f64(w.dbox + (ibase + r) * 8) : load_quad_f32(w.sbox + (ibase + r) * 8);
-            Quad B = w.dbox ? load_quad_f64(w.dbox + (ibase + c) * 8) : load_quad_f32(w.sbox + (ibase + c) * 8);
-            const double iou = iou_group16(s, A, B, lane);
-            if (live && (lane & 15) == 0 && iou > thresh && (!w.strict || hulls_overlap_strict(A, B))) {
-                atomicOr(&w.mask[(size_t)img * w.mask_words + (size_t)t * kTile + row], 1ull << col);
-                atomicOr(&w.rowflag[(size_t)img * nb + rb], 1ull << row);
-            }
         }
-        __builtin_amdgcn_wave_barrier();
     }
+    if (nq > 0) exact4(nq);
     flush_stats();
 }
 
@@ -1333,12 +1363,199 @@ __device__ __forceinline__ u64 readlane64(u64 v, int l) {
 }
 
 constexpr int kReduceThreads = 1024;
-constexpr int kFastBlk = 160;      // tiles of the current row block are parked in LDS 160 at a time (83 KiB)
-// fast path: up to kFastChunks * 160 row blocks (kFastChunks = 1: 10 240 rows)
-constexpr int kMaxBlk = 1024;  // up to 65536 rows per image
+constexpr int kFastBlk = 176;      // tiles of the current row block are parked in LDS, up to 176 of them (89 KiB)
+constexpr int kMaxBlk = 1024;      // up to 65536 rows per image
+constexpr int kMaxClsWG = 64;      // workgroups per image of the greedy pass (one per class)
 
-template <int kFastChunks>
-__global__ void __launch_bounds__(kReduceThreads) nms_reduce_kernel(
+// Greedy scan over the suppression matrix, ONE WORKGROUP PER (image, class).
+// After the class offsets of nms.py:81-83 the classes are independent greedy problems (class-major images, see
+// nms_sort_prep_kernel); an image that is not class-major (plain [M,9] rows, fp64 ResultMerge rows, >= 2 zero-area
+// boxes) is one problem handled by workgroup 0.  A problem is a serial chain over its 64-row blocks:
+//  * the 64 diagonal words of a block sit one per lane in wave 0 and the in-block scan is wave-uniform scalar code
+//    reading them with v_readlane (no LDS round trip per step); the next block's diagonal word is prefetched;
+//  * (<= kFastBlk later blocks) the words of tiles (b, b+1..) are fetched one iteration AHEAD into registers,
+//    coalesced (a tile is 512 contiguous bytes), then parked in LDS, so the OR phase of block b -- every later block
+//    gets a thread -- reads LDS instead of chasing global loads that depend on the scan's result.
+// (The first version gave every class one WAVE of a single workgroup per image: the OR phase was that wave's
+// dependent global loads, ~3.4-5.9 us per block -- 579 us for the 169-block class of the skewed 27 000-row set.)
+// Kept rows go to w.keptw (tile order, atomicOr: a block on a class boundary is written by two workgroups);
+// nms_compact_kernel turns them into the keep list.
+struct ChainCtx {
+    const u64* mask;
+    const u64* rowflag;
+    u64* keptw;
+    u64* remv;        // LDS, indexed b - b0
+    u64* kcur;        // LDS
+    u64* tbuf;        // LDS [kFastBlk][65]
+    int nb, r0, r1, b0, b1;
+};
+
+// in-block scan of block b by wave 0 (wave-uniform scalar code over the diagonal words held one per lane)
+// (the diagonal word AND the row flags of block b + 1 are fetched while block b is scanned: neither depends on the
+// scan, and a load issued inside the chain costs every block a global-memory latency)
+__device__ __forceinline__ void chain_scan(const ChainCtx& C, int b, u64& dcur, u64& rfcur) {
+    const int tid = threadIdx.x;
+    if (tid < 64) {
+        u64 dnext = 0ull, rfnext = 0ull;
+        if (b < C.b1) {
+            dnext = C.mask[tile_id(b + 1, b + 1, C.nb) * kTile + tid];
+            rfnext = C.rowflag[b + 1];
+        }
+        const int lo = max(C.r0, b * kTile) - b * kTile, hi = min(C.r1, (b + 1) * kTile) - b * kTile;
+        const u64 rowmask = (hi >= 64 ? ~0ull : ((1ull << hi) - 1ull)) & ~((1ull << lo) - 1ull);
+        const u64 dw = ((rowmask >> tid) & 1ull) ? dcur : 0ull;
+        // rem only grows and row r's bit can only be set by rows < r (upper-triangular words), so
+        // kept = ~rem_final; only rows whose diag word is non-zero can change rem -> walk just those.
+        u64 bits = __ballot(dw != 0ull);
+        const unsigned dlo = (unsigned)dw, dhi = (unsigned)(dw >> 32);
+        u64 rem = C.remv[b - C.b0];                   // same address in every lane: wave-uniform
+        rem = ((u64)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(rem >> 32)) << 32) |
+              (u64)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)rem);
+        rem |= ~rowmask;
+        bits &= ~rem;                                 // rows already removed never act: skipped without an iteration
+        while (bits) {
+            const int r = __builtin_amdgcn_readfirstlane(__ffsll((long long)bits) - 1);
+            const unsigned l2 = (unsigned)__builtin_amdgcn_readlane((int)dlo, r);
+            const unsigned h2 = (unsigned)__builtin_amdgcn_readlane((int)dhi, r);
+            rem |= ((u64)h2 << 32) | (u64)l2;         // row r is kept (not in rem): it removes its columns
+            bits &= ~rem & ~((2ull << r) - 1ull);      // next: the first later row that is still alive
+        }
+        if (tid == 0) {
+            const u64 K = ~rem;
+            if (K) atomicOr(&C.keptw[b], K);
+            *C.kcur = K & rfcur;
+        }
+        dcur = dnext;
+        rfcur = rfnext;
+    }
+}
+
+// Serial chain over the blocks of one class with the tiles of the next D - 1 row blocks in flight (a ring of D register
+// sets of RC words per thread; RC * 1024 / 64 = the most later blocks a row block of this class can have): a step parks
+// its set in LDS and refills it with row block b + D, so the global-load latency (~2 us with one workgroup's worth of
+// requests in flight) is spread over D steps instead of being paid by every one.  D * RC words must stay inside the
+// 128 VGPRs a 1024-thread workgroup gets (RC = 12 with D = 4 spilled: 344 -> 651 us on the 169-block class).
+template <int RC, int D>
+__device__ __forceinline__ void chain_fast(const ChainCtx& C) {
+    static_assert(D == 2 || D == 4, "ring depth");
+    const int tid = threadIdx.x;
+    u64 pre[D][RC];
+    auto fetch = [&](int rb, u64 (&dst)[RC]) {        // tiles (rb, rb+1 ..): e = (wd - rb - 1) * 64 + row
+#pragma unroll
+        for (int k = 0; k < RC; k++) {
+            const int e = tid + k * kReduceThreads;
+            const int wd = rb + 1 + (e >> 6);
+            dst[k] = (rb <= C.b1 && wd <= C.b1) ? C.mask[tile_id(rb, wd, C.nb) * kTile + (e & 63)] : 0ull;
+        }
+    };
+    auto park = [&](const u64 (&src)[RC]) {
+#pragma unroll
+        for (int k = 0; k < RC; k++) {
+            const int e = tid + k * kReduceThreads;
+            C.tbuf[(e >> 6) * 65 + (e & 63)] = src[k];
+        }
+    };
+    u64 dcur = 0ull, rfcur = 0ull;                    // wave 0: this lane's diagonal word / the row flags of the current block
+    if (tid < 64) {
+        dcur = C.mask[tile_id(C.b0, C.b0, C.nb) * kTile + tid];
+        rfcur = C.rowflag[C.b0];
+    }
+#pragma unroll
+    for (int i = 0; i < D; i++) fetch(C.b0 + i, pre[i]);
+    auto step = [&](int b, u64 (&set)[RC]) {
+        park(set);
+        fetch(b + D, set);
+        chain_scan(C, b, dcur, rfcur);
+        __syncthreads();
+        const u64 K2 = *C.kcur;
+        const int wd = b + 1 + tid;
+        if (K2 && wd <= C.b1) {
+            u64 acc = 0ull;
+            u64 bits = K2;
+            while (bits) {
+                const int r = __ffsll((long long)bits) - 1;
+                bits &= bits - 1;
+                acc |= C.tbuf[tid * 65 + r];
+            }
+            C.remv[wd - C.b0] |= acc;
+        }
+        __syncthreads();
+    };
+    for (int b = C.b0; b <= C.b1; b += D) {
+#pragma unroll
+        for (int i = 0; i < D; i++)
+            if (b + i <= C.b1) step(b + i, pre[i]);
+    }
+}
+
+__global__ void __launch_bounds__(kReduceThreads) nms_class_reduce_kernel(const int* __restrict__ counts, int m_cap, NmsWs w) {
+    const int img = blockIdx.y, c = blockIdx.x;
+    const int M = img_count(counts, img, m_cap);
+    if (M == 0) return;
+    const int nb = w.nblk;
+    const int ncls = w.use_perm ? (int)w.meta[img * 4 + 2] : 0;
+    int r0 = 0, r1 = M;
+    if (ncls > 0) {
+        if (c >= ncls) return;
+        r0 = w.cbase[(size_t)img * 65 + c];
+        r1 = w.cbase[(size_t)img * 65 + c + 1];
+        if (r1 <= r0) return;
+    } else if (c != 0) {
+        return;
+    }
+    __shared__ u64 remv[kMaxBlk];                     // indexed b - b0
+    __shared__ u64 kcur;
+    extern __shared__ u64 tbuf[];                     // [kFastBlk][65] tile rows of the current block
+    ChainCtx C;
+    C.mask = w.mask + (size_t)img * w.mask_words;
+    C.rowflag = w.rowflag + (size_t)img * nb;
+    C.keptw = w.keptw + (size_t)img * nb;
+    C.remv = remv; C.kcur = &kcur; C.tbuf = tbuf;
+    C.nb = nb; C.r0 = r0; C.r1 = r1; C.b0 = r0 >> 6; C.b1 = (r1 - 1) >> 6;
+    const int tid = threadIdx.x;
+    const int later = C.b1 - C.b0;                    // later blocks of the first row block
+    for (int k = tid; k <= later; k += kReduceThreads) remv[k] = 0ull;
+    __syncthreads();
+    if (later <= 16) { chain_fast<1, 4>(C); return; }
+    if (later <= 64) { chain_fast<4, 4>(C); return; }
+    if (later <= kFastBlk) { chain_fast<kFastBlk * kTile / kReduceThreads, 2>(C); return; }
+    // more than kFastBlk blocks in one chain (plain rows of a TTA-sized set): OR phase straight from global memory
+    u64 dcur = 0ull, rfcur = 0ull;
+    if (tid < 64) {
+        dcur = C.mask[tile_id(C.b0, C.b0, nb) * kTile + tid];
+        rfcur = C.rowflag[C.b0];
+    }
+    for (int b = C.b0; b <= C.b1; b++) {
+        chain_scan(C, b, dcur, rfcur);
+        __syncthreads();
+        const u64 K2 = kcur;
+        if (K2) {
+            for (int wd = b + 1 + tid; wd <= C.b1; wd += kReduceThreads) {
+                const u64* trow = C.mask + tile_id(b, wd, nb) * kTile;
+                u64 acc = 0ull;
+                u64 kb = K2;
+                while (kb) {                              // four independent loads in flight per step
+                    int rr[4];
+#pragma unroll
+                    for (int q = 0; q < 4; q++) {
+                        rr[q] = kb ? __ffsll((long long)kb) - 1 : -1;
+                        kb &= kb - 1;                     // (0 stays 0)
+                    }
+                    u64 v[4];
+#pragma unroll
+                    for (int q = 0; q < 4; q++) v[q] = rr[q] >= 0 ? trow[rr[q]] : 0ull;
+                    acc |= (v[0] | v[1]) | (v[2] | v[3]);
+                }
+                remv[wd - C.b0] |= acc;
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// Kept bits (tile order) -> keep list in GLOBAL score order + the cap of select_over_all_levels
+// (dafne_outputs.py:916-923).  One workgroup per image.
+__global__ void __launch_bounds__(kReduceThreads) nms_compact_kernel(
     const int* __restrict__ counts, int m_cap, int post_topk, NmsWs w,
     long long* __restrict__ keep, int* __restrict__ num_keep) {
     const int img = blockIdx.x;
@@ -1346,195 +1563,12 @@ __global__ void __launch_bounds__(kReduceThreads) nms_reduce_kernel(
     const int nb = w.nblk;
     const int nbu = (M + kTile - 1) / kTile;  // blocks in use
     const size_t ibase = (size_t)img * w.Mp;
-    const u64* mask = w.mask + (size_t)img * w.mask_words;
-    const u64* rowflag = w.rowflag + (size_t)img * nb;
     long long* kout = keep + (size_t)img * m_cap;
-
-    __shared__ u64 remv[kMaxBlk];
     __shared__ u64 kept[kMaxBlk];
     __shared__ int kpre[kMaxBlk + 1];
-    __shared__ u64 kcur;
     const int tid = threadIdx.x;
-    for (int k = tid; k < nb; k += kReduceThreads) {
-        remv[k] = 0ull;
-        kept[k] = 0ull;
-    }
+    for (int k = tid; k < nb; k += kReduceThreads) kept[k] = k < nbu ? w.keptw[(size_t)img * nb + k] : 0ull;
     __syncthreads();
-
-    // Greedy scan, one 64-row block per iteration.  Two things keep the serial chain short:
-    //  * the 64 diagonal words of a block sit one per lane in wave 0 and the in-block scan is wave-uniform
-    //    scalar code reading them with v_readlane (no LDS round trip per step);
-    //  * (fast == true, <= kFastBlk blocks) the words of tiles (b, b+1..) are fetched one iteration AHEAD into
-    //    registers, coalesced (a tile is 512 contiguous bytes), then parked in LDS, so the OR phase of block b
-    //    reads LDS instead of chasing global loads that depend on the scan's result.
-    // Class-major image with enough classes: the classes are independent greedy problems.  One WAVE per class
-    // walks that class's blocks (a block shared by two classes is scanned by both, each on its own rows), so the
-    // serial chain is a class's ~M/(64 C) blocks instead of all M/64.
-    const int ncls = w.use_perm ? (int)w.meta[img * 4 + 2] : 0;
-    if (ncls >= 4) {
-        const int* cb = w.cbase + (size_t)img * 65;
-        const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
-        for (int c = wave; c < ncls; c += kReduceThreads / 64) {
-            const int r0 = cb[c], r1 = cb[c + 1];
-            if (r1 <= r0) continue;
-            const int b0 = r0 >> 6, b1 = (r1 - 1) >> 6;
-            // the diagonal word and the row flags of block b+1 are fetched while block b is scanned (they do not depend
-            // on the scan): two global-load latencies leave the serial chain of every block
-            u64 dw_nx = mask[tile_id(b0, b0, nb) * kTile + lane];
-            u64 rf_nx = rowflag[b0];
-            for (int b = b0; b <= b1; b++) {
-                const int lo = max(r0, b * kTile) - b * kTile, hi = min(r1, (b + 1) * kTile) - b * kTile;
-                const u64 rowmask = (hi >= 64 ? ~0ull : ((1ull << hi) - 1ull)) & ~((1ull << lo) - 1ull);
-                const u64 dw = ((rowmask >> lane) & 1ull) ? dw_nx : 0ull;
-                const u64 rf = rf_nx;
-                if (b < b1) {
-                    dw_nx = mask[tile_id(b + 1, b + 1, nb) * kTile + lane];
-                    rf_nx = rowflag[b + 1];
-                }
-                u64 bits = __ballot(dw != 0ull);
-                const unsigned dlo = (unsigned)dw, dhi = (unsigned)(dw >> 32);
-                u64 rem = remv[b];
-                rem = ((u64)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(rem >> 32)) << 32) |
-                      (u64)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)rem);
-                rem |= ~rowmask;
-                while (bits) {
-                    const int r = __builtin_amdgcn_readfirstlane(__ffsll((long long)bits) - 1);
-                    bits &= bits - 1;
-                    if (!((rem >> r) & 1ull)) {
-                        const unsigned l2 = (unsigned)__builtin_amdgcn_readlane((int)dlo, r);
-                        const unsigned h2 = (unsigned)__builtin_amdgcn_readlane((int)dhi, r);
-                        rem |= ((u64)h2 << 32) | (u64)l2;
-                    }
-                }
-                const u64 K = ~rem;                         // kept rows of this class in block b
-                if (lane == 0 && K) atomicOr(&kept[b], K);
-                const u64 K2 = K & rf;
-                if (K2) {
-                    for (int wd = b + 1 + lane; wd <= b1; wd += 64) {
-                        const u64* trow = mask + tile_id(b, wd, nb) * kTile;
-                        u64 acc = 0ull;
-                        u64 kb = K2;
-                        while (kb) {                              // four independent loads in flight per step
-                            int rr[4];
-#pragma unroll
-                            for (int q = 0; q < 4; q++) {
-                                rr[q] = kb ? __ffsll((long long)kb) - 1 : -1;
-                                kb &= kb - 1;                     // (0 stays 0)
-                            }
-                            u64 v[4];
-#pragma unroll
-                            for (int q = 0; q < 4; q++) v[q] = rr[q] >= 0 ? trow[rr[q]] : 0ull;
-                            acc |= (v[0] | v[1]) | (v[2] | v[3]);
-                        }
-                        if (acc) atomicOr(&remv[wd], acc);
-                    }
-                }
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // this wave's LDS atomics are done
-                __builtin_amdgcn_wave_barrier();
-            }
-        }
-        __syncthreads();
-    }
-    const bool fast = ncls < 4 && nbu <= kFastChunks * kFastBlk;
-    extern __shared__ u64 tbuf[];                     // fast: [kFastBlk][65] tile rows of the current block, one chunk at a time
-    constexpr int RC = kFastBlk * kTile / kReduceThreads;      // registers per chunk of kFastBlk tiles
-    u64 pre[kFastChunks * RC];
-    const int nchunk = fast ? (nbu + kFastBlk - 1) / kFastBlk : 0;
-    auto fetch_chunk = [&](int rbk, int c) {          // tiles (rbk, rbk+1+c*kFastBlk ..): e = (wd - rbk - 1) * 64 + row
-#pragma unroll
-        for (int k = 0; k < RC; k++) {
-            const int e = tid + (c * RC + k) * kReduceThreads;
-            const int wd = rbk + 1 + (e >> 6);
-            pre[c * RC + k] = (rbk < nbu && wd < nbu) ? mask[tile_id(rbk, wd, nb) * kTile + (e & 63)] : 0ull;
-        }
-    };
-    auto park_chunk = [&](int c) {
-#pragma unroll
-        for (int k = 0; k < RC; k++) {
-            const int e = tid + k * kReduceThreads;
-            tbuf[(e >> 6) * 65 + (e & 63)] = pre[c * RC + k];
-        }
-    };
-    u64 dcur = 0ull, dnext = 0ull;                    // wave 0: this lane's diagonal word of block b / b+1
-    if (tid < 64) dcur = tid < M ? mask[tile_id(0, 0, nb) * kTile + tid] : 0ull;
-    if (fast) {
-#pragma unroll
-        for (int c = 0; c < kFastChunks; c++)
-            if (c < nchunk) fetch_chunk(0, c);
-    }
-    for (int b = 0; b < (ncls >= 4 ? 0 : nbu); b++) {
-        if (fast) {
-            park_chunk(0);
-            fetch_chunk(b + 1, 0);                    // a chunk's registers refill right after it is parked:
-        }                                             // the loads land under this iteration's scan + OR phases
-        if (tid < 64) {
-            if (b + 1 < nbu) {
-                const int row = (b + 1) * kTile + tid;
-                dnext = row < M ? mask[tile_id(b + 1, b + 1, nb) * kTile + tid] : 0ull;
-            }
-            // rem only grows and row r's bit can only be set by rows < r (upper-triangular words), so
-            // kept = ~rem_final; only rows whose diag word is non-zero can change rem -> walk just those.
-            u64 bits = __ballot(dcur != 0ull);
-            const unsigned dlo = (unsigned)dcur, dhi = (unsigned)(dcur >> 32);
-            u64 rem = remv[b];                        // same address in every lane: wave-uniform
-            rem = ((u64)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(rem >> 32)) << 32) |
-                  (u64)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)rem);
-            const int valid = min(kTile, M - b * kTile);
-            if (valid < 64) rem |= ~0ull << valid;
-            while (bits) {
-                const int r = __builtin_amdgcn_readfirstlane(__ffsll((long long)bits) - 1);
-                bits &= bits - 1;
-                if (!((rem >> r) & 1ull)) {
-                    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)dlo, r);
-                    const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)dhi, r);
-                    rem |= ((u64)hi << 32) | (u64)lo;
-                }
-            }
-            if (tid == 0) {
-                const u64 K = ~rem;
-                kept[b] = K;
-                kcur = K & rowflag[b];
-            }
-            dcur = dnext;
-        }
-        __syncthreads();
-        const u64 K2 = kcur;
-        if (fast) {
-#pragma unroll
-            for (int c = 0; c < kFastChunks; c++) {
-                if (c >= nchunk) break;
-                if (c > 0) {
-                    __syncthreads();                  // previous chunk's readers are done
-                    park_chunk(c);
-                    fetch_chunk(b + 1, c);
-                    __syncthreads();
-                }
-                const int wd = b + 1 + c * kFastBlk + tid;
-                if (K2 && tid < kFastBlk && wd < nbu) {
-                    u64 acc = 0ull;
-                    u64 bits = K2;
-                    while (bits) {
-                        const int r = __ffsll((long long)bits) - 1;
-                        bits &= bits - 1;
-                        acc |= tbuf[tid * 65 + r];
-                    }
-                    remv[wd] |= acc;
-                }
-            }
-        } else if (K2) {
-            for (int wd = b + 1 + tid; wd < nbu; wd += kReduceThreads) {
-                u64 acc = 0ull;
-                u64 bits = K2;
-                while (bits) {
-                    int r = __ffsll((long long)bits) - 1;
-                    bits &= bits - 1;
-                    acc |= mask[tile_id(b, wd, nb) * kTile + r];
-                }
-                remv[wd] |= acc;
-            }
-        }
-        __syncthreads();
-    }
 
     if (w.use_perm) {
         // The kept bits live in tile (class-major) order; the keep list is emitted in GLOBAL score order:
@@ -1697,15 +1731,18 @@ int run_nms(const float* d_dets9, int row_cap, const int* d_counts, int N, int m
     if (rc) return rc;
     static bool reduce_attr = false;
     if (!reduce_attr) {
-        DAFNE_HIP_TRY(hipFuncSetAttribute((const void*)nms_reduce_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize,
+        DAFNE_HIP_TRY(hipFuncSetAttribute((const void*)nms_class_reduce_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                           kFastBlk * 65 * (int)sizeof(u64)));
         reduce_attr = true;
     }
-    // more than 160 row blocks (the 27 000-box TTA merge): the kernel falls back to its OR phase on global memory --
-    // a 3-chunk LDS variant (nms_reduce_kernel<3>) spilled and lost 2x, so it is not instantiated
-    hipLaunchKernelGGL(nms_reduce_kernel<1>, dim3(N), dim3(kReduceThreads), (size_t)kFastBlk * 65 * sizeof(u64), st, d_counts,
-                       m_cap, post_topk, w, reinterpret_cast<long long*>(d_keep), d_num_keep);
-    return dafne::check_launch("nms_reduce");
+    // class-major images: one workgroup per class; others: workgroup 0 walks the whole image (the unused ones exit)
+    hipLaunchKernelGGL(nms_class_reduce_kernel, dim3(w.cls && w.use_perm ? kMaxClsWG : 1, N), dim3(kReduceThreads),
+                       (size_t)kFastBlk * 65 * sizeof(u64), st, d_counts, m_cap, w);
+    rc = dafne::check_launch("nms_class_reduce");
+    if (rc) return rc;
+    hipLaunchKernelGGL(nms_compact_kernel, dim3(N), dim3(kReduceThreads), 0, st, d_counts, m_cap, post_topk, w,
+                       reinterpret_cast<long long*>(d_keep), d_num_keep);
+    return dafne::check_launch("nms_compact");
 }
 
 }  // namespace
