@@ -125,10 +125,6 @@ def pack_b2b(w3, w1):
     phase 2c = conv3 rows c*256 + wave*32 + (lane & 31) over K = 256, phase 2c+1 = conv1 rows wave*32 + (lane & 31)
     over K-chunk c; K columns 16*step + 8*(lane >> 5) .. +8."""
     assert tuple(w3.shape) == (1024, 256) and tuple(w1.shape) == (256, 1024) and w3.dtype == BF16 and w1.dtype == BF16
-    if os.environ.get("DAFNE_B2B_V0"):      # A/B only: the 64-pixel kernel's packing (scratch/variants/libb2b_v0.so)
-        a1 = w3.reshape(4, 4, 2, 32, 16, 2, 8).permute(0, 1, 4, 2, 5, 3, 6)
-        a2 = w1.reshape(4, 2, 32, 4, 16, 2, 8).permute(3, 0, 4, 1, 5, 2, 6)
-        return torch.stack([a1, a2], dim=1).contiguous().reshape(8, 4, 16, 2, 64, 8)
     a1 = w3.reshape(4, 8, 32, 16, 2, 8).permute(0, 1, 3, 4, 2, 5)          # c, w, t, h, r, e
     a2 = w1.reshape(8, 32, 4, 16, 2, 8).permute(2, 0, 3, 4, 1, 5)          # c, w, t, h, r, e
     return torch.stack([a1, a2], dim=1).contiguous().reshape(8, 8, 16, 64, 8)
