@@ -196,3 +196,125 @@ def test_headline_workload_vs_oracle(headline, mode):
     assert e["match_rate"] >= b["match_rate"] - 0.10 and e["match_rate"] >= 0.5, (e, b)
     assert e["abs_score_delta"]["p99"] <= max(2.0 * b["abs_score_delta"]["p99"], 1e-3), (e, b)
     assert e["abs_corner_delta_px"]["p50"] <= max(2.0 * b["abs_corner_delta_px"]["p50"], 1e-3), (e, b)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# The other BASELINE.json configs at THEIR sizes (the small-image tests never reach these kernel / tile choices either).
+def _features_vs_oracle(feats_img0, fe, f32, tag, floor_factor=1.5):
+    out = {}
+    for k, a in zip(LEVELS, feats_img0):
+        e = a.cpu()
+        e_emu, e_32, floor = rel(e, fe[k]), rel(e, f32[k]), rel(fe[k], f32[k])
+        out[k] = {"vs_bf16_emulation": e_emu, "vs_fp32": e_32, "emulation_vs_fp32": floor}
+        assert e_emu < 2.5e-2 and e_32 < 2.5e-2 and e_32 < floor_factor * floor, (tag, k, e_emu, e_32, floor)
+    return out
+
+
+def test_config1_r50_batch8_full_size_vs_oracle():
+    """configs[1]: DOTA-1.0 1024x1024 R50-FPN bf16, batch 8 on one MI355X, as bench.py's `configs1_r50_b8` runs it
+    (pipelined, 3 sub-batches): image 0's FPN features vs the oracle, all 8 images' post-process exact on the engine's
+    own head outputs."""
+    sys.path.insert(0, ROOT)
+    import bench
+    dev = torch.device("cuda", 0)
+    cfg, model, sd = bench.build_model(50, dev, seed=0)
+    g = torch.Generator().manual_seed(0)
+    batch = torch.randint(0, 256, (BATCH, 3, SIZE, SIZE), generator=g, dtype=torch.uint8)
+    P = {k: v.float() for k, v in sd.items()}
+    with torch.no_grad():
+        x, _ = om.preprocess([batch[0]], cfg.MODEL.PIXEL_MEAN, cfg.MODEL.PIXEL_STD)
+        f32 = om.backbone_forward(P, x, 50)
+        fe = om.backbone_forward(P, x, 50, emulate_bf16=True)
+    rows, counts, hp, feats = _run(model, batch.to(dev), "pipelined3")
+    _features_vs_oracle([a.nchw_float()[0:1] for a in feats], fe, f32, "r50")
+    for i in range(BATCH):
+        _check_postprocess_exact(_rows_to_dict(rows, counts, i), _oracle_detections(_levels_numpy(hp, i), cfg.MODEL.DAFNE), ("r50", i))
+
+
+@pytest.mark.parametrize("size", [450, 1200])
+def test_config3_tta_view_sizes_vs_oracle(size):
+    """configs[3]: DOTA-1.5 R101-FPN multi-scale inference.  The TTA views of a 1024x1024 tile are 450 .. 1200 px squares
+    (dota-1.5_r101_ms.yaml:399-409), i.e. other map sizes (padded to /32: 480, 1216) than the 1024 tiles of the
+    other configs.  The smallest and the largest view -- built by the resize kernel, hflip on the large one -- go
+    through the detector exactly as OneStageRCNNWithTTA sends them (do_postprocess=False): FPN features vs the oracle on
+    the same view pixels, detections exact vs the oracle's post-process on the engine's own head outputs (THRESH_WITH_CTR
+    false, SORT_CORNERS false, 16 classes).  The class prior is raised as in bench.py's configs3 line: this config
+    thresholds the raw class score."""
+    sys.path.insert(0, ROOT)
+    import bench
+    from dafne_amd.modeling.tta import resize_u8
+    dev = torch.device("cuda", 0)
+    cfg, model, sd = bench.build_model(101, dev, seed=0, cfgname="dota-1.5_r101.yaml", cls_prior=-1.5)
+    d = cfg.MODEL.DAFNE
+    g = torch.Generator().manual_seed(5)
+    tile = torch.randint(0, 256, (3, SIZE, SIZE), generator=g, dtype=torch.uint8).to(dev)
+    view = resize_u8(tile, size, size, hflip=(size == 1200), vflip=False)
+    P = {k: v.float() for k, v in sd.items()}
+    with torch.no_grad():
+        x, _ = om.preprocess([view.cpu()], cfg.MODEL.PIXEL_MEAN, cfg.MODEL.PIXEL_STD)
+        f32 = om.backbone_forward(P, x, 101)
+        fe = om.backbone_forward(P, x, 101, emulate_bf16=True)
+    hn = (size + 31) // 32 * 32
+    assert tuple(x.shape[2:]) == (hn, hn)
+    rows, counts = model.detect_packed(view[None], do_postprocess=False)
+    torch.cuda.synchronize()
+    plan = model.plan(1, hn, hn)
+    _features_vs_oracle([a.nchw_float()[0:1] for a in plan.features], fe, f32, ("tta", size))
+    got = _rows_to_dict(rows, counts, 0)
+    det = opp.predict_proposals(_levels_numpy(plan.head, 0), d.FPN_STRIDES, thresh=d.INFERENCE_TH_TEST, topk=d.PRE_NMS_TOPK_TEST,
+                                nms_thresh=d.NMS_TH, post_topk=d.POST_NMS_TOPK_TEST, thresh_with_ctr=d.THRESH_WITH_CTR,
+                                sort_corners=d.SORT_CORNERS, fast=True)
+    exp = opp.detector_postprocess(det, (size, size), (size, size), (size, size))
+    _check_postprocess_exact(got, exp, ("tta", size))
+
+
+def test_config4_fp8_batch16_full_size_vs_oracle():
+    """configs[4]: UCAS-AOD R101-FPN with fp8 (e4m3) weights, 16 images per GPU, 1024x1024, pipelined as bench.py's
+    `configs4_fp8w_r101_b16` line runs it.  Image 0: FPN features vs the oracle's fp8 definition (bf16 kernels on exactly
+    dequantised e4m3 weights: the bf16 bound applies, and the engine must be closer to the fp8 definition than to the bf16
+    model); head outputs vs the fp8 oracle inside the bound measured on the oracle itself (its outputs with 5 % of the
+    input features moved by one bf16 ulp, as tests/test_gpu_fp8.py does at small size); all 16 images: post-process exact."""
+    sys.path.insert(0, ROOT)
+    import bench
+    dev = torch.device("cuda", 0)
+    cfg, model, sd = bench.build_model(101, dev, seed=0, cfgname="ucas_aod_r101_fp8.yaml", cls_prior=-1.5)
+    assert cfg.ENGINE.WEIGHT_DTYPE == "fp8_e4m3"
+    n = 16
+    g = torch.Generator().manual_seed(0)
+    batch = torch.randint(0, 256, (n, 3, SIZE, SIZE), generator=g, dtype=torch.uint8)
+    P = {k: v.float() for k, v in sd.items()}
+    with torch.no_grad():
+        x, _ = om.preprocess([batch[0]], cfg.MODEL.PIXEL_MEAN, cfg.MODEL.PIXEL_STD)
+        f_q = om.backbone_forward(P, x, 101, emulate_bf16=True, fp8=True)
+        f_b = om.backbone_forward(P, x, 101, emulate_bf16=True)
+    bd = batch.to(dev)
+    for _ in range(3):
+        rows, counts = model.detect_packed(bd, pipelined=True, splits=SPLITS)
+    torch.cuda.synchronize()
+    st = model._pipe[(n, SIZE, SIZE, SPLITS)]
+    slot = (st["i"] - 1) & 1
+    hp, plan0 = st["ho"][slot], st["plans"][slot][0]
+    names = [c.kernel_name() for c in plan0.calls if hasattr(c, "kernel_name")]
+    assert names.count("conv3x3_patch_fp8") == 10, names
+    eng_feats = [a.nchw_float()[0:1].cpu() for a in plan0.features]
+    for k, e in zip(LEVELS, eng_feats):
+        e_q, e_b = rel(e, f_q[k]), rel(e, f_b[k])
+        assert e_q < 2.5e-2 and e_b > 2 * e_q, ("fp8", k, e_q, e_b)
+    # head: the engine's own features through the fp8 oracle head, and a twin with 5 % of the elements one bf16 ulp off
+    with torch.no_grad():
+        h_q = om.head_forward(P, eng_feats, emulate_bf16=True, fp8=True)
+        gt = torch.Generator().manual_seed(1)
+        twin = [(f * (1 + (torch.rand(f.shape, generator=gt) < 0.05).float() * 2.0 ** -8)).to(torch.bfloat16).float() for f in eng_feats]
+        h_t = om.head_forward(P, twin, emulate_bf16=True, fp8=True)
+    for l in range(5):
+        lg = hp.logits[l][0:1].permute(0, 3, 1, 2).cpu()
+        dc = hp.delta_ctr[l][0:1].permute(0, 3, 1, 2).cpu()
+        ce = hp.center[l][0:1].permute(0, 3, 1, 2).cpu()
+        sc = float(hp.scales[l])
+        eng = (lg, (ce.repeat(1, 4, 1, 1) + dc[:, :8]) * sc, ce * sc, dc[:, 8:9])
+        for j, nme in enumerate(("logits", "reg", "center", "ctrness")):
+            e_q, e_t = rel(eng[j], h_q[j][l]), rel(h_t[j][l], h_q[j][l])
+            assert e_q < max(2.5e-2, 1.5 * e_t), ("fp8 head", nme, l, e_q, e_t)
+    d = cfg.MODEL.DAFNE
+    for i in range(n):
+        _check_postprocess_exact(_rows_to_dict(rows, counts, i), _oracle_detections(_levels_numpy(hp, i), d), ("fp8", i))
