@@ -149,7 +149,10 @@ def _defaults():
                   AUG=dict(ENABLED=False, MIN_SIZES=[1024], MAX_SIZE=1200, FLIP=True,
                            HFLIP=True, VFLIP=True, ROTATION_ANGLES=[])),
         # engine-specific knobs (not in the reference)
-        ENGINE=dict(WEIGHT_DTYPE="bf16", ACT_DTYPE="bf16"),
+        ENGINE=dict(WEIGHT_DTYPE="bf16", ACT_DTYPE="bf16",
+                    # fp8 model: "first_batch" = calibrate the e4m3 activation scales on the first batch detect_packed sees;
+                    # "off" = only the GroupNorm-fed tower layers take e4m3 activations (until calibrate_fp8 is called)
+                    FP8_ACT_CALIBRATION="first_batch"),
     )
 
 

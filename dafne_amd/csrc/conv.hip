@@ -2759,6 +2759,21 @@ int dafne_conv2d_tiles_per_image(const dafne_conv_params* prm, const dafne_conv_
     return DAFNE_OK;
 }
 
+int dafne_conv2d_fp8w_num_tiles(const dafne_conv_params* prm, const dafne_conv_seg* segs) {
+    ConvDev D;
+    if (build(D, prm, segs, true)) return -1;
+    return D.mtiles;
+}
+
+int dafne_conv2d_fp8w_tiles_per_image(const dafne_conv_params* prm, const dafne_conv_seg* segs, int32_t* out) {
+    ConvDev D;
+    int rc = build(D, prm, segs, true);
+    if (rc) return rc;
+    if (!out) return dafne::fail(DAFNE_E_INVALID, "conv fp8w: null output");
+    for (int s = 0; s < D.n_segs; s++) out[s] = D.seg[s].tiles_per_img;
+    return DAFNE_OK;
+}
+
 int dafne_conv2d_kernel_id(const dafne_conv_params* prm, const dafne_conv_seg* segs) {
     ConvDev D;
     if (build(D, prm, segs)) return -1;

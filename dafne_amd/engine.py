@@ -108,6 +108,33 @@ def pack_conv_fp8(weight, device):
     return qb.contiguous().to(device), scale.to(device).contiguous()
 
 
+def act_qscale_from_amax(amax, margin=2.0):
+    """fp8 (config 5) activation scale of a layer whose input is NOT a GroupNorm output: the largest power of two q with
+    margin * amax * q <= 448 (e4m3's largest finite value; margin 2: inputs up to twice the calibration batch's amax
+    still do not clip).  Powers of two keep x * q exact, so the only rounding is the e4m3 one.  amax 0 -> 1."""
+    import math
+    if not (amax > 0.0) or not math.isfinite(amax):
+        return 1.0
+    return float(2.0 ** math.floor(math.log2(E4M3_MAX / (margin * amax))))
+
+
+class AmaxProbe:
+    """Calibration-plan entry: max |x| of the listed activations (interior only; the halo is zero) into calib[key]."""
+
+    flops = 0
+    bytes = 0
+
+    def __init__(self, calib, key, acts):
+        self.calib, self.key, self.acts = calib, key, list(acts)
+
+    def kernel_name(self):
+        return "amax_probe"
+
+    def __call__(self, stream):
+        m = max(float(a.t.float().abs().max().item()) for a in self.acts)
+        self.calib[self.key] = max(self.calib.get(self.key, 0.0), m)
+
+
 def pack_stem(weight, bias, device):
     """[64,3,7,7] -> bf16 [64, 256]: k = (kh 0..7, kw 0..7, c 0..3), zero where kh=7, kw=7 or c=3."""
     cout = weight.shape[0]
@@ -172,6 +199,8 @@ class ConvCall:
                                       + (hout * wout * cout // 2 if (flags & F_UP) else 0))
 
     def num_tiles(self):
+        if self.fp8 is not None:
+            return _lib.load().dafne_conv2d_fp8w_num_tiles(ctypes.byref(self.prm), self.segs)
         return _lib.load().dafne_conv2d_num_tiles(ctypes.byref(self.prm), self.segs)
 
     def tile_pixels(self):
@@ -192,8 +221,8 @@ class ConvCall:
 
     def tiles_per_image(self):
         out = (ctypes.c_int32 * self.prm.n_segs)()
-        _lib.check(_lib.load().dafne_conv2d_tiles_per_image(ctypes.byref(self.prm), self.segs, out),
-                   "dafne_conv2d_tiles_per_image")
+        fn = _lib.load().dafne_conv2d_fp8w_tiles_per_image if self.fp8 is not None else _lib.load().dafne_conv2d_tiles_per_image
+        _lib.check(fn(ctypes.byref(self.prm), self.segs, out), "dafne_conv2d_tiles_per_image")
         return list(out)
 
     def __call__(self, stream):
@@ -230,8 +259,13 @@ def conv_out_hw(h, w, k, stride, pad):
 class DensePlan:
     """Backbone + FPN + head for one (N, H, W): buffers + ordered launches."""
 
-    def __init__(self, weights, n, h, w, depth, num_classes, device, with_head=True, head_outputs=None):
+    def __init__(self, weights, n, h, w, depth, num_classes, device, with_head=True, head_outputs=None, calib=None):
+        """calib (dict): build the CALIBRATION plan of an fp8 model -- every layer that could take its plain (not
+        GroupNorm-fed) input in e4m3 runs on the bf16 kernel and records max |input| under its weight key; the scales derived
+        from it (act_qscale_from_amax) go into weights["act_q8"], and plans built afterwards route those layers to the fp8
+        MFMA kernel (dafne_conv2d_nhwc_fp8w_hip with in_qscale = the layer's scale)."""
         assert h % 32 == 0 and w % 32 == 0
+        self.calib = calib
         self.n, self.h, self.w = n, h, w
         self.device = device
         self.calls = []
@@ -242,14 +276,23 @@ class DensePlan:
         pool = Pool(device)
         self.pool = pool
 
+        act_q8 = P.get("act_q8") or {}
+
         def conv(key, tin, k, stride, pad, flags, res=None, out=None, cout=None):
             wgt, bias = P[key]
             cin = tin.c
             cout = cout or wgt.shape[0]
             ho, wo = conv_out_hw(tin.h, tin.w, k, stride, pad)
             o = out or pool.get(n, ho, wo, cout)
-            c = ConvCall(wgt, bias, cin, cout, k, stride, pad, flags,
-                         [(tin.t, o.t, res.t if res is not None else None, tin.h, tin.w, ho, wo)], n)
+            q8 = P.get(key + ".fp8")
+            fp8 = None
+            if q8 is not None and k == 3 and stride == 1 and res is None and not (flags & (F_F32 | F_UP | F_RES)):
+                if calib is not None:
+                    self.calls.append(AmaxProbe(calib, key, [tin]))
+                elif key in act_q8:
+                    fp8 = (q8[1] / act_q8[key], act_q8[key])       # oscale = weight scale / in_qscale
+            c = ConvCall(q8[0] if fp8 else wgt, bias, cin, cout, k, stride, pad, flags,
+                         [(tin.t, o.t, res.t if res is not None else None, tin.h, tin.w, ho, wo)], n, fp8=fp8)
             self.calls.append(c)
             self.flops += c.flops
             return o
@@ -427,8 +470,21 @@ class HeadPlan:
                 gamma, beta = P["%s.%d.gn" % (name, 3 * i + 1)]
                 outs = [pool.get(n, f.h, f.w, C) for f in cur]
                 flags = F_GN | (F_GNIN if cur_gn is not None else 0)
-                # M-tile geometry comes from the library (the kernel choice fixes the tile shape)
+                lkey = "%s.%d" % (name, 3 * i)
+                q8 = P.get(lkey + ".fp8")
+                aq = 1.0 if cur_gn is not None else (P.get("act_q8") or {}).get(lkey)
+                calib = getattr(plan, "calib", None)
+                if q8 is not None and cur_gn is None and calib is not None:
+                    calls.append(AmaxProbe(calib, lkey, cur))            # FPN-fed layer: one scale for the five levels
+                    aq = None                                            # ... and bf16 while calibrating
+                # M-tile geometry comes from the library (the kernel choice fixes the tile shape; the fp8 kernel always
+                # uses the patch kernel's tiles, the bf16 one only when the launch has enough of them)
                 probe = ConvCall(wgt, bias, C, C, 3, 1, 1, flags & ~F_GN, seg_list(cur, outs), n, gn_in=cur_gn)
+                use_fp8 = q8 is not None and aq is not None and (cur_gn is None or probe.kernel_id() == 6)
+                if use_fp8:
+                    probe = ConvCall(q8[0], bias, C, C, 3, 1, 1, flags & ~F_GN, seg_list(cur, outs), n, gn_in=cur_gn,
+                                     fp8=(q8[1] / aq, aq))
+                is_patch = use_fp8 or probe.kernel_id() == 6
                 nt = probe.num_tiles()
                 partial = torch.empty(nt, C // 8, 2, dtype=torch.float32, device=device)
                 stats = torch.empty(len(outs), n, C // 8, 2, dtype=torch.float32, device=device)
@@ -443,16 +499,16 @@ class HeadPlan:
                     nxt = ConvCall(wn, bn_, C, cout, 3, 1, 1, fl | F_GNIN, seg_list(outs, dst, f32=f32), n,
                                    gn_in=(stats, gamma, beta))
                     fuse_next = fuse_next and nxt.kernel_id() == (7 if f32 else 6)
-                fuse_fin = fuse_next and fuse_gnfin and probe.kernel_id() == 6 and C == 256
+                fuse_fin = fuse_next and fuse_gnfin and is_patch and C == 256
                 fin = (stats, torch.zeros(len(outs), n, dtype=torch.int32, device=device), 1e-5) if fuse_fin else None
                 if fuse_fin:
                     flags |= F_GNFIN
-                q8 = P.get("%s.%d.fp8" % (name, 3 * i)) if cur_gn is not None else None
-                if q8 is not None and probe.kernel_id() == 6:
-                    # fp8 model: e4m3 weights on the fp8 MFMA kernel, the GroupNorm + ReLU output quantised on load
-                    # (in_qscale 1: a normalised, rectified map sits well inside e4m3's range)
+                if use_fp8:
+                    # fp8 model: e4m3 weights on the fp8 MFMA kernel.  GroupNorm-fed layers: the GroupNorm + ReLU output is
+                    # quantised on load (in_qscale 1: a normalised, rectified map sits well inside e4m3's range); the two
+                    # layers that read FPN features use the calibrated scale of their input
                     c = ConvCall(q8[0], bias, C, C, 3, 1, 1, flags, seg_list(cur, outs), n, gn_partial=partial,
-                                 gn_in=cur_gn, fp8=(q8[1], 1.0), gn_fin=fin)
+                                 gn_in=cur_gn, fp8=(q8[1] / aq, aq), gn_fin=fin)
                 else:
                     c = ConvCall(wgt, bias, C, C, 3, 1, 1, flags, seg_list(cur, outs), n, gn_partial=partial, gn_in=cur_gn,
                                  gn_fin=fin)
@@ -534,10 +590,16 @@ def pack_backbone_weights(sd, depth, device, prefix="backbone.", fp8=False):
             for cname in (("shortcut",) if blk == 0 else ()) + ("conv1", "conv2", "conv3"):
                 w, b = cb("%sres%d.%d.%s" % (bu, si + 2, blk, cname))
                 P["res%d.%d.%s" % (si + 2, blk, cname)] = pack_conv(w, b, device)
+                if fp8 and cname == "conv2" and w.shape[0] % 256 == 0:
+                    # res4 / res5 3x3 layers: e4m3 bytes of the (BN-folded) weight for the fp8 MFMA kernel; used once
+                    # the layer's activation scale has been calibrated (DensePlan, act_q8)
+                    P["res%d.%d.%s.fp8" % (si + 2, blk, cname)] = pack_conv_fp8(w, device)
     for lvl in (3, 4, 5):
         for kind in ("lateral", "output"):
             k = "%sfpn_%s%d" % (prefix, kind, lvl)
             P["fpn_%s%d" % (kind, lvl)] = pack_conv(_wq(sd[k + ".weight"], fp8), sd[k + ".bias"], device)
+            if fp8 and kind == "output":
+                P["fpn_output%d.fp8" % lvl] = pack_conv_fp8(sd[k + ".weight"], device)
     for nme in ("p6", "p7"):
         k = prefix + "top_block." + nme
         P[nme] = pack_conv(_wq(sd[k + ".weight"], fp8), sd[k + ".bias"], device)

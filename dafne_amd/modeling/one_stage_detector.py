@@ -51,6 +51,7 @@ class OneStageDetector(nn.Module):
         self._packed = None
         self._plans = {}
         self._graphs = {}
+        self._act_q8 = None         # fp8 model: calibrated activation scales {weight key: in_qscale} (calibrate_fp8)
         self.side_stream = None
         self._consts = {}
         self.use_graphs = False     # optional: replay each sub-batch's dense plan from a HIP graph (no gain
@@ -67,6 +68,9 @@ class OneStageDetector(nn.Module):
         self._packed = None
         self._plans = {}
         self._graphs = {}
+        self._act_q8 = None
+        if hasattr(self, "_pipe"):
+            self._pipe = {}
         self.backbone.invalidate()
         self.proposal_generator.dafne_head.invalidate()
 
@@ -80,6 +84,51 @@ class OneStageDetector(nn.Module):
             self._packed = engine.pack_model_weights(self.state_dict(), self.depth, self.device,
                                                      weight_dtype=self.cfg.ENGINE.WEIGHT_DTYPE)
         return self._packed
+
+    # ------------------------------------------------------------ fp8 activation scales (BASELINE config 5)
+    def fp8_act_scales(self):
+        """{weight key: in_qscale} of the layers whose plain (not GroupNorm-fed) input is quantised to e4m3 on load:
+        res4 / res5 3x3 layers, FPN output convolutions, the two tower layers that read FPN features.  None until
+        calibrate_fp8 ran (those layers then run the bf16 kernels on the dequantised weights)."""
+        return None if self._act_q8 is None else dict(self._act_q8)
+
+    def calibrate_fp8(self, images_u8, valid_hw=None, layout_hwc=False):
+        """Static activation calibration of the fp8 model on one batch (uint8 CUDA images as detect_packed takes them): a
+        calibration plan runs those layers on the bf16 kernels and records max |input| per layer; in_qscale = the largest
+        power of two with 2 * amax * in_qscale <= 448 (engine.act_qscale_from_amax).  detect_packed calls this on the FIRST
+        batch it sees (cfg.ENGINE.FP8_ACT_CALIBRATION == "first_batch", the default), so a given first batch always
+        yields the same model; pass a representative batch explicitly to pin the scales before serving."""
+        if self.cfg.ENGINE.WEIGHT_DTYPE != "fp8_e4m3":
+            raise RuntimeError("calibrate_fp8: ENGINE.WEIGHT_DTYPE is %r" % (self.cfg.ENGINE.WEIGHT_DTYPE,))
+        L = _lib.load()
+        if layout_hwc:
+            n, h, w, _ = images_u8.shape
+        else:
+            n, _, h, w = images_u8.shape
+        hn, wn = (h + 31) // 32 * 32, (w + 31) // 32 * 32
+        P = dict(self._weights())
+        P.pop("act_q8", None)
+        calib = {}
+        nc = self.proposal_generator.dafne_head.num_classes
+        with torch.cuda.device(images_u8.device):
+            plan = engine.DensePlan(P, n, hn, wn, self.depth, nc, self.device, calib=calib)
+            mean = (ctypes.c_float * 3)(*[float(v) for v in self.cfg.MODEL.PIXEL_MEAN])
+            std = (ctypes.c_float * 3)(*[float(v) for v in self.cfg.MODEL.PIXEL_STD])
+            vt = None
+            if valid_hw is not None and any(tuple(v) != (h, w) for v in valid_hw):
+                vt = torch.tensor([tuple(v) for v in valid_hw], dtype=torch.int32).to(self.device)
+            _lib.check(L.dafne_preprocess_image_hip(_lib.ptr(images_u8.contiguous()), int(layout_hwc), n, h, w, _lib.ptr(vt),
+                                                    mean, std, hn, wn, _lib.ptr(plan.stem_in), _lib.current_stream()),
+                       "dafne_preprocess_image_hip")
+            plan.run()
+            torch.cuda.synchronize()
+        self._act_q8 = {k: engine.act_qscale_from_amax(v) for k, v in calib.items()}
+        self._packed["act_q8"] = dict(self._act_q8)
+        self._plans = {}
+        self._graphs = {}
+        if hasattr(self, "_pipe"):
+            self._pipe = {}
+        return dict(self._act_q8)
 
     def _dev_const(self, values, dtype, shape):
         """Small constant device tensors (per-image sizes) are uploaded once and reused: a
@@ -120,6 +169,9 @@ class OneStageDetector(nn.Module):
         sub-batches use: consecutive calls with different offsets (the TTA wrapper's chunks) run concurrently."""
         if not images_u8.is_cuda or images_u8.dtype != torch.uint8:
             raise RuntimeError("detect_packed needs a uint8 CUDA tensor (the MI355X engine has no CPU path)")
+        if self.cfg.ENGINE.WEIGHT_DTYPE == "fp8_e4m3" and self._act_q8 is None \
+                and self.cfg.ENGINE.FP8_ACT_CALIBRATION == "first_batch":
+            self.calibrate_fp8(images_u8, valid_hw=valid_hw, layout_hwc=layout_hwc)
         L = _lib.load()
         if layout_hwc:
             n, h, w, _ = images_u8.shape

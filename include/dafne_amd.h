@@ -251,6 +251,11 @@ int dafne_conv2d_nhwc_bf16_hip(const dafne_conv_params* prm, const dafne_conv_se
  */
 int dafne_conv2d_nhwc_fp8w_hip(const dafne_conv_params* prm, const dafne_conv_seg* segs, const float* d_oscale,
                                float in_qscale, void* stream);
+/* M tiles of the fp8w call (rows of d_gn_partial) and per image of every segment: the fp8 kernel always uses the 3x3 patch
+ * kernel's 8 x 32 pixel tiles, whatever kernel the bf16 call of the same layer would pick; -1 / error code when the layer is
+ * not one the fp8 kernel takes */
+int dafne_conv2d_fp8w_num_tiles(const dafne_conv_params* prm, const dafne_conv_seg* segs);
+int dafne_conv2d_fp8w_tiles_per_image(const dafne_conv_params* prm, const dafne_conv_seg* segs, int32_t* out);
 int dafne_conv2d_cout_pad(int Cout);
 /* output pixels per M tile the call would use (geometry of d_gn_partial rows), -1 on error */
 int dafne_conv2d_tile_pixels(const dafne_conv_params* prm, const dafne_conv_seg* segs);

@@ -150,6 +150,13 @@ def _wt(w, E, fp8):
     return _bf(quantize_weight_e4m3(w) if fp8 else w, E)
 
 
+def _q8in(x, q):
+    """Input of a layer that takes its plain (not GroupNorm-fed) activation in e4m3 with the calibrated power-of-two scale q
+    (config 5, engine `act_q8`): the bf16 activation is multiplied by q, clamped to +-448, rounded to e4m3 and divided by q
+    again (exact)."""
+    return quantize_act_e4m3(x * q) / q
+
+
 def fold_bn(P, prefix, eps=1e-5):
     """FrozenBatchNorm2d folded into the conv: y = conv(x, w*s) + (b - mean*s)."""
     s = P[prefix + ".norm.weight"] * torch.rsqrt(P[prefix + ".norm.running_var"] + eps)
@@ -157,15 +164,22 @@ def fold_bn(P, prefix, eps=1e-5):
     return P[prefix + ".weight"] * s[:, None, None, None], b
 
 
-def backbone_forward(P, x, depth=50, emulate_bf16=False, taps=None, fp8=False):
+def backbone_forward(P, x, depth=50, emulate_bf16=False, taps=None, fp8=False, act_q8=None):
     """x: [N,3,H,W] fp32, already normalised (and padded to /32).
     Returns {"p3".."p7"}.  ``taps`` (dict) collects intermediate tensors.
-    fp8: every (BN-folded) weight is the dequantised e4m3 weight (quantize_weight_e4m3)."""
+    fp8: every (BN-folded) weight is the dequantised e4m3 weight (quantize_weight_e4m3).
+    act_q8 (with fp8): {engine weight key: in_qscale} -- the res4 / res5 3x3 layers ("res4.3.conv2") and the FPN output
+    convolutions ("fpn_output3") listed there see their input rounded to e4m3 at that scale (the engine's calibrated
+    fp8 MFMA layers, OneStageDetector.fp8_act_scales())."""
     E = emulate_bf16
     bu = "backbone.bottom_up."
+    aq = act_q8 or {}
 
     def cbr(x, prefix, stride, pad, relu=True, res=None):
         w, b = fold_bn(P, prefix)
+        key = prefix[len(bu):]
+        if fp8 and key in aq:
+            x = _q8in(x, aq[key])
         y = F.conv2d(x, _wt(w, E, fp8), b, stride=stride, padding=pad)
         if res is not None:
             y = y + res
@@ -198,7 +212,8 @@ def backbone_forward(P, x, depth=50, emulate_bf16=False, taps=None, fp8=False):
         if prev is not None:
             lat = lat + F.interpolate(prev, scale_factor=2, mode="nearest")
         prev = _bf(lat, E)
-        out["p%d" % lvl] = _bf(F.conv2d(prev, _wt(P["backbone.fpn_output%d.weight" % lvl], E, fp8),
+        pin = _q8in(prev, aq["fpn_output%d" % lvl]) if (fp8 and "fpn_output%d" % lvl in aq) else prev
+        out["p%d" % lvl] = _bf(F.conv2d(pin, _wt(P["backbone.fpn_output%d.weight" % lvl], E, fp8),
                                         P["backbone.fpn_output%d.bias" % lvl], padding=1), E)
     p6 = _bf(F.conv2d(out["p5"], _wt(P["backbone.top_block.p6.weight"], E, fp8),
                       P["backbone.top_block.p6.bias"], stride=2, padding=1), E)
@@ -208,7 +223,7 @@ def backbone_forward(P, x, depth=50, emulate_bf16=False, taps=None, fp8=False):
     return {k: out[k] for k in ("p3", "p4", "p5", "p6", "p7")}
 
 
-def head_forward(P, feats, prefix="proposal_generator.dafne_head.", emulate_bf16=False, fp8=False):
+def head_forward(P, feats, prefix="proposal_generator.dafne_head.", emulate_bf16=False, fp8=False, act_q8=None):
     """DAFNeHead.forward, center-to-corner branch with CORNER_TOWER_ON_CENTER_TOWER,
     CTR_ON_REG, USE_SCALE (dafne.py:350-370,388-414,459-494).  feats: list of 5
     [N,256,H,W].  Returns per-level lists (logits, reg, center, ctrness).
@@ -217,12 +232,17 @@ def head_forward(P, feats, prefix="proposal_generator.dafne_head.", emulate_bf16
     to e4m3 from its fp32 value (the engine's fp8 MFMA layers quantise on load); all other activations are bf16."""
     E = emulate_bf16
     assert E or not fp8
+    aq = act_q8 or {}
 
     def tower(x, name, first_q8=False):
-        """x: fp32 activation (rounded at the consumer); returns the last layer's fp32 GroupNorm + ReLU output."""
+        """x: fp32 activation (rounded at the consumer); returns the last layer's fp32 GroupNorm + ReLU output.
+        act_q8["cls_tower.0"] / ["center_tower.0"]: the FPN-fed first layer takes its bf16 input in e4m3 at that scale."""
         for i in range(4):
             q8 = fp8 and (i > 0 or first_q8)
-            xin = quantize_act_e4m3(x) if q8 else _bf(x, E)
+            if fp8 and i == 0 and not first_q8 and ("%s.0" % name) in aq:
+                xin = _q8in(_bf(x, E), aq["%s.0" % name])
+            else:
+                xin = quantize_act_e4m3(x) if q8 else _bf(x, E)
             y = F.conv2d(xin, _wt(P["%s%s.%d.weight" % (prefix, name, 3 * i)], E, fp8),
                          P["%s%s.%d.bias" % (prefix, name, 3 * i)], padding=1)
             if E:
