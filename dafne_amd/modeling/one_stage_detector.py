@@ -10,6 +10,7 @@ ResNet-FPN -> head -> decode/top-k -> rotated NMS -> rescale/clip/gather -- with
 single host sync at the very end (detection counts).
 """
 import ctypes
+import os
 
 import torch
 from torch import nn
