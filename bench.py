@@ -273,7 +273,7 @@ def _nms_one(args):
     return len(opp.batched_nms_poly(b, s_, c, 0.1, fast=True))
 
 
-def cpu_baseline(cfg, sd, depth, budget_s=12.0):
+def cpu_baseline(cfg, sd, depth, budget_s=4.0):
     """Oracle (port) on the host cores, bounded (~30 s of CPU work in total): the full path for single 1024^2 images
     (batch 1, ~budget_s) and for ONE batch of 8 ("batch 1 and batch 8"); the rotated NMS alone on the
     M = 10 000 set, one thread and all cores (8 images over a process pool: the C oracle is single-threaded)."""
@@ -510,14 +510,15 @@ def main():
 
             def side_fp8():
                 # configs[4]: R101-FPN, 2 classes, fp8 (e4m3) weights, 16 images per GPU -- reported beside the bf16 metric,
-                # never as `value` (reduced precision); the ten GroupNorm-fed tower layers run the fp8 MFMA kernel
+                # never as `value` (reduced precision); 41 of the 3x3 layers run the fp8 MFMA kernel (the first batch calibrates the
+                # activation scales)
                 cfg8, m8, _ = build_model(101, device, seed=0, cfgname="ucas_aod_r101_fp8.yaml", cls_prior=-1.5)
                 b16 = torch.cat([batch, batch.flip(0)])[:16]
                 n8 = max(args.steps // 4, 3)
                 dt8 = time_steps(lambda: m8.detect_packed(b16, pipelined=True, splits=args.splits), n8, 2, False)
                 r8, c8 = m8.detect_packed(b16, pipelined=True, splits=args.splits)
                 torch.cuda.synchronize()
-                out["configs4_fp8w_r101_b16"] = {"images_per_sec": b16.shape[0] * n8 / dt8, "detections_per_image_mean": float(c8.float().mean().item()), "dtype": "fp8 e4m3 weights (head towers on fp8 MFMA) / bf16",
+                out["configs4_fp8w_r101_b16"] = {"images_per_sec": b16.shape[0] * n8 / dt8, "detections_per_image_mean": float(c8.float().mean().item()), "dtype": "fp8 e4m3 weights; 41 3x3 layers (res4/res5, FPN outputs, head towers) on fp8 MFMA with calibrated e4m3 activations, the rest bf16",
                                                  "workload": "UCAS-AOD head (2 classes) 1024x1024 R101-FPN, batch 16, 1 GPU"}
                 m8b = build_model(101, device, seed=0, cfgname="ucas_aod_r101.yaml", cls_prior=-1.5)[1]
                 dt8b = time_steps(lambda: m8b.detect_packed(b16, pipelined=True, splits=args.splits), n8, 2, False)
