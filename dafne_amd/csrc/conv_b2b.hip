@@ -82,8 +82,24 @@ __device__ __forceinline__ unsigned pack_bf16(float a, float b) {
 //   that the next epilogue then waited for: chunks 1..3 took 19-20k cycles against 14.6k for chunk 0).
 // b2b_wait(j) = number of those instructions issued after A(j) and before the wait for it: vmcnt is in-order, so
 // `s_waitcnt vmcnt(b2b_wait(j))` is exactly "A(j) and everything older has landed".
-constexpr int b2b_st(int i) { return ((i & 31) >= 16 && ((i & 31) & 3) == 0) ? 2 : 0; }
-constexpr int b2b_res(int i) { return ((i & 31) >= 16 && ((i & 31) & 3) == 3 && (i >> 5) < 3) ? 2 : 0; }
+// experiment switches (scratch/build_variant.sh): -DDAFNE_B2B_STROW  Y chunk stored as whole 512-B pixel rows behind the first
+// four GEMM2 steps (round 1's form) instead of slab by slab; -DDAFNE_B2B_RESW  next residual chunk issued whole after GEMM2
+#ifdef DAFNE_B2B_STROW
+constexpr bool kStRow = true;
+#else
+constexpr bool kStRow = false;
+#endif
+#ifdef DAFNE_B2B_RESW
+constexpr bool kResWhole = true;
+#else
+constexpr bool kResWhole = false;
+#endif
+constexpr int b2b_st(int i) {
+    return kStRow ? (((i & 31) >= 16 && (i & 31) <= 19) ? 2 : 0) : (((i & 31) >= 16 && ((i & 31) & 3) == 0) ? 2 : 0);
+}
+constexpr int b2b_res(int i) {
+    return kResWhole ? (((i & 31) == 31 && i < 127) ? 8 : 0) : (((i & 31) >= 16 && ((i & 31) & 3) == 3 && (i >> 5) < 3) ? 2 : 0);
+}
 constexpr int b2b_wait(int j) {
     int n = 0;
     if (j <= 7) {
@@ -95,7 +111,7 @@ constexpr int b2b_wait(int j) {
     }
     return n;
 }
-static_assert(b2b_wait(0) == 15 && b2b_wait(8) == 7 && b2b_wait(127) == 4 && b2b_wait(39) == 9 && b2b_wait(27) == 15 && b2b_wait(24) == 13, "vmcnt bookkeeping");
+static_assert(kStRow || kResWhole || (b2b_wait(0) == 15 && b2b_wait(8) == 7 && b2b_wait(127) == 4 && b2b_wait(39) == 9 && b2b_wait(27) == 15 && b2b_wait(24) == 13), "vmcnt bookkeeping");
 
 __global__ void __launch_bounds__(512, 2) conv_b2b_kernel(B2bDev P) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
@@ -191,6 +207,16 @@ __global__ void __launch_bounds__(512, 2) conv_b2b_kernel(B2bDev P) {
         const int q = idx & 7;
         const u32x4 v = *(const u32x4*)(lds + kBuf + sl * kSlab + px * 128 + ((q ^ ((px >> 1) & 7)) * 16));
         *(u32x4*)(dst + (size_t)halo_index(px) * pix_bytes + col0 + sl * 128 + q * 16) = v;
+    };
+    auto store_row = [&](int i, char* dst, unsigned pix_bytes, unsigned col0) {      // pass i of 8: 32 threads write one pixel's 512 B
+        int idx = tid + kNT * i;
+        asm volatile("" : "+v"(idx));
+        int px = idx >> 5;
+        px = px < plast ? px : plast;
+        const int j = idx & 31;
+        const int sl = j >> 3, q = j & 7;
+        const u32x4 v = *(const u32x4*)(lds + kBuf + sl * kSlab + px * 128 + ((q ^ ((px >> 1) & 7)) * 16));
+        *(u32x4*)(dst + (size_t)halo_index(px) * pix_bytes + col0 + j * 16) = v;
     };
     // k16 step: acc[b] += A . B[b]  (slab q of buffer buf, step s inside the slab)
     auto consume = [&](const bf16x8& a, int q, int st, int buf, f32x16* acc) {
@@ -294,9 +320,13 @@ __global__ void __launch_bounds__(512, 2) conv_b2b_kernel(B2bDev P) {
     {                                                                                                           \
         B2B_WAIT_STEP(j);                                                                                       \
         consume(ar[(j) & 7], ((j) & 15) >> 2, (j) & 3, ((j) >> 4) & 1, ACC);                                    \
-        if (B2B_ABL_STORE && ((j) & 31) >= 16 && (((j) & 31) & 3) == 0) {                                        \
+        if (!kStRow && B2B_ABL_STORE && ((j) & 31) >= 16 && (((j) & 31) & 3) == 0) {                            \
             store_slab((((j) & 31) - 16) >> 2, 0, P.out, kCB * 2, (unsigned)((j) >> 5) * 512u);                 \
             store_slab((((j) & 31) - 16) >> 2, 1, P.out, kCB * 2, (unsigned)((j) >> 5) * 512u);                 \
+        }                                                                                                       \
+        if (kStRow && ((j) & 31) >= 16 && ((j) & 31) <= 19) {                                                   \
+            store_row(2 * ((j) & 3), P.out, kCB * 2, (unsigned)((j) >> 5) * 512u);                              \
+            store_row(2 * ((j) & 3) + 1, P.out, kCB * 2, (unsigned)((j) >> 5) * 512u);                          \
         }                                                                                                       \
         __builtin_amdgcn_sched_barrier(0);                                                                      \
         if ((j) + 8 < 128) B2B_LOAD_STEP((j) + 8)                                                               \
@@ -307,8 +337,9 @@ __global__ void __launch_bounds__(512, 2) conv_b2b_kernel(B2bDev P) {
 #define B2B_G2SLAB(C, Q)                                                                                        \
     {                                                                                                           \
         B2B_STEP4(32 * (C) + 16 + 4 * (Q), acc2)                                                                \
-        if (B2B_ABL_BAR || (Q) == 3) barrier();                                                                 \
-        if (B2B_ABL_RES && (C) + 1 < kChunks) dma_slab(P.res, kCB * 2, (unsigned)((C) + 1) * 512u, 1, (Q));                    \
+        if ((B2B_ABL_BAR && !kResWhole) || (Q) == 3) barrier();                                                 \
+        if (!kResWhole && B2B_ABL_RES && (C) + 1 < kChunks) dma_slab(P.res, kCB * 2, (unsigned)((C) + 1) * 512u, 1, (Q));      \
+        if (kResWhole && (Q) == 3 && (C) + 1 < kChunks) dma_tile(P.res, kCB * 2, (unsigned)((C) + 1) * 512u, 1);               \
         __builtin_amdgcn_sched_barrier(0);                                                                      \
     }
 #define B2B_CHUNK(C)                                                                                            \
