@@ -11,14 +11,17 @@
 // for bit.  Everything else here is integer / ordering work.
 //
 // Pipeline (all images of a batch in one set of launches, counts read on device):
-//   nms_minmax   (select path only) per-image max/min -> fp32 span+1
-//   nms_prep     rank-by-counting sort (score desc, index desc on ties), gather
-//                rows into sorted order, hull boxes, |area|, max|coord|
-//   nms_mask     one wave per 64x64 tile of the upper triangle: hull pre-filter
-//                (wave ballot) -> dense list of candidate pairs -> 16 lanes per
-//                pair, one lane per triangle pair, fp64 clip -> 64-bit row words
-//   nms_reduce   one workgroup per image: block-serial greedy scan over the
-//                suppression matrix, ordered compaction of the kept rows, cap
+//   nms_minmax / nms_offset   (select path only) per-image max/min -> fp32 span+1, class offsets (nms.py:74-90), zero-area census
+//   nms_sort_prep + nms_gather   rows into tile order: score descending, larger index first on ties, class-major when
+//                the classes are independent (in-LDS radix sort; nms_chunk_sort + nms_merge_rank above 16384 rows;
+//                nms_prep_f64 rank-by-counting for the fp64 ResultMerge rows), hull boxes, |area|, max|coord|
+//   nms_scan     one wave per 64x64 tile of the upper triangle: class test, guarded hull pre-filter and IoU upper bound
+//                (wave ballots) -> per-row-block lists of candidate pairs
+//   nms_iou      persistent waves over the pair lists: one lane per pair on the convex decision fast path, the
+//                undecided pairs pooled and clipped by 16 lanes each in polyiou.cpp's operation order -> 64-bit row
+//                words of the tile-major suppression matrix
+//   nms_class_reduce   one workgroup per (image, class): block-serial greedy scan over the class's part of the matrix
+//   nms_compact  kept bits -> keep list in global score order, kthvalue cap with ties
 //
 // Wave64 throughout: one ballot == one 64-column tile row.
 #include "common.h"
@@ -680,7 +683,7 @@ __global__ void __launch_bounds__(1024) nms_sort_prep_kernel(const float* __rest
     // class by class, a 64x64 tile of two blocks without a common class has no candidates and nms_scan skips it
     // (1/15 of the tiles remain for 15 classes).  The layout is one more stable ranking pass with the class as the
     // digit; perm maps the global score order to it and the keep list is still emitted in global score order
-    // (nms_reduce walks perm).
+    // (nms_compact walks perm).
     const bool have_cls = w.cls != nullptr && w.use_perm;
     if (threadIdx.x == 0) { badcls = 0; ncls_s = 1; }
     __syncthreads();
@@ -937,7 +940,7 @@ __global__ void __launch_bounds__(256) nms_prep_f64_kernel(const double* __restr
     if ((threadIdx.x & 63) == 0 && amax > 0.f) atomicMax(&w.meta[img * 4 + 0], __float_as_uint(amax));
 }
 
-// ------------------------------------------------------------------ nms_mask
+// ------------------------------------------------------------------ tile pre-filter
 __device__ __forceinline__ int kth_set_bit(u64 m, int t) {
     int pos = 0;
 #pragma unroll
@@ -1355,7 +1358,7 @@ __global__ void __launch_bounds__(64) nms_iou_kernel(const int* __restrict__ cou
     flush_stats();
 }
 
-// ---------------------------------------------------------------- nms_reduce
+// ------------------------------------------------- nms_class_reduce / nms_compact
 __device__ __forceinline__ u64 readlane64(u64 v, int l) {
     unsigned lo = __builtin_amdgcn_readlane((unsigned)v, l);
     unsigned hi = __builtin_amdgcn_readlane((unsigned)(v >> 32), l);
