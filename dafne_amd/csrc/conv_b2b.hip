@@ -100,18 +100,23 @@ constexpr int b2b_st(int i) {
 constexpr int b2b_res(int i) {
     return kResWhole ? (((i & 31) == 31 && i < 127) ? 8 : 0) : (((i & 31) >= 16 && ((i & 31) & 3) == 3 && (i >> 5) < 3) ? 2 : 0);
 }
+#ifdef DAFNE_B2B_RING
+constexpr int kRing = DAFNE_B2B_RING;
+#else
+constexpr int kRing = 8;                 // k16 steps of A fragments in flight per wave
+#endif
 constexpr int b2b_wait(int j) {
     int n = 0;
-    if (j <= 7) {
-        n += (7 - j) + 8;                                      // A(j+1..7), R(0)
-        for (int i = 0; i < j; i++) n += b2b_st(i) + (i + 8 < 128 ? 1 : 0) + b2b_res(i);
+    if (j < kRing) {
+        n += (kRing - 1 - j) + 8;                              // A(j+1..kRing-1), R(0)
+        for (int i = 0; i < j; i++) n += b2b_st(i) + (i + kRing < 128 ? 1 : 0) + b2b_res(i);
     } else {
-        n += b2b_res(j - 8);                                   // R pieces right behind A(j) at the end of step j - 8
-        for (int i = j - 7; i < j; i++) n += b2b_st(i) + (i + 8 < 128 ? 1 : 0) + b2b_res(i);
+        n += b2b_res(j - kRing);                               // R pieces right behind A(j) at the end of step j - kRing
+        for (int i = j - kRing + 1; i < j; i++) n += b2b_st(i) + (i + kRing < 128 ? 1 : 0) + b2b_res(i);
     }
     return n;
 }
-static_assert(kStRow || kResWhole || (b2b_wait(0) == 15 && b2b_wait(8) == 7 && b2b_wait(127) == 4 && b2b_wait(39) == 9 && b2b_wait(27) == 15 && b2b_wait(24) == 13), "vmcnt bookkeeping");
+static_assert(kRing != 8 || kStRow || kResWhole || (b2b_wait(0) == 15 && b2b_wait(8) == 7 && b2b_wait(127) == 4 && b2b_wait(39) == 9 && b2b_wait(27) == 15 && b2b_wait(24) == 13), "vmcnt bookkeeping");
 
 __global__ void __launch_bounds__(512, 2) conv_b2b_kernel(B2bDev P) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
@@ -171,16 +176,16 @@ __global__ void __launch_bounds__(512, 2) conv_b2b_kernel(B2bDev P) {
     // are, so 7 steps (~1 us of matrix work for the two waves of a SIMD) cover the L2 latency.  Readiness is tracked by
     // hand (b2b_wait); stores of a ragged tile are clamped, not predicated, to keep the instruction count exact.
     const unsigned voff = (unsigned)(wave * 16 * 1024 + lane * 16);
-    bf16x8 ar[8];
+    bf16x8 ar[kRing];
 #define B2B_LOAD_STEP(j)                                                                                        \
     {                                                                                                           \
         const char* sb = P.wf + (size_t)((j) >> 4) * kPhaseBytes + ((j) & 15) * 1024;                           \
-        asm volatile("global_load_dwordx4 %0, %1, %2" : "=&v"(ar[(j) & 7]) : "v"(voff), "s"(sb) : "memory");    \
+        asm volatile("global_load_dwordx4 %0, %1, %2" : "=&v"(ar[(j) % kRing]) : "v"(voff), "s"(sb) : "memory");    \
     }
 #define B2B_WAIT_STEP(j)                                                                                        \
     {                                                                                                           \
         constexpr int kWaitN = b2b_wait(j);                                                                     \
-        asm volatile("s_waitcnt vmcnt(%1)" : "+v"(ar[(j) & 7]) : "n"(kWaitN) : "memory");                       \
+        asm volatile("s_waitcnt vmcnt(%1)" : "+v"(ar[(j) % kRing]) : "n"(kWaitN) : "memory");                       \
     }
 
     f32x16 acc1[kPF], acc2[kPF];
@@ -295,6 +300,8 @@ __global__ void __launch_bounds__(512, 2) conv_b2b_kernel(B2bDev P) {
     dma_tile(P.in, kCM * 2, 0, 0);                                     // T
     B2B_LOAD_STEP(0) B2B_LOAD_STEP(1) B2B_LOAD_STEP(2) B2B_LOAD_STEP(3)
     B2B_LOAD_STEP(4) B2B_LOAD_STEP(5) B2B_LOAD_STEP(6) B2B_LOAD_STEP(7)
+    if (kRing > 8) { B2B_LOAD_STEP(8) B2B_LOAD_STEP(9) B2B_LOAD_STEP(10) B2B_LOAD_STEP(11) }
+    if (kRing > 12) { B2B_LOAD_STEP(12) B2B_LOAD_STEP(13) B2B_LOAD_STEP(14) B2B_LOAD_STEP(15) }
     dma_tile(P.res, kCB * 2, 0, 1);                                    // R(0): not awaited here
     B2B_WAIT_STEP(0);                                                  // T and A(0)
     barrier();
@@ -319,7 +326,7 @@ __global__ void __launch_bounds__(512, 2) conv_b2b_kernel(B2bDev P) {
 #define B2B_STEP(j, ACC)                                                                                        \
     {                                                                                                           \
         B2B_WAIT_STEP(j);                                                                                       \
-        consume(ar[(j) & 7], ((j) & 15) >> 2, (j) & 3, ((j) >> 4) & 1, ACC);                                    \
+        consume(ar[(j) % kRing], ((j) & 15) >> 2, (j) & 3, ((j) >> 4) & 1, ACC);                                    \
         if (!kStRow && B2B_ABL_STORE && ((j) & 31) >= 16 && (((j) & 31) & 3) == 0) {                            \
             store_slab((((j) & 31) - 16) >> 2, 0, P.out, kCB * 2, (unsigned)((j) >> 5) * 512u);                 \
             store_slab((((j) & 31) - 16) >> 2, 1, P.out, kCB * 2, (unsigned)((j) >> 5) * 512u);                 \
@@ -329,7 +336,7 @@ __global__ void __launch_bounds__(512, 2) conv_b2b_kernel(B2bDev P) {
             store_row(2 * ((j) & 3) + 1, P.out, kCB * 2, (unsigned)((j) >> 5) * 512u);                          \
         }                                                                                                       \
         __builtin_amdgcn_sched_barrier(0);                                                                      \
-        if ((j) + 8 < 128) B2B_LOAD_STEP((j) + 8)                                                               \
+        if ((j) + kRing < 128) B2B_LOAD_STEP((j) + kRing)                                                               \
     }
 #define B2B_STEP4(j, ACC) B2B_STEP((j), ACC) B2B_STEP((j) + 1, ACC) B2B_STEP((j) + 2, ACC) B2B_STEP((j) + 3, ACC)
     /* GEMM2 over slab Q of the Y chunk; then (every wave done with the slab, its row stores have read it) the same slab

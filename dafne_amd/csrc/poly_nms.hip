@@ -482,6 +482,7 @@ __global__ void __launch_bounds__(1024) nms_cls_layout_kernel(const float* __res
 
 // ------------------------------------------------------------------ nms_prep
 struct Quad;
+__device__ __forceinline__ int quad_fast_class(Quad& q, double& area);
 __device__ __forceinline__ bool quad_fast_ok(Quad& q, double& area);
 // fp32 lower bound of the area of a strictly convex quad with edges >= 1 px (quad_fast_ok), else -1
 __device__ __forceinline__ float convex_area_lb(Quad q) {
@@ -1106,53 +1107,64 @@ __global__ void __launch_bounds__(256) nms_scan_kernel(const int* __restrict__ c
 // px^2.  So with BOTH quads strictly convex, every edge >= 1 px and union >= 16 px^2, a fast IoU outside
 // thresh +- 1e-3 fixes the decision; everything else (non-convex, degenerate, tiny, near the threshold)
 // goes through the reference-order computation (iou_group16).  Keep lists are unchanged (all fixtures).
-__device__ __forceinline__ bool quad_fast_ok(Quad& q, double& area) {
+__device__ __forceinline__ bool quad_fast_ok(Quad& q, double& area) { return (quad_fast_class(q, area) & 1) != 0; }
+
+// bit 0: strictly convex; bit 1: "sane" -- every edge >= 1 px and every vertex >= 1 px away from the coordinate origin (the
+// reference fans both polygons from the ORIGIN, polyiou.cpp:69-93, so its 48 cuts run along origin-vertex lines as well as
+// along the edges; the sliver bound above needs every cut line to be >= 1 px long).  Bit 0 implies bit 1.
+__device__ __forceinline__ int quad_fast_class(Quad& q, double& area) {
     quad_orient(q);                       // counter-clockwise (polyiou.cpp:96-97)
     area = quad_area(q);
-    bool ok = true;
+    bool cvx = true, sane = true;
 #pragma unroll
     for (int i = 0; i < 4; i++) {
         const P2 a = q.v[i], b = q.v[(i + 1) & 3], c = q.v[(i + 2) & 3];
         const double ex = b.x - a.x, ey = b.y - a.y, fx = c.x - b.x, fy = c.y - b.y;
-        ok &= (ex * fy - ey * fx) > 1e-3;              // strictly convex corner
-        ok &= (ex * ex + ey * ey) >= 1.0;              // edge >= 1 px
+        cvx &= (ex * fy - ey * fx) > 1e-3;               // strictly convex corner
+        sane &= (ex * ex + ey * ey) >= 1.0;              // edge >= 1 px
+        sane &= (a.x * a.x + a.y * a.y) >= 1.0;          // origin-vertex cut line >= 1 px
     }
-    return ok;
+    return (cvx && sane ? 1 : 0) | (sane ? 2 : 0);
 }
 
 // returns 0: IoU < thresh - margin, 1: IoU > thresh + margin, 2: undecided (use the exact path)
 //
-// Geometric intersection area of two strictly convex CCW quads WITHOUT building the intersection polygon: its boundary
+// Geometric intersection area of two strictly convex CCW polygons WITHOUT building the intersection polygon: its boundary
 // consists of the parts of A's edges that lie inside B and of B's edges that lie inside A, and by Green's theorem the
-// area is half the sum of cross(start, end) over those parts.  The part of an edge inside the other quad is a parameter
-// interval [t0, t1] clipped by the other quad's four half-planes (Cyrus-Beck), so everything stays in registers: 32
-// signed distances g = cross(edge, vertex - edge origin), 32 interval updates, 8 cross products -- no LDS scratch, no
-// data-dependent indexing, no divergent loop (a Sutherland-Hodgman clip through LDS took ~14 000 cycles per pair).
-// Robustness: a vertex closer than 1e-6 px to the other quad's edge line could be classified on either side (and two
+// area is half the sum of cross(start, end) over those parts.  The part of an edge inside the other polygon is a parameter
+// interval [t0, t1] clipped by the other polygon's half-planes (Cyrus-Beck), so everything stays in registers: for two
+// quads 32 signed distances g = cross(edge, vertex - edge origin), 32 interval updates, 8 cross products -- no LDS scratch,
+// no data-dependent indexing, no divergent loop (a Sutherland-Hodgman clip through LDS took ~14 000 cycles per pair).
+// Robustness: a vertex closer than 1e-6 px to the other polygon's edge line could be classified on either side (and two
 // coincident edges would then be counted twice or not at all), so any |g| <= 1e-6 * |edge| sends the pair to the exact
 // path; otherwise all inside/outside decisions are certain in fp64 and the area is accurate to ~1e-9 px^2 (coordinates
 // are taken relative to A's first vertex).  The decision margins are those of the comment above.
-__device__ __forceinline__ void boundary_part(const Quad& Pq, const Quad& Qq, double& area2, bool& shaky) {
-    double g[4][4];                          // g[i][j]: vertex i of P against edge j of Q (>= 0: inside)
+template <int N>
+struct Poly {
+    P2 v[N];
+};
+template <int NP, int NQ>
+__device__ __forceinline__ void boundary_part(const P2 (&Pv)[NP], const P2 (&Qv)[NQ], double& area2, bool& shaky) {
+    double g[NP][NQ];                        // g[i][j]: vertex i of P against edge j of Q (>= 0: inside)
 #pragma unroll
-    for (int j = 0; j < 4; j++) {
-        const P2 c = Qq.v[j], d = Qq.v[(j + 1) & 3];
+    for (int j = 0; j < NQ; j++) {
+        const P2 c = Qv[j], d = Qv[(j + 1) % NQ];
         const double ex = d.x - c.x, ey = d.y - c.y;
         const double tol = 1e-12 * (ex * ex + ey * ey);
 #pragma unroll
-        for (int i = 0; i < 4; i++) {
-            const double v = ex * (Pq.v[i].y - c.y) - ey * (Pq.v[i].x - c.x);
+        for (int i = 0; i < NP; i++) {
+            const double v = ex * (Pv[i].y - c.y) - ey * (Pv[i].x - c.x);
             g[i][j] = v;
             shaky |= v * v <= tol;
         }
     }
 #pragma unroll
-    for (int i = 0; i < 4; i++) {
-        const P2 a = Pq.v[i], b = Pq.v[(i + 1) & 3];
+    for (int i = 0; i < NP; i++) {
+        const P2 a = Pv[i], b = Pv[(i + 1) % NP];
         double t0 = 0.0, t1 = 1.0;
 #pragma unroll
-        for (int j = 0; j < 4; j++) {
-            const double ga = g[i][j], gb = g[(i + 1) & 3][j];
+        for (int j = 0; j < NQ; j++) {
+            const double ga = g[i][j], gb = g[(i + 1) % NP][j];
             const double tc = ga / (ga - gb);            // only used when the signs differ (ga != gb then)
             const bool na = ga < 0.0, nb = gb < 0.0;
             t0 = (na && !nb) ? fmax(t0, tc) : t0;        // entering the half-plane
@@ -1167,22 +1179,64 @@ __device__ __forceinline__ void boundary_part(const Quad& Pq, const Quad& Qq, do
     }
 }
 
+// General quads (reflex vertex, self-intersecting "bow-tie": what a head with untrained weights emits, 79 % of the listed
+// pairs of the bench pipeline).  polyiou.cpp's intersectArea is sum_ij s_i s_j |T_i n T_j| over the origin fans of the two
+// orientation-normalised polygons = the integral of W_A * W_B, W = the polygon's winding-number function -- and W does not
+// depend on the fan's apex.  So the same number comes from the fans at vertex 0: two triangles per quad, four
+// triangle pairs, each two CONVEX polygons for boundary_part (made counter-clockwise, the sign carried outside).  A fan
+// triangle with |cross| < 1e-3 (area < 5e-4 px^2) is dropped: <= 4 such terms, <= 1e-3 px^2 of the integral, < 7e-5 in
+// IoU at union >= 16 px^2; with the reference's own sliver bound (above; every cut line >= 1 px: `sane`) the geometric
+// IoU is within 2e-4 of polyiou.cpp's, and the +-1e-3 margin decides.
+__device__ __forceinline__ void quad_fan(const Quad& q, Poly<3> (&t)[2], double (&sg)[2], bool (&live)[2]) {
+#pragma unroll
+    for (int k = 0; k < 2; k++) {
+        const P2 a = q.v[0], b = q.v[1 + k], c = q.v[2 + k];
+        const double cr = (b.x - a.x) * (c.y - a.y) - (c.x - a.x) * (b.y - a.y);
+        live[k] = fabs(cr) >= 1e-3;
+        sg[k] = cr < 0.0 ? -1.0 : 1.0;
+        t[k].v[0] = a;
+        t[k].v[1] = cr < 0.0 ? c : b;
+        t[k].v[2] = cr < 0.0 ? b : c;
+    }
+}
+
 __device__ __forceinline__ int fast_decision(Scratch s, Quad A, Quad B, double thresh) {
     double aa, ab;
-    const bool oka = quad_fast_ok(A, aa), okb = quad_fast_ok(B, ab);       // both counter-clockwise afterwards
-    if (!(oka && okb)) return 2;
+    const int ca = quad_fast_class(A, aa), cb = quad_fast_class(B, ab);       // both counter-clockwise afterwards
+    if (!(ca & cb & 2)) return 2;
     const P2 o = A.v[0];
 #pragma unroll
     for (int k = 0; k < 4; k++) {
         A.v[k].x -= o.x; A.v[k].y -= o.y;
         B.v[k].x -= o.x; B.v[k].y -= o.y;
     }
-    double area2 = 0.0;
     bool shaky = false;
-    boundary_part(A, B, area2, shaky);
-    boundary_part(B, A, area2, shaky);
+    double inter;
+    if (ca & cb & 1) {
+        double area2 = 0.0;
+        boundary_part<4, 4>(A.v, B.v, area2, shaky);
+        boundary_part<4, 4>(B.v, A.v, area2, shaky);
+        inter = fmax(0.5 * area2, 0.0);
+    } else {
+        Poly<3> ta[2], tb[2];
+        double sa[2], sb[2];
+        bool la[2], lb[2];
+        quad_fan(A, ta, sa, la);
+        quad_fan(B, tb, sb, lb);
+        double sum2 = 0.0;
+#pragma unroll
+        for (int i = 0; i < 2; i++)
+#pragma unroll
+            for (int j = 0; j < 2; j++)
+                if (la[i] && lb[j]) {
+                    double a2 = 0.0;
+                    boundary_part<3, 3>(ta[i].v, tb[j].v, a2, shaky);
+                    boundary_part<3, 3>(tb[j].v, ta[i].v, a2, shaky);
+                    sum2 += sa[i] * sb[j] * fmax(a2, 0.0);
+                }
+        inter = 0.5 * sum2;
+    }
     if (shaky) return 2;
-    const double inter = fmax(0.5 * area2, 0.0);
     const double uni = aa + ab - inter;
     if (!(uni >= 16.0)) return 2;
     const double iou = inter / uni;

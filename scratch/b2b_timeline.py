@@ -6,14 +6,15 @@ from dafne_amd import engine, _lib
 L = _lib.load(); d = torch.device("cuda", 0)
 N, H, W = 8, 64, 64            # top halo row of d_next = 66 px x 512 B: room for 64 x 12 stamps? 33792 B >= 6144 B
 g = torch.Generator().manual_seed(5)
-ta = engine.Act.from_nchw(torch.randn(N, 256, H, W, generator=g).to(d))
-xa = engine.Act.from_nchw(torch.randn(N, 1024, H, W, generator=g).to(d))
+K = int(sys.argv[1]) if len(sys.argv) > 1 else 1      # buffer sets cycled (K >= 2: beyond the Infinity Cache, real HBM traffic)
+sets = [(engine.Act.from_nchw(torch.relu(torch.randn(N, 256, H, W, generator=g)).to(d)), engine.Act.from_nchw(torch.relu(torch.randn(N, 1024, H, W, generator=g)).to(d)),
+         engine.Act(N, H, W, 1024, d), engine.Act(N, H, W, 256, d)) for _ in range(K)]
 w3p, b3p = engine.pack_conv(torch.randn(1024, 256, 1, 1, generator=g) / 16, torch.randn(1024, generator=g), d)
 w1p, b1p = engine.pack_conv(torch.randn(256, 1024, 1, 1, generator=g) / 32, torch.randn(256, generator=g), d)
 wf = engine.pack_b2b(w3p, w1p)
-y, z = engine.Act(N, H, W, 1024, d), engine.Act(N, H, W, 256, d)
 st = _lib.current_stream()
-for _ in range(3):
+for it in range(3 * K):
+    ta, xa, y, z = sets[it % K]
     _lib.check(L.dafne_bottleneck_tail_head_hip(_lib.ptr(ta.t), _lib.ptr(xa.t), _lib.ptr(wf), _lib.ptr(b3p), _lib.ptr(b1p),
                                                 N, H, W, _lib.ptr(y.t), _lib.ptr(z.t), st), "b2b")
 torch.cuda.synchronize()

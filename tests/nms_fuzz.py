@@ -153,3 +153,82 @@ def expected_keep_counts(dets, thr):
     """2-box images: the second (lower score) box survives iff iou_poly(box0, box1) <= thr (fp64, on the float32 rows)."""
     iou = oracle.iou_poly_pairs(np.ascontiguousarray(dets[:, 0, :8]), np.ascontiguousarray(dets[:, 1, :8]))
     return np.where(iou > thr, 1, 2).astype(np.int32), iou
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# General quads: reflex vertices and self-intersecting "bow-ties" (what a head with untrained weights emits).  The HIP
+# path decides these with the winding-number form of the fast path (two fan triangles per quad, four convex triangle
+# pairs, poly_nms.hip `fast_decision`) and everything within 1e-3 of the threshold with the reference-order clip.
+#
+# Types (index % 5):
+#   0  four random points in a rotated w x h box (convex, dart or bow-tie, whatever comes out) + shifted copy
+#   1  dart: a triangle whose fourth vertex is pushed 20-80 % of the way towards the opposite vertex + shifted copy
+#   2  bow-tie: a rectangle with two vertices swapped (0,1,3,2) and jittered + shifted copy
+#   3  type 0 / 1 / 2 shape against a plain rotated rectangle
+#   4  type 0 with one vertex within 0.5 px of the coordinate ORIGIN (the reference fans from the origin: short cut lines)
+# Half of the pairs aim at thr +- 5e-3, the other half at thr +- 5e-2 (so that the fast path gets to decide).
+def is_convex(q):
+    """[n,8] -> bool [n]: strictly convex (all corner cross products of one sign)."""
+    x, y = q[:, 0::2].astype(np.float64), q[:, 1::2].astype(np.float64)
+    ex, ey = np.roll(x, -1, 1) - x, np.roll(y, -1, 1) - y
+    cr = ex * np.roll(ey, -1, 1) - ey * np.roll(ex, -1, 1)
+    return (cr > 0).all(1) | (cr < 0).all(1)
+
+
+def make_general_pairs(n, thr, seed):
+    """-> (dets [n,2,9] float32 with scores 0.9 / 0.8, type [n] int)."""
+    rng = np.random.default_rng(seed)
+    typ = np.arange(n) % 5
+    w = np.exp(rng.uniform(np.log(4.0), np.log(1500.0), n))
+    h = w / np.exp(rng.uniform(0.0, np.log(8.0), n))
+    ang = rng.uniform(0, 2 * np.pi, n)
+    cx, cy = rng.uniform(0, 2000, n), rng.uniform(0, 2000, n)
+    ca, sa = np.cos(ang), np.sin(ang)
+
+    def place(p):                              # local [n,4,2] -> rotated + translated [n,8]
+        q = np.empty((len(p), 8))
+        q[:, 0::2] = cx[:, None] + p[:, :, 0] * ca[:, None] - p[:, :, 1] * sa[:, None]
+        q[:, 1::2] = cy[:, None] + p[:, :, 0] * sa[:, None] + p[:, :, 1] * ca[:, None]
+        return q
+
+    shape = np.where(typ == 3, rng.integers(0, 3, n), np.where(typ == 4, 0, typ))
+    p = np.zeros((n, 4, 2))
+    r4 = rng.uniform(-0.5, 0.5, (n, 4, 2)) * np.stack([w, h], 1)[:, None, :]
+    p[shape == 0] = r4[shape == 0]
+    k = shape == 1                             # dart
+    tri = np.stack([np.stack([-w / 2, -h / 2], 1), np.stack([w / 2, -h / 2], 1), np.stack([0 * w, h / 2], 1)], 1)
+    depth = rng.uniform(0.2, 0.8, n)
+    mid = 0.5 * (tri[:, 0] + tri[:, 1])
+    inner = mid + depth[:, None] * (tri[:, 2] - mid)
+    dart = np.stack([tri[:, 0], inner, tri[:, 1], tri[:, 2]], 1)       # reflex vertex between the base corners
+    p[k] = dart[k]
+    k = shape == 2                             # bow-tie
+    rect = np.stack([np.stack([-w / 2, -h / 2], 1), np.stack([w / 2, -h / 2], 1), np.stack([w / 2, h / 2], 1), np.stack([-w / 2, h / 2], 1)], 1)
+    bow = rect[:, [0, 1, 3, 2]] + rng.uniform(-0.15, 0.15, (n, 4, 2)) * np.stack([w, h], 1)[:, None, :]
+    p[k] = bow[k]
+    a = place(p)
+    b0 = a.copy()
+    k3 = typ == 3
+    ang2 = rng.uniform(0, np.pi, n)
+    w2, h2 = w * np.exp(rng.uniform(-0.4, 0.4, n)), h * np.exp(rng.uniform(-0.4, 0.4, n))
+    b0[k3] = _rect(w2, h2, ang2, cx, cy)[k3]
+    k4 = np.nonzero(typ == 4)[0]
+    if len(k4):
+        off = a[k4, 0:2] - rng.uniform(-0.5, 0.5, (len(k4), 2))
+        a[k4, 0::2] -= off[:, 0:1]; a[k4, 1::2] -= off[:, 1:2]
+        b0[k4, 0::2] -= off[:, 0:1]; b0[k4, 1::2] -= off[:, 1:2]
+    wide = (np.arange(n) // 5) % 2 == 1
+    target = thr + np.where(wide, rng.uniform(-5e-2, 5e-2, n), rng.uniform(-5e-3, 5e-3, n))
+    phi = rng.uniform(0, 2 * np.pi, n)
+    ux, uy = np.cos(phi), np.sin(phi)
+    t = _bisect_shift(a, b0, ux, uy, np.zeros(n), 1.5 * (w + w2), target, iters=22)
+    b = _shift(b0, t * ux, t * uy)
+    koff = np.nonzero((np.arange(n) // 10) % 4 == 3)[0]            # a quarter at fp32 class-offset magnitudes (not type 4)
+    koff = koff[typ[koff] != 4]
+    off = rng.integers(1, 16, len(koff)) * (rng.uniform(100.0, 3000.0, len(koff)) + 1.0)
+    a[koff] += off[:, None]
+    b[koff] += off[:, None]
+    dets = np.zeros((n, 2, 9), np.float32)
+    dets[:, 0, :8], dets[:, 1, :8] = a.astype(np.float32), b.astype(np.float32)
+    dets[:, 0, 8], dets[:, 1, 8] = 0.9, 0.8
+    return dets, typ

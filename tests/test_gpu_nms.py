@@ -437,6 +437,48 @@ def test_decision_fuzz_one_million_pairs(thr):
     assert paths[0] + paths[1] > 0               # and the fast path still decided some
 
 
+@pytest.mark.parametrize("thr", [0.05, 0.1, 0.3, 0.5])
+def test_decision_fuzz_general_quads(thr):
+    """100 000 two-box images per threshold of NON-convex quads (random four points, darts, bow-ties, against each other and
+    against rectangles; a vertex within 0.5 px of the coordinate origin; fp32 class-offset magnitudes), half of them with the
+    reference IoU within 5e-3 of the threshold, half within 5e-2 (tests/nms_fuzz.py make_general_pairs).  These are the
+    quads an untrained head emits (79 % of the bench pipeline's listed pairs): the winding-number form of the fast path
+    decides the ones away from the threshold, the reference-order clip the rest.  Every keep count must equal the
+    oracle's decision iou_poly(fp64) > thr -- with the fast paths on and with them switched off."""
+    import nms_fuzz
+    from dafne_amd import _lib
+    L = _lib.load()
+    n = 100000
+    dets, typ = nms_fuzz.make_general_pairs(n, thr, seed=int(thr * 1000) + 7)
+    want, iou = nms_fuzz.expected_keep_counts(dets, thr)
+    nonconvex = ~(nms_fuzz.is_convex(dets[:, 0, :8]) & nms_fuzz.is_convex(dets[:, 1, :8]))
+    assert nonconvex.mean() > 0.8
+    d = torch.from_numpy(dets).to(dev())
+    nbytes = L.dafne_poly_nms_workspace_bytes(n, 2)
+    for exact_only in (0, 1):
+        keep = torch.empty((n, 2), dtype=torch.int64, device=dev())
+        nk = torch.zeros(n, dtype=torch.int32, device=dev())
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=dev())
+        L.dafne_poly_nms_set_exact_only(exact_only)
+        try:
+            _lib.check(L.dafne_poly_nms_batched_hip(_lib.ptr(d), None, n, 2, thr, 0, _lib.ptr(keep), _lib.ptr(nk), _lib.ptr(ws),
+                                                    nbytes, _lib.current_stream()), "nms")
+            got = nk.cpu().numpy()
+        finally:
+            L.dafne_poly_nms_set_exact_only(0)
+        bad = np.nonzero(got != want)[0]
+        assert len(bad) == 0, (thr, exact_only, bad[:10], typ[bad[:10]], iou[bad[:10]])
+        off = L.dafne_poly_nms_stats_offset(n, 2, 0)
+        paths = ws[off:off + 16 * n].view(torch.int32).reshape(n, 4).sum(0).cpu().numpy()
+        if not exact_only:
+            listed = int(paths.sum())
+            print("NMS_FUZZ_GENERAL thr=%.2f pairs=%d non-convex=%d listed=%d fast-suppress=%d fast-keep=%d exact=%d"
+                  % (thr, n, int(nonconvex.sum()), listed, paths[0], paths[1], paths[2] + paths[3]))
+            assert paths[0] + paths[1] >= 0.25 * listed       # the general fast path carries the pairs away from the threshold
+            assert paths[2] + paths[3] >= 0.1 * listed        # ... and the reference-order path the ones at it
+        del ws, keep, nk
+
+
 def test_shims_import_by_the_reference_names(golden):
     """shims/poly_nms.py and shims/polyiou.py are what a maintainer puts on PYTHONPATH in place of the external
     `poly_nms` CUDA extension (nms.py:6,91) and the SWIG `polyiou` module (voc_eval.py:184, ResultMerge:38-43): import

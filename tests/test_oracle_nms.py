@@ -83,3 +83,19 @@ def test_fuzz_pair_generator_hugs_the_threshold():
             assert (np.abs(iou[k] - thr) <= 5.5e-3).mean() > 0.95, (thr, f)
             assert 0.3 < (want[k] == 1).mean() < 0.7, (thr, f)
         assert (np.abs(iou[fam == 8] - thr) <= 5.5e-3).mean() > 0.4      # the axis-aligned half
+
+
+def test_general_quad_generator_is_nonconvex_and_hugs_the_threshold():
+    """tests/nms_fuzz.py make_general_pairs (input of the GPU fuzz of the winding-number fast path): mostly non-convex pairs,
+    the shifted-copy types within 5.5e-2 of the threshold on both sides, bow-ties with NEGATIVE reference IoU included."""
+    import nms_fuzz
+    dets, typ = nms_fuzz.make_general_pairs(10000, 0.1, seed=5)
+    want, iou = nms_fuzz.expected_keep_counts(dets, 0.1)
+    nonconvex = ~(nms_fuzz.is_convex(dets[:, 0, :8]) & nms_fuzz.is_convex(dets[:, 1, :8]))
+    assert nonconvex.mean() > 0.8
+    for t in (0, 1, 4):
+        k = typ == t
+        assert (np.abs(iou[k] - 0.1) <= 5.5e-2).mean() > 0.9, t
+        assert 0.3 < (want[k] == 1).mean() < 0.7, t
+    assert (iou < 0).any()                                # winding-number products of bow-ties can be negative (polyiou.cpp:69-93)
+    assert (np.abs(dets[typ == 4, 0, 0:2]) <= 0.5).all()  # vertex 0 within 0.5 px of the origin
