@@ -157,6 +157,16 @@ def pack_b2b(w3, w1):
     return torch.stack([a1, a2], dim=1).contiguous().reshape(8, 8, 16, 64, 8)
 
 
+def pack_b2b_narrow(w3, w1):
+    """Fragment-major weights of dafne_bottleneck_tail_head_narrow_hip from the packed 1x1 weights of conv3 ([256, 64] bf16)
+    and the next block's conv1 ([64, 256] bf16): bf16 [8 waves][4 steps][64 lanes][8] then [2 halves][16 steps][64 lanes][8];
+    row = wave (half) * 32 + (lane & 31), K columns 16*step + 8*(lane >> 5) .. +8."""
+    assert tuple(w3.shape) == (256, 64) and tuple(w1.shape) == (64, 256) and w3.dtype == BF16 and w1.dtype == BF16
+    a1 = w3.reshape(8, 32, 4, 2, 8).permute(0, 2, 3, 1, 4)                 # w, t, h, r, e
+    a2 = w1.reshape(2, 32, 16, 2, 8).permute(0, 2, 3, 1, 4)                # c, t, h, r, e
+    return torch.cat([a1.reshape(-1), a2.reshape(-1)]).contiguous()
+
+
 def fold_frozen_bn(weight, bn_w, bn_b, bn_mean, bn_var, eps=1e-5):
     s = bn_w * torch.rsqrt(bn_var + eps)
     return weight * s[:, None, None, None], bn_b - bn_mean * s
@@ -322,6 +332,7 @@ class DensePlan:
 
         feats = {}
         fuse_b2b = os.environ.get("DAFNE_FUSE_B2B", "1") != "0"
+        fuse_narrow = fuse_b2b and os.environ.get("DAFNE_FUSE_B2B_NARROW", "1") != "0"
         for si, nb in enumerate(STAGE_BLOCKS[depth]):
             y1_next = None
             for b in range(nb):
@@ -353,6 +364,21 @@ class DensePlan:
                                              (_lib.ptr(y2.t), _lib.ptr(sc.t), _lib.ptr(P[key]), _lib.ptr(b3), _lib.ptr(b1),
                                               n, y2.h, y2.w, _lib.ptr(y3.t), _lib.ptr(y1_next.t)),
                                              (y2, sc, P[key], b3, b1, y3, y1_next), "conv_b2b", flops=fl, nbytes=nb_))
+                    self.flops += fl
+                elif fuse_narrow and b + 1 < nb and tuple(w3.shape) == (256, 64) and tuple(P[nxt][0].shape) == (64, 256):
+                    # res2: the same pair as a streaming kernel (conv_b2b_narrow.hip)
+                    w1, b1 = P[nxt]
+                    key = p + "b2b"
+                    if key not in P:
+                        P[key] = pack_b2b_narrow(w3, w1)
+                    y3 = pool.get(n, y2.h, y2.w, 256)
+                    y1_next = pool.get(n, y2.h, y2.w, 64)
+                    fl = 2 * n * y2.h * y2.w * (64 * 256 + 256 * 64)
+                    nb_ = n * y2.h * y2.w * (64 + 256 + 256 + 64) * 2 + 2 * 256 * 64 * 2
+                    self.calls.append(FnCall(L.dafne_bottleneck_tail_head_narrow_hip,
+                                             (_lib.ptr(y2.t), _lib.ptr(sc.t), _lib.ptr(P[key]), _lib.ptr(b3), _lib.ptr(b1),
+                                              n, y2.h, y2.w, _lib.ptr(y3.t), _lib.ptr(y1_next.t)),
+                                             (y2, sc, P[key], b3, b1, y3, y1_next), "conv_b2b_narrow", flops=fl, nbytes=nb_))
                     self.flops += fl
                 else:
                     y3 = conv(p + "conv3", y2, 1, 1, 0, F_RELU | F_RES, res=sc)

@@ -307,6 +307,19 @@ int dafne_bottleneck_tail_head_hip(const void* d_in, const void* d_res, const vo
                                    const float* d_bias1, int n_images, int H, int W, void* d_out, void* d_next,
                                    void* stream);
 /*
+ * The same pair for the narrow stage res2 (same reference block):  d_out = relu(conv3(d_in) + bias3 + d_res)  (1x1,
+ * 64 -> 256; d_res = the block's shortcut: the identity input or the projection's output) and
+ * d_next = relu(conv1'(d_out) + bias1)  (1x1, 256 -> 64).  d_in / d_next [N,H+2,W+2,64], d_res / d_out [N,H+2,W+2,256],
+ * bf16 NHWC with a 1-pixel halo (interior written).  d_wfrag: bf16, conv3 fragment-major [8 waves][4 k16 steps][64 lanes][8]
+ * (rows wave*32 + (lane & 31), K columns 16*step + 8*(lane >> 5) .. +8) followed by conv1' [2 halves][16 steps][64 lanes][8]
+ * (rows half*32 + (lane & 31), same K columns)  (engine.pack_b2b_narrow).  A streaming kernel: persistent workgroups,
+ * both weight matrices in registers, 160 KB of HBM traffic per 128 pixels instead of 224 KB.  Bit-identical to
+ * dafne_conv2d_nhwc_bf16_hip(conv3, RELU|RESIDUAL) followed by (conv1', RELU).
+ */
+int dafne_bottleneck_tail_head_narrow_hip(const void* d_in, const void* d_res, const void* d_wfrag, const float* d_bias3,
+                                          const float* d_bias1, int n_images, int H, int W, void* d_out, void* d_next,
+                                          void* stream);
+/*
  * detectron2 BasicStem in one kernel [recalled; the backbone of backbone/fpn.py:58-91]: conv 7x7 / s2 / p3
  * (FrozenBN folded into d_weight / d_bias) + ReLU + max-pool 3x3 / s2 / p1.  d_in: the layout
  * dafne_preprocess_image_hip writes, bf16 [N, H+6, W+6, 4]; d_weight: bf16 [64, 256] with k = (kh 0..7, kw 0..7,

@@ -445,6 +445,46 @@ def test_stem_pool_fused_equals_conv_then_pool(N, H, W):
         close_bf16(pf.nchw_float().cpu(), ref)
 
 
+@pytest.mark.parametrize("N,H,W", [(1, 8, 16), (2, 64, 64), (3, 13, 21), (1, 1, 1), (3, 128, 128), (2, 256, 256)])
+def test_bottleneck_tail_head_narrow_equals_two_convs(N, H, W):
+    """dafne_bottleneck_tail_head_narrow_hip (res2: conv3 64 -> 256 + shortcut + ReLU, then the next block's conv1 256 -> 64 +
+    ReLU, one persistent streaming kernel) against the two launches of the generic path: bit for bit on both outputs --
+    ragged last tile, several tiles per workgroup (384 and 1024 tiles on 256 CUs), halo untouched -- and against torch
+    within bf16 rounding."""
+    from dafne_amd import engine, _lib
+    L = _lib.load()
+    d = dev()
+    g = torch.Generator().manual_seed(2000 + H * W)
+    t = bfr(torch.randn(N, 64, H, W, generator=g))
+    x = bfr(torch.randn(N, 256, H, W, generator=g))
+    w3 = bfr(torch.randn(256, 64, 1, 1, generator=g) / 8.0)
+    b3 = torch.randn(256, generator=g) * 0.2
+    w1 = bfr(torch.randn(64, 256, 1, 1, generator=g) / 16.0)
+    b1 = torch.randn(64, generator=g) * 0.2
+    st = _lib.current_stream()
+    ta, xa = engine.Act.from_nchw(t.to(d)), engine.Act.from_nchw(x.to(d))
+    w3p, b3p = engine.pack_conv(w3, b3, d)
+    w1p, b1p = engine.pack_conv(w1, b1, d)
+    y_u, z_u = engine.Act(N, H, W, 256, d), engine.Act(N, H, W, 64, d)
+    engine.ConvCall(w3p, b3p, 64, 256, 1, 1, 0, engine.F_RELU | engine.F_RES, [(ta.t, y_u.t, xa.t, H, W, H, W)], N)(st)
+    engine.ConvCall(w1p, b1p, 256, 64, 1, 1, 0, engine.F_RELU, [(y_u.t, z_u.t, None, H, W, H, W)], N)(st)
+    wf = engine.pack_b2b_narrow(w3p, w1p)
+    y_f, z_f = engine.Act(N, H, W, 256, d), engine.Act(N, H, W, 64, d)
+    for _ in range(2):          # twice: the second launch finds the outputs already written (no read-modify-write anywhere)
+        _lib.check(L.dafne_bottleneck_tail_head_narrow_hip(_lib.ptr(ta.t), _lib.ptr(xa.t), _lib.ptr(wf), _lib.ptr(b3p),
+                                                           _lib.ptr(b1p), N, H, W, _lib.ptr(y_f.t), _lib.ptr(z_f.t), st), "b2b_narrow")
+    torch.cuda.synchronize()
+    assert torch.equal(y_f.t, y_u.t)
+    assert torch.equal(z_f.t, z_u.t)
+    assert float(z_f.t[:, 0].abs().max()) == 0 and float(y_f.t[:, :, -1].abs().max()) == 0
+    if N * H * W <= 3 * 128 * 128:
+        y_ref = bfr(F.relu(F.conv2d(t, w3, b3) + x))
+        close_bf16(y_f.nchw_float().cpu(), y_ref)
+        z_ref = bfr(F.relu(F.conv2d(y_ref, w1, b1)))
+        got = z_f.nchw_float().cpu()
+        assert float((got - z_ref).abs().max()) < 0.02 * float(z_ref.abs().max())
+
+
 @pytest.mark.parametrize("N,H,W", [(1, 8, 16), (2, 64, 64), (3, 13, 21), (1, 1, 1)])
 def test_bottleneck_tail_head_fused_equals_two_convs(N, H, W):
     """dafne_bottleneck_tail_head_hip (conv3 + residual + ReLU, then the next block's conv1 + ReLU, one kernel)
