@@ -21,6 +21,11 @@
 // K is walked in ascending order in both GEMMs and the epilogue expressions are those of the separate kernels: results
 // are bit-identical to conv3 (+residual) followed by conv1 (tests/test_gpu_conv.py).
 // HBM per 128-pixel tile: 16 (T) + 64 (X) in, 64 (Y) + 16 (Z) out = 160 KB against 224 KB for the two launches.
+//
+// PROJ (block 0 of the stage): the shortcut is itself a 1x1 convolution of the block's 64-channel input X0 (projection,
+// no ReLU).  Then X is never materialised: the X0 tile rides the LDS ring next to T (16 KB instead of 64 KB of shortcut
+// rows), a third resident weight matrix gives S = bf16(Wsc . X0 + bias_sc) -- rounded to bf16 exactly as the separate
+// launch stores it -- and the epilogue adds it from registers.  112 KB per tile against 304 KB for the three launches.
 #include "common.h"
 
 namespace {
@@ -38,17 +43,20 @@ constexpr int kCM = 64, kCB = 256;
 constexpr int kOffT = 0;                 // 2 x 16 KB ring of T tiles
 constexpr int kOffY = 2 * kSlab;         // 4 slabs: the Y tile (shortcut rows first, updated in place)
 constexpr int kOffZ = kOffY + 4 * kSlab; // Z staging tile
-constexpr int kOffBias = kOffZ + kSlab;  // fp32 [256 conv3 | 64 conv1]
-constexpr int kSmemTotal = kOffBias + (kCB + kCM) * 4;
+constexpr int kOffBias = kOffZ + kSlab;  // fp32 [256 conv3 | 64 conv1 | 256 projection]
+constexpr int kOffX0 = kOffBias + 4096;  // PROJ: 2 x 16 KB ring of X0 tiles
+constexpr int kSmemTotal = kOffBias + 4096;
+constexpr int kSmemTotalProj = kOffX0 + 2 * kSlab;
+static_assert((2 * kCB + kCM) * 4 <= 4096 && kSmemTotalProj <= 160 * 1024, "LDS budget");
 constexpr int kNW = 8, kNT = 512;
-static_assert(kSmemTotal <= 160 * 1024, "LDS budget");
 
 struct NarrowDev {
     const char* in;      // bf16 [N, H+2, W+2, 64]
-    const char* res;     // bf16 [N, H+2, W+2, 256]
-    const char* wf;      // bf16 [8 waves][4 steps][64 lanes][8] (conv3) | [2 halves][16 steps][64 lanes][8] (conv1)
+    const char* res;     // bf16 [N, H+2, W+2, 256]; PROJ: the block input X0 [N, H+2, W+2, 64]
+    const char* wf;      // bf16 [8 waves][4 steps][64 lanes][8] (conv3) | [2 halves][16 steps][64 lanes][8] (conv1) | PROJ: [8][4][64][8] (projection)
     const float* b3;     // [256]
     const float* b1;     // [64]
+    const float* bsc;    // PROJ: [256]
     char* out;           // bf16 [N, H+2, W+2, 256]
     char* next;          // bf16 [N, H+2, W+2, 64]
     int N, H, W, tiles_per_img, tiles;
@@ -62,6 +70,7 @@ __device__ __forceinline__ unsigned pack_bf16(float a, float b) {
     return __builtin_bit_cast(unsigned, r);
 }
 
+template <bool PROJ>
 __global__ void __launch_bounds__(512, 2) conv_b2b_narrow_kernel(NarrowDev P) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const int tid = threadIdx.x;
@@ -94,23 +103,34 @@ __global__ void __launch_bounds__(512, 2) conv_b2b_narrow_kernel(NarrowDev P) {
 #pragma unroll
         for (int s = 0; s < 16; s++) asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(a1[s]) : "v"(w1 + s * 1024) : "memory");
         if (tid < kCB + kCM) ((float*)(lds + kOffBias))[tid] = tid < kCB ? P.b3[tid] : P.b1[tid - kCB];
+        if (PROJ && tid < kCB) ((float*)(lds + kOffBias))[kCB + kCM + tid] = P.bsc[tid];
+    }
+    bf16x8 asc[PROJ ? 4 : 1];
+    if (PROJ) {
+        const char* ws = P.wf + (8 * 4 + 2 * 16) * 1024 + (size_t)wave * 4 * 1024 + lane * 16;
+#pragma unroll
+        for (int s = 0; s < 4; s++) asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(asc[s]) : "v"(ws + s * 1024) : "memory");
     }
 
     // ---- per-tile loads: T by DMA (16 pieces of 8 px x 128 B; wave w moves pieces w and w + 8), X rows into registers
-    u32x4 rr[8];
+    u32x4 rr[PROJ ? 1 : 8];
     auto issue_loads = [&](int t, int buf) {
 #pragma unroll
         for (int ii = 0; ii < 2; ii++) {
             const int px = (wave + kNW * ii) * 8 + (lane >> 3);
             const unsigned q = (unsigned)(((lane & 7) ^ ((px >> 1) & 7)) * 16);
-            __builtin_amdgcn_global_load_lds((gvoid*)(P.in + (size_t)halo_index(t, px) * (kCM * 2) + q),
-                                             (lvoid*)(lds + kOffT + buf * kSlab + (wave + kNW * ii) * 1024), 16, 0, 0);
+            const size_t hp = (size_t)halo_index(t, px) * (kCM * 2) + q;
+            __builtin_amdgcn_global_load_lds((gvoid*)(P.in + hp), (lvoid*)(lds + kOffT + buf * kSlab + (wave + kNW * ii) * 1024), 16, 0, 0);
+            if (PROJ)
+                __builtin_amdgcn_global_load_lds((gvoid*)(P.res + hp), (lvoid*)(lds + kOffX0 + buf * kSlab + (wave + kNW * ii) * 1024), 16, 0, 0);
         }
+        if (!PROJ) {
 #pragma unroll
-        for (int i = 0; i < 8; i++) {
-            const int idx = tid + kNT * i;
-            const char* src = P.res + (size_t)halo_index(t, idx >> 5) * (kCB * 2) + (idx & 31) * 16;
-            asm volatile("global_load_dwordx4 %0, %1, off nt" : "=v"(rr[i]) : "v"(src) : "memory");
+            for (int i = 0; i < 8; i++) {
+                const int idx = tid + kNT * i;
+                const char* src = P.res + (size_t)halo_index(t, idx >> 5) * (kCB * 2) + (idx & 31) * 16;
+                asm volatile("global_load_dwordx4 %0, %1, off nt" : "=v"(rr[i]) : "v"(src) : "memory");
+            }
         }
     };
 
@@ -134,6 +154,10 @@ __global__ void __launch_bounds__(512, 2) conv_b2b_narrow_kernel(NarrowDev P) {
     for (int s = 0; s < 4; s++) asm volatile("" : "+v"(a3[s]));
 #pragma unroll
     for (int s = 0; s < 16; s++) asm volatile("" : "+v"(a1[s]));
+    if (PROJ) {
+#pragma unroll
+        for (int s = 0; s < 4; s++) asm volatile("" : "+v"(asc[s]));
+    }
 
     for (int kk = 0; kk < my_tiles; kk++) {
         const int t = (int)blockIdx.x + kk * G;
@@ -143,18 +167,47 @@ __global__ void __launch_bounds__(512, 2) conv_b2b_narrow_kernel(NarrowDev P) {
         // ---- 1. this tile's loads have landed: only the previous tile's 8 + 2 stores are younger
         if (kk > 0) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
         // ---- 2. shortcut rows -> Y buffer ([slab][px][64 ch], 16-byte chunk ^ ((px >> 1) & 7))
+        if (!PROJ) {
 #pragma unroll
-        for (int i = 0; i < 8; i++) {
-            asm volatile("" : "+v"(rr[i]));
-            const int idx = tid + kNT * i;
-            const int px = idx >> 5, j = idx & 31;
-            const unsigned ad = lds_base + (unsigned)(kOffY + (j >> 3) * kSlab + px * 128 + (((j & 7) ^ ((px >> 1) & 7)) * 16));
-            asm volatile("ds_write_b128 %0, %1" ::"v"(ad), "v"(rr[i]) : "memory");
+            for (int i = 0; i < 8; i++) {
+                asm volatile("" : "+v"(rr[i]));
+                const int idx = tid + kNT * i;
+                const int px = idx >> 5, j = idx & 31;
+                const unsigned ad = lds_base + (unsigned)(kOffY + (j >> 3) * kSlab + px * 128 + (((j & 7) ^ ((px >> 1) & 7)) * 16));
+                asm volatile("ds_write_b128 %0, %1" ::"v"(ad), "v"(rr[i]) : "memory");
+            }
         }
         barrier();       // T tile + shortcut rows visible; every wave is done with the previous tile's LDS reads
         // ---- 3. next tile's loads
         if (kk + 1 < my_tiles) issue_loads(t + G, buf ^ 1);
         __builtin_amdgcn_sched_barrier(0);
+        // ---- 4a. PROJ: S = bf16(Wsc . X0 + bias_sc), kept as packed bf16 pairs in the accumulator layout
+        u32x2 sres[PROJ ? 4 : 1][4];
+        if (PROJ) {
+            f32x16 accs[4];
+#pragma unroll
+            for (int b = 0; b < 4; b++)
+#pragma unroll
+                for (int k = 0; k < 16; k++) accs[b][k] = 0.f;
+#pragma unroll
+            for (int s = 0; s < 4; s++) {
+                bf16x8 bfr[4];
+#pragma unroll
+                for (int b = 0; b < 4; b++) bfr[b] = *(const bf16x8*)(lds + kOffX0 + buf * kSlab + b * 4096 + bs[s]);
+#pragma unroll
+                for (int b = 0; b < 4; b++) accs[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(asc[s], bfr[b], accs[b], 0, 0, 0);
+            }
+#pragma unroll
+            for (int g = 0; g < 4; g++) {
+                const float* bp = (const float*)(lds + kOffBias) + kCB + kCM + wave * 32 + 8 * g + 4 * half;
+                const float c0 = bp[0], c1 = bp[1], c2 = bp[2], c3 = bp[3];
+#pragma unroll
+                for (int b = 0; b < 4; b++) {
+                    sres[g][b].x = pack_bf16(accs[b][4 * g] + c0, accs[b][4 * g + 1] + c1);
+                    sres[g][b].y = pack_bf16(accs[b][4 * g + 2] + c2, accs[b][4 * g + 3] + c3);
+                }
+            }
+        }
         // ---- 4. GEMM1: Y (32 channels of this wave x 128 px) = W3 . T
         f32x16 acc1[4];
 #pragma unroll
@@ -183,11 +236,17 @@ __global__ void __launch_bounds__(512, 2) conv_b2b_narrow_kernel(NarrowDev P) {
                     const int g = 2 * gp + gg;
                     ead[gg] = ebase + (unsigned)(((((wave & 1) * 4 + g) ^ ((frow >> 1) & 7))) * 16);
                     const unsigned bad = lbias + (unsigned)((wave * 32 + 8 * g + 4 * half) * 4);
-                    asm volatile("ds_read_b128 %4, %6\n\tds_read_b64 %0, %5\n\tds_read_b64 %1, %5 offset:4096\n\t"
-                                 "ds_read_b64 %2, %5 offset:8192\n\tds_read_b64 %3, %5 offset:12288"
-                                 : "=&v"(rc[gg][0]), "=&v"(rc[gg][1]), "=&v"(rc[gg][2]), "=&v"(rc[gg][3]), "=&v"(bv[gg])
-                                 : "v"(ead[gg]), "v"(bad)
-                                 : "memory");
+                    if (PROJ) {
+                        asm volatile("ds_read_b128 %0, %1" : "=&v"(bv[gg]) : "v"(bad) : "memory");
+#pragma unroll
+                        for (int b = 0; b < 4; b++) rc[gg][b] = sres[g][b];
+                    } else {
+                        asm volatile("ds_read_b128 %4, %6\n\tds_read_b64 %0, %5\n\tds_read_b64 %1, %5 offset:4096\n\t"
+                                     "ds_read_b64 %2, %5 offset:8192\n\tds_read_b64 %3, %5 offset:12288"
+                                     : "=&v"(rc[gg][0]), "=&v"(rc[gg][1]), "=&v"(rc[gg][2]), "=&v"(rc[gg][3]), "=&v"(bv[gg])
+                                     : "v"(ead[gg]), "v"(bad)
+                                     : "memory");
+                    }
                 }
                 asm volatile("s_waitcnt lgkmcnt(0)"
                              : "+v"(rc[0][0]), "+v"(rc[0][1]), "+v"(rc[0][2]), "+v"(rc[0][3]), "+v"(rc[1][0]), "+v"(rc[1][1]),
@@ -273,13 +332,12 @@ __global__ void __launch_bounds__(512, 2) conv_b2b_narrow_kernel(NarrowDev P) {
 
 extern "C" {
 
-int dafne_bottleneck_tail_head_narrow_hip(const void* d_in, const void* d_res, const void* d_wfrag, const float* d_bias3,
-                                          const float* d_bias1, int n_images, int H, int W, void* d_out, void* d_next,
-                                          void* stream) {
-    if (!d_in || !d_res || !d_wfrag || !d_bias3 || !d_bias1 || !d_out || !d_next) return dafne::fail(DAFNE_E_INVALID, "bottleneck_tail_head_narrow: null argument");
+static int narrow_launch(const void* d_in, const void* d_res, const void* d_wfrag, const float* d_bias3, const float* d_bias_sc,
+                         const float* d_bias1, int n_images, int H, int W, void* d_out, void* d_next, void* stream, bool proj) {
+    if (!d_in || !d_res || !d_wfrag || !d_bias3 || !d_bias1 || !d_out || !d_next || (proj && !d_bias_sc)) return dafne::fail(DAFNE_E_INVALID, "bottleneck_tail_head_narrow: null argument");
     if (n_images < 1 || H < 1 || W < 1 || (long long)H * W > (1 << 20)) return dafne::fail(DAFNE_E_INVALID, "bottleneck_tail_head_narrow: bad size");
     NarrowDev D;
-    D.in = (const char*)d_in; D.res = (const char*)d_res; D.wf = (const char*)d_wfrag; D.b3 = d_bias3; D.b1 = d_bias1;
+    D.in = (const char*)d_in; D.res = (const char*)d_res; D.wf = (const char*)d_wfrag; D.b3 = d_bias3; D.b1 = d_bias1; D.bsc = d_bias_sc;
     D.out = (char*)d_out; D.next = (char*)d_next;
     D.N = n_images; D.H = H; D.W = W;
     D.tiles_per_img = (H * W + kPx - 1) / kPx;
@@ -291,11 +349,25 @@ int dafne_bottleneck_tail_head_narrow_hip(const void* d_in, const void* d_res, c
         int dev = 0;
         DAFNE_HIP_TRY(hipGetDevice(&dev));
         DAFNE_HIP_TRY(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
-        DAFNE_HIP_TRY(hipFuncSetAttribute((const void*)conv_b2b_narrow_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kSmemTotal));
+        DAFNE_HIP_TRY(hipFuncSetAttribute((const void*)conv_b2b_narrow_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, kSmemTotal));
+        DAFNE_HIP_TRY(hipFuncSetAttribute((const void*)conv_b2b_narrow_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, kSmemTotalProj));
     }
     const int grid = D.tiles < n_cu ? D.tiles : n_cu;
-    hipLaunchKernelGGL(conv_b2b_narrow_kernel, dim3(grid), dim3(kNT), kSmemTotal, (hipStream_t)stream, D);
+    if (proj) hipLaunchKernelGGL(conv_b2b_narrow_kernel<true>, dim3(grid), dim3(kNT), kSmemTotalProj, (hipStream_t)stream, D);
+    else hipLaunchKernelGGL(conv_b2b_narrow_kernel<false>, dim3(grid), dim3(kNT), kSmemTotal, (hipStream_t)stream, D);
     return dafne::check_launch("conv_b2b_narrow");
+}
+
+int dafne_bottleneck_tail_head_narrow_hip(const void* d_in, const void* d_res, const void* d_wfrag, const float* d_bias3,
+                                          const float* d_bias1, int n_images, int H, int W, void* d_out, void* d_next,
+                                          void* stream) {
+    return narrow_launch(d_in, d_res, d_wfrag, d_bias3, nullptr, d_bias1, n_images, H, W, d_out, d_next, stream, false);
+}
+
+int dafne_bottleneck_proj_tail_head_narrow_hip(const void* d_in, const void* d_x0, const void* d_wfrag, const float* d_bias3,
+                                               const float* d_bias_sc, const float* d_bias1, int n_images, int H, int W,
+                                               void* d_out, void* d_next, void* stream) {
+    return narrow_launch(d_in, d_x0, d_wfrag, d_bias3, d_bias_sc, d_bias1, n_images, H, W, d_out, d_next, stream, true);
 }
 
 }  // extern "C"

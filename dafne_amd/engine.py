@@ -157,14 +157,18 @@ def pack_b2b(w3, w1):
     return torch.stack([a1, a2], dim=1).contiguous().reshape(8, 8, 16, 64, 8)
 
 
-def pack_b2b_narrow(w3, w1):
+def pack_b2b_narrow(w3, w1, wsc=None):
     """Fragment-major weights of dafne_bottleneck_tail_head_narrow_hip from the packed 1x1 weights of conv3 ([256, 64] bf16)
     and the next block's conv1 ([64, 256] bf16): bf16 [8 waves][4 steps][64 lanes][8] then [2 halves][16 steps][64 lanes][8];
-    row = wave (half) * 32 + (lane & 31), K columns 16*step + 8*(lane >> 5) .. +8."""
+    row = wave (half) * 32 + (lane & 31), K columns 16*step + 8*(lane >> 5) .. +8.  wsc: the projection shortcut's
+    weights ([256, 64], block 0), appended in conv3's layout for dafne_bottleneck_proj_tail_head_narrow_hip."""
     assert tuple(w3.shape) == (256, 64) and tuple(w1.shape) == (64, 256) and w3.dtype == BF16 and w1.dtype == BF16
-    a1 = w3.reshape(8, 32, 4, 2, 8).permute(0, 2, 3, 1, 4)                 # w, t, h, r, e
-    a2 = w1.reshape(2, 32, 16, 2, 8).permute(0, 2, 3, 1, 4)                # c, t, h, r, e
-    return torch.cat([a1.reshape(-1), a2.reshape(-1)]).contiguous()
+    parts = [w3.reshape(8, 32, 4, 2, 8).permute(0, 2, 3, 1, 4).reshape(-1),               # w, t, h, r, e
+             w1.reshape(2, 32, 16, 2, 8).permute(0, 2, 3, 1, 4).reshape(-1)]              # c, t, h, r, e
+    if wsc is not None:
+        assert tuple(wsc.shape) == (256, 64) and wsc.dtype == BF16
+        parts.append(wsc.reshape(8, 32, 4, 2, 8).permute(0, 2, 3, 1, 4).reshape(-1))
+    return torch.cat(parts).contiguous()
 
 
 def fold_frozen_bn(weight, bn_w, bn_b, bn_mean, bn_var, eps=1e-5):
@@ -338,8 +342,13 @@ class DensePlan:
             for b in range(nb):
                 p = "res%d.%d." % (si + 2, b)
                 stride = 2 if (b == 0 and si > 0) else 1
+                w3, b3 = P[p + "conv3"]
+                nxt = "res%d.%d.conv1" % (si + 2, b + 1)
+                # res2.0: the projection shortcut is computed inside the fused tail (conv_b2b_narrow.hip, PROJ)
+                proj_fused = (fuse_narrow and b == 0 and stride == 1 and nb > 1 and tuple(w3.shape) == (256, 64)
+                              and tuple(P[p + "shortcut"][0].shape) == (256, 64) and tuple(P[nxt][0].shape) == (64, 256))
                 if b == 0:
-                    sc = conv(p + "shortcut", x, 1, stride, 0, 0)
+                    sc = None if proj_fused else conv(p + "shortcut", x, 1, stride, 0, 0)
                 else:
                     sc = x
                 if y1_next is not None:
@@ -348,9 +357,22 @@ class DensePlan:
                     y1 = conv(p + "conv1", x, 1, stride, 0, F_RELU)       # STRIDE_IN_1X1
                 y2 = conv(p + "conv2", y1, 3, 1, 1, F_RELU)
                 pool.put(y1)
-                w3, b3 = P[p + "conv3"]
-                nxt = "res%d.%d.conv1" % (si + 2, b + 1)
-                if fuse_b2b and b + 1 < nb and tuple(w3.shape) == (1024, 256) and tuple(P[nxt][0].shape) == (256, 1024):
+                if proj_fused:
+                    w1, b1 = P[nxt]
+                    wsc, bsc = P[p + "shortcut"]
+                    key = p + "b2b"
+                    if key not in P:
+                        P[key] = pack_b2b_narrow(w3, w1, wsc)
+                    y3 = pool.get(n, y2.h, y2.w, 256)
+                    y1_next = pool.get(n, y2.h, y2.w, 64)
+                    fl = 2 * n * y2.h * y2.w * (64 * 256 * 2 + 256 * 64)
+                    nb_ = n * y2.h * y2.w * (64 + 64 + 256 + 64) * 2 + 3 * 256 * 64 * 2
+                    self.calls.append(FnCall(L.dafne_bottleneck_proj_tail_head_narrow_hip,
+                                             (_lib.ptr(y2.t), _lib.ptr(x.t), _lib.ptr(P[key]), _lib.ptr(b3), _lib.ptr(bsc), _lib.ptr(b1),
+                                              n, y2.h, y2.w, _lib.ptr(y3.t), _lib.ptr(y1_next.t)),
+                                             (y2, x, P[key], b3, bsc, b1, y3, y1_next), "conv_b2b_narrow_proj", flops=fl, nbytes=nb_))
+                    self.flops += fl
+                elif fuse_b2b and b + 1 < nb and tuple(w3.shape) == (1024, 256) and tuple(P[nxt][0].shape) == (256, 1024):
                     # conv3 + residual + ReLU and the next block's conv1 + ReLU in one kernel (conv_b2b.hip)
                     w1, b1 = P[nxt]
                     key = p + "b2b"
@@ -383,7 +405,7 @@ class DensePlan:
                 else:
                     y3 = conv(p + "conv3", y2, 1, 1, 0, F_RELU | F_RES, res=sc)
                 pool.put(y2)
-                if b == 0:
+                if b == 0 and sc is not None:
                     pool.put(sc)
                 if not any(x is f for k, f in feats.items() if k != "res2"):
                     pool.put(x)          # res3/res4 outputs stay alive for the FPN laterals

@@ -320,6 +320,16 @@ int dafne_bottleneck_tail_head_narrow_hip(const void* d_in, const void* d_res, c
                                           const float* d_bias1, int n_images, int H, int W, void* d_out, void* d_next,
                                           void* stream);
 /*
+ * Block 0 of res2, whose shortcut is a projection (1x1, 64 -> 256, no ReLU) of the block's input d_x0 [N,H+2,W+2,64]:
+ *   shortcut = bf16(proj(d_x0) + bias_sc);  d_out = relu(conv3(d_in) + bias3 + shortcut);  d_next = relu(conv1'(d_out) + bias1).
+ * The 256-channel shortcut map is never written or read (112 KB of HBM traffic per 128 pixels instead of 304 KB for the
+ * three launches).  d_wfrag: the layout above followed by the projection's weights [8 waves][4 steps][64 lanes][8]
+ * (engine.pack_b2b_narrow(w3, w1, wsc)).  Bit-identical to dafne_conv2d_nhwc_bf16_hip(proj), (conv3, RELU|RESIDUAL), (conv1', RELU).
+ */
+int dafne_bottleneck_proj_tail_head_narrow_hip(const void* d_in, const void* d_x0, const void* d_wfrag, const float* d_bias3,
+                                               const float* d_bias_sc, const float* d_bias1, int n_images, int H, int W,
+                                               void* d_out, void* d_next, void* stream);
+/*
  * detectron2 BasicStem in one kernel [recalled; the backbone of backbone/fpn.py:58-91]: conv 7x7 / s2 / p3
  * (FrozenBN folded into d_weight / d_bias) + ReLU + max-pool 3x3 / s2 / p1.  d_in: the layout
  * dafne_preprocess_image_hip writes, bf16 [N, H+6, W+6, 4]; d_weight: bf16 [64, 256] with k = (kh 0..7, kw 0..7,

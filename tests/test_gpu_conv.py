@@ -485,6 +485,45 @@ def test_bottleneck_tail_head_narrow_equals_two_convs(N, H, W):
         assert float((got - z_ref).abs().max()) < 0.02 * float(z_ref.abs().max())
 
 
+@pytest.mark.parametrize("N,H,W", [(1, 8, 16), (3, 13, 21), (1, 1, 1), (3, 128, 128), (2, 256, 256)])
+def test_bottleneck_proj_tail_head_narrow_equals_three_convs(N, H, W):
+    """dafne_bottleneck_proj_tail_head_narrow_hip (res2 block 0: projection shortcut 64 -> 256 computed in the kernel and
+    rounded to bf16 like the separate launch, conv3 + shortcut + ReLU, next conv1 + ReLU) against the three generic
+    launches: bit for bit on both outputs."""
+    from dafne_amd import engine, _lib
+    L = _lib.load()
+    d = dev()
+    g = torch.Generator().manual_seed(3000 + H * W)
+    t = bfr(torch.randn(N, 64, H, W, generator=g))
+    x0 = bfr(torch.relu(torch.randn(N, 64, H, W, generator=g)))
+    w3 = bfr(torch.randn(256, 64, 1, 1, generator=g) / 8.0)
+    b3 = torch.randn(256, generator=g) * 0.2
+    ws = bfr(torch.randn(256, 64, 1, 1, generator=g) / 8.0)
+    bs_ = torch.randn(256, generator=g) * 0.2
+    w1 = bfr(torch.randn(64, 256, 1, 1, generator=g) / 16.0)
+    b1 = torch.randn(64, generator=g) * 0.2
+    st = _lib.current_stream()
+    ta, xa = engine.Act.from_nchw(t.to(d)), engine.Act.from_nchw(x0.to(d))
+    w3p, b3p = engine.pack_conv(w3, b3, d)
+    wsp, bsp = engine.pack_conv(ws, bs_, d)
+    w1p, b1p = engine.pack_conv(w1, b1, d)
+    sc_u, y_u, z_u = engine.Act(N, H, W, 256, d), engine.Act(N, H, W, 256, d), engine.Act(N, H, W, 64, d)
+    engine.ConvCall(wsp, bsp, 64, 256, 1, 1, 0, 0, [(xa.t, sc_u.t, None, H, W, H, W)], N)(st)
+    engine.ConvCall(w3p, b3p, 64, 256, 1, 1, 0, engine.F_RELU | engine.F_RES, [(ta.t, y_u.t, sc_u.t, H, W, H, W)], N)(st)
+    engine.ConvCall(w1p, b1p, 256, 64, 1, 1, 0, engine.F_RELU, [(y_u.t, z_u.t, None, H, W, H, W)], N)(st)
+    wf = engine.pack_b2b_narrow(w3p, w1p, wsp)
+    y_f, z_f = engine.Act(N, H, W, 256, d), engine.Act(N, H, W, 64, d)
+    for _ in range(2):
+        _lib.check(L.dafne_bottleneck_proj_tail_head_narrow_hip(_lib.ptr(ta.t), _lib.ptr(xa.t), _lib.ptr(wf), _lib.ptr(b3p),
+                                                                _lib.ptr(bsp), _lib.ptr(b1p), N, H, W, _lib.ptr(y_f.t),
+                                                                _lib.ptr(z_f.t), st), "b2b_narrow_proj")
+    torch.cuda.synchronize()
+    assert float(y_f.t.float().abs().max()) > 0
+    assert torch.equal(y_f.t, y_u.t)
+    assert torch.equal(z_f.t, z_u.t)
+    assert float(z_f.t[:, 0].abs().max()) == 0 and float(y_f.t[:, :, -1].abs().max()) == 0
+
+
 @pytest.mark.parametrize("N,H,W", [(1, 8, 16), (2, 64, 64), (3, 13, 21), (1, 1, 1)])
 def test_bottleneck_tail_head_fused_equals_two_convs(N, H, W):
     """dafne_bottleneck_tail_head_hip (conv3 + residual + ReLU, then the next block's conv1 + ReLU, one kernel)
