@@ -95,6 +95,8 @@ SIGNATURES = {
                                                c_void_p, c_void_p, c_void_p]),
     "dafne_bottleneck_tail_head_narrow_hip": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
                                                       c_void_p, c_void_p, c_void_p]),
+    "dafne_bottleneck_tail_head_mid_hip": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
+                                                   c_void_p, c_void_p, c_void_p]),
     "dafne_bottleneck_proj_tail_head_narrow_hip": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
                                                            c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "dafne_stem_pool_hip": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),

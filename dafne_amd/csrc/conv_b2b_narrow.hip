@@ -114,6 +114,8 @@ __global__ void __launch_bounds__(512, 2) conv_b2b_narrow_kernel(NarrowDev P) {
 
     // ---- per-tile loads: T by DMA (16 pieces of 8 px x 128 B; wave w moves pieces w and w + 8), X rows into registers
     u32x4 rr[PROJ ? 1 : 8];
+#pragma unroll
+    for (int i = 0; i < (PROJ ? 1 : 8); i++) rr[i] = u32x4{0u, 0u, 0u, 0u};
     auto issue_loads = [&](int t, int buf) {
 #pragma unroll
         for (int ii = 0; ii < 2; ii++) {
@@ -129,7 +131,9 @@ __global__ void __launch_bounds__(512, 2) conv_b2b_narrow_kernel(NarrowDev P) {
             for (int i = 0; i < 8; i++) {
                 const int idx = tid + kNT * i;
                 const char* src = P.res + (size_t)halo_index(t, idx >> 5) * (kCB * 2) + (idx & 31) * 16;
-                asm volatile("global_load_dwordx4 %0, %1, off nt" : "=v"(rr[i]) : "v"(src) : "memory");
+                // "+v": the destination stays the register that carries rr[i] around the tile loop (with "=v" the compiler
+                // may load into a fresh register and copy it right behind the still outstanding load)
+                asm volatile("global_load_dwordx4 %0, %1, off nt" : "+v"(rr[i]) : "v"(src) : "memory");
             }
         }
     };

@@ -171,6 +171,18 @@ def pack_b2b_narrow(w3, w1, wsc=None):
     return torch.cat(parts).contiguous()
 
 
+def pack_b2b_mid(w3, w1):
+    """Weights of dafne_bottleneck_tail_head_mid_hip (res3) from the packed 1x1 weights of conv3 ([512, 128] bf16) and the next
+    block's conv1 ([128, 512] bf16): bf16 [16 quarter blocks][4 channel quarters][4 k16 steps][64 lanes][8], in the order the
+    kernel consumes them (per 256-channel chunk c: four conv3 blocks (rp, sh), then four conv1 blocks (rp, sh))."""
+    assert tuple(w3.shape) == (512, 128) and tuple(w1.shape) == (128, 512) and w3.dtype == BF16 and w1.dtype == BF16
+    # conv3: rows (c, rp, ct, r), cols (sh, s, hl, e)  ->  (c, rp, sh, ct, s, hl, r, e)
+    a1 = w3.reshape(2, 2, 4, 32, 2, 4, 2, 8).permute(0, 1, 4, 2, 5, 6, 3, 7).reshape(2, 4, -1)
+    # conv1: rows (ct, r), cols (c, rp, sh, s, hl, e)  ->  (c, rp, sh, ct, s, hl, r, e)
+    a2 = w1.reshape(4, 32, 2, 2, 2, 4, 2, 8).permute(2, 3, 4, 0, 5, 6, 1, 7).reshape(2, 4, -1)
+    return torch.cat([a1, a2], dim=1).contiguous().reshape(-1)
+
+
 def fold_frozen_bn(weight, bn_w, bn_b, bn_mean, bn_var, eps=1e-5):
     s = bn_w * torch.rsqrt(bn_var + eps)
     return weight * s[:, None, None, None], bn_b - bn_mean * s
@@ -337,6 +349,7 @@ class DensePlan:
         feats = {}
         fuse_b2b = os.environ.get("DAFNE_FUSE_B2B", "1") != "0"
         fuse_narrow = fuse_b2b and os.environ.get("DAFNE_FUSE_B2B_NARROW", "1") != "0"
+        fuse_mid = fuse_b2b and os.environ.get("DAFNE_FUSE_B2B_MID", "1") != "0"
         for si, nb in enumerate(STAGE_BLOCKS[depth]):
             y1_next = None
             for b in range(nb):
@@ -386,6 +399,21 @@ class DensePlan:
                                              (_lib.ptr(y2.t), _lib.ptr(sc.t), _lib.ptr(P[key]), _lib.ptr(b3), _lib.ptr(b1),
                                               n, y2.h, y2.w, _lib.ptr(y3.t), _lib.ptr(y1_next.t)),
                                              (y2, sc, P[key], b3, b1, y3, y1_next), "conv_b2b", flops=fl, nbytes=nb_))
+                    self.flops += fl
+                elif fuse_mid and b + 1 < nb and tuple(w3.shape) == (512, 128) and tuple(P[nxt][0].shape) == (128, 512):
+                    # res3: the pair with the weights streamed through LDS (conv_b2b_mid.hip)
+                    w1, b1 = P[nxt]
+                    key = p + "b2b"
+                    if key not in P:
+                        P[key] = pack_b2b_mid(w3, w1)
+                    y3 = pool.get(n, y2.h, y2.w, 512)
+                    y1_next = pool.get(n, y2.h, y2.w, 128)
+                    fl = 2 * n * y2.h * y2.w * (128 * 512 + 512 * 128)
+                    nb_ = n * y2.h * y2.w * (128 + 512 + 512 + 128) * 2 + 2 * 512 * 128 * 2
+                    self.calls.append(FnCall(L.dafne_bottleneck_tail_head_mid_hip,
+                                             (_lib.ptr(y2.t), _lib.ptr(sc.t), _lib.ptr(P[key]), _lib.ptr(b3), _lib.ptr(b1),
+                                              n, y2.h, y2.w, _lib.ptr(y3.t), _lib.ptr(y1_next.t)),
+                                             (y2, sc, P[key], b3, b1, y3, y1_next), "conv_b2b_mid", flops=fl, nbytes=nb_))
                     self.flops += fl
                 elif fuse_narrow and b + 1 < nb and tuple(w3.shape) == (256, 64) and tuple(P[nxt][0].shape) == (64, 256):
                     # res2: the same pair as a streaming kernel (conv_b2b_narrow.hip)

@@ -320,6 +320,19 @@ int dafne_bottleneck_tail_head_narrow_hip(const void* d_in, const void* d_res, c
                                           const float* d_bias1, int n_images, int H, int W, void* d_out, void* d_next,
                                           void* stream);
 /*
+ * The tail + head pair for res3:  d_out = relu(conv3(d_in) + bias3 + d_res)  (1x1, 128 -> 512) and
+ * d_next = relu(conv1'(d_out) + bias1)  (1x1, 512 -> 128).  d_in / d_next [N,H+2,W+2,128], d_res / d_out [N,H+2,W+2,512].
+ * d_wfrag: bf16 [16 quarter blocks][4 channel quarters][4 k16 steps][64 lanes][8] in the order the kernel consumes them:
+ * for each 256-channel chunk c of d_out: conv3 rows c*256 + rp*128 + quarter*32 + (lane & 31) over K columns
+ * 16*(4*sh + step) + 8*(lane >> 5) .. +8 for (rp, sh) = (0,0) (0,1) (1,0) (1,1), then conv1' rows quarter*32 + (lane & 31)
+ * over K columns c*256 + rp*128 + 16*(4*sh + step) + 8*(lane >> 5) .. +8 in the same (rp, sh) order  (engine.pack_b2b_mid).
+ * Persistent workgroups; waves 0-3 issue every HBM access, waves 4-7 the weight stream (separate vmcnt queues).
+ * Bit-identical to dafne_conv2d_nhwc_bf16_hip(conv3, RELU|RESIDUAL) followed by (conv1', RELU).
+ */
+int dafne_bottleneck_tail_head_mid_hip(const void* d_in, const void* d_res, const void* d_wfrag, const float* d_bias3,
+                                       const float* d_bias1, int n_images, int H, int W, void* d_out, void* d_next,
+                                       void* stream);
+/*
  * Block 0 of res2, whose shortcut is a projection (1x1, 64 -> 256, no ReLU) of the block's input d_x0 [N,H+2,W+2,64]:
  *   shortcut = bf16(proj(d_x0) + bias_sc);  d_out = relu(conv3(d_in) + bias3 + shortcut);  d_next = relu(conv1'(d_out) + bias1).
  * The 256-channel shortcut map is never written or read (112 KB of HBM traffic per 128 pixels instead of 304 KB for the

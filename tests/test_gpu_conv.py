@@ -485,6 +485,43 @@ def test_bottleneck_tail_head_narrow_equals_two_convs(N, H, W):
         assert float((got - z_ref).abs().max()) < 0.02 * float(z_ref.abs().max())
 
 
+@pytest.mark.parametrize("N,H,W", [(1, 8, 16), (2, 64, 64), (3, 13, 21), (1, 1, 1), (3, 128, 128), (1, 40, 410)])
+def test_bottleneck_tail_head_mid_equals_two_convs(N, H, W):
+    """dafne_bottleneck_tail_head_mid_hip (res3: conv3 128 -> 512 + shortcut + ReLU, then the next block's conv1 512 -> 128 +
+    ReLU; persistent, weights streamed through LDS by waves 4-7, HBM traffic by waves 0-3) against the two launches of the
+    generic path: bit for bit on both outputs -- a single tile, ragged tiles, 1 / 3 / 3 tiles per workgroup."""
+    from dafne_amd import engine, _lib
+    L = _lib.load()
+    d = dev()
+    g = torch.Generator().manual_seed(4000 + H * W)
+    t = bfr(torch.randn(N, 128, H, W, generator=g))
+    x = bfr(torch.randn(N, 512, H, W, generator=g))
+    w3 = bfr(torch.randn(512, 128, 1, 1, generator=g) / 11.0)
+    b3 = torch.randn(512, generator=g) * 0.2
+    w1 = bfr(torch.randn(128, 512, 1, 1, generator=g) / 22.0)
+    b1 = torch.randn(128, generator=g) * 0.2
+    st = _lib.current_stream()
+    ta, xa = engine.Act.from_nchw(t.to(d)), engine.Act.from_nchw(x.to(d))
+    w3p, b3p = engine.pack_conv(w3, b3, d)
+    w1p, b1p = engine.pack_conv(w1, b1, d)
+    y_u, z_u = engine.Act(N, H, W, 512, d), engine.Act(N, H, W, 128, d)
+    engine.ConvCall(w3p, b3p, 128, 512, 1, 1, 0, engine.F_RELU | engine.F_RES, [(ta.t, y_u.t, xa.t, H, W, H, W)], N)(st)
+    engine.ConvCall(w1p, b1p, 512, 128, 1, 1, 0, engine.F_RELU, [(y_u.t, z_u.t, None, H, W, H, W)], N)(st)
+    wf = engine.pack_b2b_mid(w3p, w1p)
+    y_f, z_f = engine.Act(N, H, W, 512, d), engine.Act(N, H, W, 128, d)
+    for _ in range(2):
+        _lib.check(L.dafne_bottleneck_tail_head_mid_hip(_lib.ptr(ta.t), _lib.ptr(xa.t), _lib.ptr(wf), _lib.ptr(b3p),
+                                                        _lib.ptr(b1p), N, H, W, _lib.ptr(y_f.t), _lib.ptr(z_f.t), st), "b2b_mid")
+    torch.cuda.synchronize()
+    assert float(y_f.t.float().abs().max()) > 0
+    assert torch.equal(y_f.t, y_u.t)
+    assert torch.equal(z_f.t, z_u.t)
+    assert float(z_f.t[:, 0].abs().max()) == 0 and float(y_f.t[:, :, -1].abs().max()) == 0
+    if N * H * W <= 2 * 64 * 64:
+        y_ref = bfr(F.relu(F.conv2d(t, w3, b3) + x))
+        close_bf16(y_f.nchw_float().cpu(), y_ref)
+
+
 @pytest.mark.parametrize("N,H,W", [(1, 8, 16), (3, 13, 21), (1, 1, 1), (3, 128, 128), (2, 256, 256)])
 def test_bottleneck_proj_tail_head_narrow_equals_three_convs(N, H, W):
     """dafne_bottleneck_proj_tail_head_narrow_hip (res2 block 0: projection shortcut 64 -> 256 computed in the kernel and
