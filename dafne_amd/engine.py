@@ -303,6 +303,9 @@ class DensePlan:
         self.pool = pool
 
         act_q8 = P.get("act_q8") or {}
+        # conv3x3_c64.hip: 65 -> 49 us per launch when it has the GPU to itself, but nothing in the timed 3-stream layout (its
+        # persistent workgroups hold every CU's LDS, so the other sub-batches' kernels cannot share the chip with it): opt-in
+        use_c64 = os.environ.get("DAFNE_CONV_C64", "0") == "1"
 
         def conv(key, tin, k, stride, pad, flags, res=None, out=None, cout=None):
             wgt, bias = P[key]
@@ -310,6 +313,16 @@ class DensePlan:
             cout = cout or wgt.shape[0]
             ho, wo = conv_out_hw(tin.h, tin.w, k, stride, pad)
             o = out or pool.get(n, ho, wo, cout)
+            if (use_c64 and k == 3 and stride == 1 and pad == 1 and cin == 64 and cout == 64 and res is None
+                    and (flags & ~F_RELU) == 0 and tuple(wgt.shape) == (64, 576) and bias is not None):
+                # res2 conv2: persistent kernel with the weights in registers (conv3x3_c64.hip)
+                fl = 2 * n * ho * wo * 64 * 576
+                self.calls.append(FnCall(L.dafne_conv3x3_c64_hip,
+                                         (_lib.ptr(tin.t), _lib.ptr(wgt), _lib.ptr(bias), n, ho, wo, 1 if flags & F_RELU else 0, _lib.ptr(o.t)),
+                                         (tin, wgt, bias, o), "conv3x3_c64", flops=fl,
+                                         nbytes=2 * n * ho * wo * 64 * 2 + wgt.numel() * 2))
+                self.flops += fl
+                return o
             q8 = P.get(key + ".fp8")
             fp8 = None
             if q8 is not None and k == 3 and stride == 1 and res is None and not (flags & (F_F32 | F_UP | F_RES)):

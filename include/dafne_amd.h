@@ -293,6 +293,15 @@ size_t dafne_resize_workspace_bytes(int C, int H, int new_w);
 int dafne_resize_bilinear_u8_hip(const uint8_t* d_in, int layout_hwc, int C, int H, int W, int new_h, int new_w,
                                  int hflip, int vflip, uint8_t* d_out, void* d_ws, size_t ws_bytes, void* stream);
 /*
+ * conv2 of the res2 bottlenecks [detectron2 BottleneckBlock, recalled; the ResNet of backbone/fpn.py:58-91]: 3x3 / stride 1 /
+ * pad 1, 64 -> 64 channels, + bias (FrozenBN folded), optional ReLU.  d_in / d_out: bf16 NHWC [N,H+2,W+2,64] with a zero
+ * 1-pixel halo (interior of d_out written); d_weight: bf16 [64, 576], k = (kh, kw, channel) -- the layout
+ * dafne_conv2d_nhwc_bf16_hip takes for this layer (engine.pack_conv).  Persistent workgroups with all weights in registers
+ * and the input patch of an 8 x 32 output tile staged once in LDS.  Bit-identical to dafne_conv2d_nhwc_bf16_hip.
+ */
+int dafne_conv3x3_c64_hip(const void* d_in, const void* d_weight, const float* d_bias, int n_images, int H, int W, int relu,
+                          void* d_out, void* stream);
+/*
  * Tail of one res4 bottleneck + head of the next in one kernel [detectron2 BottleneckBlock, recalled; the ResNet of
  * backbone/fpn.py:58-91]:  d_out = relu(conv3(d_in) + bias3 + d_res)  (1x1, 256 -> 1024, identity shortcut) and
  * d_next = relu(conv1'(d_out) + bias1)  (1x1, 1024 -> 256, the NEXT block's first convolution, stride 1).

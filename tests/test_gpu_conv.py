@@ -485,6 +485,35 @@ def test_bottleneck_tail_head_narrow_equals_two_convs(N, H, W):
         assert float((got - z_ref).abs().max()) < 0.02 * float(z_ref.abs().max())
 
 
+@pytest.mark.parametrize("N,H,W,relu", [(1, 8, 32, 1), (2, 64, 64, 1), (3, 13, 21, 0), (1, 1, 1, 1), (2, 256, 256, 1),
+                                          (1, 40, 410, 1), (5, 72, 104, 1)])
+def test_conv3x3_c64_equals_generic_conv(N, H, W, relu):
+    """dafne_conv3x3_c64_hip (res2 conv2: persistent, weights in registers, patch staged once per 8 x 32 tile) against
+    dafne_conv2d_nhwc_bf16_hip: bit for bit -- ragged tiles in both directions, 1 / 2 / 4 tiles per workgroup, halo
+    untouched -- and against torch within bf16 rounding."""
+    from dafne_amd import engine, _lib
+    L = _lib.load()
+    d = dev()
+    g = torch.Generator().manual_seed(5000 + H * W)
+    x = bfr(torch.randn(N, 64, H, W, generator=g))
+    w = bfr(torch.randn(64, 64, 3, 3, generator=g) / 24.0)
+    b = torch.randn(64, generator=g) * 0.2
+    st = _lib.current_stream()
+    xa = engine.Act.from_nchw(x.to(d))
+    wp, bp = engine.pack_conv(w, b, d)
+    y_u, y_f = engine.Act(N, H, W, 64, d), engine.Act(N, H, W, 64, d)
+    engine.ConvCall(wp, bp, 64, 64, 3, 1, 1, engine.F_RELU if relu else 0, [(xa.t, y_u.t, None, H, W, H, W)], N)(st)
+    for _ in range(2):
+        _lib.check(L.dafne_conv3x3_c64_hip(_lib.ptr(xa.t), _lib.ptr(wp), _lib.ptr(bp), N, H, W, relu, _lib.ptr(y_f.t), st), "c64")
+    torch.cuda.synchronize()
+    assert float(y_f.t.float().abs().max()) > 0
+    assert torch.equal(y_f.t, y_u.t)
+    assert float(y_f.t[:, 0].abs().max()) == 0 and float(y_f.t[:, :, -1].abs().max()) == 0 and float(y_f.t[:, -1].abs().max()) == 0
+    if N * H * W <= 2 * 64 * 64:
+        ref = F.conv2d(x, w, b, padding=1)
+        close_bf16(y_f.nchw_float().cpu(), bfr(F.relu(ref) if relu else ref))
+
+
 @pytest.mark.parametrize("N,H,W", [(1, 8, 16), (2, 64, 64), (3, 13, 21), (1, 1, 1), (3, 128, 128), (1, 40, 410)])
 def test_bottleneck_tail_head_mid_equals_two_convs(N, H, W):
     """dafne_bottleneck_tail_head_mid_hip (res3: conv3 128 -> 512 + shortcut + ReLU, then the next block's conv1 512 -> 128 +
