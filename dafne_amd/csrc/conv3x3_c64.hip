@@ -15,6 +15,8 @@
 //     (kh = line - 1): 48 fragment reads for 72 MFMAs, no barrier inside a tile;
 //   * accumulation order per output = tap-major (kh, kw), k16 ascending -- the generic kernel's K order -- and the same
 //     epilogue expression: results are bit-identical to dafne_conv2d_nhwc_bf16_hip (tests/test_gpu_conv.py).
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace {
@@ -236,7 +238,9 @@ int dafne_conv3x3_c64_hip(const void* d_in, const void* d_weight, const float* d
         DAFNE_HIP_TRY(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
         DAFNE_HIP_TRY(hipFuncSetAttribute((const void*)conv3x3_c64_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kSmemTotal));
     }
-    const int grid = D.tiles < n_cu ? D.tiles : n_cu;
+    static const int cap = getenv("DAFNE_STREAM_GRID") ? atoi(getenv("DAFNE_STREAM_GRID")) : 0;
+    const int lim = cap > 0 && cap < n_cu ? cap : n_cu;
+    const int grid = D.tiles < lim ? D.tiles : lim;
     hipLaunchKernelGGL(conv3x3_c64_kernel, dim3(grid), dim3(kNT), kSmemTotal, (hipStream_t)stream, D);
     return dafne::check_launch("conv3x3_c64");
 }

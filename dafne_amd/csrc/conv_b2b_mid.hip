@@ -22,6 +22,8 @@
 // (+residual) followed by conv1 (tests/test_gpu_conv.py).  HBM per 64-pixel tile: 16 (T) + 64 (X) in, 64 (Y) + 16 (Z) out.
 #include <type_traits>
 
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace {
@@ -373,7 +375,9 @@ int dafne_bottleneck_tail_head_mid_hip(const void* d_in, const void* d_res, cons
         DAFNE_HIP_TRY(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
         DAFNE_HIP_TRY(hipFuncSetAttribute((const void*)conv_b2b_mid_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kSmemTotal));
     }
-    const int grid = D.tiles < n_cu ? D.tiles : n_cu;
+    static const int cap = getenv("DAFNE_STREAM_GRID") ? atoi(getenv("DAFNE_STREAM_GRID")) : 0;
+    const int lim = cap > 0 && cap < n_cu ? cap : n_cu;
+    const int grid = D.tiles < lim ? D.tiles : lim;
     hipLaunchKernelGGL(conv_b2b_mid_kernel, dim3(grid), dim3(kNT), kSmemTotal, (hipStream_t)stream, D);
     return dafne::check_launch("conv_b2b_mid");
 }

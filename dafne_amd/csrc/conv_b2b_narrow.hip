@@ -26,6 +26,8 @@
 // no ReLU).  Then X is never materialised: the X0 tile rides the LDS ring next to T (16 KB instead of 64 KB of shortcut
 // rows), a third resident weight matrix gives S = bf16(Wsc . X0 + bias_sc) -- rounded to bf16 exactly as the separate
 // launch stores it -- and the epilogue adds it from registers.  112 KB per tile against 304 KB for the three launches.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace {
@@ -356,7 +358,9 @@ static int narrow_launch(const void* d_in, const void* d_res, const void* d_wfra
         DAFNE_HIP_TRY(hipFuncSetAttribute((const void*)conv_b2b_narrow_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, kSmemTotal));
         DAFNE_HIP_TRY(hipFuncSetAttribute((const void*)conv_b2b_narrow_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, kSmemTotalProj));
     }
-    const int grid = D.tiles < n_cu ? D.tiles : n_cu;
+    static const int cap = getenv("DAFNE_STREAM_GRID") ? atoi(getenv("DAFNE_STREAM_GRID")) : 0;
+    const int lim = cap > 0 && cap < n_cu ? cap : n_cu;
+    const int grid = D.tiles < lim ? D.tiles : lim;
     if (proj) hipLaunchKernelGGL(conv_b2b_narrow_kernel<true>, dim3(grid), dim3(kNT), kSmemTotalProj, (hipStream_t)stream, D);
     else hipLaunchKernelGGL(conv_b2b_narrow_kernel<false>, dim3(grid), dim3(kNT), kSmemTotal, (hipStream_t)stream, D);
     return dafne::check_launch("conv_b2b_narrow");
