@@ -2319,6 +2319,21 @@ __global__ void __launch_bounds__(512) conv3x3_slab_kernel(ConvDev P) {
         const float gmean = __uint_as_float(ms.x), grstd = __uint_as_float(ms.y);
         const float gam[8] = {g0[0], g0[1], g0[2], g0[3], g1[0], g1[1], g1[2], g1[3]};
         const float bet[8] = {b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]};
+        // all six pieces are read first (one LDS round trip instead of six), then converted and written back one by one
+        u32x4 vv[6];
+        unsigned adr[6];
+#pragma unroll
+        for (int i = 0; i < 6; i++) {
+            const int pi = ppi[i];
+            int r = pi * 8 + (lane >> 3);
+            r = r < kPRows ? r : kPRows - 1;
+            const int px = r % kPCols;
+            const int phys = (lane & 7) ^ ((px >> 1) & 7);
+            adr[i] = lds_base + (unsigned)((slab & 1) * kSlabPatch + pi * 1024 + (lane >> 3) * 128 + phys * 16);
+            asm volatile("ds_read_b128 %0, %1" : "=&v"(vv[i]) : "v"(adr[i]) : "memory");
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(vv[0]), "+v"(vv[1]), "+v"(vv[2]), "+v"(vv[3]), "+v"(vv[4]), "+v"(vv[5]) : : "memory");
+#pragma unroll
         for (int i = 0; i < 6; i++) {
             if (i == 5 && 5 * NW + wave >= kPPieces) continue;
             const int pi = ppi[i];
@@ -2327,10 +2342,8 @@ __global__ void __launch_bounds__(512) conv3x3_slab_kernel(ConvDev P) {
             const int py = r / kPCols, px = r - py * kPCols;
             const int gy = Y0 + py, gx = X0 + px;
             const bool inside = gy >= 1 && gy <= H && gx >= 1 && gx <= W;
-            const int phys = (lane & 7) ^ ((px >> 1) & 7);
-            const unsigned ad = lds_base + (unsigned)((slab & 1) * kSlabPatch + pi * 1024 + (lane >> 3) * 128 + phys * 16);
-            u32x4 v;
-            asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(v) : "v"(ad) : "memory");
+            const unsigned ad = adr[i];
+            const u32x4 v = vv[i];
             const unsigned u[4] = {v.x, v.y, v.z, v.w};
             float y[8];
 #pragma unroll
