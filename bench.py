@@ -21,9 +21,10 @@ Extra objects on the JSON line:
   roofline      dominant kernel = the kernel with the most GPU time per step (whole batch on one stream: every launch
                 has the GPU to itself, the layout `--mode serial` runs and profiles/r02_kernel_stats_isolated.txt
                 profiles with rocprofv3): algorithmic FLOPs of its launches / their HIP-event time vs the dense bf16
-                MFMA peak (2.5 PFLOP/s).  "shared_stream" inside it repeats the bookkeeping for the timed region's
+                MFMA peak (2.5 PFLOP/s).  Its sibling "roofline_timed" repeats the bookkeeping for the timed region's
                 layout (3 sub-batches on concurrent streams, where a launch's duration includes sharing the GPU);
-                every instantiation is listed under "kernels" (timed layout) and "roofline_isolated"
+                every instantiation is listed under "kernels" (timed layout) and "kernels_isolated".  Rounds 1's
+                "roofline" was the timed layout, round 2 nested it as roofline.shared_stream: compare like with like
   roofline_nms  the rotated NMS on the SURVEY 8(d) candidate sets: class-filtered pairs per second and algorithmic bytes
                 per second against HBM
   cpu_baseline  the torch fp32 oracle (oracle/model.py + oracle/postprocess.py, a
@@ -101,21 +102,24 @@ def build_model(depth, device, seed=0, cfgname=None, cls_prior=None):
     return cfg, m, sd
 
 
-def time_steps(step_fn, steps, warmup, distributed):
+def time_steps(step_fn, steps, warmup, distributed, device="cuda"):
+    """W untimed steps, then EXACTLY `steps` steps bracketed by barrier + device synchronize on both sides; the
+    result is the MAX over ranks (the slowest rank's time).  device "cpu" is the gloo test's layout (no GPU)."""
+    sync = torch.cuda.synchronize if str(device).startswith("cuda") else (lambda: None)
     for _ in range(warmup):
         step_fn()
     if distributed:
         dist.barrier()
-    torch.cuda.synchronize()
+    sync()
     t0 = time.perf_counter()
     for _ in range(steps):
         step_fn()
     if distributed:
         dist.barrier()
-    torch.cuda.synchronize()
+    sync()
     dt = time.perf_counter() - t0
     if distributed:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        t = torch.tensor([dt], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     return dt
@@ -337,7 +341,24 @@ def cpu_baseline(cfg, sd, depth, budget_s=4.0):
     return out
 
 
-def main():
+def headline(args, world, dt, det_mean):
+    """The contract's JSON line (without the extras): value = images of ALL ranks / the slowest rank's time."""
+    out = {
+        "metric": "images/sec on 1024x1024 DOTA tiles, R%d-FPN" % args.depth,
+        "value": args.batch * world * args.steps / dt, "unit": "images/sec", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+        "config": {"workload": "DOTA-1.0 %dx%d R%d-FPN bf16, batch %d per GPU (per-GPU shard of configs[2]; "
+                               "the model BASELINE.json's metric names), uint8 tiles resident in HBM -> detections"
+                               % (args.size, args.size, args.depth, args.batch),
+                   "per_gpu_batch": args.batch, "global_batch": args.batch * world, "classes": 15,
+                   "parallelism": "dp%d (independent images, RCCL gather of detections)" % world,
+                   "detections_per_image_mean": det_mean},
+    }
+    return out
+
+
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
@@ -350,11 +371,45 @@ def main():
     ap.add_argument("--mode", choices=["pipelined", "serial"], default="pipelined",
                     help="pipelined (default, the timed configuration): sub-batches on concurrent streams, post-process of step i "
                          "under the convolutions of step i+1.  serial: the whole batch, every kernel alone on ONE stream -- the "
-                         "layout the isolated roofline is quoted on (profiles/r02_kernel_stats_isolated.txt)")
+                         "layout the isolated roofline is quoted on (profiles/r03_kernel_stats_isolated.txt)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip roofline profile pass, R50 and NMS side metrics")
-    args = ap.parse_args()
+    return ap.parse_args(argv)
 
+
+def _free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _spawned(local_rank, args, port, target):
+    """One worker of a self-launched N-GPU run: the environment torch.distributed.run would have set."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(local_rank), LOCAL_RANK=str(local_rank),
+                      WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus))
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    target(args)
+
+
+def launch(args, target=None):
+    """`python bench.py --gpus N` starts itself: with no WORLD_SIZE in the environment and N > 1 it spawns one worker
+    per GPU (rank = local rank = GPU index, 127.0.0.1 rendezvous on a free port), the counterpart of the reference's
+    `launch(main, num_gpus, ...)` (tools/plain_train_net.py:660-671).  Under torch.distributed.run (WORLD_SIZE set) the
+    process IS one worker and runs `target` directly.  target: picklable callable(args); default `run`."""
+    target = target or run
+    if "WORLD_SIZE" in os.environ or args.gpus <= 1:
+        return target(args)
+    import torch.multiprocessing as mp
+    mp.spawn(_spawned, args=(args, _free_port(), target), nprocs=args.gpus, join=True)
+    return None
+
+
+def run(args, make_step=None, backend="nccl", device_kind="cuda"):
+    """One worker.  make_step(args, rank, world, device) -> (step_fn, finish_fn) replaces the detector (tests: a stub on
+    CPU over gloo); finish_fn(out) may add keys to the JSON line on rank 0.  Returns the JSON dict on rank 0."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -362,13 +417,41 @@ def main():
     if distributed:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    if args.gpus != world:
+        raise SystemExit("bench.py: --gpus %d but the launched world size is %d (torch.distributed.run --nproc-per-node "
+                         "must equal --gpus)" % (args.gpus, world))
+    if device_kind == "cuda":
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+        torch.cuda.set_device(local_rank)
+        device = torch.device("cuda", local_rank)
+    else:
+        device = torch.device("cpu")
     if distributed:
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
-    assert args.gpus == world, "--gpus must equal the launched world size"
+        if device_kind == "cuda":
+            dist.init_process_group(backend, rank=rank, world_size=world, device_id=device)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
+    try:
+        out = _run_worker(args, make_step, rank, world, distributed, device)
+    except BaseException:
+        raise                                   # no barrier on the error path: the launcher must see the failure, not a hang
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if distributed:
+        dist.barrier()
+        dist.destroy_process_group()
+    return out if rank == 0 else None
+
+
+def _run_worker(args, make_step, rank, world, distributed, device):
+    if make_step is not None:
+        step, finish = make_step(args, rank, world, device)
+        dt = time_steps(step, args.steps, args.warmup, distributed, device)
+        out = headline(args, world, dt, None)
+        if rank == 0 and finish is not None:
+            finish(out)
+        return out
 
     from dafne_amd.evaluation.gather import gather_detections
     cfg, model, sd = build_model(args.depth, device, seed=0)
@@ -390,24 +473,10 @@ def main():
                 gather_detections(rows, counts, dst=0)
         return rows, counts
 
-    dt = time_steps(step, args.steps, args.warmup, distributed)
-    n_imgs = args.batch * world * args.steps
-    value = n_imgs / dt
+    dt = time_steps(step, args.steps, args.warmup, distributed, device)
     rows, counts = step()
     torch.cuda.synchronize()
-
-    out = {
-        "metric": "images/sec on 1024x1024 DOTA tiles, R%d-FPN" % args.depth,
-        "value": value, "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-        "config": {"workload": "DOTA-1.0 %dx%d R%d-FPN bf16, batch %d per GPU (per-GPU shard of configs[2]; "
-                               "the model BASELINE.json's metric names), uint8 tiles resident in HBM -> detections"
-                               % (args.size, args.size, args.depth, args.batch),
-                   "per_gpu_batch": args.batch, "global_batch": args.batch * world, "classes": 15,
-                   "parallelism": "dp%d (independent images, RCCL gather of detections)" % world,
-                   "detections_per_image_mean": float(counts.float().mean().item())},
-    }
+    out = headline(args, world, dt, float(counts.float().mean().item()))
     out["config"]["mode"] = args.mode
     # extras only at N=1: at N>1 the other ranks would sit in the final barrier while rank 0 measures side metrics
     if rank == 0 and world == 1 and not args.no_extras:
@@ -445,7 +514,9 @@ def main():
             out["roofline"]["traffic"] = tr
             out["roofline"]["traffic_unit"] = "bytes per launch (2 x FETCH_SIZE + WRITE_SIZE), " + src
         if ds:
-            out["roofline"]["shared_stream"] = {
+            out["roofline_timed"] = {
+                "bound": "mfma", "kernel": kname, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "traffic": None,
+                "layout": "timed region: %d sub-batches on concurrent streams (a launch's duration includes sharing the GPU)" % args.splits,
                 "achieved": ds["tflops"], "frac": ds["tflops"] / PEAK_BF16_TFLOPS, "launches_per_step": ds["launches"],
                 "avg_launch_us": ds["avg_launch_us"], "concurrent_streams": args.splits,
                 "achieved_over_union_of_launches": ds["flops"] / (ds["union_ms"] * 1e-3) / 1e12 if ds.get("union_ms", 0) > 0 else None,
@@ -453,8 +524,8 @@ def main():
                         "launch's duration includes that sharing (as rocprofv3 reports it for the default command)" % args.splits}
             tr2, src2 = pmc_traffic("pmc_traffic.json")
             if tr2 is not None:
-                out["roofline"]["shared_stream"]["traffic"] = tr2
-                out["roofline"]["shared_stream"]["traffic_unit"] = "bytes per launch at sub-batch size, " + src2
+                out["roofline_timed"]["traffic"] = tr2
+                out["roofline_timed"]["traffic_unit"] = "bytes per launch at sub-batch size, " + src2
         out["kernels"] = {k: {"tflops": v["tflops"], "ms_per_step": v["ms"], "launches": v["launches"],
                               "hbm_gbps_algorithmic": v["bytes"] / (v["ms"] * 1e-3) / 1e9} for k, v in prof.items()}
         # the HBM-bound kernel family next to the MFMA-bound dominant one: persistent weight-stationary 1x1 layers
@@ -465,10 +536,10 @@ def main():
                                    "launches_per_step": wi["launches"], "avg_launch_us": 1e3 * wi["ms_per_step"] / max(wi["launches"], 1),
                                    "algorithmic_bytes_per_step": wi["bytes"]}
             if wsk:
-                out["roofline_hbm"]["shared_stream"] = {"achieved": wsk["bytes"] / (wsk["ms"] * 1e-3) / 1e9,
+                out["roofline_hbm"]["timed_layout"] = {"achieved": wsk["bytes"] / (wsk["ms"] * 1e-3) / 1e9,
                                                         "frac": wsk["bytes"] / (wsk["ms"] * 1e-3) / 1e9 / PEAK_HBM_GBPS,
                                                         "launches_per_step": wsk["launches"], "avg_launch_us": wsk["avg_launch_us"]}
-        out["roofline_isolated"] = {k: {kk: vv for kk, vv in v.items() if kk not in ("flops", "bytes")} for k, v in iso.items()}
+        out["kernels_isolated"] = {k: {kk: vv for kk, vv in v.items() if kk not in ("flops", "bytes")} for k, v in iso.items()}
         tot_flops = sum(v["flops"] for v in prof.values())
         out["model_tflops_end_to_end"] = tot_flops / (dt / args.steps) / 1e12
         out["mfma_frac_end_to_end"] = out["model_tflops_end_to_end"] / PEAK_BF16_TFLOPS
@@ -558,11 +629,11 @@ def main():
             out["cpu_baseline"] = cpu_baseline(cfg, sd, args.depth)
         except Exception as e:      # noqa: BLE001
             out["cpu_baseline"] = {"error": "%s: %s" % (type(e).__name__, e)}
-    if rank == 0:
-        print(json.dumps(out))
-    if distributed:
-        dist.barrier()
-        dist.destroy_process_group()
+    return out
+
+
+def main(argv=None):
+    return launch(parse_args(argv))
 
 
 if __name__ == "__main__":

@@ -1,0 +1,108 @@
+"""CPU, world_size 2 over gloo: `python bench.py --gpus N` starts itself (bench.launch: the counterpart of the reference's
+`launch(main, num_gpus, ...)`, tools/plain_train_net.py:660-671).  The detector is stubbed; what runs is bench.py's own
+argument / environment handling, the `time_steps` barrier + MAX-over-ranks reduction, the whole-job value and the
+rank-0-only JSON line."""
+import json
+import os
+import subprocess
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def _stub_make_step(args, rank, world, device):
+    import torch.distributed as dist
+    from dafne_amd.evaluation.gather import gather_detections
+    calls = {"n": 0}
+    rows = torch.zeros(args.batch, 8, 18)
+    counts = torch.full((args.batch,), rank + 1, dtype=torch.int32)
+
+    def step():
+        calls["n"] += 1
+        time.sleep(0.02 * (rank + 1))            # rank 1 is the slow one: the MAX reduction must report ITS time
+        if world > 1:
+            gather_detections(rows, counts, dst=0)   # the per-step detection gather of the real step
+
+    def finish(out):
+        out["stub"] = {"calls_rank0": calls["n"], "env": {k: os.environ.get(k) for k in
+                                                          ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")},
+                       "dist_initialized": dist.is_initialized()}
+    return step, finish
+
+
+def stub_target(args):
+    """Picklable worker body for bench.launch: bench.run with the detector stubbed, gloo on CPU."""
+    import bench
+    return bench.run(args, make_step=_stub_make_step, backend="gloo", device_kind="cpu")
+
+
+_DRIVER = """
+import sys
+sys.path.insert(0, %r)
+sys.path.insert(0, %r)
+import bench
+from test_bench_launch import stub_target
+bench.launch(bench.parse_args(sys.argv[1:]), target=stub_target)
+"""
+
+
+def _run(argv, env_extra=None, launcher=None):
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(env_extra or {})
+    cmd = [sys.executable] + (launcher or []) + ["-c", _DRIVER % (ROOT, os.path.join(ROOT, "tests"))] + argv
+    if launcher:        # torch.distributed.run wants a script path
+        path = os.path.join(ROOT, "tests", "_bench_stub_main.py")
+        cmd = [sys.executable] + launcher + [path] + argv
+    p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300, cwd=ROOT)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    return lines
+
+
+def test_plain_command_self_launches_two_ranks():
+    lines = _run(["--gpus", "2", "--steps", "3", "--warmup", "1", "--batch", "4"])
+    assert len(lines) == 1, lines                          # rank 0 only
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["steps"] == 3 and out["warmup"] == 1 and out["scaling"] == "weak"
+    assert out["config"]["global_batch"] == 8 and out["config"]["per_gpu_batch"] == 4
+    assert out["stub"]["calls_rank0"] == 4                 # W + K steps, exactly
+    assert out["stub"]["env"]["WORLD_SIZE"] == "2" and out["stub"]["env"]["RANK"] == "0"
+    assert out["stub"]["env"]["MASTER_ADDR"] == "127.0.0.1" and out["stub"]["dist_initialized"]
+    # 3 steps of the SLOW rank (40 ms each): max over ranks, not rank 0's own 20 ms
+    assert out["ms_per_step"] >= 39.0
+    assert abs(out["value"] - 8 * 3 / (out["ms_per_step"] * 3e-3)) < 1e-6 * out["value"]
+
+
+def test_single_gpu_runs_in_process():
+    lines = _run(["--gpus", "1", "--steps", "2", "--warmup", "0"])
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 1 and out["stub"]["calls_rank0"] == 2 and not out["stub"]["dist_initialized"]
+    assert out["stub"]["env"]["WORLD_SIZE"] is None
+
+
+def test_under_torch_distributed_run():
+    """The driver's N > 1 form: python -m torch.distributed.run --nproc-per-node 2 ... bench.py --gpus 2."""
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    lines = _run(["--gpus", "2", "--steps", "2", "--warmup", "1"],
+                 launcher=["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                           "--master-port", str(port)])
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["stub"]["calls_rank0"] == 3 and out["stub"]["env"]["MASTER_PORT"] == str(port)
+
+
+def test_world_size_mismatch_is_an_error_not_an_assert():
+    env = {k: v for k, v in os.environ.items()}
+    env.update(WORLD_SIZE="2", RANK="0", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT="1")
+    p = subprocess.run([sys.executable, "-c", _DRIVER % (ROOT, os.path.join(ROOT, "tests")), "--gpus", "4"], env=env,
+                       capture_output=True, text=True, timeout=120, cwd=ROOT)
+    assert p.returncode != 0 and "world size" in p.stderr
