@@ -57,17 +57,16 @@ SIGNATURES = {
     "dafne_last_error": (ctypes.c_char_p, []),
     "dafne_poly_iou_pairs_hip": (c_int, [c_void_p, c_void_p, c_i64, c_void_p, c_void_p]),
     "dafne_poly_nms_workspace_bytes": (c_size_t, [c_int, c_int]),
-    "dafne_poly_nms_set_exact_only": (None, [c_int]),
     "dafne_poly_nms_stats_offset": (c_size_t, [c_int, c_int, c_int]),
-    "dafne_poly_nms_hip": (c_int, [c_void_p, c_int, c_double, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "dafne_poly_nms_hip": (c_int, [c_void_p, c_int, c_double, c_void_p, c_void_p, c_void_p, c_size_t, c_int, c_void_p]),
     "dafne_poly_nms_batched_hip": (c_int, [c_void_p, c_void_p, c_int, c_int, c_double, c_int, c_void_p,
-                                           c_void_p, c_void_p, c_size_t, c_void_p]),
+                                           c_void_p, c_void_p, c_size_t, c_int, c_void_p]),
     "dafne_poly_nms_f64_workspace_bytes": (c_size_t, [c_int, c_int]),
     "dafne_poly_nms_f64_batched_hip": (c_int, [c_void_p, c_void_p, c_int, c_int, c_double, c_int, c_void_p,
-                                               c_void_p, c_void_p, c_size_t, c_void_p]),
+                                               c_void_p, c_void_p, c_size_t, c_int, c_void_p]),
     "dafne_select_over_all_levels_hip": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int,
                                                  c_double, c_int, c_void_p, c_void_p, c_void_p, c_size_t,
-                                                 c_void_p]),
+                                                 c_int, c_void_p]),
     "dafne_decode_workspace_bytes": (c_size_t, [ctypes.POINTER(DecodeParams), ctypes.POINTER(LevelDesc)]),
     "dafne_decode_levels_hip": (c_int, [ctypes.POINTER(DecodeParams), ctypes.POINTER(LevelDesc)] +
                                 [c_void_p] * 8 + [c_void_p, c_size_t, c_void_p]),

@@ -61,6 +61,28 @@ def load_checkpoint_file(path):
     return {k: (v if isinstance(v, torch.Tensor) else torch.from_numpy(np.asarray(v))) for k, v in sd.items()}
 
 
+FP8_SCALES_KEY = "fp8_act_scales"       # engine-specific entry beside "model" in a .pth checkpoint
+
+
+def load_fp8_act_scales(path):
+    """The fp8 model's calibrated activation scales stored beside the weights ({weight key: in_qscale}), or None."""
+    if not isinstance(path, str) or path.endswith(".pkl"):
+        return None
+    data = torch.load(path, map_location="cpu", weights_only=False)
+    sc = data.get(FP8_SCALES_KEY) if isinstance(data, dict) else None
+    return None if sc is None else {str(k): float(v) for k, v in dict(sc).items()}
+
+
+def save_checkpoint(model, path):
+    """{"model": state_dict} in detectron2's .pth layout; an fp8 model's calibrated activation scales travel with the
+    weights (they are part of the model: ADVICE round 2), so a served model never depends on what it sees first."""
+    data = {"model": {k: v.detach().cpu() for k, v in model.state_dict().items()}}
+    sc = model.fp8_act_scales() if hasattr(model, "fp8_act_scales") else None
+    if sc is not None:
+        data[FP8_SCALES_KEY] = dict(sc)
+    torch.save(data, path)
+
+
 def load_weights(model, path_or_state, strict=False):
     """Copy matching tensors into `model`; returns (missing, unexpected) key lists.
     Caffe2-style BGR stems etc. are taken as they are (the released DAFNe configs use
@@ -80,4 +102,8 @@ def load_weights(model, path_or_state, strict=False):
                 v.copy_(sd[k].to(v.dtype))
     if hasattr(model, "invalidate"):
         model.invalidate()
+    sc = load_fp8_act_scales(path_or_state)
+    if sc is not None and getattr(getattr(model, "cfg", None), "ENGINE", None) is not None \
+            and model.cfg.ENGINE.WEIGHT_DTYPE == "fp8_e4m3" and model.device.type == "cuda":
+        model.set_fp8_act_scales(sc)
     return missing, unexpected

@@ -150,9 +150,11 @@ def _defaults():
                            HFLIP=True, VFLIP=True, ROTATION_ANGLES=[])),
         # engine-specific knobs (not in the reference)
         ENGINE=dict(WEIGHT_DTYPE="bf16", ACT_DTYPE="bf16",
-                    # fp8 model: "first_batch" = calibrate the e4m3 activation scales on the first batch detect_packed sees;
-                    # "off" = only the GroupNorm-fed tower layers take e4m3 activations (until calibrate_fp8 is called)
-                    FP8_ACT_CALIBRATION="first_batch"),
+                    # fp8 model (the activation scales are part of the model: they change its outputs).  "explicit" (default):
+                    # detect_packed RAISES until calibrate_fp8(batch) or set_fp8_act_scales(scales) has been called -- results
+                    # never depend on image order, batch size or world size; "off" = only the GroupNorm-fed tower layers take e4m3
+                    # activations; "first_batch" = opt-in convenience: calibrate on the first batch detect_packed sees
+                    FP8_ACT_CALIBRATION="explicit"),
     )
 
 

@@ -2612,12 +2612,7 @@ int launch(const ConvDev& D, hipStream_t st) {
     constexpr int epi_b16 = BM * (BN * 2 + 16) + NW * (WC * TC * 32 / 8) * 2 * 4;
     constexpr int epi = epi_f32 > epi_b16 ? epi_f32 : epi_b16;
     constexpr int smem = stage2 > epi ? stage2 : epi;
-    static bool attr_done = false;   // idempotent attribute; a benign race sets it twice
-    if (!attr_done) {
-        DAFNE_HIP_TRY(hipFuncSetAttribute((const void*)conv_igemm_kernel<WC, WP, TC, TP>,
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, smem));
-        attr_done = true;
-    }
+    DAFNE_MAX_LDS_ONCE(smem, (const void*)conv_igemm_kernel<WC, WP, TC, TP>);
     hipLaunchKernelGGL((conv_igemm_kernel<WC, WP, TC, TP>), dim3(D.mtiles * D.ntiles), dim3(WC * WP * 64), smem, st, D);
     return dafne::check_launch("conv_igemm");
 }
@@ -2638,12 +2633,7 @@ bool stream_eligible(const ConvDev& D) {
 }
 
 int launch_patch(const ConvDev& D, hipStream_t st) {
-    static bool attr_done = false;
-    if (!attr_done) {
-        DAFNE_HIP_TRY(hipFuncSetAttribute((const void*)conv3x3_patch_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, kPSmem));
-        DAFNE_HIP_TRY(hipFuncSetAttribute((const void*)conv3x3_patch_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, kPSmem));
-        attr_done = true;
-    }
+    DAFNE_MAX_LDS_ONCE(kPSmem, (const void*)conv3x3_patch_kernel<false>, (const void*)conv3x3_patch_kernel<true>);
     const dim3 grid(D.mtiles * D.ntiles), block(512);
     if (D.flags & DAFNE_CONV_GN_INPUT) hipLaunchKernelGGL(conv3x3_patch_kernel<true>, grid, block, kPSmem, st, D);
     else hipLaunchKernelGGL(conv3x3_patch_kernel<false>, grid, block, kPSmem, st, D);
@@ -2651,12 +2641,7 @@ int launch_patch(const ConvDev& D, hipStream_t st) {
 }
 
 int launch_patch_fp8(const ConvDev& D, hipStream_t st) {
-    static bool attr_done = false;
-    if (!attr_done) {
-        DAFNE_HIP_TRY(hipFuncSetAttribute((const void*)conv3x3_patch_fp8_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, kQSmem));
-        DAFNE_HIP_TRY(hipFuncSetAttribute((const void*)conv3x3_patch_fp8_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, kQSmem));
-        attr_done = true;
-    }
+    DAFNE_MAX_LDS_ONCE(kQSmem, (const void*)conv3x3_patch_fp8_kernel<false>, (const void*)conv3x3_patch_fp8_kernel<true>);
     const dim3 grid(D.mtiles * D.ntiles), block(512);
     if (D.flags & DAFNE_CONV_GN_INPUT) hipLaunchKernelGGL(conv3x3_patch_fp8_kernel<true>, grid, block, kQSmem, st, D);
     else hipLaunchKernelGGL(conv3x3_patch_fp8_kernel<false>, grid, block, kQSmem, st, D);
@@ -2664,12 +2649,7 @@ int launch_patch_fp8(const ConvDev& D, hipStream_t st) {
 }
 
 int launch_slab(const ConvDev& D, hipStream_t st) {
-    static bool attr_done = false;
-    if (!attr_done) {
-        DAFNE_HIP_TRY(hipFuncSetAttribute((const void*)conv3x3_slab_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, kSlabSmem));
-        DAFNE_HIP_TRY(hipFuncSetAttribute((const void*)conv3x3_slab_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, kSlabSmem));
-        attr_done = true;
-    }
+    DAFNE_MAX_LDS_ONCE(kSlabSmem, (const void*)conv3x3_slab_kernel<false>, (const void*)conv3x3_slab_kernel<true>);
     const dim3 grid(D.mtiles), block(512);
     if (D.flags & DAFNE_CONV_GN_INPUT) hipLaunchKernelGGL(conv3x3_slab_kernel<true>, grid, block, kSlabSmem, st, D);
     else hipLaunchKernelGGL(conv3x3_slab_kernel<false>, grid, block, kSlabSmem, st, D);
@@ -2682,25 +2662,16 @@ bool ws_eligible(const ConvDev& D) {
 }
 
 int resident_slots(int* out) {
-    static int slots = 0;   // resident workgroups: 2 per CU
-    if (!slots) {
-        int dev = 0, cus = 0;
-        DAFNE_HIP_TRY(hipGetDevice(&dev));
-        DAFNE_HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
-        slots = 2 * (cus > 0 ? cus : 256);
-    }
-    *out = slots;
+    int cus = 0;            // resident workgroups: 2 per CU of the current device
+    if (int rc = dafne::device_cus(&cus)) return rc;
+    *out = 2 * cus;
     return DAFNE_OK;
 }
 
 template <int WC, int WP, int KS, bool RES, int RB>
 int launch_ws_cfg(const ConvDev& D, hipStream_t st) {
     constexpr int smem = kWRing + kSRes;
-    static bool attr_done = false;
-    if (!attr_done) {
-        DAFNE_HIP_TRY(hipFuncSetAttribute((const void*)conv_ws_kernel<WC, WP, KS, RES, RB>, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
-        attr_done = true;
-    }
+    DAFNE_MAX_LDS_ONCE(smem, (const void*)conv_ws_kernel<WC, WP, KS, RES, RB>);
     int slots = 0;
     if (int rc = resident_slots(&slots)) return rc;
     const int T = D.mtiles * D.ntiles;
@@ -2727,14 +2698,9 @@ int launch_ws(const ConvDev& D, hipStream_t st) {
 
 int launch_stream(const ConvDev& D, hipStream_t st) {
     constexpr int smem = kSNS * kSHS + kSRes;
-    static int slots = 0;   // resident workgroups: 2 per CU
-    if (!slots) {
-        int dev = 0, cus = 0;
-        DAFNE_HIP_TRY(hipGetDevice(&dev));
-        DAFNE_HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
-        DAFNE_HIP_TRY(hipFuncSetAttribute((const void*)conv_stream_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
-        slots = 2 * (cus > 0 ? cus : 256);
-    }
+    DAFNE_MAX_LDS_ONCE(smem, (const void*)conv_stream_kernel);
+    int slots = 0;          // resident workgroups: 2 per CU
+    if (int rc = resident_slots(&slots)) return rc;
     const int T = D.mtiles * D.ntiles;
     const int G = T < slots ? T : slots;
     hipLaunchKernelGGL(conv_stream_kernel, dim3(G), dim3(256), smem, st, D);

@@ -231,13 +231,9 @@ int dafne_conv3x3_c64_hip(const void* d_in, const void* d_weight, const float* d
     const long long tiles = (long long)D.tiles_per_img * n_images;
     if (tiles > (1ll << 24)) return dafne::fail(DAFNE_E_UNSUPPORTED, "conv3x3_c64: too many tiles");
     D.tiles = (int)tiles;
-    static int n_cu = 0;
-    if (!n_cu) {
-        int dev = 0;
-        DAFNE_HIP_TRY(hipGetDevice(&dev));
-        DAFNE_HIP_TRY(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
-        DAFNE_HIP_TRY(hipFuncSetAttribute((const void*)conv3x3_c64_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kSmemTotal));
-    }
+    DAFNE_MAX_LDS_ONCE(kSmemTotal, (const void*)conv3x3_c64_kernel);
+    int n_cu = 0;
+    if (int rc = dafne::device_cus(&n_cu)) return rc;
     static const int cap = getenv("DAFNE_STREAM_GRID") ? atoi(getenv("DAFNE_STREAM_GRID")) : 0;
     const int lim = cap > 0 && cap < n_cu ? cap : n_cu;
     const int grid = D.tiles < lim ? D.tiles : lim;

@@ -407,11 +407,7 @@ int dafne_bottleneck_tail_head_hip(const void* d_in, const void* d_res, const vo
     const long long tiles = (long long)D.tiles_per_img * n_images;
     if (tiles > (1ll << 24)) return dafne::fail(DAFNE_E_UNSUPPORTED, "bottleneck_tail_head: too many tiles");
     D.tiles = (int)tiles;
-    static bool attr_done = false;
-    if (!attr_done) {
-        DAFNE_HIP_TRY(hipFuncSetAttribute((const void*)conv_b2b_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kSmemTotal));
-        attr_done = true;
-    }
+    DAFNE_MAX_LDS_ONCE(kSmemTotal, (const void*)conv_b2b_kernel);
     hipLaunchKernelGGL(conv_b2b_kernel, dim3(D.tiles), dim3(kNT), kSmemTotal, (hipStream_t)stream, D);
     return dafne::check_launch("conv_b2b");
 }

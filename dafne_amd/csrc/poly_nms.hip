@@ -289,12 +289,10 @@ struct NmsWs {
     size_t mask_words;         // per image
 };
 
-// dafne_poly_nms_set_exact_only(): parity runs can switch the three analytic shortcuts off -- the guarded hull
-// pre-filter and the IoU upper bound of nms_scan, the convex decision fast path of nms_iou -- so that every pair of a
-// live tile is clipped in polyiou.cpp's own operation order.  Process-wide, read per call.
-int g_exact_only = 0;
-
-size_t carve(NmsWs& w, void* base, int N, int m_cap, bool f64 = false) {
+// flags & DAFNE_NMS_EXACT_ONLY (per call): parity runs switch the three analytic shortcuts off -- the guarded hull
+// pre-filter and the IoU upper bound of nms_scan, the decision fast paths of nms_iou -- so that every pair of a live
+// tile is clipped in polyiou.cpp's own operation order.  The library holds no mutable global state.
+size_t carve(NmsWs& w, void* base, int N, int m_cap, bool f64 = false, int flags = 0) {
     int Mp = (m_cap + kTile - 1) / kTile * kTile;
     if (Mp == 0) Mp = kTile;
     int nblk = Mp / kTile;
@@ -330,7 +328,7 @@ size_t carve(NmsWs& w, void* base, int N, int m_cap, bool f64 = false) {
     w.posidx = c.take<int>(n * Mp);
     w.use_perm = 0;
     w.strict = 0;
-    w.fast = (g_exact_only || getenv("DAFNE_NMS_NO_FAST") != nullptr) ? 0 : 1;
+    w.fast = (flags & DAFNE_NMS_EXACT_ONLY) ? 0 : 1;
     w.mask_words = ntiles * kTile;
     w.mask = c.take<u64>(n * w.mask_words);
     return dafne::align_up(c.off, 256);
@@ -1273,9 +1271,6 @@ __global__ void __launch_bounds__(64) nms_iou_kernel(const int* __restrict__ cou
     __shared__ u64 exq[2 * kTile];
     const int chunks = w.pair_cap / kTile;
     auto record = [&](int r, int c) {
-#ifdef DAFNE_NMS_ABL_NOATOMIC
-        return;
-#endif
         atomicOr(&w.mask[(size_t)img * w.mask_words + tile_id(r >> 6, c >> 6, nb) * kTile + (r & 63)], 1ull << (c & 63));
         atomicOr(&w.rowflag[(size_t)img * nb + (r >> 6)], 1ull << (r & 63));
     };
@@ -1320,14 +1315,7 @@ __global__ void __launch_bounds__(64) nms_iou_kernel(const int* __restrict__ cou
                     const int r = (int)(unsigned)en, c = (int)(en >> 32);
                     const Quad A = w.dbox ? load_quad_f64(w.dbox + (ibase + r) * 8) : load_quad_f32(w.sbox + (ibase + r) * 8);
                     const Quad B = w.dbox ? load_quad_f64(w.dbox + (ibase + c) * 8) : load_quad_f32(w.sbox + (ibase + c) * 8);
-#ifdef DAFNE_NMS_ABL_NOFAST
-                    dec = (A.v[0].x > 1e30) ? 1 : 0;
-#else
                     dec = fast_decision(s, A, B, thresh);
-#endif
-#ifdef DAFNE_NMS_ABL_NOEXACT
-                    if (dec == 2) dec = 0;
-#endif
                     if (dec == 1 && (!w.strict || hulls_overlap_strict(A, B))) record(r, c);
                 }
             }
@@ -1743,30 +1731,18 @@ int run_nms(const float* d_dets9, int row_cap, const int* d_counts, int N, int m
     dim3 gp((m_cap + 255) / 256, N);
     if (d_dets9_f64)
         hipLaunchKernelGGL(nms_prep_f64_kernel, gp, dim3(256), 0, st, d_dets9_f64, row_cap, d_counts, m_cap, w);
-    else if (m_cap <= kSortMax && getenv("DAFNE_NMS_COUNTING_SORT") == nullptr) {
-        static bool attr_done = false;
-        if (!attr_done) {
-            DAFNE_HIP_TRY(hipFuncSetAttribute((const void*)nms_sort_prep_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                              kSortMax * (int)sizeof(u64) + kSortHistBytes));
-            attr_done = true;
-        }
+    else if (m_cap <= kSortMax) {
+        DAFNE_MAX_LDS_ONCE(kSortMax * (int)sizeof(u64) + kSortHistBytes, (const void*)nms_sort_prep_kernel);
         const int n = ((m_cap + 1023) >> 10) << 10;                   // padded sequence of the largest image
         w.use_perm = 1;
-        if (getenv("DAFNE_NMS_NO_CLASS_ORDER")) w.cls = nullptr;      // experiments: score order is the tile order
         hipLaunchKernelGGL(nms_sort_prep_kernel, dim3(N), dim3(1024), (size_t)n * sizeof(u64) + kSortHistBytes, st, d_dets9, row_cap,
                            d_counts, m_cap, w);
         hipLaunchKernelGGL(nms_gather_kernel, gp, dim3(256), 0, st, d_dets9, row_cap, d_counts, m_cap, w);
     } else {
         w.use_perm = 1;
-        if (getenv("DAFNE_NMS_NO_CLASS_ORDER")) w.cls = nullptr;
         if (w.cls) hipLaunchKernelGGL(nms_cls_layout_kernel, dim3(N), dim3(1024), 0, st, d_dets9, row_cap, d_counts, m_cap, w);
-        if (m_cap < (1 << 24) && getenv("DAFNE_NMS_COUNTING_SORT") == nullptr) {
-            static bool attr2_done = false;
-            if (!attr2_done) {
-                DAFNE_HIP_TRY(hipFuncSetAttribute((const void*)nms_chunk_sort_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                                  kSortMax * (int)sizeof(u64) + kSortHistBytes));
-                attr2_done = true;
-            }
+        if (m_cap < (1 << 24)) {
+            DAFNE_MAX_LDS_ONCE(kSortMax * (int)sizeof(u64) + kSortHistBytes, (const void*)nms_chunk_sort_kernel);
             const int K = (m_cap + kSortMax - 1) / kSortMax;
             hipLaunchKernelGGL(nms_chunk_sort_kernel, dim3(K, N, 2), dim3(1024), (size_t)kSortMax * sizeof(u64) + kSortHistBytes, st,
                                d_dets9, row_cap, d_counts, m_cap, w, N);
@@ -1789,12 +1765,7 @@ int run_nms(const float* d_dets9, int row_cap, const int* d_counts, int N, int m
     hipLaunchKernelGGL(nms_iou_kernel, dim3(iou_blocks, N), dim3(64), 0, st, d_counts, m_cap, thresh, w, ntiles);
     rc = dafne::check_launch("nms_iou");
     if (rc) return rc;
-    static bool reduce_attr = false;
-    if (!reduce_attr) {
-        DAFNE_HIP_TRY(hipFuncSetAttribute((const void*)nms_class_reduce_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                          kFastBlk * 65 * (int)sizeof(u64)));
-        reduce_attr = true;
-    }
+    DAFNE_MAX_LDS_ONCE(kFastBlk * 65 * (int)sizeof(u64), (const void*)nms_class_reduce_kernel);
     // class-major images: one workgroup per class; others: workgroup 0 walks the whole image (the unused ones exit)
     hipLaunchKernelGGL(nms_class_reduce_kernel, dim3(w.cls && w.use_perm ? kMaxClsWG : 1, N), dim3(kReduceThreads),
                        (size_t)kFastBlk * 65 * sizeof(u64), st, d_counts, m_cap, w);
@@ -1819,8 +1790,6 @@ int dafne_poly_iou_pairs_hip(const double* d_p, const double* d_q, int64_t n, do
     return dafne::check_launch("iou_pairs");
 }
 
-void dafne_poly_nms_set_exact_only(int on) { g_exact_only = on ? 1 : 0; }
-
 size_t dafne_poly_nms_stats_offset(int n_images, int m_cap, int f64_rows) {
     if (n_images <= 0 || m_cap < 0) return 0;
     NmsWs w;
@@ -1836,8 +1805,9 @@ size_t dafne_poly_nms_workspace_bytes(int n_images, int m_cap) {
 
 int dafne_poly_nms_batched_hip(const float* d_dets9, const int32_t* d_counts, int n_images,
                                int m_cap, double thresh, int post_topk, int64_t* d_keep,
-                               int32_t* d_num_keep, void* d_ws, size_t ws_bytes, void* stream) {
+                               int32_t* d_num_keep, void* d_ws, size_t ws_bytes, int flags, void* stream) {
     if (n_images <= 0 || m_cap < 0 || !d_num_keep) return dafne::fail(DAFNE_E_INVALID, "poly_nms: bad args");
+    if (flags & ~DAFNE_NMS_EXACT_ONLY) return dafne::fail(DAFNE_E_INVALID, "poly_nms: unknown flags 0x%x", flags);
     hipStream_t st = (hipStream_t)stream;
     if (m_cap == 0) {
         DAFNE_HIP_TRY(hipMemsetAsync(d_num_keep, 0, sizeof(int32_t) * n_images, st));
@@ -1845,7 +1815,7 @@ int dafne_poly_nms_batched_hip(const float* d_dets9, const int32_t* d_counts, in
     }
     if (!d_dets9 || !d_keep || !d_ws) return dafne::fail(DAFNE_E_INVALID, "poly_nms: null pointer");
     NmsWs w;
-    size_t need = carve(w, d_ws, n_images, m_cap);
+    size_t need = carve(w, d_ws, n_images, m_cap, false, flags);
     if (ws_bytes < need) return dafne::fail(DAFNE_E_WORKSPACE, "poly_nms: workspace %zu < %zu", ws_bytes, need);
     if (w.nblk > kMaxBlk) return dafne::fail(DAFNE_E_UNSUPPORTED, "poly_nms: m_cap %d > %d", m_cap, kMaxBlk * kTile);
     w.cls = nullptr;           // plain [M,9] rows carry no class: score order is the tile order
@@ -1860,8 +1830,9 @@ size_t dafne_poly_nms_f64_workspace_bytes(int n_images, int m_cap) {
 
 int dafne_poly_nms_f64_batched_hip(const double* d_dets9, const int32_t* d_counts, int n_images,
                                    int m_cap, double thresh, int strict_hbb, int64_t* d_keep,
-                                   int32_t* d_num_keep, void* d_ws, size_t ws_bytes, void* stream) {
+                                   int32_t* d_num_keep, void* d_ws, size_t ws_bytes, int flags, void* stream) {
     if (n_images <= 0 || m_cap < 0 || !d_num_keep) return dafne::fail(DAFNE_E_INVALID, "poly_nms_f64: bad args");
+    if (flags & ~DAFNE_NMS_EXACT_ONLY) return dafne::fail(DAFNE_E_INVALID, "poly_nms_f64: unknown flags 0x%x", flags);
     hipStream_t st = (hipStream_t)stream;
     if (m_cap == 0) {
         DAFNE_HIP_TRY(hipMemsetAsync(d_num_keep, 0, sizeof(int32_t) * n_images, st));
@@ -1869,7 +1840,7 @@ int dafne_poly_nms_f64_batched_hip(const double* d_dets9, const int32_t* d_count
     }
     if (!d_dets9 || !d_keep || !d_ws) return dafne::fail(DAFNE_E_INVALID, "poly_nms_f64: null pointer");
     NmsWs w;
-    size_t need = carve(w, d_ws, n_images, m_cap, true);
+    size_t need = carve(w, d_ws, n_images, m_cap, true, flags);
     if (ws_bytes < need) return dafne::fail(DAFNE_E_WORKSPACE, "poly_nms_f64: workspace %zu < %zu", ws_bytes, need);
     if (w.nblk > kMaxBlk) return dafne::fail(DAFNE_E_UNSUPPORTED, "poly_nms_f64: m_cap %d > %d", m_cap, kMaxBlk * kTile);
     w.strict = strict_hbb ? 1 : 0;
@@ -1877,17 +1848,18 @@ int dafne_poly_nms_f64_batched_hip(const double* d_dets9, const int32_t* d_count
 }
 
 int dafne_poly_nms_hip(const float* d_dets9, int M, double thresh, int64_t* d_keep,
-                       int32_t* d_num_keep, void* d_ws, size_t ws_bytes, void* stream) {
+                       int32_t* d_num_keep, void* d_ws, size_t ws_bytes, int flags, void* stream) {
     return dafne_poly_nms_batched_hip(d_dets9, nullptr, 1, M, thresh, 0, d_keep, d_num_keep, d_ws,
-                                      ws_bytes, stream);
+                                      ws_bytes, flags, stream);
 }
 
 int dafne_select_over_all_levels_hip(const float* d_boxes8, const float* d_scores,
                                      const int32_t* d_classes, const int32_t* d_counts,
                                      int n_images, int m_cap, double nms_thresh, int post_topk,
                                      int64_t* d_keep, int32_t* d_num_keep, void* d_ws,
-                                     size_t ws_bytes, void* stream) {
+                                     size_t ws_bytes, int flags, void* stream) {
     if (n_images <= 0 || m_cap < 0 || !d_num_keep) return dafne::fail(DAFNE_E_INVALID, "select: bad args");
+    if (flags & ~DAFNE_NMS_EXACT_ONLY) return dafne::fail(DAFNE_E_INVALID, "select: unknown flags 0x%x", flags);
     hipStream_t st = (hipStream_t)stream;
     if (m_cap == 0) {
         DAFNE_HIP_TRY(hipMemsetAsync(d_num_keep, 0, sizeof(int32_t) * n_images, st));
@@ -1898,7 +1870,7 @@ int dafne_select_over_all_levels_hip(const float* d_boxes8, const float* d_score
     if ((uintptr_t)d_boxes8 & 15) return dafne::fail(DAFNE_E_INVALID, "select: d_boxes8 must be 16-byte aligned");
     if (!(nms_thresh > 0)) return dafne::fail(DAFNE_E_UNSUPPORTED, "select: nms_thresh <= 0 bypasses NMS in the reference; handle on the caller side");
     NmsWs w;
-    size_t need = carve(w, d_ws, n_images, m_cap);
+    size_t need = carve(w, d_ws, n_images, m_cap, false, flags);
     if (ws_bytes < need) return dafne::fail(DAFNE_E_WORKSPACE, "select: workspace %zu < %zu", ws_bytes, need);
     if (w.nblk > kMaxBlk) return dafne::fail(DAFNE_E_UNSUPPORTED, "select: m_cap %d > %d", m_cap, kMaxBlk * kTile);
     DAFNE_HIP_TRY(hipMemsetAsync(w.meta, 0, zero_bytes(w, n_images), st));

@@ -221,14 +221,9 @@ int dafne_stem_pool_hip(const void* d_in, const void* d_weight, const float* d_b
     const long long tiles = (long long)D.tiles_x * D.tiles_y * n_images;
     if (tiles > (1ll << 30)) return dafne::fail(DAFNE_E_UNSUPPORTED, "stem_pool: too many tiles");
     D.tiles = (int)tiles;
-    static int cus = 0;
-    if (!cus) {
-        int dev = 0;
-        DAFNE_HIP_TRY(hipGetDevice(&dev));
-        DAFNE_HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
-        DAFNE_HIP_TRY(hipFuncSetAttribute((const void*)stem_pool_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kSmem));
-        if (cus < 1) cus = 256;
-    }
+    DAFNE_MAX_LDS_ONCE(kSmem, (const void*)stem_pool_kernel);
+    int cus = 0;
+    if (int rc = dafne::device_cus(&cus)) return rc;
     const int grid = D.tiles < cus ? D.tiles : cus;
     hipLaunchKernelGGL(stem_pool_kernel, dim3(grid), dim3(512), kSmem, (hipStream_t)stream, D);
     return dafne::check_launch("stem_pool");

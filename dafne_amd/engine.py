@@ -118,6 +118,36 @@ def act_qscale_from_amax(amax, margin=2.0):
     return float(2.0 ** math.floor(math.log2(E4M3_MAX / (margin * amax))))
 
 
+def reduce_amax_over_ranks(calib, group=None):
+    """fp8 calibration in a multi-process job: every rank must end up with the SAME activation scales, whatever images its
+    shard holds -- element-wise MAX of the per-layer amax values over the ranks (one all-reduce of a small float64 vector
+    in sorted-key order; RCCL on the GPU, gloo in the CPU tests).  Returns the reduced dict; a no-op without a process
+    group."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) < 2:
+        return dict(calib)
+    keys = sorted(calib)
+    # every rank calibrates the same architecture: same keys.  A mismatch would silently pair different layers.
+    sig = [len(keys), sum(hash_str(k) for k in keys) % (1 << 52)]
+    dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend(group) == "nccl" else torch.device("cpu")
+    t = torch.tensor([float(calib[k]) for k in keys] + [float(s) for s in sig] + [-float(s) for s in sig],
+                     dtype=torch.float64, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+    v = t.cpu().tolist()
+    n = len(keys)
+    if v[n:n + 2] != [float(s) for s in sig] or v[n + 2:n + 4] != [-float(s) for s in sig]:
+        raise RuntimeError("fp8 calibration: the ranks calibrated different layer sets")
+    return {k: v[i] for i, k in enumerate(keys)}
+
+
+def hash_str(s):
+    """Process-independent string hash (python's hash() is salted per process)."""
+    h = 1469598103934665603
+    for ch in s.encode():
+        h = ((h ^ ch) * 1099511628211) & ((1 << 64) - 1)
+    return h % (1 << 40)
+
+
 class AmaxProbe:
     """Calibration-plan entry: max |x| of the listed activations (interior only; the halo is zero) into calib[key]."""
 

@@ -70,7 +70,7 @@ def _merge_nms_batched(arrays, thresh, strict_hbb=True, device=None):
             ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
             _lib.check(L.dafne_poly_nms_f64_batched_hip(_lib.ptr(d), _lib.ptr(c), n, m_cap, float(thresh),
                                                         1 if strict_hbb else 0, _lib.ptr(keep), _lib.ptr(nk),
-                                                        _lib.ptr(ws), nbytes, _lib.current_stream()),
+                                                        _lib.ptr(ws), nbytes, 0, _lib.current_stream()),
                        "dafne_poly_nms_f64_batched_hip")
             kh, nh = keep.cpu().numpy(), nk.cpu().numpy()
             for k, i in enumerate(ids):

@@ -56,14 +56,19 @@ class DAFNeOutputs(nn.Module):
                                 pre_nms_topk=self.pre_nms_topk_test, thresh_with_ctr=self.thresh_with_ctr,
                                 sort_corners=self.sort_corners, out=out)
 
+    def packed_k_cap(self, n_levels=5):
+        """Row capacity of the packed detections select_packed returns by default -- what a caller sizing a gather
+        buffer must use (tools/eval_net.py, evaluation/driver.py) instead of restating the rule."""
+        m_cap = n_levels * self.pre_nms_topk_test
+        return min(m_cap, max(self.post_nms_topk_test, 1) + 256) if self.post_nms_topk_test > 0 else m_cap
+
     def select_packed(self, cand, sizes=None, k_cap=None, scale_corners=True):
         if self.nms_thresh > 0:
             keep, nk = pp.select(cand, self.nms_thresh, self.post_nms_topk_test)
         else:   # ml_nms returns its input unchanged (nms.py:22-23); only the cap applies
             keep, nk = _identity_keep_with_cap(cand, self.post_nms_topk_test)
         if k_cap is None:
-            k_cap = min(cand.m_cap, max(self.post_nms_topk_test, 1) + 256) if self.post_nms_topk_test > 0 \
-                else cand.m_cap
+            k_cap = self.packed_k_cap(cand.m_cap // max(self.pre_nms_topk_test, 1))
         return pp.gather(cand, keep, nk, sizes=sizes, k_cap=k_cap, scale_corners=scale_corners)
 
     # ---- reference-signature path ----------------------------------------------
@@ -112,7 +117,7 @@ class DAFNeOutputs(nn.Module):
                 ws = torch.empty(max(nbytes, 256), dtype=torch.uint8, device=dev)
                 _lib.check(L.dafne_select_over_all_levels_hip(
                     _lib.ptr(b), _lib.ptr(sc), _lib.ptr(c), None, 1, n, float(self.nms_thresh),
-                    int(max(self.post_nms_topk, 0)), _lib.ptr(keep), _lib.ptr(nk), _lib.ptr(ws), nbytes,
+                    int(max(self.post_nms_topk, 0)), _lib.ptr(keep), _lib.ptr(nk), _lib.ptr(ws), nbytes, 0,
                     _lib.current_stream()), "dafne_select_over_all_levels_hip")
                 results.append(bl[keep[: int(nk.item())]])
         return results

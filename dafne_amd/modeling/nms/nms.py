@@ -36,7 +36,7 @@ def poly_gpu_nms(dets, thresh, device_id=0):
         nk = torch.zeros(1, dtype=torch.int32, device=dev)
         ws, nbytes = _ws(1, m, dev)
         _lib.check(L.dafne_poly_nms_hip(_lib.ptr(d), m, float(thresh), _lib.ptr(keep), _lib.ptr(nk),
-                                        _lib.ptr(ws), nbytes, _lib.current_stream()), "dafne_poly_nms_hip")
+                                        _lib.ptr(ws), nbytes, 0, _lib.current_stream()), "dafne_poly_nms_hip")
         n = int(nk.item())
         return keep[:n].cpu().tolist()
 
@@ -62,7 +62,7 @@ def batched_nms_poly(boxes, scores, idxs, iou_threshold):
         ws, nbytes = _ws(1, m, dev)
         _lib.check(L.dafne_select_over_all_levels_hip(
             _lib.ptr(b), _lib.ptr(s), _lib.ptr(c), None, 1, m, float(iou_threshold), 0,
-            _lib.ptr(keep), _lib.ptr(nk), _lib.ptr(ws), nbytes, _lib.current_stream()),
+            _lib.ptr(keep), _lib.ptr(nk), _lib.ptr(ws), nbytes, 0, _lib.current_stream()),
             "dafne_select_over_all_levels_hip")
         return keep[: int(nk.item())]
 

@@ -90,15 +90,30 @@ class OneStageDetector(nn.Module):
     def fp8_act_scales(self):
         """{weight key: in_qscale} of the layers whose plain (not GroupNorm-fed) input is quantised to e4m3 on load:
         res4 / res5 3x3 layers, FPN output convolutions, the two tower layers that read FPN features.  None until
-        calibrate_fp8 ran (those layers then run the bf16 kernels on the dequantised weights)."""
+        calibrate_fp8 / set_fp8_act_scales ran.  Persist them with the weights (they are part of the model)."""
         return None if self._act_q8 is None else dict(self._act_q8)
 
-    def calibrate_fp8(self, images_u8, valid_hw=None, layout_hwc=False):
+    def set_fp8_act_scales(self, scales):
+        """Install persisted activation scales ({weight key: in_qscale}, what fp8_act_scales() returned / what
+        checkpoint.load_weights finds under "fp8_act_scales") instead of calibrating: the scales are part of the fp8 model."""
+        if self.cfg.ENGINE.WEIGHT_DTYPE != "fp8_e4m3":
+            raise RuntimeError("set_fp8_act_scales: ENGINE.WEIGHT_DTYPE is %r" % (self.cfg.ENGINE.WEIGHT_DTYPE,))
+        self._weights()
+        self._act_q8 = {str(k): float(v) for k, v in dict(scales).items()}
+        self._packed["act_q8"] = dict(self._act_q8)
+        self._plans = {}
+        self._graphs = {}
+        if hasattr(self, "_pipe"):
+            self._pipe = {}
+
+    def calibrate_fp8(self, images_u8, valid_hw=None, layout_hwc=False, group=None):
         """Static activation calibration of the fp8 model on one batch (uint8 CUDA images as detect_packed takes them): a
         calibration plan runs those layers on the bf16 kernels and records max |input| per layer; in_qscale = the largest
-        power of two with 2 * amax * in_qscale <= 448 (engine.act_qscale_from_amax).  detect_packed calls this on the FIRST
-        batch it sees (cfg.ENGINE.FP8_ACT_CALIBRATION == "first_batch", the default), so a given first batch always
-        yields the same model; pass a representative batch explicitly to pin the scales before serving."""
+        power of two with 2 * amax * in_qscale <= 448 (engine.act_qscale_from_amax).  Explicit by default
+        (cfg.ENGINE.FP8_ACT_CALIBRATION == "explicit": detect_packed raises until this or set_fp8_act_scales ran).  In a
+        multi-process job (torch.distributed initialised) the per-layer amax values are MAX-reduced over the ranks of
+        `group` before the scales are derived, so every rank serves the SAME quantised model whatever its shard holds:
+        every rank must call this (it is a collective)."""
         if self.cfg.ENGINE.WEIGHT_DTYPE != "fp8_e4m3":
             raise RuntimeError("calibrate_fp8: ENGINE.WEIGHT_DTYPE is %r" % (self.cfg.ENGINE.WEIGHT_DTYPE,))
         L = _lib.load()
@@ -123,6 +138,7 @@ class OneStageDetector(nn.Module):
                        "dafne_preprocess_image_hip")
             plan.run()
             torch.cuda.synchronize()
+        calib = engine.reduce_amax_over_ranks(calib, group)
         self._act_q8 = {k: engine.act_qscale_from_amax(v) for k, v in calib.items()}
         self._packed["act_q8"] = dict(self._act_q8)
         self._plans = {}
@@ -170,9 +186,14 @@ class OneStageDetector(nn.Module):
         sub-batches use: consecutive calls with different offsets (the TTA wrapper's chunks) run concurrently."""
         if not images_u8.is_cuda or images_u8.dtype != torch.uint8:
             raise RuntimeError("detect_packed needs a uint8 CUDA tensor (the MI355X engine has no CPU path)")
-        if self.cfg.ENGINE.WEIGHT_DTYPE == "fp8_e4m3" and self._act_q8 is None \
-                and self.cfg.ENGINE.FP8_ACT_CALIBRATION == "first_batch":
-            self.calibrate_fp8(images_u8, valid_hw=valid_hw, layout_hwc=layout_hwc)
+        if self.cfg.ENGINE.WEIGHT_DTYPE == "fp8_e4m3" and self._act_q8 is None:
+            mode = self.cfg.ENGINE.FP8_ACT_CALIBRATION
+            if mode == "first_batch":
+                self.calibrate_fp8(images_u8, valid_hw=valid_hw, layout_hwc=layout_hwc)
+            elif mode != "off":
+                raise RuntimeError("fp8 model without activation scales: call calibrate_fp8(batch) or set_fp8_act_scales(scales) "
+                                   "first (ENGINE.FP8_ACT_CALIBRATION=%r; 'off' runs only the GroupNorm-fed tower layers in "
+                                   "e4m3, 'first_batch' calibrates on whatever batch comes first)" % (mode,))
         L = _lib.load()
         if layout_hwc:
             n, h, w, _ = images_u8.shape

@@ -75,9 +75,9 @@ def decode_levels(levels, *, num_classes, pre_nms_thresh, pre_nms_topk, thresh_w
     return cand
 
 
-def select(cand, nms_thresh, post_topk):
+def select(cand, nms_thresh, post_topk, nms_flags=0):
     """ml_nms + cap for every image of the batch.  Returns (keep[N,m_cap] int64,
-    num_keep[N] int32), device tensors."""
+    num_keep[N] int32), device tensors.  nms_flags: per-call DAFNE_NMS_* bits (parity runs)."""
     L = _lib.load()
     dev = cand.corners.device
     n, m = cand.n, cand.m_cap
@@ -89,7 +89,7 @@ def select(cand, nms_thresh, post_topk):
         _lib.check(L.dafne_select_over_all_levels_hip(
             _lib.ptr(cand.corners), _lib.ptr(cand.scores), _lib.ptr(cand.classes), _lib.ptr(cand.counts),
             n, m, float(nms_thresh), int(post_topk), _lib.ptr(keep), _lib.ptr(nk), _lib.ptr(ws), nbytes,
-            _lib.current_stream()), "dafne_select_over_all_levels_hip")
+            int(nms_flags), _lib.current_stream()), "dafne_select_over_all_levels_hip")
     return keep, nk
 
 

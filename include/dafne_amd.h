@@ -72,7 +72,7 @@ int dafne_poly_iou_pairs_hip(const double* d_p, const double* d_q, int64_t n,
 size_t dafne_poly_nms_f64_workspace_bytes(int n_images, int m_cap);
 int dafne_poly_nms_f64_batched_hip(const double* d_dets9, const int32_t* d_counts, int n_images, int m_cap,
                                    double thresh, int strict_hbb, int64_t* d_keep, int32_t* d_num_keep,
-                                   void* d_ws, size_t ws_bytes, void* stream);
+                                   void* d_ws, size_t ws_bytes, int flags, void* stream);
 
 /*
  * Greedy polygon NMS, the replacement for poly_nms.poly_gpu_nms (nms.py:91).
@@ -86,22 +86,23 @@ int dafne_poly_nms_f64_batched_hip(const double* d_dets9, const int32_t* d_count
  */
 size_t dafne_poly_nms_workspace_bytes(int n_images, int m_cap);
 /*
- * Parity switch.  The in-model NMS decides `iou_poly > thresh` (polyiou.cpp:112-133 in fp64) and takes three analytic
- * shortcuts on the way, each with a proven margin: a guarded hull-separation pre-filter, an IoU
- * upper bound for convex pairs, and a one-lane geometric clip for convex pairs far from the threshold.
- * dafne_poly_nms_set_exact_only(1) turns all three off for every later NMS call of the process (every pair of every
- * live tile then runs the reference-order clip; same results, slower): what tests/test_gpu_nms.py uses to show the
- * shortcuts change nothing.  Also set by the environment variable DAFNE_NMS_NO_FAST.
+ * `flags` (every NMS entry point takes it, per call; the library holds no mutable global state, so concurrent callers
+ * on other threads / streams are unaffected): 0 = default.  DAFNE_NMS_EXACT_ONLY is the parity switch.  The in-model
+ * NMS decides `iou_poly > thresh` (polyiou.cpp:112-133 in fp64) and takes three analytic shortcuts on the way, each with
+ * a proven margin: a guarded hull-separation pre-filter, an IoU upper bound for convex pairs, and
+ * a one-lane geometric clip for pairs far from the threshold.  With DAFNE_NMS_EXACT_ONLY all three are off for THIS
+ * call (every pair of every live tile runs the reference-order clip; same results, slower): what tests/test_gpu_nms.py
+ * uses to show the shortcuts change nothing.  Unknown bits -> DAFNE_E_INVALID.
  *
  * dafne_poly_nms_stats_offset: byte offset inside the NMS workspace of uint32 stats[n_images][4], valid after a
  * call has completed: pairs decided by (0) the fast path as "suppress", (1) the fast path as "keep", (2) the
  * reference-order path, (3) the reference-order path of tiles that overflowed the pair lists.  f64_rows: 1 for the
  * dafne_poly_nms_f64_* workspace layout.
  */
-void dafne_poly_nms_set_exact_only(int on);
+#define DAFNE_NMS_EXACT_ONLY 1
 size_t dafne_poly_nms_stats_offset(int n_images, int m_cap, int f64_rows);
 int dafne_poly_nms_hip(const float* d_dets9, int M, double thresh, int64_t* d_keep,
-                       int32_t* d_num_keep, void* d_ws, size_t ws_bytes, void* stream);
+                       int32_t* d_num_keep, void* d_ws, size_t ws_bytes, int flags, void* stream);
 /*
  * Batched form: n_images independent problems in one set of launches.
  *   d_dets9   [n_images, m_cap, 9]; d_counts [n_images] int32 DEVICE (rows used
@@ -112,7 +113,7 @@ int dafne_poly_nms_hip(const float* d_dets9, int M, double thresh, int64_t* d_ke
  */
 int dafne_poly_nms_batched_hip(const float* d_dets9, const int32_t* d_counts, int n_images,
                                int m_cap, double thresh, int post_topk, int64_t* d_keep,
-                               int32_t* d_num_keep, void* d_ws, size_t ws_bytes, void* stream);
+                               int32_t* d_num_keep, void* d_ws, size_t ws_bytes, int flags, void* stream);
 /*
  * ml_nms + the post-NMS cap for a batch (nms.py:10-92, dafne_outputs.py:907-925):
  * class 5 -> 4, offset = float(class) * (max(boxes) - min(boxes) + 1) in fp32 per
@@ -124,7 +125,7 @@ int dafne_select_over_all_levels_hip(const float* d_boxes8, const float* d_score
                                      const int32_t* d_classes, const int32_t* d_counts,
                                      int n_images, int m_cap, double nms_thresh, int post_topk,
                                      int64_t* d_keep, int32_t* d_num_keep, void* d_ws,
-                                     size_t ws_bytes, void* stream);
+                                     size_t ws_bytes, int flags, void* stream);
 
 /* ------------------------------------------------------ decode / top-k / sort */
 typedef struct dafne_level_desc {

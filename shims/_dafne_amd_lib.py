@@ -22,13 +22,13 @@ def lib():
         L.dafne_poly_nms_workspace_bytes.restype = cs
         L.dafne_poly_nms_workspace_bytes.argtypes = [ci, ci]
         L.dafne_poly_nms_hip.restype = ci
-        L.dafne_poly_nms_hip.argtypes = [vp, ci, cd, vp, vp, vp, cs, vp]
+        L.dafne_poly_nms_hip.argtypes = [vp, ci, cd, vp, vp, vp, cs, ci, vp]
         L.dafne_poly_iou_pairs_hip.restype = ci
         L.dafne_poly_iou_pairs_hip.argtypes = [vp, vp, ctypes.c_int64, vp, vp]
         L.dafne_poly_nms_f64_workspace_bytes.restype = cs
         L.dafne_poly_nms_f64_workspace_bytes.argtypes = [ci, ci]
         L.dafne_poly_nms_f64_batched_hip.restype = ci
-        L.dafne_poly_nms_f64_batched_hip.argtypes = [vp, vp, ci, ci, cd, ci, vp, vp, vp, cs, vp]
+        L.dafne_poly_nms_f64_batched_hip.argtypes = [vp, vp, ci, ci, cd, ci, vp, vp, vp, cs, ci, vp]
         _L = L
     return _L
 

@@ -31,6 +31,6 @@ def poly_gpu_nms(dets, thresh, device_id=0):
         n = torch.zeros(1, dtype=torch.int32, device=dev)
         nbytes = L.dafne_poly_nms_workspace_bytes(1, m)
         ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
-        check(L.dafne_poly_nms_hip(d.data_ptr(), m, float(thresh), keep.data_ptr(), n.data_ptr(), ws.data_ptr(), nbytes,
+        check(L.dafne_poly_nms_hip(d.data_ptr(), m, float(thresh), keep.data_ptr(), n.data_ptr(), ws.data_ptr(), nbytes, 0,
                                    torch.cuda.current_stream().cuda_stream), "dafne_poly_nms_hip")
         return keep[: int(n.item())].cpu().tolist()

@@ -157,3 +157,48 @@ def test_single_process_driver_and_instances_roundtrip():
     assert torch.equal(out[0], rows) and out[1].tolist() == [3, 0]
     with pytest.raises(Exception):
         instances_to_rows([inst], 2)                     # more detections than the gather capacity
+
+
+def _amax_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from dafne_amd import engine
+    # every rank saw other images: per-layer amax differs, rank 1 even has a layer at 0 (an all-dark shard)
+    calib = {"res4.0.conv2": 3.5 + rank, "fpn_output3": 40.0 / (rank + 1), "cls_tower.0": 0.0 if rank else 7.25}
+    red = engine.reduce_amax_over_ranks(calib)
+    scales = {k: engine.act_qscale_from_amax(v) for k, v in red.items()}
+    bad = None
+    try:                                    # a rank that calibrated another layer set must not be paired silently
+        engine.reduce_amax_over_ranks({("x" if rank else "y"): 1.0})
+    except RuntimeError as e:
+        bad = str(e)
+    q.put((rank, red, scales, bad))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_fp8_calibration_is_identical_on_every_rank():
+    """the fp8 model's activation scales must not depend on a rank's shard.  calibrate_fp8
+    MAX-reduces the per-layer amax over the ranks (engine.reduce_amax_over_ranks); here two ranks with different amax
+    dicts end with the same reduced values and the same power-of-two scales."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_amax_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=120) for _ in range(2)), key=lambda r: r[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (_, red0, sc0, bad0), (_, red1, sc1, bad1) = res
+    assert red0 == red1 == {"res4.0.conv2": 4.5, "fpn_output3": 40.0, "cls_tower.0": 7.25}
+    assert sc0 == sc1 and sc0["fpn_output3"] == 4.0 and sc0["res4.0.conv2"] == 32.0     # 2 * amax * q <= 448
+    assert bad0 and bad1 and "different layer sets" in bad0
+
+
+def test_reduce_amax_without_process_group_is_identity():
+    from dafne_amd import engine
+    assert engine.reduce_amax_over_ranks({"a": 1.5, "b": 0.0}) == {"a": 1.5, "b": 0.0}

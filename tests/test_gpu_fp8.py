@@ -219,22 +219,39 @@ def test_fp8_model_backbone_and_head_vs_oracle():
 
 def test_fp8_model_uses_the_fp8_kernel_and_runs_end_to_end():
     """Config 5 end to end at a small size.  Without activation calibration the ten GroupNorm-fed tower layers go to
-    conv3x3_patch_fp8; after the first batch calibrated the plain-input layers (ENGINE.FP8_ACT_CALIBRATION first_batch, the
-    default) so do the 23 + 3 res4 / res5 3x3 layers, the 3 FPN output convolutions and the 2 FPN-fed tower layers: 41.
-    Detections are well formed."""
+    conv3x3_patch_fp8; after calibrate_fp8 pinned the plain-input layers' scales so do the 23 + 3 res4 / res5 3x3 layers,
+    the 3 FPN output convolutions and the 2 FPN-fed tower layers: 41.  Calibration is EXPLICIT by default: an fp8 model
+    without scales raises instead of quantising by whatever batch comes first; scales can be installed and persisted with
+    the weights.  Detections are well formed."""
     import numpy as np
     cfg, m, P = _build("ucas_aod_r101_fp8.yaml", seed=17)
     g = torch.Generator().manual_seed(3)
     h, w = 256, 320
     img = torch.randint(0, 256, (3, h, w), generator=g, dtype=torch.uint8)
+    assert cfg.ENGINE.FP8_ACT_CALIBRATION == "explicit"
+    with pytest.raises(RuntimeError, match="calibrate_fp8"):
+        m([{"image": img, "height": h, "width": w}])
     cfg.ENGINE.FP8_ACT_CALIBRATION = "off"
     m([{"image": img, "height": h, "width": w}])
     assert m.fp8_act_scales() is None
     names = [c.kernel_name() for c in m.plan(1, h, w).calls if hasattr(c, "kernel_name")]
     assert names.count("conv3x3_patch_fp8") == 10, names      # layers 1..3 of three towers + corners_tower.0
-    cfg.ENGINE.FP8_ACT_CALIBRATION = "first_batch"
+    cfg.ENGINE.FP8_ACT_CALIBRATION = "explicit"
+    m.calibrate_fp8(img.unsqueeze(0).to(dev()))
     out = m([{"image": img, "height": h, "width": w}])[0]["instances"]
     scales = m.fp8_act_scales()
+    # the scales travel with the weights: save -> a fresh model -> load gives the same model, no calibration
+    import os
+    import tempfile
+    from dafne_amd.checkpoint import load_weights, save_checkpoint
+    with tempfile.TemporaryDirectory() as td:
+        path = os.path.join(td, "fp8.pth")
+        save_checkpoint(m, path)
+        cfg2, m2, _ = _build("ucas_aod_r101_fp8.yaml", seed=99)
+        load_weights(m2, path)
+    assert m2.fp8_act_scales() == scales
+    out2 = m2([{"image": img, "height": h, "width": w}])[0]["instances"]
+    assert torch.equal(out2.pred_corners, out.pred_corners) and torch.equal(out2.scores, out.scores)
     assert len(scales) == 31 and all(v > 0 and np.log2(v) == np.round(np.log2(v)) for v in scales.values()), scales
     plan = m.plan(1, h, w)
     names = [c.kernel_name() for c in plan.calls if hasattr(c, "kernel_name")]
@@ -252,6 +269,7 @@ def test_fp8_model_pipelined_equals_serial():
     cfg, m, P = _build("ucas_aod_r101_fp8.yaml", seed=13)
     g = torch.Generator().manual_seed(6)
     batches = [torch.randint(0, 256, (3, 3, 128, 160), generator=g, dtype=torch.uint8).to(dev()) for _ in range(3)]
+    m.calibrate_fp8(batches[0])
     serial = [m.detect_packed(b) for b in batches]
     torch.cuda.synchronize()
     serial = [(r.clone(), c.clone()) for r, c in serial]
@@ -274,6 +292,7 @@ def test_fp8_calibrated_model_vs_oracle():
     cfg, m, P = _build("ucas_aod_r101_fp8.yaml", seed=23)
     g = torch.Generator().manual_seed(5)
     img = torch.randint(0, 256, (2, 3, 192, 256), generator=g, dtype=torch.uint8)
+    m.calibrate_fp8(img.to(dev()))
     m.detect_packed(img.to(dev()))
     torch.cuda.synchronize()
     aq = m.fp8_act_scales()

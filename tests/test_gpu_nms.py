@@ -8,6 +8,8 @@ import oracle
 from oracle import postprocess as pp
 from conftest import NMS_SET_KINDS, nms_candidate_set, rrects
 
+NMS_EXACT_ONLY = 1          # include/dafne_amd.h DAFNE_NMS_EXACT_ONLY
+
 pytestmark = pytest.mark.gpu
 
 CASES = ["rand1", "rand2", "rand63", "rand64", "rand65", "rand300", "rand1000", "ties45",
@@ -106,7 +108,7 @@ def test_batched_with_device_counts_and_cap():
     post = 400
     _lib.check(L.dafne_select_over_all_levels_hip(_lib.ptr(tb), _lib.ptr(ts), _lib.ptr(tc), _lib.ptr(tn), N, cap,
                                                   0.1, post, _lib.ptr(keep), _lib.ptr(nk), _lib.ptr(ws), nbytes,
-                                                  _lib.current_stream()))
+                                                  0, _lib.current_stream()))
     torch.cuda.synchronize()
     for i, m in enumerate(counts):
         det = {"pred_corners": boxes[i, :m], "scores": scores[i, :m], "pred_classes": classes[i, :m].astype(np.int64)}
@@ -190,7 +192,7 @@ def test_fast_path_decisions_around_the_threshold():
     nbytes = L.dafne_poly_nms_workspace_bytes(n, 2)
     ws = torch.empty(nbytes, dtype=torch.uint8, device=dev())
     _lib.check(L.dafne_poly_nms_batched_hip(_lib.ptr(d), None, n, 2, 0.1, 0, _lib.ptr(keep), _lib.ptr(nk), _lib.ptr(ws), nbytes,
-                                            _lib.current_stream()), "nms")
+                                            0, _lib.current_stream()), "nms")
     got = nk.cpu().numpy()
     want = np.array([len(oracle.poly_nms(dets[i], 0.1)) for i in range(n)])
     assert np.array_equal(got, want), np.nonzero(got != want)[0][:10]
@@ -229,7 +231,7 @@ def test_class_major_tile_order_matches_global_greedy(n_zero):
     ws = torch.empty(nbytes, dtype=torch.uint8, device=d)
     post = 300
     _lib.check(L.dafne_select_over_all_levels_hip(_lib.ptr(tb), _lib.ptr(ts), _lib.ptr(tc), _lib.ptr(tn), N, cap, 0.1, post,
-                                                  _lib.ptr(keep), _lib.ptr(nk), _lib.ptr(ws), nbytes, _lib.current_stream()))
+                                                  _lib.ptr(keep), _lib.ptr(nk), _lib.ptr(ws), nbytes, 0, _lib.current_stream()))
     torch.cuda.synchronize()
     for i, m in enumerate(counts):
         exp_keep = pp.batched_nms_poly(boxes[i, :m], scores[i, :m], classes[i, :m].astype(np.int64), 0.1, fast=True)
@@ -260,7 +262,7 @@ def test_class_major_order_on_the_counting_path(n_zero):
     nbytes = L.dafne_poly_nms_workspace_bytes(1, m)
     ws = torch.empty(nbytes, dtype=torch.uint8, device=d)
     _lib.check(L.dafne_select_over_all_levels_hip(_lib.ptr(tb), _lib.ptr(ts), _lib.ptr(tc), None, 1, m, 0.1, 1000,
-                                                  _lib.ptr(keep), _lib.ptr(nk), _lib.ptr(ws), nbytes, _lib.current_stream()))
+                                                  _lib.ptr(keep), _lib.ptr(nk), _lib.ptr(ws), nbytes, 0, _lib.current_stream()))
     torch.cuda.synchronize()
     exp_keep = pp.batched_nms_poly(boxes[0], scores[0], classes[0].astype(np.int64), 0.1, fast=True)
     if len(exp_keep) > 1000:
@@ -287,7 +289,7 @@ def test_chunked_sort_path_with_ragged_counts():
     nbytes = L.dafne_poly_nms_workspace_bytes(2, m_cap)
     ws = torch.empty(nbytes, dtype=torch.uint8, device=d)
     _lib.check(L.dafne_select_over_all_levels_hip(_lib.ptr(tb), _lib.ptr(ts), _lib.ptr(tc), _lib.ptr(tn), 2, m_cap, 0.1, 1000,
-                                                  _lib.ptr(keep), _lib.ptr(nk), _lib.ptr(ws), nbytes, _lib.current_stream()))
+                                                  _lib.ptr(keep), _lib.ptr(nk), _lib.ptr(ws), nbytes, 0, _lib.current_stream()))
     torch.cuda.synchronize()
     for i, m in enumerate(counts):
         exp_keep = pp.batched_nms_poly(boxes[i, :m], scores[i, :m], classes[i, :m].astype(np.int64), 0.1, fast=True)
@@ -327,7 +329,7 @@ def test_coincident_edges_duplicates_and_nesting():
         assert got.cpu().tolist() == pp.batched_nms_poly(b, s, c.astype(np.int64), thr).tolist()
 
 
-def _select(boxes, scores, classes, thr, post, counts=None):
+def _select(boxes, scores, classes, thr, post, counts=None, flags=0):
     """dafne_select_over_all_levels_hip on [N,M,*] arrays -> (list of keep lists, stats [N,4])."""
     from dafne_amd import _lib
     L = _lib.load()
@@ -340,7 +342,7 @@ def _select(boxes, scores, classes, thr, post, counts=None):
     nbytes = L.dafne_poly_nms_workspace_bytes(N, m)
     ws = torch.empty(nbytes, dtype=torch.uint8, device=d)
     _lib.check(L.dafne_select_over_all_levels_hip(_lib.ptr(tb), _lib.ptr(ts), _lib.ptr(tc), _lib.ptr(tn), N, m, thr, post,
-                                                  _lib.ptr(keep), _lib.ptr(nk), _lib.ptr(ws), nbytes, _lib.current_stream()))
+                                                  _lib.ptr(keep), _lib.ptr(nk), _lib.ptr(ws), nbytes, int(flags), _lib.current_stream()))
     torch.cuda.synchronize()
     off = L.dafne_poly_nms_stats_offset(N, m, 0)
     stats = ws[off:off + 16 * N].view(torch.int32).reshape(N, 4).cpu().numpy()
@@ -375,7 +377,7 @@ def test_full_size_sets_exact_vs_oracle(kind, m):
 
 
 def test_exact_only_mode_changes_nothing():
-    """dafne_poly_nms_set_exact_only(1) switches off the hull pre-filter, the IoU upper bound and the convex decision
+    """The per-call flag DAFNE_NMS_EXACT_ONLY switches off the hull pre-filter, the IoU upper bound and the convex decision
     fast path: every pair of every live tile goes through polyiou.cpp's operation order.  Same keep lists as the
     default mode and as the UNFILTERED oracle, on dense / skewed sets and a batch with ragged counts."""
     from dafne_amd import _lib
@@ -385,11 +387,7 @@ def test_exact_only_mode_changes_nothing():
     B = np.stack([x[0] for x in sets]); S = np.stack([x[1] for x in sets]); C = np.stack([x[2] for x in sets])
     counts = [3000, 2500, 1777]
     fast, st_fast = _select(B, S, C, 0.1, 300, counts)
-    try:
-        L.dafne_poly_nms_set_exact_only(1)
-        exact, st_exact = _select(B, S, C, 0.1, 300, counts)
-    finally:
-        L.dafne_poly_nms_set_exact_only(0)
+    exact, st_exact = _select(B, S, C, 0.1, 300, counts, flags=NMS_EXACT_ONLY)
     assert st_exact[:, :2].sum() == 0 and st_exact[:, 2:].sum() > st_fast[:, 2:].sum()
     assert st_fast[:, :2].sum() > 0
     for i, n in enumerate(counts):
@@ -422,7 +420,7 @@ def test_decision_fuzz_one_million_pairs(thr):
         nbytes = L.dafne_poly_nms_workspace_bytes(chunk, 2)
         ws = torch.empty(nbytes, dtype=torch.uint8, device=dev())
         _lib.check(L.dafne_poly_nms_batched_hip(_lib.ptr(d), None, chunk, 2, thr, 0, _lib.ptr(keep), _lib.ptr(nk), _lib.ptr(ws),
-                                                nbytes, _lib.current_stream()), "nms")
+                                                nbytes, 0, _lib.current_stream()), "nms")
         got = nk.cpu().numpy()
         bad = np.nonzero(got != want)[0]
         assert len(bad) == 0, (thr, c0, bad[:10], fam[bad[:10]], iou[bad[:10]])
@@ -459,13 +457,9 @@ def test_decision_fuzz_general_quads(thr):
         keep = torch.empty((n, 2), dtype=torch.int64, device=dev())
         nk = torch.zeros(n, dtype=torch.int32, device=dev())
         ws = torch.empty(nbytes, dtype=torch.uint8, device=dev())
-        L.dafne_poly_nms_set_exact_only(exact_only)
-        try:
-            _lib.check(L.dafne_poly_nms_batched_hip(_lib.ptr(d), None, n, 2, thr, 0, _lib.ptr(keep), _lib.ptr(nk), _lib.ptr(ws),
-                                                    nbytes, _lib.current_stream()), "nms")
-            got = nk.cpu().numpy()
-        finally:
-            L.dafne_poly_nms_set_exact_only(0)
+        _lib.check(L.dafne_poly_nms_batched_hip(_lib.ptr(d), None, n, 2, thr, 0, _lib.ptr(keep), _lib.ptr(nk), _lib.ptr(ws),
+                                                nbytes, NMS_EXACT_ONLY if exact_only else 0, _lib.current_stream()), "nms")
+        got = nk.cpu().numpy()
         bad = np.nonzero(got != want)[0]
         assert len(bad) == 0, (thr, exact_only, bad[:10], typ[bad[:10]], iou[bad[:10]])
         off = L.dafne_poly_nms_stats_offset(n, 2, 0)

@@ -45,13 +45,16 @@ def parse_args(argv=None):
     return ap.parse_args(argv)
 
 
-def synthetic_inputs(n, h, w, seed):
-    """Image i is a pure function of (seed, i): every rank can build exactly its own shard."""
+def synthetic_inputs(n, h, w, seed, lo=0, hi=None, pixels=True):
+    """Image i is a pure function of (seed, i): every rank builds exactly its own shard [lo, hi); pixels=False gives the
+    metadata only (rank 0 needs ids / file names of ALL images, not their pixels)."""
     out = []
-    for i in range(n):
-        g = torch.Generator().manual_seed(seed * 1000003 + i)
-        out.append({"image": torch.randint(0, 256, (3, h, w), generator=g, dtype=torch.uint8), "height": h, "width": w,
-                    "image_id": i, "file_name": "P%04d__1__0___%d.png" % (i // 4, 824 * (i % 4))})
+    for i in range(lo, n if hi is None else hi):
+        d = {"height": h, "width": w, "image_id": i, "file_name": "P%04d__1__0___%d.png" % (i // 4, 824 * (i % 4))}
+        if pixels:
+            g = torch.Generator().manual_seed(seed * 1000003 + i)
+            d["image"] = torch.randint(0, 256, (3, h, w), generator=g, dtype=torch.uint8)
+        out.append(d)
     return out
 
 
@@ -83,10 +86,16 @@ def run(args, rank=0, world=1, local_rank=0):
     w = args.width or cfg.INPUT.MIN_SIZE_TEST
     n = args.num_images
     lo, hi = shard_range(n, rank, world)
-    all_meta = synthetic_inputs(n, h, w, args.seed) if rank == 0 and world == 1 else None
-    mine = all_meta[lo:hi] if all_meta is not None else synthetic_inputs(n, h, w, args.seed)[lo:hi]
-    k_cap = max(cfg.MODEL.DAFNE.POST_NMS_TOPK_TEST, 1) + 256
+    mine = synthetic_inputs(n, h, w, args.seed, lo, hi)
+    k_cap = model.proposal_generator.dafne_outputs.packed_k_cap()      # the detector's own capacity rule
     tta = OneStageRCNNWithTTA(cfg, model) if args.tta else None
+    if cfg.ENGINE.WEIGHT_DTYPE == "fp8_e4m3" and model.fp8_act_scales() is None and cfg.ENGINE.FP8_ACT_CALIBRATION == "explicit":
+        # no scales came with the weights: calibrate on the first batch of every rank's shard; calibrate_fp8 MAX-reduces the
+        # amax values over the ranks (a collective), so all ranks serve the same quantised model at any world size.  A rank
+        # with an empty shard contributes the batch of image 0.
+        cal = mine[:args.batch] if mine else synthetic_inputs(n, h, w, args.seed, 0, min(1, n))
+        if cal:
+            model.calibrate_fp8(torch.stack([x["image"] for x in cal]).to(dev))
 
     def detect_batch(b0, b1):
         chunk = mine[b0 - lo:b1 - lo]
@@ -102,7 +111,7 @@ def run(args, rank=0, world=1, local_rank=0):
     if rank != 0:
         return None
     rows_all, counts_all = out
-    meta = all_meta if all_meta is not None else synthetic_inputs(n, h, w, args.seed)
+    meta = synthetic_inputs(n, h, w, args.seed, pixels=False)
     preds = to_predictions(rows_all, counts_all, image_ids=[m["image_id"] for m in meta])
     for p, m in zip(preds, meta):
         p.update(file_name=m["file_name"], height=m["height"], width=m["width"])
@@ -138,11 +147,10 @@ def _distributed_main(args):
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     torch.cuda.set_device(local_rank)
     dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
-    try:
-        return run(args, rank, world, local_rank)
-    finally:
-        dist.barrier()
-        dist.destroy_process_group()
+    out = run(args, rank, world, local_rank)        # an exception propagates: no barrier on the error path (it would hang
+    dist.barrier()                                  # the healthy ranks or mask the error); the launcher tears the job down
+    dist.destroy_process_group()
+    return out
 
 
 def main(argv=None):
