@@ -91,6 +91,9 @@ SIGNATURES = {
                                            ctypes.POINTER(c_float), ctypes.POINTER(c_float), c_int, c_int,
                                            c_void_p, c_void_p]),
     "dafne_conv3x3_c64_hip": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "dafne_bottleneck_body_scratch_bytes": (c_size_t, []),
+    "dafne_bottleneck_body_hip": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
+                                          c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "dafne_bottleneck_tail_head_hip": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
                                                c_void_p, c_void_p, c_void_p]),
     "dafne_bottleneck_tail_head_narrow_hip": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,

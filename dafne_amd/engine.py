@@ -187,6 +187,15 @@ def pack_b2b(w3, w1):
     return torch.stack([a1, a2], dim=1).contiguous().reshape(8, 8, 16, 64, 8)
 
 
+def pack_bneck(w2, w3, w1):
+    """Fragment-major weights of dafne_bottleneck_body_hip: the 3x3 conv2 ([256, 2304] bf16 in pack_conv's K order = 64-channel
+    slab, kh, kw, channel) as [8 waves][144 k16 steps][64 lanes][8] (rows wave*32 + (lane & 31), K columns 16*step +
+    8*(lane >> 5) .. +8), followed by pack_b2b(conv3, next conv1)."""
+    assert tuple(w2.shape) == (256, 2304) and w2.dtype == BF16
+    a0 = w2.reshape(8, 32, 144, 2, 8).permute(0, 2, 3, 1, 4)                # w, j, h, r, e
+    return torch.cat([a0.contiguous().reshape(-1), pack_b2b(w3, w1).reshape(-1)]).contiguous()
+
+
 def pack_b2b_narrow(w3, w1, wsc=None):
     """Fragment-major weights of dafne_bottleneck_tail_head_narrow_hip from the packed 1x1 weights of conv3 ([256, 64] bf16)
     and the next block's conv1 ([64, 256] bf16): bf16 [8 waves][4 steps][64 lanes][8] then [2 halves][16 steps][64 lanes][8];
@@ -393,6 +402,8 @@ class DensePlan:
         fuse_b2b = os.environ.get("DAFNE_FUSE_B2B", "1") != "0"
         fuse_narrow = fuse_b2b and os.environ.get("DAFNE_FUSE_B2B_NARROW", "1") != "0"
         fuse_mid = fuse_b2b and os.environ.get("DAFNE_FUSE_B2B_MID", "1") != "0"
+        fuse_bneck = fuse_b2b and os.environ.get("DAFNE_FUSE_BNECK", "1") != "0"
+        bneck_scratch = None
         for si, nb in enumerate(STAGE_BLOCKS[depth]):
             y1_next = None
             for b in range(nb):
@@ -411,6 +422,38 @@ class DensePlan:
                     y1, y1_next = y1_next, None                       # computed by the previous block's fused tail
                 else:
                     y1 = conv(p + "conv1", x, 1, stride, 0, F_RELU)       # STRIDE_IN_1X1
+                w2, b2 = P[p + "conv2"]
+                q8_2 = P.get(p + "conv2.fp8")
+                body_fused = (fuse_bneck and b + 1 < nb and tuple(w3.shape) == (1024, 256) and tuple(P[nxt][0].shape) == (256, 1024)
+                              and tuple(w2.shape) == (256, 2304) and y1.c == 256
+                              # an fp8 model's conv2 takes e4m3 activations on the fp8 MFMA kernel (its definition): not fused
+                              and not (q8_2 is not None and (calib is not None or (p + "conv2") in act_q8)))
+                if body_fused:
+                    # res4: conv2 (3x3) + conv3 + residual + ReLU + the next block's conv1 + ReLU in ONE kernel
+                    # (conv_bneck.hip): neither the 3x3's output nor conv3's is read back from HBM
+                    w1, b1 = P[nxt]
+                    key = p + "bneck"
+                    if key not in P:
+                        P[key] = pack_bneck(w2, w3, w1)
+                    if bneck_scratch is None:
+                        bneck_scratch = torch.empty(L.dafne_bottleneck_body_scratch_bytes(), dtype=torch.uint8, device=device)
+                    y3 = pool.get(n, y1.h, y1.w, 1024)
+                    y1_next = pool.get(n, y1.h, y1.w, 256)
+                    fl = 2 * n * y1.h * y1.w * (256 * 2304 + 256 * 1024 + 1024 * 256)
+                    nb_ = n * y1.h * y1.w * (256 + 1024 + 1024 + 256) * 2 + (256 * 2304 + 2 * 1024 * 256) * 2
+                    self.calls.append(FnCall(L.dafne_bottleneck_body_hip,
+                                             (_lib.ptr(y1.t), _lib.ptr(sc.t), _lib.ptr(P[key]), _lib.ptr(b2), _lib.ptr(b3), _lib.ptr(b1),
+                                              n, y1.h, y1.w, _lib.ptr(y3.t), _lib.ptr(y1_next.t), _lib.ptr(bneck_scratch),
+                                              bneck_scratch.numel()),
+                                             (y1, sc, P[key], b2, b3, b1, y3, y1_next, bneck_scratch), "conv_bneck", flops=fl, nbytes=nb_))
+                    self.flops += fl
+                    pool.put(y1)
+                    if b == 0 and sc is not None:
+                        pool.put(sc)
+                    if not any(x is f for k, f in feats.items() if k != "res2"):
+                        pool.put(x)
+                    x = y3
+                    continue
                 y2 = conv(p + "conv2", y1, 3, 1, 1, F_RELU)
                 pool.put(y1)
                 if proj_fused:

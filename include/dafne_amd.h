@@ -317,6 +317,22 @@ int dafne_bottleneck_tail_head_hip(const void* d_in, const void* d_res, const vo
                                    const float* d_bias1, int n_images, int H, int W, void* d_out, void* d_next,
                                    void* stream);
 /*
+ * The whole body of a res4 bottleneck + the head of the next in one kernel (same reference block; conv_bneck.hip):
+ *   T = relu(conv2(d_in) + bias2)  (3x3, 256 -> 256, pad 1; d_in = the block's conv1 output),
+ *   d_out = relu(conv3(T) + bias3 + d_res)  (1x1, 256 -> 1024),  d_next = relu(conv1'(d_out) + bias1)  (1x1, 1024 -> 256).
+ * T never reaches HBM.  Tensors as for dafne_bottleneck_tail_head_hip (bf16 NHWC, 1-pixel halo, interior written); any
+ * H, W (4 x 32 pixel tiles; rows of out-of-image tile pixels are written to d_scratch, which needs
+ * dafne_bottleneck_body_scratch_bytes() bytes and holds nothing afterwards).  d_wfrag: conv2 fragment-major, bf16
+ * [8 waves][144 k16 steps][64 lanes][8] (rows wave*32 + (lane & 31); K columns 16*step + 8*(lane >> 5) .. +8 of
+ * dafne_conv2d_nhwc_bf16_hip's packed weight: 64-channel slab, kh, kw, channel), followed by
+ * dafne_bottleneck_tail_head_hip's d_wfrag  (engine.pack_bneck).  Bit-identical to dafne_conv2d_nhwc_bf16_hip(conv2, RELU)
+ * followed by dafne_bottleneck_tail_head_hip.
+ */
+size_t dafne_bottleneck_body_scratch_bytes(void);
+int dafne_bottleneck_body_hip(const void* d_in, const void* d_res, const void* d_wfrag, const float* d_bias2,
+                              const float* d_bias3, const float* d_bias1, int n_images, int H, int W, void* d_out,
+                              void* d_next, void* d_scratch, size_t scratch_bytes, void* stream);
+/*
  * The same pair for the narrow stage res2 (same reference block):  d_out = relu(conv3(d_in) + bias3 + d_res)  (1x1,
  * 64 -> 256; d_res = the block's shortcut: the identity input or the projection's output) and
  * d_next = relu(conv1'(d_out) + bias1)  (1x1, 256 -> 64).  d_in / d_next [N,H+2,W+2,64], d_res / d_out [N,H+2,W+2,256],

@@ -627,3 +627,63 @@ def test_bottleneck_tail_head_fused_equals_two_convs(N, H, W):
     z_ref = bfr(F.relu(F.conv2d(y_ref, w1, b1)))
     got = z_f.nchw_float().cpu()
     assert float((got - z_ref).abs().max()) < 0.02 * float(z_ref.abs().max())
+
+
+@pytest.mark.parametrize("N,H,W", [(1, 8, 32), (8, 64, 64), (3, 13, 21), (2, 30, 44), (1, 1, 1), (1, 5, 70)])
+def test_bottleneck_body_fused_equals_three_convs(N, H, W):
+    """dafne_bottleneck_body_hip (conv2 3x3 + ReLU, conv3 + residual + ReLU, the next block's conv1 + ReLU in one kernel;
+    the 3x3's output never reaches HBM) against the three launches of the generic path: bit for bit on both outputs --
+    the headline shape (8 x 64 x 64, 256 exact tiles) and ragged sizes (partial 4 x 32 tiles in both directions, more
+    than one tile column, a single pixel) --, the zero halo untouched, nothing written outside the two outputs; and
+    against torch within bf16 rounding."""
+    from dafne_amd import engine, _lib
+    L = _lib.load()
+    d = dev()
+    g = torch.Generator().manual_seed(2000 + H * W)
+    u = bfr(torch.randn(N, 256, H, W, generator=g))
+    x = bfr(torch.randn(N, 1024, H, W, generator=g))
+    w2 = bfr(torch.randn(256, 256, 3, 3, generator=g) / 48.0)
+    b2 = torch.randn(256, generator=g) * 0.2
+    w3 = bfr(torch.randn(1024, 256, 1, 1, generator=g) / 16.0)
+    b3 = torch.randn(1024, generator=g) * 0.2
+    w1 = bfr(torch.randn(256, 1024, 1, 1, generator=g) / 32.0)
+    b1 = torch.randn(256, generator=g) * 0.2
+    st = _lib.current_stream()
+    ua, xa = engine.Act.from_nchw(u.to(d)), engine.Act.from_nchw(x.to(d))
+    w2p, b2p = engine.pack_conv(w2, b2, d)
+    w3p, b3p = engine.pack_conv(w3, b3, d)
+    w1p, b1p = engine.pack_conv(w1, b1, d)
+    # separate launches
+    t_u, y_u, z_u = engine.Act(N, H, W, 256, d), engine.Act(N, H, W, 1024, d), engine.Act(N, H, W, 256, d)
+    engine.ConvCall(w2p, b2p, 256, 256, 3, 1, 1, engine.F_RELU, [(ua.t, t_u.t, None, H, W, H, W)], N)(st)
+    engine.ConvCall(w3p, b3p, 256, 1024, 1, 1, 0, engine.F_RELU | engine.F_RES, [(t_u.t, y_u.t, xa.t, H, W, H, W)], N)(st)
+    engine.ConvCall(w1p, b1p, 1024, 256, 1, 1, 0, engine.F_RELU, [(y_u.t, z_u.t, None, H, W, H, W)], N)(st)
+    # fused: outputs are the interiors of two views inside ONE guarded allocation (a stray row would land in the guards)
+    wf = engine.pack_bneck(w2p, w3p, w1p)
+    ny, nz = y_u.t.numel(), z_u.t.numel()
+    guard = 4096
+    slab = torch.full((guard + ny + guard + nz + guard,), 7.0, dtype=torch.bfloat16, device=d)
+    y_t = slab[guard:guard + ny].view_as(y_u.t)
+    z_t = slab[2 * guard + ny:2 * guard + ny + nz].view_as(z_u.t)
+    y_t.zero_()
+    z_t.zero_()
+    nscr = L.dafne_bottleneck_body_scratch_bytes()
+    scr = torch.empty(nscr, dtype=torch.uint8, device=d)
+    for _ in range(2):        # twice: the second launch finds the patch region of LDS / the dump area dirty
+        _lib.check(L.dafne_bottleneck_body_hip(_lib.ptr(ua.t), _lib.ptr(xa.t), _lib.ptr(wf), _lib.ptr(b2p), _lib.ptr(b3p),
+                                               _lib.ptr(b1p), N, H, W, _lib.ptr(y_t), _lib.ptr(z_t), _lib.ptr(scr), nscr, st), "bneck")
+    torch.cuda.synchronize()
+    assert torch.equal(y_t, y_u.t)
+    assert torch.equal(z_t, z_u.t)
+    assert float(z_t[:, 0].abs().max()) == 0 and float(y_t[:, :, -1].abs().max()) == 0
+    for lo, hi in ((0, guard), (guard + ny, 2 * guard + ny), (2 * guard + ny + nz, 3 * guard + ny + nz)):
+        assert bool((slab[lo:hi] == 7.0).all())
+    t_ref = bfr(F.relu(F.conv2d(u, w2, b2, padding=1)))
+    close_bf16(t_u.nchw_float().cpu(), t_ref)
+    y_ref = bfr(F.relu(F.conv2d(t_u.nchw_float().cpu(), w3, b3) + x))
+    y_got = engine.Act(N, H, W, 1024, d)
+    y_got.t.copy_(y_t)
+    close_bf16(y_got.nchw_float().cpu(), y_ref)
+    with pytest.raises(_lib.DafneHipError):
+        _lib.check(L.dafne_bottleneck_body_hip(_lib.ptr(ua.t), _lib.ptr(xa.t), _lib.ptr(wf), _lib.ptr(b2p), _lib.ptr(b3p),
+                                               _lib.ptr(b1p), N, H, W, _lib.ptr(y_t), _lib.ptr(z_t), _lib.ptr(scr), 1024, st), "bneck")
