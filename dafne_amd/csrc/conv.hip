@@ -63,6 +63,7 @@ struct ConvDev {
     int stem;          // 7x7 s2 stem on the 4-channel padded image
     int patch;         // 3x3 patch kernel (2-D tiles)
     int slab;          // 3x3 narrow-Cout fp32 kernel (2-D tiles, whole-slab operands)
+    int rp;            // 3x3 resident-patch kernel (4 x 32 tiles, Cin = 256, fragment-major weights)
     const float* in_stats;   // GN_INPUT: [n_segs][N][Cin/8][2] mean, rstd of the input
     const float* in_gamma;   //           [Cin]
     const float* in_beta;    //           [Cin]
@@ -1811,6 +1812,331 @@ __global__ void __launch_bounds__(512) conv3x3_patch_kernel(ConvDev P) {
 }
 
 // ---------------------------------------------------------------------------------------
+// 3x3 stride-1 convolution, 256 input channels, with the WHOLE input patch resident in LDS and the weights streamed
+// L2 -> registers (round 3; the structure of conv_bneck.hip's phase A as a stand-alone layer): head towers, FPN outputs.
+//
+// conv3x3_patch_kernel above stages weights AND pixels through LDS in half-K pieces: 36 K steps x 4 phases, a barrier
+// per phase, two wave groups that must stay exactly one phase apart -- measured 935-1000 TFLOP/s, the matrix pipe busy
+// ~50 % of the cycles the chip runs.  Here a workgroup (8 waves, one per CU) owns a 4 x 32 pixel tile and 256 output
+// channels; the (4+2) x (32+2) x 256-channel patch (four 26-KB slabs, [pixel][128 B], chunk XOR (pixel >> 1) & 7) is
+// DMA'd once and stays; a wave owns 32 output channels and all 128 pixels, its weight fragments (fragment-major packing,
+// one coalesced 1-KiB load per k16 step, ring of 8) go straight to registers: every fragment feeds 4 MFMAs and is fetched
+// by exactly one wave, and the 144 k16 steps run with ONE barrier (after slab 0 has landed; slabs 1..3 trickle in behind
+// the weight loads, one piece per wave and step, and are guarded by a second barrier at step 36).  conv_bneck's stamps:
+// 305 cycles per step against 256 of pure MFMA issue.
+//   * K order = (64-channel slab, kh, kw, k16 step) = conv_igemm_kernel's;
+//   * GN_INPUT: every wave normalises the pieces IT loaded (GroupNorm + ReLU in place, out-of-image pixels stay zero),
+//     slab 0 before the first barrier, slabs 1..3 one piece per step in steps 13..24, i.e. under the other waves' MFMAs;
+//   * epilogue: bias / ReLU / GroupNorm sums in the accumulator layout (a wave holds all 128 pixels of its 32 channels:
+//     no cross-wave reduction), bf16 tile staged once through LDS, 16-byte row stores; GN_FINALIZE as in the patch kernel.
+constexpr int kRH = 4, kRW = 32, kRPx = kRH * kRW;
+constexpr int kRCols = kRW + 2, kRRows = kRH + 2;
+constexpr int kRPieces = (kRRows * kRCols + 7) / 8;     // 26 pieces of 8 px x 128 B per slab
+constexpr int kRSlab = kRPieces * 1024;                 // 26 624 B
+constexpr int kRCin = 256, kRSteps = 9 * kRCin / 16;    // 144 k16 steps
+constexpr int kRRing = 8;
+constexpr int kROffTab = 4 * kRSlab;                    // GN table: stats [32][2] + gamma [256] + beta [256] fp32
+constexpr int kROffRed = kROffTab + 9 * kRCin;          // [32 groups][2] fp32 + finalize flag
+constexpr int kRSmem = kROffRed + 512;
+constexpr int kRRowB = 256 * 2 + 16;                    // epilogue staging row: 256 channels bf16 + 16 B pad
+static_assert(kRPx * kRRowB <= 4 * kRSlab && kRSmem <= 160 * 1024 && 32 * 32 * 2 * 4 + 4 <= 4 * kRSlab, "LDS budget");
+constexpr int kRTrickle = 12;                           // slabs 1..3: 12 pieces per wave, one per step 0..11
+
+// vector-memory program order of a wave: [patch slab 0: 4 DMA] A(0)..A(7) | step s: [wait A(s)] MFMAs | A(s+8) | one patch
+// piece of slabs 1..3 (s < 12).  rp_wait(j) = instructions issued after A(j) before its wait (vmcnt retires in order).
+constexpr int rp_wait(int j) {
+    int n = 0;
+    if (j < kRRing) {
+        n += kRRing - 1 - j;
+        for (int s = 0; s < j; s++) n += 1 + (s < kRTrickle ? 1 : 0);
+    } else {
+        n += (j - kRRing < kRTrickle ? 1 : 0);
+        for (int s = j - kRRing + 1; s < j; s++) n += (s + kRRing < kRSteps ? 1 : 0) + (s < kRTrickle ? 1 : 0);
+    }
+    return n;
+}
+static_assert(rp_wait(0) == 7 && rp_wait(8) == 15 && rp_wait(12) == 15 && rp_wait(20) == 7 && rp_wait(143) == 0 && rp_wait(137) == 6, "vmcnt bookkeeping");
+
+template <int J>
+__device__ __forceinline__ void rp_load(bf16x8 (&ar)[kRRing], const char* wf, unsigned voff) {
+    if constexpr (J < kRSteps) {
+        const char* sb = wf + (size_t)J * 1024;
+        asm volatile("global_load_dwordx4 %0, %1, %2" : "=&v"(ar[J % kRRing]) : "v"(voff), "s"(sb) : "memory");
+    }
+}
+template <int J>
+__device__ __forceinline__ void rp_wait_for(bf16x8 (&ar)[kRRing]) {
+    constexpr int kWaitN = rp_wait(J);
+    asm volatile("s_waitcnt vmcnt(%1)" : "+v"(ar[J % kRRing]) : "n"(kWaitN) : "memory");
+}
+template <int I, int N, class F>
+__device__ __forceinline__ void rp_static_for(F&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        rp_static_for<I + 1, N>(f);
+    }
+}
+
+template <bool GNIN>
+__global__ void __launch_bounds__(512, 2) conv3x3_rp_kernel(ConvDev P) {
+    constexpr int NT = 512, NW = 8;
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int frow = lane & 31, half = lane >> 5;
+    const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) char*)lds;
+
+    const int T = P.mtiles * P.ntiles;
+    const int bid = xcd_remap(blockIdx.x, T);
+    const int nt = bid % P.ntiles;
+    const int mt = bid / P.ntiles;
+    int si = 0;
+#pragma unroll
+    for (int k = 1; k < kMaxSegs; k++)
+        if (k < P.n_segs && mt >= P.seg[k].tile0) si = k;
+    const SegDev& S = P.seg[si];
+    const int tloc = mt - S.tile0;
+    const int img = tloc / S.tiles_per_img;
+    const int tt = tloc - img * S.tiles_per_img;
+    const int ty = tt / S.tiles_x, tx = tt - ty * S.tiles_x;
+    const int Y0 = ty * kRH, X0 = tx * kRW;
+    const int H = S.Hout, W = S.Wout, Hp = H + 2, Wp = W + 2;
+
+#ifdef DAFNE_RP_TIMING
+    unsigned long long rp_ts[6];
+    rp_ts[0] = __builtin_amdgcn_s_memtime();
+#define RP_STAMP(i) rp_ts[i] = __builtin_amdgcn_s_memtime()
+#else
+#define RP_STAMP(i)
+#endif
+    // ---- GroupNorm table of this image (input side) -> LDS, before any DMA is in flight
+    if (GNIN) {
+        float* tab_stats = (float*)(lds + kROffTab);
+        float* tab_gamma = tab_stats + kRCin / 4;
+        float* tab_beta = tab_gamma + kRCin;
+        const float* st = P.in_stats + ((size_t)si * P.N + img) * (kRCin / 8) * 2;
+        if (tid < kRCin / 4) tab_stats[tid] = st[tid];
+        if (tid < kRCin) {
+            tab_gamma[tid] = P.in_gamma[tid];
+            tab_beta[tid] = P.in_beta[tid];
+        }
+        __syncthreads();
+    }
+
+    // ---- patch DMA map: piece pc = 8 consecutive patch pixels (patch pixel pp = p * 34 + q <-> haloed input pixel
+    // (Y0 + p, X0 + q)); wave w moves pieces w, w + 8, w + 16 and w + 24 of every slab -- the six waves without a fourth
+    // piece re-load THEIR OWN third piece (same wave, in order: it lands before the wave touches the piece)
+    unsigned pofs[4];
+    int ppc[4];
+    const unsigned max_pix = (unsigned)(P.N * Hp * Wp - 1);
+#pragma unroll
+    for (int ii = 0; ii < 4; ii++) {
+        int pc = wave + NW * ii;
+        if (pc >= kRPieces) pc -= NW;
+        ppc[ii] = pc;
+        const int pp = pc * 8 + (lane >> 3);
+        const int p = pp / kRCols, q = pp - p * kRCols;
+        unsigned g = (unsigned)((img * Hp + Y0 + p) * Wp + X0 + q);
+        g = g < max_pix ? g : max_pix;                       // ragged tiles reach past the image (and the buffer)
+        pofs[ii] = g * (unsigned)(kRCin * 2) + (unsigned)(((lane & 7) ^ ((pp >> 1) & 7)) * 16);
+    }
+    auto patch_piece = [&](int sl, int ii) {
+        __builtin_amdgcn_global_load_lds((gvoid*)(S.in + pofs[ii] + sl * 128), (lvoid*)(lds + sl * kRSlab + ppc[ii] * 1024), 16, 0, 0);
+    };
+    // GroupNorm + ReLU of one landed patch piece, in place (inline-asm LDS ops: a plain LDS access would make the
+    // compiler drain vmcnt).  A lane handles LOGICAL chunk lane&7 (8 channels = one group) of pixel lane>>3 of the piece.
+    auto gn_piece = [&](int sl, int ii) {
+        if (ii == 3 && wave + 3 * NW >= kRPieces) return;                 // duplicate of this wave's piece ii = 2
+        const int pc = ppc[ii];
+        const int pp = pc * 8 + (lane >> 3);
+        const int p = pp / kRCols, q = pp - p * kRCols;
+        const int gy = Y0 + p, gx = X0 + q;                               // haloed coordinates
+        const bool inside = gy >= 1 && gy <= H && gx >= 1 && gx <= W && pp < kRRows * kRCols;
+        const int phys = (lane & 7) ^ ((pp >> 1) & 7);
+        const unsigned ad = lds_base + (unsigned)(sl * kRSlab + pc * 1024 + (lane >> 3) * 128 + phys * 16);
+        const int ch = sl * kBK + (lane & 7) * 8;
+        const unsigned ts = lds_base + (unsigned)(kROffTab + (ch >> 3) * 8);
+        const unsigned tg = lds_base + (unsigned)(kROffTab + kRCin + ch * 4);
+        const unsigned tb = tg + (unsigned)kRCin * 4u;
+        u32x4 v;
+        u32x2 ms;
+        f32x4 g0, g1, b0, b1;
+        asm volatile("ds_read_b128 %0, %6\n\tds_read_b64 %1, %7\n\tds_read_b128 %2, %8\n\tds_read_b128 %3, %8 offset:16\n\t"
+                     "ds_read_b128 %4, %9\n\tds_read_b128 %5, %9 offset:16\n\ts_waitcnt lgkmcnt(0)"
+                     : "=&v"(v), "=&v"(ms), "=&v"(g0), "=&v"(g1), "=&v"(b0), "=&v"(b1)
+                     : "v"(ad), "v"(ts), "v"(tg), "v"(tb)
+                     : "memory");
+        const float gmean = __uint_as_float(ms.x), grstd = __uint_as_float(ms.y);
+        const float gam[8] = {g0[0], g0[1], g0[2], g0[3], g1[0], g1[1], g1[2], g1[3]};
+        const float bet[8] = {b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]};
+        const unsigned u[4] = {v.x, v.y, v.z, v.w};
+        float y[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const float x = bf2f((unsigned short)(k & 1 ? u[k >> 1] >> 16 : u[k >> 1] & 0xffff));
+            y[k] = fmaxf((x - gmean) * grstd * gam[k] + bet[k], 0.f);      // expression of gn_apply_kernel
+        }
+        u32x4 o;
+        o.x = inside ? pack_bf16(y[0], y[1]) : 0u;
+        o.y = inside ? pack_bf16(y[2], y[3]) : 0u;
+        o.z = inside ? pack_bf16(y[4], y[5]) : 0u;
+        o.w = inside ? pack_bf16(y[6], y[7]) : 0u;
+        asm volatile("ds_write_b128 %0, %1" ::"v"(ad), "v"(o) : "memory");
+    };
+
+    // ---- B fragment offsets: patch row p (0..5) at tap column kw (0..2): pixel pp = p * 34 + kw + frow; k16 step kc reads
+    // the 16-byte chunk (2 kc + half) ^ sw, sw = (pp >> 1) & 7, i.e. pb ^ (kc << 5) with
+    // pb = pp * 128 | ((half ^ (sw & 1)) << 4) | ((sw >> 1) << 5)
+    unsigned pb[kRRows * 3];
+#pragma unroll
+    for (int p = 0; p < kRRows; p++)
+#pragma unroll
+        for (int kw = 0; kw < 3; kw++) {
+            const int pp = p * kRCols + kw + frow;
+            const int sw = (pp >> 1) & 7;
+            pb[p * 3 + kw] = (unsigned)(pp * 128 + ((half ^ (sw & 1)) << 4) + ((sw >> 1) << 5));
+        }
+
+    const char* wf = P.w + (size_t)nt * (NW * kRSteps * 1024);
+    const unsigned voff = (unsigned)(wave * kRSteps * 1024 + lane * 16);
+    bf16x8 ar[kRRing];
+    auto load_step = [&](auto J) { rp_load<decltype(J)::value>(ar, wf, voff); };
+    auto barrier = [&]() {
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+    };
+
+    // ---- prologue
+#pragma unroll
+    for (int ii = 0; ii < 4; ii++) patch_piece(0, ii);
+    rp_static_for<0, kRRing>(load_step);
+    if (GNIN) {
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");      // this wave's slab-0 pieces have landed (the 8 A loads are younger)
+#pragma unroll
+        for (int ii = 0; ii < 4; ii++) gn_piece(0, ii);
+    }
+    f32x16 acc[4];
+#pragma unroll
+    for (int b = 0; b < 4; b++)
+#pragma unroll
+        for (int k = 0; k < 16; k++) acc[b][k] = 0.f;
+
+    rp_static_for<0, kRSteps>([&](auto J) {
+        constexpr int j = decltype(J)::value;
+        constexpr int sl = j / 36, t = j % 36, kh = t / 12, kw = (t >> 2) % 3, kc = t & 3;
+        rp_wait_for<j>(ar);
+        if constexpr (j == 0) { barrier(); RP_STAMP(1); }   // slab 0 of every wave has landed (and is normalised)
+        if constexpr (j == 36) barrier();            // slabs 1..3: landed by each wave's wait at step 20, normalised by step 24
+        // GN_INPUT: the pieces issued at steps 4(sl-1) .. 4(sl-1)+3 are covered by the wait of step 12 + 4(sl-1)
+        if constexpr (GNIN && j >= 13 && j < 25) gn_piece(1 + (j - 13) / 4, (j - 13) & 3);
+        bf16x8 bfr[4];
+#pragma unroll
+        for (int r = 0; r < 4; r++)
+            bfr[r] = *(const bf16x8*)(lds + ((pb[(r + kh) * 3 + kw] ^ (unsigned)(kc << 5)) + (unsigned)(sl * kRSlab)));
+#pragma unroll
+        for (int r = 0; r < 4; r++) acc[r] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ar[j % kRRing], bfr[r], acc[r], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        load_step(std::integral_constant<int, j + kRRing>{});
+        if constexpr (j < kRTrickle) patch_piece(1 + j / 4, j & 3);
+    });
+
+    // ------------------------------------------------------------ epilogue (bias, ReLU, GN sums, bf16)
+    const bool relu = P.flags & DAFNE_CONV_RELU;
+    const bool gn = P.flags & DAFNE_CONV_GN_STATS;
+    const bool fin = gn && (P.flags & DAFNE_CONV_GN_FINALIZE);     // wave-uniform
+    float fin_sq[2] = {0.f, 0.f};
+    bool fin_writer = false;
+    char* stg = lds;
+    float* redb = (float*)(lds + kROffRed);   // [32 groups][2]
+    float4 bia4[4];
+#pragma unroll
+    for (int g = 0; g < 4; g++) bia4[g] = *(const float4*)(P.bias + nt * 256 + wave * 32 + 8 * g + 4 * half);
+    float gsum[4], gsq[4];
+#pragma unroll
+    for (int g = 0; g < 4; g++) gsum[g] = gsq[g] = 0.f;
+    RP_STAMP(2);
+    __syncthreads();   // every wave is done with the patch
+    RP_STAMP(3);
+#pragma unroll
+    for (int b = 0; b < 4; b++) {
+        const int px = b * 32 + frow;
+        const bool valid = (Y0 + b) < H && (X0 + frow) < W;
+#pragma unroll
+        for (int g = 0; g < 4; g++) {
+            float v0 = acc[b][4 * g] + bia4[g].x, v1 = acc[b][4 * g + 1] + bia4[g].y;
+            float v2 = acc[b][4 * g + 2] + bia4[g].z, v3 = acc[b][4 * g + 3] + bia4[g].w;
+            if (relu) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f); }
+            if (gn && valid) {
+                gsum[g] += (v0 + v1) + (v2 + v3);
+                gsq[g] += (v0 * v0 + v1 * v1) + (v2 * v2 + v3 * v3);
+            }
+            uint2 pk;
+            pk.x = pack_bf16(v0, v1);
+            pk.y = pack_bf16(v2, v3);
+            *(uint2*)(stg + px * kRRowB + (wave * 32 + 8 * g + 4 * half) * 2) = pk;
+        }
+    }
+    if (gn) {
+        // deterministic: butterfly over the wave (32 pixel columns x 2 channel halves); the wave holds all 128 pixels
+#pragma unroll
+        for (int g = 0; g < 4; g++) {
+            float sv = gsum[g], qv = gsq[g];
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                sv += __shfl_xor(sv, o, 64);
+                qv += __shfl_xor(qv, o, 64);
+            }
+            if (lane == 0) {
+                redb[(wave * 4 + g) * 2 + 0] = sv;
+                redb[(wave * 4 + g) * 2 + 1] = qv;
+            }
+        }
+    }
+    __syncthreads();
+    if (gn && tid < 32) {
+        const float sv = redb[tid * 2 + 0], qv = redb[tid * 2 + 1];
+        const int group = (nt * 256) / 8 + tid;
+        if (fin) {
+            fin_sq[0] = sv;
+            fin_sq[1] = qv;
+            fin_writer = true;
+        } else {
+            float* o = P.gn_partial + ((size_t)mt * (P.Cout / 8) + group) * 2;
+            o[0] = sv;
+            o[1] = qv;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < kRPx * 32 / NT; i++) {       // 16-byte chunks: 128 px x 32 per thread block pass
+        const int idx = tid + i * NT;
+        const int p = idx >> 5, cc = idx & 31;
+        const int gy = Y0 + (p >> 5), gx = X0 + (p & 31);
+        if (gy < H && gx < W) {
+            const size_t opix = (size_t)(img * Hp + gy + 1) * Wp + gx + 1;
+            const uint4 v = *(const uint4*)(stg + p * kRRowB + cc * 16);
+            *(uint4*)(S.out + (opix * P.Cout + nt * 256 + cc * 8) * 2) = v;
+        }
+    }
+    if (fin) {
+        __syncthreads();                     // the staging tile has been read: its LDS is free for the reduction
+        gn_fused_finalize(P, S, si, img, mt, fin_sq, fin_writer, tid, (float*)lds, (int*)(lds + 32 * 32 * 2 * 4));
+    }
+#ifdef DAFNE_RP_TIMING
+    RP_STAMP(4);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    RP_STAMP(5);
+    if (tid == 0 && blockIdx.x < 2048) {      // rows 4096.. of the partial buffer (scratch/rp_micro.py allocates 8192)
+        unsigned long long* o = (unsigned long long*)(P.gn_partial + (size_t)4096 * 64) + blockIdx.x * 8;
+        for (int k = 0; k < 6; k++) o[k] = rp_ts[k];
+        o[6] = __builtin_amdgcn_s_memrealtime();
+    }
+#endif
+}
+
+// ---------------------------------------------------------------------------------------
 // fp8 (OCP e4m3) twin of conv3x3_patch_kernel: BASELINE config 5 (fp8 weights, CDNA4 fp8 MFMA conv path).
 //
 // Weights are e4m3 bytes in the same [Cout][Cin/64][KH][KW][64] order (64 B per tap row) with one fp32
@@ -2508,7 +2834,15 @@ bool slab_eligible(const dafne_conv_params* p, const dafne_conv_seg* segs) {
     return true;
 }
 
-int build(ConvDev& D, const dafne_conv_params* p, const dafne_conv_seg* segs, bool fp8 = false) {
+// shape conditions of the resident-patch kernel (conv3x3_rp_kernel)
+bool rp_shape_ok(const dafne_conv_params* p, const dafne_conv_seg* segs) {
+    if (!patch_shape_ok(p, segs) || p->Cin != kRCin) return false;
+    for (int s = 0; s < p->n_segs; s++)
+        if ((long long)p->n_images * (segs[s].Hout + 2) * (segs[s].Wout + 2) * (kRCin * 2) > 0xffffffffll) return false;
+    return true;
+}
+
+int build(ConvDev& D, const dafne_conv_params* p, const dafne_conv_seg* segs, bool fp8 = false, bool rp = false) {
     if (!p || !segs) return dafne::fail(DAFNE_E_INVALID, "conv: null params");
     D.oscale = nullptr;
     D.in_qscale = 1.f;
@@ -2550,15 +2884,23 @@ int build(ConvDev& D, const dafne_conv_params* p, const dafne_conv_seg* segs, bo
         D.patch = 1;
         D.kbytes = D.ksteps * kBK;
     }
-    D.slab = !D.patch && slab_eligible(p, segs) ? 1 : 0;
-    if ((p->flags & DAFNE_CONV_GN_INPUT) && !D.patch && !D.slab)
+    D.rp = 0;
+    if (rp) {
+        if (stem || !rp_shape_ok(p, segs))
+            return dafne::fail(DAFNE_E_UNSUPPORTED, "conv3x3_c256: needs 3x3 s1 p1, Cin == 256, Cout %% 256 == 0, bias, bf16 output, "
+                                                    "no residual / top-down add");
+        D.patch = 0;
+        D.rp = 1;
+    }
+    D.slab = !D.patch && !D.rp && slab_eligible(p, segs) ? 1 : 0;
+    if ((p->flags & DAFNE_CONV_GN_INPUT) && !D.patch && !D.slab && !D.rp)
         return dafne::fail(DAFNE_E_UNSUPPORTED, "conv: GN_INPUT needs the 3x3 patch kernel (3x3 s1 p1, Cout %% 256 == 0, Cin <= 512, bias, "
                                                 "no residual / fp32 output) or the slab kernel (3x3 s1 p1, Cout <= 32, fp32 output, Cin <= 256)");
     if ((p->flags & DAFNE_CONV_GN_INPUT) && (!p->d_in_gn_stats || !p->d_in_gn_gamma || !p->d_in_gn_beta))
         return dafne::fail(DAFNE_E_INVALID, "conv: GN_INPUT without statistics / affine pointers");
     D.gn_stats_out = nullptr; D.gn_counters = nullptr; D.gn_eps = 0.f;
     if (p->flags & DAFNE_CONV_GN_FINALIZE) {
-        if (!(p->flags & DAFNE_CONV_GN_STATS) || !D.patch || p->Cout != 256)
+        if (!(p->flags & DAFNE_CONV_GN_STATS) || !(D.patch || D.rp) || p->Cout != 256)
             return dafne::fail(DAFNE_E_UNSUPPORTED, "conv: GN_FINALIZE needs GN_STATS on a 3x3 patch-kernel layer with Cout == 256");
         if (!p->d_gn_stats_out || !p->d_gn_counters || !(p->gn_eps > 0.f))
             return dafne::fail(DAFNE_E_INVALID, "conv: GN_FINALIZE without statistics / counter buffers or eps");
@@ -2573,6 +2915,11 @@ int build(ConvDev& D, const dafne_conv_params* p, const dafne_conv_seg* segs, bo
         D.bn = 32; D.bm = 256;
         D.Cout_pad = 32;
         c.bn = 32; c.bm = 256;
+    }
+    if (D.rp) {
+        D.bn = 256; D.bm = kRPx;
+        D.Cout_pad = p->Cout;
+        c.bn = 256; c.bm = kRPx;
     }
     int t = 0;
     for (int s = 0; s < p->n_segs; s++) {
@@ -2593,7 +2940,8 @@ int build(ConvDev& D, const dafne_conv_params* p, const dafne_conv_seg* segs, bo
         o.in = (const char*)g.d_in; o.out = (char*)g.d_out; o.res = (const char*)g.d_res;
         o.Hin = g.Hin; o.Win = g.Win; o.Hout = g.Hout; o.Wout = g.Wout;
         o.tiles_x = (g.Wout + kPW - 1) / kPW;
-        o.tiles_per_img = (D.patch || D.slab) ? o.tiles_x * ((g.Hout + kPH - 1) / kPH) : (g.Hout * g.Wout + c.bm - 1) / c.bm;
+        o.tiles_per_img = (D.patch || D.slab) ? o.tiles_x * ((g.Hout + kPH - 1) / kPH)
+                          : D.rp ? o.tiles_x * ((g.Hout + kRH - 1) / kRH) : (g.Hout * g.Wout + c.bm - 1) / c.bm;
         o.tile0 = t;
         t += o.tiles_per_img * p->n_images;
     }
@@ -2646,6 +2994,14 @@ int launch_patch_fp8(const ConvDev& D, hipStream_t st) {
     if (D.flags & DAFNE_CONV_GN_INPUT) hipLaunchKernelGGL(conv3x3_patch_fp8_kernel<true>, grid, block, kQSmem, st, D);
     else hipLaunchKernelGGL(conv3x3_patch_fp8_kernel<false>, grid, block, kQSmem, st, D);
     return dafne::check_launch("conv3x3_patch_fp8");
+}
+
+int launch_rp(const ConvDev& D, hipStream_t st) {
+    DAFNE_MAX_LDS_ONCE(kRSmem, (const void*)conv3x3_rp_kernel<false>, (const void*)conv3x3_rp_kernel<true>);
+    const dim3 grid(D.mtiles * D.ntiles), block(512);
+    if (D.flags & DAFNE_CONV_GN_INPUT) hipLaunchKernelGGL(conv3x3_rp_kernel<true>, grid, block, kRSmem, st, D);
+    else hipLaunchKernelGGL(conv3x3_rp_kernel<false>, grid, block, kRSmem, st, D);
+    return dafne::check_launch("conv3x3_rp");
 }
 
 int launch_slab(const ConvDev& D, hipStream_t st) {
@@ -2751,6 +3107,36 @@ int dafne_conv2d_fp8w_tiles_per_image(const dafne_conv_params* prm, const dafne_
     if (!out) return dafne::fail(DAFNE_E_INVALID, "conv fp8w: null output");
     for (int s = 0; s < D.n_segs; s++) out[s] = D.seg[s].tiles_per_img;
     return DAFNE_OK;
+}
+
+/* conv3x3_rp_kernel: tile geometry, eligibility, launch */
+int dafne_conv3x3_c256_ok(const dafne_conv_params* prm, const dafne_conv_seg* segs) {
+    ConvDev D;
+    return build(D, prm, segs, false, true) == DAFNE_OK ? 1 : 0;
+}
+
+int dafne_conv3x3_c256_num_tiles(const dafne_conv_params* prm, const dafne_conv_seg* segs) {
+    ConvDev D;
+    if (build(D, prm, segs, false, true)) return -1;
+    return D.mtiles;
+}
+
+int dafne_conv3x3_c256_tiles_per_image(const dafne_conv_params* prm, const dafne_conv_seg* segs, int32_t* out) {
+    ConvDev D;
+    int rc = build(D, prm, segs, false, true);
+    if (rc) return rc;
+    if (!out) return dafne::fail(DAFNE_E_INVALID, "conv3x3_c256: null output");
+    for (int s = 0; s < D.n_segs; s++) out[s] = D.seg[s].tiles_per_img;
+    return DAFNE_OK;
+}
+
+int dafne_conv3x3_c256_hip(const dafne_conv_params* prm, const dafne_conv_seg* segs, const void* d_wfrag, void* stream) {
+    ConvDev D;
+    int rc = build(D, prm, segs, false, true);
+    if (rc) return rc;
+    if (!d_wfrag) return dafne::fail(DAFNE_E_INVALID, "conv3x3_c256: null fragment-major weights");
+    D.w = (const char*)d_wfrag;
+    return launch_rp(D, (hipStream_t)stream);
 }
 
 int dafne_conv2d_kernel_id(const dafne_conv_params* prm, const dafne_conv_seg* segs) {

@@ -196,6 +196,21 @@ def pack_bneck(w2, w3, w1):
     return torch.cat([a0.contiguous().reshape(-1), pack_b2b(w3, w1).reshape(-1)]).contiguous()
 
 
+def pack_conv3x3_frag(w):
+    """Fragment-major weights of dafne_conv3x3_c256_hip from a packed 3x3 weight ([Cout, 2304] bf16, pack_conv's K order):
+    bf16 [Cout/256][8 waves][144 k16 steps][64 lanes][8]: rows nt*256 + wave*32 + (lane & 31), K columns 16*step +
+    8*(lane >> 5) .. +8."""
+    cout = w.shape[0]
+    assert w.dim() == 2 and w.shape[1] == 2304 and cout % 256 == 0 and w.dtype == BF16
+    return w.reshape(cout // 256, 8, 32, 144, 2, 8).permute(0, 1, 3, 4, 2, 5).contiguous().reshape(-1)   # nt, w, j, h, r, e
+
+
+def use_rp_kernel():
+    """conv3x3_rp_kernel (resident patch, weights streamed to registers) for the 256-channel 3x3 layers; DAFNE_CONV_RP=0
+    keeps them on conv3x3_patch_kernel (A/B runs)."""
+    return os.environ.get("DAFNE_CONV_RP", "1") != "0"
+
+
 def pack_b2b_narrow(w3, w1, wsc=None):
     """Fragment-major weights of dafne_bottleneck_tail_head_narrow_hip from the packed 1x1 weights of conv3 ([256, 64] bf16)
     and the next block's conv1 ([64, 256] bf16): bf16 [8 waves][4 steps][64 lanes][8] then [2 halves][16 steps][64 lanes][8];
@@ -232,16 +247,20 @@ class ConvCall:
     """One dafne_conv2d_nhwc_bf16_hip launch with its argument structs kept alive."""
 
     def __init__(self, w, b, cin, cout, k, stride, pad, flags, segs, n_images, gn_partial=None, gn_in=None, fp8=None,
-                 gn_fin=None):
+                 gn_fin=None, wfrag=None):
         """gn_in: (stats [n_segs,N,Cin/8,2], gamma [Cin], beta [Cin]) of the INPUT maps when they hold the raw
         output of the previous tower convolution (flag F_GNIN: GroupNorm + ReLU applied on load).
         fp8: (oscale fp32 [Cout], in_qscale) -> `w` holds e4m3 bytes (pack_conv_fp8) and the call goes to
         dafne_conv2d_nhwc_fp8w_hip (fp8 MFMA, activations quantised on load).
         gn_fin: (stats out [n_segs,N,Cout/8,2] fp32, counters [n_segs,N] int32 zeros, eps) with flag F_GNFIN: the last
-        tile of every image finalises the GroupNorm statistics of the OUTPUT (no dafne_groupnorm_finalize_hip launch)."""
+        tile of every image finalises the GroupNorm statistics of the OUTPUT (no dafne_groupnorm_finalize_hip launch).
+        wfrag: fragment-major bf16 weights (pack_conv3x3_frag) -> the call goes to dafne_conv3x3_c256_hip (resident-patch
+        kernel: 3x3 s1 p1, Cin 256, Cout % 256 == 0; its own tile geometry)."""
         L = _lib.load()
         self.fp8 = fp8
-        self.keep = (w, b, gn_partial, [s for s in segs], gn_in, fp8, gn_fin)
+        self.wfrag = wfrag
+        assert fp8 is None or wfrag is None
+        self.keep = (w, b, gn_partial, [s for s in segs], gn_in, fp8, gn_fin, wfrag)
         gi = [t.data_ptr() for t in gn_in] if gn_in is not None else [None, None, None]
         gf = (gn_fin[0].data_ptr(), gn_fin[1].data_ptr(), float(gn_fin[2])) if gn_fin is not None else (None, None, 0.0)
         self.prm = _lib.ConvParams(n_images, len(segs), cin, cout, k, k, stride, pad, flags,
@@ -263,7 +282,13 @@ class ConvCall:
                                       + (hout * wout * cout * 2 if (flags & F_RES) else 0)
                                       + (hout * wout * cout // 2 if (flags & F_UP) else 0))
 
+    def rp_ok(self):
+        """Can dafne_conv3x3_c256_hip take this call (shape / flags)?"""
+        return self.fp8 is None and bool(_lib.load().dafne_conv3x3_c256_ok(ctypes.byref(self.prm), self.segs))
+
     def num_tiles(self):
+        if self.wfrag is not None:
+            return _lib.load().dafne_conv3x3_c256_num_tiles(ctypes.byref(self.prm), self.segs)
         if self.fp8 is not None:
             return _lib.load().dafne_conv2d_fp8w_num_tiles(ctypes.byref(self.prm), self.segs)
         return _lib.load().dafne_conv2d_num_tiles(ctypes.byref(self.prm), self.segs)
@@ -282,11 +307,15 @@ class ConvCall:
         """The HIP kernel this call dispatches to (conv.hip), for per-kernel attribution in bench.py."""
         if self.fp8 is not None:
             return "conv3x3_patch_fp8"
+        if self.wfrag is not None:
+            return "conv3x3_rp"
         return self.KERNEL_NAMES[self.kernel_id()]
 
     def tiles_per_image(self):
         out = (ctypes.c_int32 * self.prm.n_segs)()
         fn = _lib.load().dafne_conv2d_fp8w_tiles_per_image if self.fp8 is not None else _lib.load().dafne_conv2d_tiles_per_image
+        if self.wfrag is not None:
+            fn = _lib.load().dafne_conv3x3_c256_tiles_per_image
         _lib.check(fn(ctypes.byref(self.prm), self.segs, out), "dafne_conv2d_tiles_per_image")
         return list(out)
 
@@ -296,6 +325,11 @@ class ConvCall:
                                                         ctypes.c_float(self.fp8[1]), stream)
             if rc:
                 _lib.check(rc, "dafne_conv2d_nhwc_fp8w_hip")
+            return
+        if self.wfrag is not None:
+            rc = _lib.load().dafne_conv3x3_c256_hip(ctypes.byref(self.prm), self.segs, _lib.ptr(self.wfrag), stream)
+            if rc:
+                _lib.check(rc, "dafne_conv3x3_c256_hip")
             return
         rc = self.fn(ctypes.byref(self.prm), self.segs, stream)
         if rc:
@@ -371,6 +405,12 @@ class DensePlan:
                     fp8 = (q8[1] / act_q8[key], act_q8[key])       # oscale = weight scale / in_qscale
             c = ConvCall(q8[0] if fp8 else wgt, bias, cin, cout, k, stride, pad, flags,
                          [(tin.t, o.t, res.t if res is not None else None, tin.h, tin.w, ho, wo)], n, fp8=fp8)
+            if fp8 is None and k == 3 and cin == 256 and use_rp_kernel() and c.kernel_id() == 6 and c.rp_ok():
+                # 256-channel 3x3 layers the patch kernel would take (FPN outputs): resident-patch kernel
+                if key + ".frag" not in P:
+                    P[key + ".frag"] = pack_conv3x3_frag(wgt)
+                c = ConvCall(wgt, bias, cin, cout, k, stride, pad, flags,
+                             [(tin.t, o.t, None, tin.h, tin.w, ho, wo)], n, wfrag=P[key + ".frag"])
             self.calls.append(c)
             self.flops += c.flops
             return o
@@ -642,11 +682,19 @@ class HeadPlan:
                 # M-tile geometry comes from the library (the kernel choice fixes the tile shape; the fp8 kernel always
                 # uses the patch kernel's tiles, the bf16 one only when the launch has enough of them)
                 probe = ConvCall(wgt, bias, C, C, 3, 1, 1, flags & ~F_GN, seg_list(cur, outs), n, gn_in=cur_gn)
-                use_fp8 = q8 is not None and aq is not None and (cur_gn is None or probe.kernel_id() == 6)
+                rp_on = use_rp_kernel() and C == 256
+                use_fp8 = q8 is not None and aq is not None and (cur_gn is None or probe.kernel_id() == 6 or (rp_on and probe.rp_ok()))
+                use_rp = rp_on and not use_fp8 and probe.rp_ok() and (cur_gn is not None or probe.kernel_id() == 6)
+                wfrag = None
+                if use_rp:
+                    if lkey + ".frag" not in P:
+                        P[lkey + ".frag"] = pack_conv3x3_frag(wgt)
+                    wfrag = P[lkey + ".frag"]
+                    probe = ConvCall(wgt, bias, C, C, 3, 1, 1, flags & ~F_GN, seg_list(cur, outs), n, gn_in=cur_gn, wfrag=wfrag)
                 if use_fp8:
                     probe = ConvCall(q8[0], bias, C, C, 3, 1, 1, flags & ~F_GN, seg_list(cur, outs), n, gn_in=cur_gn,
                                      fp8=(q8[1] / aq, aq))
-                is_patch = use_fp8 or probe.kernel_id() == 6
+                is_patch = use_fp8 or use_rp or probe.kernel_id() == 6
                 nt = probe.num_tiles()
                 partial = torch.empty(nt, C // 8, 2, dtype=torch.float32, device=device)
                 stats = torch.empty(len(outs), n, C // 8, 2, dtype=torch.float32, device=device)
@@ -660,7 +708,7 @@ class HeadPlan:
                     dst = [torch.empty(1, dtype=torch.float32, device=device)] * len(outs) if f32 else outs
                     nxt = ConvCall(wn, bn_, C, cout, 3, 1, 1, fl | F_GNIN, seg_list(outs, dst, f32=f32), n,
                                    gn_in=(stats, gamma, beta))
-                    fuse_next = fuse_next and nxt.kernel_id() == (7 if f32 else 6)
+                    fuse_next = fuse_next and (nxt.kernel_id() == (7 if f32 else 6) or (not f32 and rp_on and nxt.rp_ok()))
                 fuse_fin = fuse_next and fuse_gnfin and is_patch and C == 256
                 fin = (stats, torch.zeros(len(outs), n, dtype=torch.int32, device=device), 1e-5) if fuse_fin else None
                 if fuse_fin:
@@ -673,7 +721,7 @@ class HeadPlan:
                                  gn_in=cur_gn, fp8=(q8[1] / aq, aq), gn_fin=fin)
                 else:
                     c = ConvCall(wgt, bias, C, C, 3, 1, 1, flags, seg_list(cur, outs), n, gn_partial=partial, gn_in=cur_gn,
-                                 gn_fin=fin)
+                                 gn_fin=fin, wfrag=wfrag)
                 calls.append(c)
                 plan.flops += c.flops
                 gsegs = (_lib.GnSeg * len(outs))()

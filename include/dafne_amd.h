@@ -236,6 +236,23 @@ typedef struct dafne_conv_params {
  */
 int dafne_conv2d_nhwc_bf16_hip(const dafne_conv_params* prm, const dafne_conv_seg* segs, void* stream);
 /*
+ * 3x3 / stride 1 / pad 1 layers with 256 input channels (the DAFNe head towers, dafne.py:318-348, and the FPN output
+ * convolutions [d2 FPN recalled]) on the resident-patch kernel (conv3x3_rp_kernel): 4 x 32 pixel tiles x 256 output
+ * channels, the whole (4+2) x (32+2) x 256-channel input patch resident in LDS, weights streamed L2 -> registers.
+ * Same parameter block, flags (RELU, GN_STATS, GN_INPUT, GN_FINALIZE), statistics layout and result definition as
+ * dafne_conv2d_nhwc_bf16_hip (same K order, same epilogue expressions: outputs are bit-identical to that call; the
+ * GroupNorm partial sums are grouped by THIS kernel's tiles, so d_gn_partial needs dafne_conv3x3_c256_num_tiles rows and
+ * a finalised mean / rstd may differ from the other kernel's in the last bit).  prm->d_weight is ignored; d_wfrag: bf16
+ * [Cout/256][8 waves][144 k16 steps][64 lanes][8] = rows nt*256 + wave*32 + (lane & 31), K columns 16*step +
+ * 8*(lane >> 5) .. +8 of the packed weight [Cout][Cin/64][KH][KW][64]  (engine.pack_conv3x3_frag).
+ * Shapes: Cin == 256, Cout % 256 == 0, bias, bf16 output, no residual / top-down add; else DAFNE_E_UNSUPPORTED
+ * (dafne_conv3x3_c256_ok: 1 / 0).
+ */
+int dafne_conv3x3_c256_ok(const dafne_conv_params* prm, const dafne_conv_seg* segs);
+int dafne_conv3x3_c256_num_tiles(const dafne_conv_params* prm, const dafne_conv_seg* segs);
+int dafne_conv3x3_c256_tiles_per_image(const dafne_conv_params* prm, const dafne_conv_seg* segs, int32_t* out);
+int dafne_conv3x3_c256_hip(const dafne_conv_params* prm, const dafne_conv_seg* segs, const void* d_wfrag, void* stream);
+/*
  * fp8-weight twin (BASELINE config 5: "fp8 weights, CDNA4 fp8 MFMA conv path"; SURVEY 8(b) item 5
  * dafne_conv2d_nhwc_{bf16,fp8w}_hip).  The reference has no fp8 path: this entry DEFINES it.
  *   d_weight   OCP e4m3 bytes [Cout][Cin/64][KH][KW][64] (same K order as the bf16 layout, 1 byte per element)

@@ -687,3 +687,160 @@ def test_bottleneck_body_fused_equals_three_convs(N, H, W):
     with pytest.raises(_lib.DafneHipError):
         _lib.check(L.dafne_bottleneck_body_hip(_lib.ptr(ua.t), _lib.ptr(xa.t), _lib.ptr(wf), _lib.ptr(b2p), _lib.ptr(b3p),
                                                _lib.ptr(b1p), N, H, W, _lib.ptr(y_t), _lib.ptr(z_t), _lib.ptr(scr), 1024, st), "bneck")
+
+
+def _rp_call(wp, bp, cout, flags, segs, N, d, **kw):
+    from dafne_amd import engine
+    return engine.ConvCall(wp, bp, 256, cout, 3, 1, 1, flags, segs, N, wfrag=engine.pack_conv3x3_frag(wp), **kw)
+
+
+@pytest.mark.parametrize("cout,sizes,N,relu", [
+    (256, [(64, 64)], 8, True),                                   # res4-like: exact 4 x 32 tiles
+    (256, [(128, 128), (64, 64), (32, 32), (16, 16), (8, 8)], 2, False),      # the five head levels in one launch
+    (512, [(33, 47), (5, 70)], 3, True),                          # two channel tiles; ragged rows and columns, 3 tile columns
+    (256, [(1, 1), (3, 2)], 1, False),                            # smaller than a tile
+])
+def test_resident_patch_kernel_equals_generic_conv(cout, sizes, N, relu):
+    """dafne_conv3x3_c256_hip (conv3x3_rp_kernel: whole 256-channel patch resident in LDS, weights streamed L2 -> registers,
+    4 x 32 tiles) against dafne_conv2d_nhwc_bf16_hip on the same operands: same K order and epilogue expressions ->
+    bit-identical outputs on every level, halo untouched; and against torch within bf16 rounding."""
+    from dafne_amd import engine, _lib
+    d = dev()
+    g = torch.Generator().manual_seed(cout + sum(h * w for h, w in sizes))
+    xs = [bfr(torch.randn(N, 256, h, w, generator=g)) for h, w in sizes]
+    w = bfr(torch.randn(cout, 256, 3, 3, generator=g) / 48.0)
+    b = torch.randn(cout, generator=g) * 0.1
+    wp, bp = engine.pack_conv(w, b, d)
+    ins = [engine.Act.from_nchw(x.to(d)) for x in xs]
+    out_g = [engine.Act(N, h, wd, cout, d) for h, wd in sizes]
+    out_r = [engine.Act(N, h, wd, cout, d) for h, wd in sizes]
+    fl = engine.F_RELU if relu else 0
+    st = _lib.current_stream()
+    engine.ConvCall(wp, bp, 256, cout, 3, 1, 1, fl, [(i.t, o.t, None, i.h, i.w, i.h, i.w) for i, o in zip(ins, out_g)], N)(st)
+    c = _rp_call(wp, bp, cout, fl, [(i.t, o.t, None, i.h, i.w, i.h, i.w) for i, o in zip(ins, out_r)], N, d)
+    assert c.rp_ok() and c.kernel_name() == "conv3x3_rp"
+    assert c.num_tiles() == sum(N * ((h + 3) // 4) * ((wd + 31) // 32) for h, wd in sizes)
+    c(st)
+    c(st)
+    torch.cuda.synchronize()
+    for a, r, x in zip(out_g, out_r, xs):
+        assert torch.equal(a.t, r.t)
+        assert float(r.t[:, 0].abs().max()) == 0 and float(r.t[:, -1].abs().max()) == 0
+        assert float(r.t[:, :, 0].abs().max()) == 0 and float(r.t[:, :, -1].abs().max()) == 0
+        ref = F.conv2d(x, w, b, padding=1)
+        close_bf16(r.nchw_float().cpu(), bfr(F.relu(ref) if relu else ref))
+
+
+def test_resident_patch_kernel_shape_rules():
+    from dafne_amd import engine, _lib
+    d = dev()
+    wp, bp = engine.pack_conv(torch.zeros(256, 128, 3, 3), torch.zeros(256), d)
+    a, o = engine.Act(1, 8, 8, 128, d), engine.Act(1, 8, 8, 256, d)
+    c = engine.ConvCall(wp, bp, 128, 256, 3, 1, 1, 0, [(a.t, o.t, None, 8, 8, 8, 8)], 1)
+    assert not c.rp_ok()                                  # Cin != 256
+    wp, bp = engine.pack_conv(torch.zeros(256, 256, 3, 3), torch.zeros(256), d)
+    a = engine.Act(1, 8, 8, 256, d)
+    c = engine.ConvCall(wp, bp, 256, 256, 3, 1, 1, engine.F_RES, [(a.t, o.t, o.t, 8, 8, 8, 8)], 1)
+    assert not c.rp_ok()                                  # residual epilogue
+    with pytest.raises(_lib.DafneHipError):
+        _lib.check(_lib.load().dafne_conv3x3_c256_hip(ctypes.byref(c.prm), c.segs, _lib.ptr(wp), _lib.current_stream()), "c256")
+
+
+def _gsegs(outs, tpis, N):
+    from dafne_amd import _lib
+    gsegs = (_lib.GnSeg * len(outs))()
+    t0 = 0
+    for k, (o, tpi) in enumerate(zip(outs, tpis)):
+        gsegs[k] = _lib.GnSeg(o.t.data_ptr(), o.h, o.w, t0, tpi)
+        t0 += tpi * N
+    return gsegs
+
+
+@pytest.mark.parametrize("fused_finalize", [False, True])
+def test_resident_patch_kernel_gn_chain(fused_finalize):
+    """Two tower layers over three ragged levels on the resident-patch kernel: layer 1 emits its raw output + per-tile
+    GroupNorm partial sums (finalised by a separate launch, or by the last tile of every image: GN_FINALIZE), layer 2
+    applies GroupNorm + ReLU to its patch in LDS (GN_INPUT).  Layer 1's output is bit-identical to the patch kernel's;
+    the statistics agree with it to fp32 summation order and with torch; given THE SAME statistics layer 2 is bit-identical
+    to the patch kernel's GN_INPUT form; and the whole chain matches torch within bf16 noise."""
+    from dafne_amd import engine, _lib
+    d = dev()
+    L = _lib.load()
+    g = torch.Generator().manual_seed(91)
+    C, N = 256, 5
+    sizes = [(40, 72), (17, 33), (8, 8)]
+    xs = [bfr(torch.randn(N, C, h, w, generator=g)) for h, w in sizes]
+    w1 = bfr(torch.randn(C, C, 3, 3, generator=g) / (C * 9) ** 0.5)
+    w2 = bfr(torch.randn(C, C, 3, 3, generator=g) / (C * 9) ** 0.5)
+    b1, b2 = torch.randn(C, generator=g) * 0.1, torch.randn(C, generator=g) * 0.1
+    gamma = (1 + 0.2 * torch.randn(C, generator=g)).to(d)
+    beta = (0.3 * torch.randn(C, generator=g)).to(d)
+    ins = [engine.Act.from_nchw(x.to(d)) for x in xs]
+    wp1, bp1 = engine.pack_conv(w1, b1, d)
+    wp2, bp2 = engine.pack_conv(w2, b2, d)
+    st = _lib.current_stream()
+
+    def layer1(outs, rp):
+        segs = [(i.t, o.t, None, i.h, i.w, i.h, i.w) for i, o in zip(ins, outs)]
+        mk = (lambda fl, **kw: _rp_call(wp1, bp1, C, fl, segs, N, d, **kw)) if rp else \
+             (lambda fl, **kw: engine.ConvCall(wp1, bp1, C, C, 3, 1, 1, fl, segs, N, **kw))
+        probe = mk(0)
+        partial = torch.zeros(probe.num_tiles(), C // 8, 2, dtype=torch.float32, device=d)
+        stats = torch.zeros(len(outs), N, C // 8, 2, dtype=torch.float32, device=d)
+        fin = rp and fused_finalize
+        counters = torch.zeros(len(outs), N, dtype=torch.int32, device=d)
+        c = mk(engine.F_GN | (engine.F_GNFIN if fin else 0), gn_partial=partial, gn_fin=(stats, counters, 1e-5) if fin else None)
+        c(st)
+        tpis = c.tiles_per_image()
+        assert sum(t * N for t in tpis) == c.num_tiles()
+        if fin:
+            c(st)                                        # the counters were reset by the first launch
+        else:
+            _lib.check(L.dafne_groupnorm_finalize_hip(_gsegs(outs, tpis, N), len(outs), N, C, _lib.ptr(partial), _lib.ptr(stats),
+                                                      ctypes.c_float(1e-5), st), "finalize")
+        return stats, partial, tpis
+
+    raw_r = [engine.Act(N, h, w, C, d) for h, w in sizes]
+    raw_p = [engine.Act(N, h, w, C, d) for h, w in sizes]
+    stats_r, partial_r, tpis_r = layer1(raw_r, True)
+    stats_p, _, _ = layer1(raw_p, False)
+    torch.cuda.synchronize()
+    for a, b_ in zip(raw_r, raw_p):
+        assert torch.equal(a.t, b_.t)
+    assert torch.allclose(stats_r, stats_p, rtol=2e-5, atol=2e-6)          # other tile grouping of the fp32 partial sums
+    for k, x in enumerate(xs):
+        y = F.conv2d(x, w1, b1, padding=1).reshape(N, C // 8, -1)
+        assert torch.allclose(stats_r[k, :, :, 0].cpu(), y.mean(-1), atol=2e-3)
+        assert torch.allclose(stats_r[k, :, :, 1].cpu(), torch.rsqrt(y.var(-1, unbiased=False) + 1e-5), rtol=5e-3)
+    # layer 2 with GN_INPUT (normalisation applied to the patch in LDS) against the SAME kernel on a map normalised by the
+    # separate pass (dafne_groupnorm_relu_nhwc_bf16_hip from the same partial sums): same arithmetic, same rounding points.
+    # (Against the patch kernel's GN_INPUT form the outputs differ in ~2e-4 of the elements by one bf16 ulp: that kernel
+    # walks K as (slab, kw, K half, kh), this one as (slab, kh, kw, k16) like conv_igemm_kernel.)
+    out_r = [engine.Act(N, h, w, C, d) for h, w in sizes]
+    out_u = [engine.Act(N, h, w, C, d) for h, w in sizes]
+    _rp_call(wp2, bp2, C, engine.F_GNIN, [(i.t, o.t, None, i.h, i.w, i.h, i.w) for i, o in zip(raw_r, out_r)], N, d,
+             gn_in=(stats_r, gamma, beta))(st)
+    norm = [engine.Act(N, h, w, C, d) for h, w in sizes]
+    for a, b_ in zip(norm, raw_r):
+        a.t.copy_(b_.t)
+    stats_u = torch.zeros_like(stats_r)
+    _lib.check(L.dafne_groupnorm_relu_nhwc_bf16_hip(_gsegs(norm, tpis_r, N), len(norm), N, C, _lib.ptr(partial_r), _lib.ptr(stats_u),
+                                                    _lib.ptr(gamma), _lib.ptr(beta), ctypes.c_float(1e-5), st), "gn")
+    _rp_call(wp2, bp2, C, 0, [(i.t, o.t, None, i.h, i.w, i.h, i.w) for i, o in zip(norm, out_u)], N, d)(st)
+    out_p = [engine.Act(N, h, w, C, d) for h, w in sizes]
+    cp = engine.ConvCall(wp2, bp2, C, C, 3, 1, 1, engine.F_GNIN, [(i.t, o.t, None, i.h, i.w, i.h, i.w) for i, o in zip(raw_r, out_p)],
+                         N, gn_in=(stats_r, gamma, beta))
+    assert cp.kernel_id() == 6
+    cp(st)
+    torch.cuda.synchronize()
+    assert torch.equal(stats_u, stats_r)              # the fused finalisation reduces in the separate kernel's order
+    for a, b_, c_ in zip(out_r, out_u, out_p):
+        assert torch.equal(a.t, b_.t)
+        assert float(a.t[:, 0].abs().max()) == 0 and float(a.t[:, :, -1].abs().max()) == 0
+        dlt = (a.t.float() - c_.t.float()).abs()
+        assert float((dlt > 0).float().mean()) < 2e-3 and float(dlt.max()) <= 2.0 ** -7 * float(c_.t.float().abs().max())
+    for x, a in zip(xs, out_r):
+        y1n = bfr(_gn_ref(F.conv2d(x, w1, b1, padding=1), gamma.cpu(), beta.cpu(), C // 8))
+        ref = bfr(F.conv2d(y1n, w2, b2, padding=1))
+        got = a.nchw_float().cpu()
+        assert (got - ref).abs().max() < 0.06 * ref.abs().max()
