@@ -1818,56 +1818,93 @@ __global__ void __launch_bounds__(512) conv3x3_patch_kernel(ConvDev P) {
 // conv3x3_patch_kernel above stages weights AND pixels through LDS in half-K pieces: 36 K steps x 4 phases, a barrier
 // per phase, two wave groups that must stay exactly one phase apart -- measured 935-1000 TFLOP/s, the matrix pipe busy
 // ~50 % of the cycles the chip runs.  Here a workgroup (8 waves, one per CU) owns a 4 x 32 pixel tile and 256 output
-// channels; the (4+2) x (32+2) x 256-channel patch (four 26-KB slabs, [pixel][128 B], chunk XOR (pixel >> 1) & 7) is
-// DMA'd once and stays; a wave owns 32 output channels and all 128 pixels, its weight fragments (fragment-major packing,
+// channels; the (4+2) x (32+2) x 256-channel patch (four 26-KB slabs, [pixel][128 B], chunk XOR (patch column >> 1) & 7:
+// conflict-free ds_read_b128 at every tap offset, and -- the row pitch being even -- independent of the patch row, so a
+// fragment address is ONE per-lane register per tap column plus an immediate) is DMA'd once and stays; a wave owns 32 output channels and all 128 pixels, its weight fragments (fragment-major packing,
 // one coalesced 1-KiB load per k16 step, ring of 8) go straight to registers: every fragment feeds 4 MFMAs and is fetched
-// by exactly one wave, and the 144 k16 steps run with ONE barrier (after slab 0 has landed; slabs 1..3 trickle in behind
-// the weight loads, one piece per wave and step, and are guarded by a second barrier at step 36).  conv_bneck's stamps:
-// 305 cycles per step against 256 of pure MFMA issue.
-//   * K order = (64-channel slab, kh, kw, k16 step) = conv_igemm_kernel's;
-//   * GN_INPUT: every wave normalises the pieces IT loaded (GroupNorm + ReLU in place, out-of-image pixels stay zero),
-//     slab 0 before the first barrier, slabs 1..3 one piece per step in steps 13..24, i.e. under the other waves' MFMAs;
-//   * epilogue: bias / ReLU / GroupNorm sums in the accumulator layout (a wave holds all 128 pixels of its 32 channels:
-//     no cross-wave reduction), bf16 tile staged once through LDS, 16-byte row stores; GN_FINALIZE as in the patch kernel.
+// by exactly one wave, and the 144 k16 steps of a tile need no barrier for their operands (272 cycles per step measured,
+// 256 = pure MFMA issue).  K order = (64-channel slab, kh, kw, k16 step) = conv_igemm_kernel's: bit-identical outputs.
+//
+// A 128-pixel tile is only ~40k cycles of matrix work, and the first version (one tile per workgroup) spent another 15k
+// per tile on its prologue (patch latency), epilogue (8k: bias loads, staging, GroupNorm butterfly, stores) and store
+// drain with the matrix pipe idle -- no faster than the patch kernel.  So the kernel is PERSISTENT and software-pipelined
+// across tiles (workgroup p of G runs tiles p, p + G, ...):
+//   * the NEXT tile's patch lands while the current tile computes: slab s of the patch is dead after step 36 (s + 1) - 1, a
+//     barrier at steps 36 / 72 / 108 retires it and the next tile's slab s is DMA'd into its place in steps 40.. / 76.. /
+//     112.. (one piece per wave and step), slab 3 right behind the tile's last step;
+//   * GN_INPUT: a wave normalises the pieces IT loaded (GroupNorm + ReLU in place, out-of-image pixels stay zero) ~13
+//     steps after issuing them -- next tile's slabs 0..2 in steps 53.. / 89.. / 125.., its slab 3 in steps 13..16 of the
+//     next tile itself (first read at step 108) -- under the other waves' MFMAs; statistics of the next tile's image by
+//     one 256-B DMA piece (double-buffered);
+//   * the epilogue is short and asynchronous: at the end of a tile bias / ReLU / GroupNorm sums are applied in the
+//     accumulator layout (a wave holds all 128 pixels of its 32 channels: no cross-wave reduction), the bf16 values are
+//     paired across the two half-waves with v_permlane32_swap (16 contiguous bytes per lane) and stored straight from
+//     registers -- 8 stores per lane that drain under the next tile's first steps (no LDS staging, no barrier, nothing
+//     held in registers across tiles).  The GroupNorm sums are reduced with DPP in the next tile's steps 1..8 and
+//     published by its barriers; with GN_FINALIZE the arrival ticket is taken in step 14 (no drain: the in-order vmcnt
+//     waits of the weight ring already cover the partial-sum stores of step 38.. of wave 0), the rare last-tile reduction
+//     runs behind the barrier of step 72;
+//   * every s_waitcnt vmcnt(n) is exact (rp_wait): stores are never predicated -- rows of out-of-image pixels go to a
+//     caller-provided dump area.
 constexpr int kRH = 4, kRW = 32, kRPx = kRH * kRW;
 constexpr int kRCols = kRW + 2, kRRows = kRH + 2;
 constexpr int kRPieces = (kRRows * kRCols + 7) / 8;     // 26 pieces of 8 px x 128 B per slab
 constexpr int kRSlab = kRPieces * 1024;                 // 26 624 B
 constexpr int kRCin = 256, kRSteps = 9 * kRCin / 16;    // 144 k16 steps
 constexpr int kRRing = 8;
-constexpr int kROffTab = 4 * kRSlab;                    // GN table: stats [32][2] + gamma [256] + beta [256] fp32
-constexpr int kROffRed = kROffTab + 9 * kRCin;          // [32 groups][2] fp32 + finalize flag
-constexpr int kRSmem = kROffRed + 512;
-constexpr int kRRowB = 256 * 2 + 16;                    // epilogue staging row: 256 channels bf16 + 16 B pad
-static_assert(kRPx * kRRowB <= 4 * kRSlab && kRSmem <= 160 * 1024 && 32 * 32 * 2 * 4 + 4 <= 4 * kRSlab, "LDS budget");
-constexpr int kRTrickle = 12;                           // slabs 1..3: 12 pieces per wave, one per step 0..11
+constexpr int kRMaxCout = 1024;
+constexpr int kROffStat = 4 * kRSlab;                   // GN_INPUT statistics of (segment, image): 2 x [32][2] fp32
+constexpr int kROffGB = kROffStat + 512;                // gamma [256], beta [256] fp32
+constexpr int kROffBias = kROffGB + 2048;               // bias fp32 [Cout <= 1024]
+constexpr int kROffRed = kROffBias + kRMaxCout * 4;     // [32 groups][2] fp32, finalize flag at +256
+constexpr int kROffFin = kROffRed + 512;                // GN_FINALIZE reduction scratch: 32 x 32 x 2 fp32
+constexpr int kRSmem = kROffFin + 32 * 32 * 2 * 4;
+static_assert(kRSmem <= 160 * 1024, "LDS budget");
+constexpr int kRDumpBytes = 64 * 1024;
 
-// vector-memory program order of a wave: [patch slab 0: 4 DMA] A(0)..A(7) | step s: [wait A(s)] MFMAs | A(s+8) | one patch
-// piece of slabs 1..3 (s < 12).  rp_wait(j) = instructions issued after A(j) before its wait (vmcnt retires in order).
-constexpr int rp_wait(int j) {
+// Vector-memory program order of a wave inside a tile (steady state; A(s + 8) of steps >= 136 are the next tile's first):
+//   step s: [wait A(s)] MFMAs | A(s + 8) | rp_post(s) more operations:
+//     37 (GN_INPUT): the statistics piece of the next tile's image; 40..43 / 76..79 / 112..115: one patch piece of the next
+//     tile's slab 0 / 1 / 2; 143: the four pieces of slab 3 and the tile's 8 row stores.
+// rp_wait(j) = operations issued after A(j) and before the wait for it (vmcnt retires in order).  Steps 0..7 look back
+// into the previous tile; the FIRST tile of a workgroup has the prologue there instead (16 patch pieces, then A(0..7)).
+constexpr int rp_post(int s, bool gnin) {
     int n = 0;
-    if (j < kRRing) {
-        n += kRRing - 1 - j;
-        for (int s = 0; s < j; s++) n += 1 + (s < kRTrickle ? 1 : 0);
-    } else {
-        n += (j - kRRing < kRTrickle ? 1 : 0);
-        for (int s = j - kRRing + 1; s < j; s++) n += (s + kRRing < kRSteps ? 1 : 0) + (s < kRTrickle ? 1 : 0);
-    }
+    if (gnin && s == 37) n += 1;
+    if ((s >= 40 && s < 44) || (s >= 76 && s < 80) || (s >= 112 && s < 116)) n += 1;
+    if (s == kRSteps - 1) n += 4 + 8;
     return n;
 }
-static_assert(rp_wait(0) == 7 && rp_wait(8) == 15 && rp_wait(12) == 15 && rp_wait(20) == 7 && rp_wait(143) == 0 && rp_wait(137) == 6, "vmcnt bookkeeping");
+constexpr int rp_wait(int j, bool gnin, bool first) {
+    int n = 0;
+    if (first && j < kRRing) {
+        n += kRRing - 1 - j;
+        for (int s = 0; s < j; s++) n += 1 + rp_post(s, gnin);
+        return n;
+    }
+    n += rp_post((j - kRRing + kRSteps) % kRSteps, gnin);
+    for (int s = j - kRRing + 1; s < j; s++) n += 1 + rp_post((s + kRSteps) % kRSteps, gnin);
+    return n;
+}
+static_assert(rp_wait(0, false, true) == 7 && rp_wait(0, false, false) == 19 && rp_wait(7, false, false) == 19 && rp_wait(8, false, false) == 7 &&
+              rp_wait(48, false, false) == 11 && rp_wait(48, true, false) == 11 && rp_wait(45, true, false) == 12 && rp_wait(52, false, false) == 7 &&
+              rp_wait(143, true, false) == 7, "vmcnt bookkeeping");
 
 template <int J>
-__device__ __forceinline__ void rp_load(bf16x8 (&ar)[kRRing], const char* wf, unsigned voff) {
-    if constexpr (J < kRSteps) {
-        const char* sb = wf + (size_t)J * 1024;
-        asm volatile("global_load_dwordx4 %0, %1, %2" : "=&v"(ar[J % kRRing]) : "v"(voff), "s"(sb) : "memory");
-    }
+__device__ __forceinline__ void rp_load(bf16x8 (&ar)[kRRing], const char* wf_cur, const char* wf_nxt, unsigned voff) {
+    const char* sb = (J < kRSteps ? wf_cur : wf_nxt) + (size_t)(J % kRSteps) * 1024;
+    asm volatile("global_load_dwordx4 %0, %1, %2" : "=&v"(ar[J % kRRing]) : "v"(voff), "s"(sb) : "memory");
 }
-template <int J>
-__device__ __forceinline__ void rp_wait_for(bf16x8 (&ar)[kRRing]) {
-    constexpr int kWaitN = rp_wait(J);
-    asm volatile("s_waitcnt vmcnt(%1)" : "+v"(ar[J % kRRing]) : "n"(kWaitN) : "memory");
+template <int J, bool GNIN>
+__device__ __forceinline__ void rp_wait_for(bf16x8 (&ar)[kRRing], bool first) {
+    constexpr int kN = rp_wait(J, GNIN, false);
+    if constexpr (J < kRRing) {
+        constexpr int kF = rp_wait(J, GNIN, true);
+        if (first) asm volatile("s_waitcnt vmcnt(%1)" : "+v"(ar[J % kRRing]) : "n"(kF) : "memory");
+        else asm volatile("s_waitcnt vmcnt(%1)" : "+v"(ar[J % kRRing]) : "n"(kN) : "memory");
+    } else {
+        asm volatile("s_waitcnt vmcnt(%1)" : "+v"(ar[J % kRRing]) : "n"(kN) : "memory");
+    }
 }
 template <int I, int N, class F>
 __device__ __forceinline__ void rp_static_for(F&& f) {
@@ -1877,131 +1914,174 @@ __device__ __forceinline__ void rp_static_for(F&& f) {
     }
 }
 
+// sum over the 64 lanes in a fixed tree (deterministic), DPP only; the total is valid in lane 63
+__device__ __forceinline__ float rp_wave_total(float v) {
+    auto dpp = [](float x, auto CTRL, auto RM) {
+        return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), decltype(CTRL)::value, decltype(RM)::value, 0xF, false));
+    };
+    v += dpp(v, std::integral_constant<int, 0xB1>{}, std::integral_constant<int, 0xF>{});      // quad_perm [1,0,3,2]
+    v += dpp(v, std::integral_constant<int, 0x4E>{}, std::integral_constant<int, 0xF>{});      // quad_perm [2,3,0,1]
+    v += dpp(v, std::integral_constant<int, 0x141>{}, std::integral_constant<int, 0xF>{});     // row_half_mirror
+    v += dpp(v, std::integral_constant<int, 0x140>{}, std::integral_constant<int, 0xF>{});     // row_mirror: every lane = its row's sum
+    v += dpp(v, std::integral_constant<int, 0x142>{}, std::integral_constant<int, 0xA>{});     // row_bcast15 into rows 1, 3
+    v += dpp(v, std::integral_constant<int, 0x143>{}, std::integral_constant<int, 0xC>{});     // row_bcast31 into rows 2, 3
+    return v;
+}
+
+// the four B fragments of k16 step J (patch rows kh .. kh + 3 at tap column kw, chunk kc of slab sl): inline asm, completion
+// is awaited by the caller (lgkmcnt)
+template <int J>
+__device__ __forceinline__ void rp_bread(bf16x8 (&b)[4], const unsigned (&pb)[3], unsigned lds_base) {
+    constexpr int sl = J / 36, t = J % 36, kh = t / 12, kw = (t >> 2) % 3, kc = t & 3;
+    const unsigned ad = lds_base + ((pb[kw] ^ (unsigned)(kc << 5)) + (unsigned)(sl * kRSlab));
+    constexpr int o0 = (kh + 0) * kRCols * 128, o1 = (kh + 1) * kRCols * 128, o2 = (kh + 2) * kRCols * 128, o3 = (kh + 3) * kRCols * 128;
+    asm volatile("ds_read_b128 %0, %4 offset:%5\n\tds_read_b128 %1, %4 offset:%6\n\tds_read_b128 %2, %4 offset:%7\n\tds_read_b128 %3, %4 offset:%8"
+                 : "=&v"(b[0]), "=&v"(b[1]), "=&v"(b[2]), "=&v"(b[3])
+                 : "v"(ad), "n"(o0), "n"(o1), "n"(o2), "n"(o3)
+                 : "memory");
+}
+
+struct RpTile {
+    int nt, mt, si, img, Y0, X0, H, W, valid;
+};
+
 template <bool GNIN>
-__global__ void __launch_bounds__(512, 2) conv3x3_rp_kernel(ConvDev P) {
+__global__ void __launch_bounds__(512, 2) conv3x3_rp_kernel(ConvDev P, char* dump) {
     constexpr int NT = 512, NW = 8;
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int frow = lane & 31, half = lane >> 5;
+    const int lane_ = lane, frow_ = frow, half_ = half;
     const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) char*)lds;
 
     const int T = P.mtiles * P.ntiles;
-    const int bid = xcd_remap(blockIdx.x, T);
-    const int nt = bid % P.ntiles;
-    const int mt = bid / P.ntiles;
-    int si = 0;
-#pragma unroll
-    for (int k = 1; k < kMaxSegs; k++)
-        if (k < P.n_segs && mt >= P.seg[k].tile0) si = k;
-    const SegDev& S = P.seg[si];
-    const int tloc = mt - S.tile0;
-    const int img = tloc / S.tiles_per_img;
-    const int tt = tloc - img * S.tiles_per_img;
-    const int ty = tt / S.tiles_x, tx = tt - ty * S.tiles_x;
-    const int Y0 = ty * kRH, X0 = tx * kRW;
-    const int H = S.Hout, W = S.Wout, Hp = H + 2, Wp = W + 2;
+    const int G = (int)gridDim.x;
+    const int pos = xcd_remap(blockIdx.x, G);             // workgroups of one XCD take neighbouring tiles (shared halo rows in its L2)
+    const int nmine = (T - pos + G - 1) / G;              // tiles pos, pos + G, ...   (G <= T: nmine >= 1)
 
-#ifdef DAFNE_RP_TIMING
-    unsigned long long rp_ts[6];
-    rp_ts[0] = __builtin_amdgcn_s_memtime();
-#define RP_STAMP(i) rp_ts[i] = __builtin_amdgcn_s_memtime()
-#else
-#define RP_STAMP(i)
-#endif
-    // ---- GroupNorm table of this image (input side) -> LDS, before any DMA is in flight
-    if (GNIN) {
-        float* tab_stats = (float*)(lds + kROffTab);
-        float* tab_gamma = tab_stats + kRCin / 4;
-        float* tab_beta = tab_gamma + kRCin;
-        const float* st = P.in_stats + ((size_t)si * P.N + img) * (kRCin / 8) * 2;
-        if (tid < kRCin / 4) tab_stats[tid] = st[tid];
-        if (tid < kRCin) {
-            tab_gamma[tid] = P.in_gamma[tid];
-            tab_beta[tid] = P.in_beta[tid];
-        }
-        __syncthreads();
-    }
+    auto decode = [&](int t) {
+        RpTile c;
+        c.valid = t < T;
+        t = t < T ? t : T - 1;
+        c.nt = t % P.ntiles;
+        c.mt = t / P.ntiles;
+        int si = 0;
+#pragma unroll
+        for (int k = 1; k < kMaxSegs; k++)
+            if (k < P.n_segs && c.mt >= P.seg[k].tile0) si = k;
+        c.si = si;
+        const SegDev& S = P.seg[si];
+        const int tloc = c.mt - S.tile0;
+        c.img = tloc / S.tiles_per_img;
+        const int tt = tloc - c.img * S.tiles_per_img;
+        const int ty = tt / S.tiles_x;
+        c.Y0 = ty * kRH;
+        c.X0 = (tt - ty * S.tiles_x) * kRW;
+        c.H = S.Hout;
+        c.W = S.Wout;
+        return c;
+    };
 
     // ---- patch DMA map: piece pc = 8 consecutive patch pixels (patch pixel pp = p * 34 + q <-> haloed input pixel
     // (Y0 + p, X0 + q)); wave w moves pieces w, w + 8, w + 16 and w + 24 of every slab -- the six waves without a fourth
     // piece re-load THEIR OWN third piece (same wave, in order: it lands before the wave touches the piece)
-    unsigned pofs[4];
     int ppc[4];
-    const unsigned max_pix = (unsigned)(P.N * Hp * Wp - 1);
 #pragma unroll
     for (int ii = 0; ii < 4; ii++) {
         int pc = wave + NW * ii;
         if (pc >= kRPieces) pc -= NW;
         ppc[ii] = pc;
-        const int pp = pc * 8 + (lane >> 3);
-        const int p = pp / kRCols, q = pp - p * kRCols;
-        unsigned g = (unsigned)((img * Hp + Y0 + p) * Wp + X0 + q);
-        g = g < max_pix ? g : max_pix;                       // ragged tiles reach past the image (and the buffer)
-        pofs[ii] = g * (unsigned)(kRCin * 2) + (unsigned)(((lane & 7) ^ ((pp >> 1) & 7)) * 16);
     }
-    auto patch_piece = [&](int sl, int ii) {
-        __builtin_amdgcn_global_load_lds((gvoid*)(S.in + pofs[ii] + sl * 128), (lvoid*)(lds + sl * kRSlab + ppc[ii] * 1024), 16, 0, 0);
+    unsigned pofs[4];                                      // of the tile whose patch is being fetched
+    const char* pin = nullptr;
+    auto patch_map = [&](const RpTile& c) {
+        int lane = lane_;
+        asm volatile("" : "+v"(lane));       // per-lane parts recomputed per tile (hoisted they spill; a reload drains vmcnt)
+        const int Hp = c.H + 2, Wp = c.W + 2;
+        const unsigned max_pix = (unsigned)(P.N * Hp * Wp - 1);
+#pragma unroll
+        for (int ii = 0; ii < 4; ii++) {
+            const int pp = ppc[ii] * 8 + (lane >> 3);
+            const int p = pp / kRCols, q = pp - p * kRCols;
+            unsigned g = (unsigned)((c.img * Hp + c.Y0 + p) * Wp + c.X0 + q);
+            g = g < max_pix ? g : max_pix;                   // ragged tiles reach past the image (and the buffer)
+            pofs[ii] = g * (unsigned)(kRCin * 2) + (unsigned)(((lane & 7) ^ ((q >> 1) & 7)) * 16);
+        }
+        pin = P.seg[c.si].in;
     };
-    // GroupNorm + ReLU of one landed patch piece, in place (inline-asm LDS ops: a plain LDS access would make the
+    auto patch_piece = [&](int sl, int ii) {
+        __builtin_amdgcn_global_load_lds((gvoid*)(pin + pofs[ii] + sl * 128), (lvoid*)(lds + sl * kRSlab + ppc[ii] * 1024), 16, 0, 0);
+    };
+    // GroupNorm + ReLU of one landed patch piece of tile c, in place (inline-asm LDS ops: a plain LDS access would make the
     // compiler drain vmcnt).  A lane handles LOGICAL chunk lane&7 (8 channels = one group) of pixel lane>>3 of the piece.
-    auto gn_piece = [&](int sl, int ii) {
+    auto gn_piece = [&](const RpTile& c, int sl, int ii, int statbuf) {
         if (ii == 3 && wave + 3 * NW >= kRPieces) return;                 // duplicate of this wave's piece ii = 2
+        int lane = lane_;
+        asm volatile("" : "+v"(lane));       // recompute the per-lane addresses at every call: hoisted out of the tile loop they spill
         const int pc = ppc[ii];
         const int pp = pc * 8 + (lane >> 3);
         const int p = pp / kRCols, q = pp - p * kRCols;
-        const int gy = Y0 + p, gx = X0 + q;                               // haloed coordinates
-        const bool inside = gy >= 1 && gy <= H && gx >= 1 && gx <= W && pp < kRRows * kRCols;
-        const int phys = (lane & 7) ^ ((pp >> 1) & 7);
+        const int gy = c.Y0 + p, gx = c.X0 + q;                           // haloed coordinates
+        const bool inside = gy >= 1 && gy <= c.H && gx >= 1 && gx <= c.W && pp < kRRows * kRCols;
+        const int phys = (lane & 7) ^ ((q >> 1) & 7);
         const unsigned ad = lds_base + (unsigned)(sl * kRSlab + pc * 1024 + (lane >> 3) * 128 + phys * 16);
         const int ch = sl * kBK + (lane & 7) * 8;
-        const unsigned ts = lds_base + (unsigned)(kROffTab + (ch >> 3) * 8);
-        const unsigned tg = lds_base + (unsigned)(kROffTab + kRCin + ch * 4);
+        const unsigned ts = lds_base + (unsigned)(kROffStat + statbuf * 256 + (ch >> 3) * 8);
+        const unsigned tg = lds_base + (unsigned)(kROffGB + ch * 4);
         const unsigned tb = tg + (unsigned)kRCin * 4u;
+        // two halves of 4 channels (register budget: the constants of 8 channels at once spill inside the tile loop)
         u32x4 v;
         u32x2 ms;
-        f32x4 g0, g1, b0, b1;
-        asm volatile("ds_read_b128 %0, %6\n\tds_read_b64 %1, %7\n\tds_read_b128 %2, %8\n\tds_read_b128 %3, %8 offset:16\n\t"
-                     "ds_read_b128 %4, %9\n\tds_read_b128 %5, %9 offset:16\n\ts_waitcnt lgkmcnt(0)"
-                     : "=&v"(v), "=&v"(ms), "=&v"(g0), "=&v"(g1), "=&v"(b0), "=&v"(b1)
+        f32x4 gq, bq;
+        asm volatile("ds_read_b128 %0, %4\n\tds_read_b64 %1, %5\n\tds_read_b128 %2, %6\n\tds_read_b128 %3, %7\n\ts_waitcnt lgkmcnt(0)"
+                     : "=&v"(v), "=&v"(ms), "=&v"(gq), "=&v"(bq)
                      : "v"(ad), "v"(ts), "v"(tg), "v"(tb)
                      : "memory");
         const float gmean = __uint_as_float(ms.x), grstd = __uint_as_float(ms.y);
-        const float gam[8] = {g0[0], g0[1], g0[2], g0[3], g1[0], g1[1], g1[2], g1[3]};
-        const float bet[8] = {b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]};
-        const unsigned u[4] = {v.x, v.y, v.z, v.w};
-        float y[8];
-#pragma unroll
-        for (int k = 0; k < 8; k++) {
-            const float x = bf2f((unsigned short)(k & 1 ? u[k >> 1] >> 16 : u[k >> 1] & 0xffff));
-            y[k] = fmaxf((x - gmean) * grstd * gam[k] + bet[k], 0.f);      // expression of gn_apply_kernel
-        }
         u32x4 o;
-        o.x = inside ? pack_bf16(y[0], y[1]) : 0u;
-        o.y = inside ? pack_bf16(y[2], y[3]) : 0u;
-        o.z = inside ? pack_bf16(y[4], y[5]) : 0u;
-        o.w = inside ? pack_bf16(y[6], y[7]) : 0u;
+        {
+            const float x0 = bf2f((unsigned short)(v.x & 0xffff)), x1 = bf2f((unsigned short)(v.x >> 16));
+            const float x2 = bf2f((unsigned short)(v.y & 0xffff)), x3 = bf2f((unsigned short)(v.y >> 16));
+            const float y0 = fmaxf((x0 - gmean) * grstd * gq[0] + bq[0], 0.f), y1 = fmaxf((x1 - gmean) * grstd * gq[1] + bq[1], 0.f);      // expression of gn_apply_kernel
+            const float y2 = fmaxf((x2 - gmean) * grstd * gq[2] + bq[2], 0.f), y3 = fmaxf((x3 - gmean) * grstd * gq[3] + bq[3], 0.f);
+            o.x = inside ? pack_bf16(y0, y1) : 0u;
+            o.y = inside ? pack_bf16(y2, y3) : 0u;
+        }
+        asm volatile("ds_read_b128 %0, %2 offset:16\n\tds_read_b128 %1, %3 offset:16\n\ts_waitcnt lgkmcnt(0)"
+                     : "=&v"(gq), "=&v"(bq)
+                     : "v"(tg), "v"(tb)
+                     : "memory");
+        {
+            const float x0 = bf2f((unsigned short)(v.z & 0xffff)), x1 = bf2f((unsigned short)(v.z >> 16));
+            const float x2 = bf2f((unsigned short)(v.w & 0xffff)), x3 = bf2f((unsigned short)(v.w >> 16));
+            const float y0 = fmaxf((x0 - gmean) * grstd * gq[0] + bq[0], 0.f), y1 = fmaxf((x1 - gmean) * grstd * gq[1] + bq[1], 0.f);
+            const float y2 = fmaxf((x2 - gmean) * grstd * gq[2] + bq[2], 0.f), y3 = fmaxf((x3 - gmean) * grstd * gq[3] + bq[3], 0.f);
+            o.z = inside ? pack_bf16(y0, y1) : 0u;
+            o.w = inside ? pack_bf16(y2, y3) : 0u;
+        }
         asm volatile("ds_write_b128 %0, %1" ::"v"(ad), "v"(o) : "memory");
     };
+    // statistics (mean, rstd of the 32 groups) of tile c's image -> stat buffer b: one 256-byte DMA piece, issued by every wave
+    auto stat_piece = [&](const RpTile& c, int b) {
+        const float* st = P.in_stats + ((size_t)c.si * P.N + c.img) * (kRCin / 8) * 2;
+        __builtin_amdgcn_global_load_lds((gvoid*)(st + lane), (lvoid*)(lds + kROffStat + b * 256), 4, 0, 0);
+    };
 
-    // ---- B fragment offsets: patch row p (0..5) at tap column kw (0..2): pixel pp = p * 34 + kw + frow; k16 step kc reads
-    // the 16-byte chunk (2 kc + half) ^ sw, sw = (pp >> 1) & 7, i.e. pb ^ (kc << 5) with
-    // pb = pp * 128 | ((half ^ (sw & 1)) << 4) | ((sw >> 1) << 5)
-    unsigned pb[kRRows * 3];
+    // ---- B fragment offsets: patch row p (0..5) at tap column kw (0..2): pixel p * 34 + q, q = kw + frow; k16 step kc reads
+    // the 16-byte chunk (2 kc + half) ^ sw, sw = (q >> 1) & 7, i.e. (pb[kw] ^ (kc << 5)) + p * 34 * 128 with
+    // pb[kw] = q * 128 | ((half ^ (sw & 1)) << 4) | ((sw >> 1) << 5)
+    unsigned pb[3];
 #pragma unroll
-    for (int p = 0; p < kRRows; p++)
-#pragma unroll
-        for (int kw = 0; kw < 3; kw++) {
-            const int pp = p * kRCols + kw + frow;
-            const int sw = (pp >> 1) & 7;
-            pb[p * 3 + kw] = (unsigned)(pp * 128 + ((half ^ (sw & 1)) << 4) + ((sw >> 1) << 5));
-        }
+    for (int kw = 0; kw < 3; kw++) {
+        const int q = kw + frow;
+        const int sw = (q >> 1) & 7;
+        pb[kw] = (unsigned)(q * 128 + ((half ^ (sw & 1)) << 4) + ((sw >> 1) << 5));
+    }
 
-    const char* wf = P.w + (size_t)nt * (NW * kRSteps * 1024);
     const unsigned voff = (unsigned)(wave * kRSteps * 1024 + lane * 16);
     bf16x8 ar[kRRing];
-    auto load_step = [&](auto J) { rp_load<decltype(J)::value>(ar, wf, voff); };
     auto barrier = [&]() {
         __builtin_amdgcn_sched_barrier(0);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -2009,131 +2089,286 @@ __global__ void __launch_bounds__(512, 2) conv3x3_rp_kernel(ConvDev P) {
         __builtin_amdgcn_sched_barrier(0);
     };
 
-    // ---- prologue
-#pragma unroll
-    for (int ii = 0; ii < 4; ii++) patch_piece(0, ii);
-    rp_static_for<0, kRRing>(load_step);
-    if (GNIN) {
-        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");      // this wave's slab-0 pieces have landed (the 8 A loads are younger)
-#pragma unroll
-        for (int ii = 0; ii < 4; ii++) gn_piece(0, ii);
-    }
-    f32x16 acc[4];
-#pragma unroll
-    for (int b = 0; b < 4; b++)
-#pragma unroll
-        for (int k = 0; k < 16; k++) acc[b][k] = 0.f;
-
-    rp_static_for<0, kRSteps>([&](auto J) {
-        constexpr int j = decltype(J)::value;
-        constexpr int sl = j / 36, t = j % 36, kh = t / 12, kw = (t >> 2) % 3, kc = t & 3;
-        rp_wait_for<j>(ar);
-        if constexpr (j == 0) { barrier(); RP_STAMP(1); }   // slab 0 of every wave has landed (and is normalised)
-        if constexpr (j == 36) barrier();            // slabs 1..3: landed by each wave's wait at step 20, normalised by step 24
-        // GN_INPUT: the pieces issued at steps 4(sl-1) .. 4(sl-1)+3 are covered by the wait of step 12 + 4(sl-1)
-        if constexpr (GNIN && j >= 13 && j < 25) gn_piece(1 + (j - 13) / 4, (j - 13) & 3);
-        bf16x8 bfr[4];
-#pragma unroll
-        for (int r = 0; r < 4; r++)
-            bfr[r] = *(const bf16x8*)(lds + ((pb[(r + kh) * 3 + kw] ^ (unsigned)(kc << 5)) + (unsigned)(sl * kRSlab)));
-#pragma unroll
-        for (int r = 0; r < 4; r++) acc[r] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ar[j % kRRing], bfr[r], acc[r], 0, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);
-        load_step(std::integral_constant<int, j + kRRing>{});
-        if constexpr (j < kRTrickle) patch_piece(1 + j / 4, j & 3);
-    });
-
-    // ------------------------------------------------------------ epilogue (bias, ReLU, GN sums, bf16)
     const bool relu = P.flags & DAFNE_CONV_RELU;
     const bool gn = P.flags & DAFNE_CONV_GN_STATS;
     const bool fin = gn && (P.flags & DAFNE_CONV_GN_FINALIZE);     // wave-uniform
-    float fin_sq[2] = {0.f, 0.f};
-    bool fin_writer = false;
-    char* stg = lds;
-    float* redb = (float*)(lds + kROffRed);   // [32 groups][2]
-    float4 bia4[4];
+    const int G8 = P.Cout / 8;
+
+    // ---- prologue: layer constants -> LDS (plain loads: nothing asynchronous is in flight yet), first tile's patch
+    RpTile cur = decode(pos);
+    {
+        float* gb = (float*)(lds + kROffGB);
+        float* lb = (float*)(lds + kROffBias);
+        if (GNIN && tid < kRCin) {
+            gb[tid] = P.in_gamma[tid];
+            gb[kRCin + tid] = P.in_beta[tid];
+        }
+        for (int k = tid; k < P.Cout; k += NT) lb[k] = P.bias[k];
+        if (GNIN && tid < 64) ((float*)(lds + kROffStat))[tid] = (P.in_stats + ((size_t)cur.si * P.N + cur.img) * (kRCin / 8) * 2)[tid];
+        __syncthreads();
+    }
+    patch_map(cur);
 #pragma unroll
-    for (int g = 0; g < 4; g++) bia4[g] = *(const float4*)(P.bias + nt * 256 + wave * 32 + 8 * g + 4 * half);
-    float gsum[4], gsq[4];
+    for (int sl = 0; sl < 4; sl++)
+#pragma unroll
+        for (int ii = 0; ii < 4; ii++) patch_piece(sl, ii);
+    {
+        const char* wf0 = P.w + (size_t)cur.nt * (NW * kRSteps * 1024);
+        rp_static_for<0, kRRing>([&](auto J) { rp_load<decltype(J)::value>(ar, wf0, wf0, voff); });
+    }
+    if (GNIN) {
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");      // this wave's 16 patch pieces have landed (the 8 A loads are younger)
+#pragma unroll
+        for (int sl = 0; sl < 4; sl++)
+#pragma unroll
+            for (int ii = 0; ii < 4; ii++) gn_piece(cur, sl, ii, 0);
+    }
+
+    f32x16 acc[4];
+    bf16x8 bfr[2][4];
+    float gsum[4], gsq[4];                    // GroupNorm sums of the previous tile (this wave's 4 groups), reduced in steps 1..8
 #pragma unroll
     for (int g = 0; g < 4; g++) gsum[g] = gsq[g] = 0.f;
-    RP_STAMP(2);
-    __syncthreads();   // every wave is done with the patch
-    RP_STAMP(3);
-#pragma unroll
-    for (int b = 0; b < 4; b++) {
-        const int px = b * 32 + frow;
-        const bool valid = (Y0 + b) < H && (X0 + frow) < W;
-#pragma unroll
-        for (int g = 0; g < 4; g++) {
-            float v0 = acc[b][4 * g] + bia4[g].x, v1 = acc[b][4 * g + 1] + bia4[g].y;
-            float v2 = acc[b][4 * g + 2] + bia4[g].z, v3 = acc[b][4 * g + 3] + bia4[g].w;
-            if (relu) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f); }
-            if (gn && valid) {
-                gsum[g] += (v0 + v1) + (v2 + v3);
-                gsq[g] += (v0 * v0 + v1 * v1) + (v2 * v2 + v3 * v3);
-            }
-            uint2 pk;
-            pk.x = pack_bf16(v0, v1);
-            pk.y = pack_bf16(v2, v3);
-            *(uint2*)(stg + px * kRRowB + (wave * 32 + 8 * g + 4 * half) * 2) = pk;
-        }
-    }
-    if (gn) {
-        // deterministic: butterfly over the wave (32 pixel columns x 2 channel halves); the wave holds all 128 pixels
-#pragma unroll
-        for (int g = 0; g < 4; g++) {
-            float sv = gsum[g], qv = gsq[g];
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) {
-                sv += __shfl_xor(sv, o, 64);
-                qv += __shfl_xor(qv, o, 64);
-            }
-            if (lane == 0) {
-                redb[(wave * 4 + g) * 2 + 0] = sv;
-                redb[(wave * 4 + g) * 2 + 1] = qv;
-            }
-        }
-    }
-    __syncthreads();
-    if (gn && tid < 32) {
-        const float sv = redb[tid * 2 + 0], qv = redb[tid * 2 + 1];
-        const int group = (nt * 256) / 8 + tid;
-        if (fin) {
-            fin_sq[0] = sv;
-            fin_sq[1] = qv;
-            fin_writer = true;
-        } else {
-            float* o = P.gn_partial + ((size_t)mt * (P.Cout / 8) + group) * 2;
-            o[0] = sv;
-            o[1] = qv;
-        }
-    }
-#pragma unroll
-    for (int i = 0; i < kRPx * 32 / NT; i++) {       // 16-byte chunks: 128 px x 32 per thread block pass
-        const int idx = tid + i * NT;
-        const int p = idx >> 5, cc = idx & 31;
-        const int gy = Y0 + (p >> 5), gx = X0 + (p & 31);
-        if (gy < H && gx < W) {
-            const size_t opix = (size_t)(img * Hp + gy + 1) * Wp + gx + 1;
-            const uint4 v = *(const uint4*)(stg + p * kRRowB + cc * 16);
-            *(uint4*)(S.out + (opix * P.Cout + nt * 256 + cc * 8) * 2) = v;
-        }
-    }
-    if (fin) {
-        __syncthreads();                     // the staging tile has been read: its LDS is free for the reduction
-        gn_fused_finalize(P, S, si, img, mt, fin_sq, fin_writer, tid, (float*)lds, (int*)(lds + 32 * 32 * 2 * 4));
-    }
+    RpTile prv = cur;
+    prv.valid = 0;
+
 #ifdef DAFNE_RP_TIMING
-    RP_STAMP(4);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    RP_STAMP(5);
-    if (tid == 0 && blockIdx.x < 2048) {      // rows 4096.. of the partial buffer (scratch/rp_micro.py allocates 8192)
-        unsigned long long* o = (unsigned long long*)(P.gn_partial + (size_t)4096 * 64) + blockIdx.x * 8;
-        for (int k = 0; k < 6; k++) o[k] = rp_ts[k];
-        o[6] = __builtin_amdgcn_s_memrealtime();
-    }
+    unsigned long long rp_ts[8];
+#define RP_STAMP(i) rp_ts[i] = __builtin_amdgcn_s_memtime()
+#else
+#define RP_STAMP(i)
 #endif
+    // the GroupNorm partial sums of the previous tile: behind a barrier that follows the redb writes of step 9
+    auto gn_publish = [&]() {
+        if (gn && prv.valid && tid < 32) {
+            int td = tid;
+            asm volatile("" : "+v"(td));              // (a hoisted tid * 8 spills: its reload would drain vmcnt)
+            const float* redb = (const float*)(lds + kROffRed);
+            const float sv = redb[td * 2 + 0], qv = redb[td * 2 + 1];
+            float* o = P.gn_partial + ((size_t)prv.mt * G8 + prv.nt * 32 + td) * 2;
+            if (fin) {
+                typedef unsigned long long u64a;
+                const u64a vv = ((u64a)__float_as_uint(qv) << 32) | (u64a)__float_as_uint(sv);
+                __hip_atomic_store((u64a*)o, vv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            } else {
+                o[0] = sv;
+                o[1] = qv;
+            }
+        }
+    };
+    auto gn_ticket = [&]() {
+        if (fin && tid == 0) {
+            int last = 0;
+            if (prv.valid) {
+                const int old = __hip_atomic_fetch_add(P.gn_counters + prv.si * P.N + prv.img, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                last = old == P.seg[prv.si].tiles_per_img - 1;
+            }
+            *(int*)(lds + kROffRed + 256) = last;
+        }
+    };
+    // the last tile of an image to arrive reduces all its partials in gn_finalize_kernel's order (cf. gn_fused_finalize);
+    // every thread of the workgroup calls this behind a barrier that follows gn_ticket
+    auto gn_last_tile = [&]() {
+        if (fin && *(const int*)(lds + kROffRed + 256)) {
+            typedef unsigned long long u64a;
+            const SegDev& S = P.seg[prv.si];
+            float* scratch = (float*)(lds + kROffFin);
+            const int t0 = S.tile0 + prv.img * S.tiles_per_img;
+            const int g = tid & 31;
+#pragma unroll
+            for (int kk = 0; kk < 2; kk++) {
+                const int sl2 = (tid >> 5) + 16 * kk;
+                float sum = 0.f, sqs = 0.f;
+                if (g < G8)
+                    for (int tt = sl2; tt < S.tiles_per_img; tt += 32) {
+                        const u64a vv = __hip_atomic_load((const u64a*)(P.gn_partial + ((size_t)(t0 + tt) * G8 + g) * 2), __ATOMIC_RELAXED,
+                                                          __HIP_MEMORY_SCOPE_AGENT);
+                        sum += __uint_as_float((unsigned)vv);
+                        sqs += __uint_as_float((unsigned)(vv >> 32));
+                    }
+                scratch[(sl2 * 32 + g) * 2 + 0] = sum;
+                scratch[(sl2 * 32 + g) * 2 + 1] = sqs;
+            }
+            __syncthreads();
+            if (tid < 32 && tid < G8) {
+                float a = 0.f, b = 0.f;
+#pragma unroll
+                for (int kk = 0; kk < 32; kk++) {
+                    a += scratch[(kk * 32 + tid) * 2 + 0];
+                    b += scratch[(kk * 32 + tid) * 2 + 1];
+                }
+                const float cnt = (float)(S.Hout * S.Wout * 8);
+                const float mean = a / cnt;
+                float var = b / cnt - mean * mean;
+                var = var > 0.f ? var : 0.f;
+                float* o = P.gn_stats_out + (((size_t)prv.si * P.N + prv.img) * G8 + tid) * 2;
+                o[0] = mean;
+                o[1] = rsqrtf(var + P.gn_eps);
+            }
+            if (tid == 0) __hip_atomic_store(P.gn_counters + prv.si * P.N + prv.img, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __syncthreads();
+        }
+    };
+    auto gn_reduce_write = [&]() {             // after the 8 rp_wave_total: lane 63 holds the wave's sums
+        if (gn && lane == 63) {
+            float* redb = (float*)(lds + kROffRed);
+#pragma unroll
+            for (int g = 0; g < 4; g++) {
+                redb[(wave * 4 + g) * 2 + 0] = gsum[g];
+                redb[(wave * 4 + g) * 2 + 1] = gsq[g];
+            }
+        }
+    };
+
+    for (int k = 0; k < nmine; k++) {
+        const bool first = k == 0;
+        RP_STAMP(0);
+#ifdef DAFNE_RP_TIMING
+        const unsigned long long rp_rt0 = __builtin_amdgcn_s_memrealtime();
+#endif
+        const RpTile nxt = decode(pos + (k + 1 < nmine ? k + 1 : k) * G);     // the last tile re-fetches itself (nobody reads it)
+        const char* wf_cur = P.w + (size_t)cur.nt * (NW * kRSteps * 1024);
+        const char* wf_nxt = P.w + (size_t)nxt.nt * (NW * kRSteps * 1024);
+        const int sb_cur = k & 1, sb_nxt = (k + 1) & 1;
+#pragma unroll
+        for (int b = 0; b < 4; b++)
+#pragma unroll
+            for (int kk = 0; kk < 16; kk++) acc[b][kk] = 0.f;
+
+        rp_static_for<0, kRSteps>([&](auto J) {
+            constexpr int j = decltype(J)::value;
+            constexpr int sl = j / 36, t = j % 36, kh = t / 12, kw = (t >> 2) % 3, kc = t & 3;
+            rp_wait_for<j, GNIN>(ar, first);
+            if constexpr (j == 0 || j == 36 || j == 72 || j == 108) {
+                barrier();
+                if constexpr (j == 0) RP_STAMP(1);
+                if constexpr (j == 36) RP_STAMP(2);
+                if constexpr (j == 72) RP_STAMP(3);
+                if constexpr (j == 108) RP_STAMP(4);
+            }
+            // ---- GN_INPUT: pieces this wave loaded ~13 steps ago
+            if constexpr (GNIN) {
+                if constexpr (j >= 13 && j < 17) { if (!first) gn_piece(cur, 3, j - 13, sb_cur); }
+                if constexpr (j >= 53 && j < 57) gn_piece(nxt, 0, j - 53, sb_nxt);
+                if constexpr (j >= 89 && j < 93) gn_piece(nxt, 1, j - 89, sb_nxt);
+                if constexpr (j >= 125 && j < 129) gn_piece(nxt, 2, j - 125, sb_nxt);
+            }
+            if constexpr (j == 37) patch_map(nxt);
+            // ---- the previous tile's GroupNorm sums
+            if constexpr (j >= 1 && j < 9) {
+                if (gn) {
+                    constexpr int g = (j - 1) >> 1;
+                    if constexpr (((j - 1) & 1) == 0) gsum[g] = rp_wave_total(gsum[g]);
+                    else gsq[g] = rp_wave_total(gsq[g]);
+                }
+            }
+            if constexpr (j == 9) gn_reduce_write();
+            if constexpr (j == 38) gn_publish();               // behind the barrier of step 36: the sums of all 32 groups
+            if constexpr (j == 50) gn_ticket();                // wave 0's waits since step 47 cover its partial-sum stores of step 38
+            if constexpr (j == 73) gn_last_tile();             // behind the barrier of step 72
+            // ---- this tile's matrix work.  The B fragments of step j + 1 are requested before the MFMAs of step j (two register
+            // sets; hipcc serialised read -> wait -> MFMA four times per step on one set); the counted lgkmcnt leaves exactly
+            // those four reads in flight (other LDS / scalar-memory operations in flight only make the wait stricter)
+            if constexpr (j == 0) rp_bread<0>(bfr[0], pb, lds_base);
+            if constexpr (j + 1 < kRSteps) {
+                rp_bread<j + 1>(bfr[(j + 1) & 1], pb, lds_base);
+                asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(bfr[j & 1][0]), "+v"(bfr[j & 1][1]), "+v"(bfr[j & 1][2]), "+v"(bfr[j & 1][3]) :: "memory");
+            } else {
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(bfr[j & 1][0]), "+v"(bfr[j & 1][1]), "+v"(bfr[j & 1][2]), "+v"(bfr[j & 1][3]) :: "memory");
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int r = 0; r < 4; r++) acc[r] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ar[j % kRRing], bfr[j & 1][r], acc[r], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            rp_load<j + kRRing>(ar, wf_cur, wf_nxt, voff);
+            // ---- counted vector-memory operations behind the weight load (rp_post)
+            if constexpr (GNIN && j == 37) stat_piece(nxt, sb_nxt);
+            if constexpr (j >= 40 && j < 44) patch_piece(0, j - 40);
+            if constexpr (j >= 76 && j < 80) patch_piece(1, j - 76);
+            if constexpr (j >= 112 && j < 116) patch_piece(2, j - 112);
+            __builtin_amdgcn_sched_barrier(0);
+        });
+        RP_STAMP(5);
+        // ---- end of tile: slab 3 of the next tile, then this tile's epilogue
+        barrier();                                             // every wave is done with slab 3
+        RP_STAMP(6);
+#pragma unroll
+        for (int ii = 0; ii < 4; ii++) patch_piece(3, ii);
+        {
+            f32x4 bia4[4];
+            const unsigned bad = lds_base + (unsigned)(kROffBias + (cur.nt * 256 + wave * 32 + 4 * half) * 4);
+            asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:32\n\tds_read_b128 %2, %4 offset:64\n\tds_read_b128 %3, %4 offset:96\n\t"
+                         "s_waitcnt lgkmcnt(0)"
+                         : "=&v"(bia4[0]), "=&v"(bia4[1]), "=&v"(bia4[2]), "=&v"(bia4[3])
+                         : "v"(bad)
+                         : "memory");
+#pragma unroll
+            for (int g = 0; g < 4; g++) gsum[g] = gsq[g] = 0.f;
+            // output row of this lane: pixel (Y0 + b, X0 + frow), 16 bytes at channel nt*256 + wave*32 + 8*(2 gp + half)
+            const int Wp = cur.W + 2;
+            const size_t rowpitch = (size_t)Wp * P.Cout * 2;
+            char* obase = P.seg[cur.si].out + ((size_t)(cur.img * (cur.H + 2) + cur.Y0 + 1) * Wp + cur.X0 + frow + 1) * P.Cout * 2
+                          + (cur.nt * 256 + wave * 32 + 8 * half) * 2;
+            char* dbase = dump + (size_t)tid * 128;
+            const bool colok = cur.valid && (cur.X0 + frow) < cur.W;
+#pragma unroll
+            for (int b = 0; b < 4; b++) {
+                const bool valid = colok && (cur.Y0 + b) < cur.H;
+                u32x2 pk[4];
+#pragma unroll
+                for (int g = 0; g < 4; g++) {
+                    float v0 = acc[b][4 * g] + bia4[g][0], v1 = acc[b][4 * g + 1] + bia4[g][1];
+                    float v2 = acc[b][4 * g + 2] + bia4[g][2], v3 = acc[b][4 * g + 3] + bia4[g][3];
+                    if (relu) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f); }
+                    if (gn && valid) {
+                        gsum[g] += (v0 + v1) + (v2 + v3);
+                        gsq[g] += (v0 * v0 + v1 * v1) + (v2 * v2 + v3 * v3);
+                    }
+                    pk[g].x = pack_bf16(v0, v1);
+                    pk[g].y = pack_bf16(v2, v3);
+                }
+#pragma unroll
+                for (int gp = 0; gp < 2; gp++) {
+                    // lanes 0..31 get (group 2gp: own channels 0..3 | the upper half-wave's 4..7), lanes 32..63 the same of group 2gp+1
+                    u32x2 a = pk[2 * gp], c2 = pk[2 * gp + 1];
+                    const auto r0 = __builtin_amdgcn_permlane32_swap(a.x, c2.x, false, false);
+                    const auto r1 = __builtin_amdgcn_permlane32_swap(a.y, c2.y, false, false);
+                    const u32x4 v = {r0[0], r1[0], r0[1], r1[1]};
+                    char* ad = valid ? obase + b * rowpitch + gp * 32 : dbase + (b * 2 + gp) * 16;
+                    *(u32x4*)ad = v;
+                }
+            }
+        }
+        prv = cur;
+        cur = nxt;
+#ifdef DAFNE_RP_TIMING
+        RP_STAMP(7);
+        if (tid == 0 && k == 2) {                 // the third tile of every workgroup: steady state
+            unsigned long long* o = (unsigned long long*)(P.gn_partial + (size_t)4096 * 64) + blockIdx.x * 16;
+            for (int q = 0; q < 8; q++) o[q] = rp_ts[q];
+            o[8] = rp_rt0;
+            o[9] = __builtin_amdgcn_s_memrealtime();
+        }
+#endif
+    }
+
+    // ---- the last tile's GroupNorm sums, straight-line
+    if (gn) {
+#pragma unroll
+        for (int g = 0; g < 4; g++) {
+            gsum[g] = rp_wave_total(gsum[g]);
+            gsq[g] = rp_wave_total(gsq[g]);
+        }
+        gn_reduce_write();
+        barrier();
+        gn_publish();
+        if (fin) {
+            if (tid < 64) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // wave 0's partial-sum stores are complete
+            gn_ticket();
+            barrier();
+            gn_last_tile();
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------------------
@@ -2836,7 +3071,7 @@ bool slab_eligible(const dafne_conv_params* p, const dafne_conv_seg* segs) {
 
 // shape conditions of the resident-patch kernel (conv3x3_rp_kernel)
 bool rp_shape_ok(const dafne_conv_params* p, const dafne_conv_seg* segs) {
-    if (!patch_shape_ok(p, segs) || p->Cin != kRCin) return false;
+    if (!patch_shape_ok(p, segs) || p->Cin != kRCin || p->Cout > kRMaxCout) return false;
     for (int s = 0; s < p->n_segs; s++)
         if ((long long)p->n_images * (segs[s].Hout + 2) * (segs[s].Wout + 2) * (kRCin * 2) > 0xffffffffll) return false;
     return true;
@@ -2996,11 +3231,21 @@ int launch_patch_fp8(const ConvDev& D, hipStream_t st) {
     return dafne::check_launch("conv3x3_patch_fp8");
 }
 
-int launch_rp(const ConvDev& D, hipStream_t st) {
+int launch_rp(const ConvDev& D, char* dump, hipStream_t st) {
     DAFNE_MAX_LDS_ONCE(kRSmem, (const void*)conv3x3_rp_kernel<false>, (const void*)conv3x3_rp_kernel<true>);
-    const dim3 grid(D.mtiles * D.ntiles), block(512);
-    if (D.flags & DAFNE_CONV_GN_INPUT) hipLaunchKernelGGL(conv3x3_rp_kernel<true>, grid, block, kRSmem, st, D);
-    else hipLaunchKernelGGL(conv3x3_rp_kernel<false>, grid, block, kRSmem, st, D);
+    int cus = 0;                                           // persistent: at most one workgroup per CU, tiles dealt round-robin
+    if (int rc = dafne::device_cus(&cus)) return rc;
+    const int T = D.mtiles * D.ntiles;
+    // balanced: with R = ceil(T / CUs) rounds, ceil(T / R) workgroups do R (or R - 1) tiles each -- no half-empty last round
+    // (348 tiles: 174 workgroups x 2, not 256 of which 92 do a second tile), and the CUs left over stay free for the
+    // kernels of the other sub-batch streams
+    static const int cap = getenv("DAFNE_RP_GRID") ? atoi(getenv("DAFNE_RP_GRID")) : 0;
+    const int lim = cap > 0 && cap < cus ? cap : cus;
+    const int rounds = (T + lim - 1) / lim;
+    const int G = (T + rounds - 1) / rounds;
+    const dim3 grid(G), block(512);
+    if (D.flags & DAFNE_CONV_GN_INPUT) hipLaunchKernelGGL(conv3x3_rp_kernel<true>, grid, block, kRSmem, st, D, dump);
+    else hipLaunchKernelGGL(conv3x3_rp_kernel<false>, grid, block, kRSmem, st, D, dump);
     return dafne::check_launch("conv3x3_rp");
 }
 
@@ -3130,13 +3375,17 @@ int dafne_conv3x3_c256_tiles_per_image(const dafne_conv_params* prm, const dafne
     return DAFNE_OK;
 }
 
-int dafne_conv3x3_c256_hip(const dafne_conv_params* prm, const dafne_conv_seg* segs, const void* d_wfrag, void* stream) {
+size_t dafne_conv3x3_c256_scratch_bytes(void) { return (size_t)kRDumpBytes; }
+
+int dafne_conv3x3_c256_hip(const dafne_conv_params* prm, const dafne_conv_seg* segs, const void* d_wfrag, void* d_scratch,
+                           size_t scratch_bytes, void* stream) {
     ConvDev D;
     int rc = build(D, prm, segs, false, true);
     if (rc) return rc;
     if (!d_wfrag) return dafne::fail(DAFNE_E_INVALID, "conv3x3_c256: null fragment-major weights");
+    if (!d_scratch || scratch_bytes < (size_t)kRDumpBytes) return dafne::fail(DAFNE_E_WORKSPACE, "conv3x3_c256: scratch %zu < %d", scratch_bytes, kRDumpBytes);
     D.w = (const char*)d_wfrag;
-    return launch_rp(D, (hipStream_t)stream);
+    return launch_rp(D, (char*)d_scratch, (hipStream_t)stream);
 }
 
 int dafne_conv2d_kernel_id(const dafne_conv_params* prm, const dafne_conv_seg* segs) {

@@ -205,6 +205,17 @@ def pack_conv3x3_frag(w):
     return w.reshape(cout // 256, 8, 32, 144, 2, 8).permute(0, 1, 3, 4, 2, 5).contiguous().reshape(-1)   # nt, w, j, h, r, e
 
 
+_RP_SCRATCH = {}
+
+
+def rp_scratch(device):
+    """Dump area of dafne_conv3x3_c256_hip (rows of out-of-image tile pixels; contents are never read): one per device."""
+    key = str(device)
+    if key not in _RP_SCRATCH:
+        _RP_SCRATCH[key] = torch.empty(_lib.load().dafne_conv3x3_c256_scratch_bytes(), dtype=torch.uint8, device=device)
+    return _RP_SCRATCH[key]
+
+
 def use_rp_kernel():
     """conv3x3_rp_kernel (resident patch, weights streamed to registers) for the 256-channel 3x3 layers; DAFNE_CONV_RP=0
     keeps them on conv3x3_patch_kernel (A/B runs)."""
@@ -327,7 +338,8 @@ class ConvCall:
                 _lib.check(rc, "dafne_conv2d_nhwc_fp8w_hip")
             return
         if self.wfrag is not None:
-            rc = _lib.load().dafne_conv3x3_c256_hip(ctypes.byref(self.prm), self.segs, _lib.ptr(self.wfrag), stream)
+            scr = rp_scratch(self.wfrag.device)
+            rc = _lib.load().dafne_conv3x3_c256_hip(ctypes.byref(self.prm), self.segs, _lib.ptr(self.wfrag), _lib.ptr(scr), scr.numel(), stream)
             if rc:
                 _lib.check(rc, "dafne_conv3x3_c256_hip")
             return

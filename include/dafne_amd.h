@@ -245,13 +245,17 @@ int dafne_conv2d_nhwc_bf16_hip(const dafne_conv_params* prm, const dafne_conv_se
  * a finalised mean / rstd may differ from the other kernel's in the last bit).  prm->d_weight is ignored; d_wfrag: bf16
  * [Cout/256][8 waves][144 k16 steps][64 lanes][8] = rows nt*256 + wave*32 + (lane & 31), K columns 16*step +
  * 8*(lane >> 5) .. +8 of the packed weight [Cout][Cin/64][KH][KW][64]  (engine.pack_conv3x3_frag).
- * Shapes: Cin == 256, Cout % 256 == 0, bias, bf16 output, no residual / top-down add; else DAFNE_E_UNSUPPORTED
- * (dafne_conv3x3_c256_ok: 1 / 0).
+ * The kernel is persistent (one workgroup per CU walks the tiles) and never predicates a store: rows of out-of-image
+ * tile pixels go to d_scratch (>= dafne_conv3x3_c256_scratch_bytes(); holds nothing afterwards; may be shared by calls).
+ * Shapes: Cin == 256, Cout % 256 == 0, Cout <= 1024, bias, bf16 output, no residual / top-down add; else
+ * DAFNE_E_UNSUPPORTED (dafne_conv3x3_c256_ok: 1 / 0).
  */
 int dafne_conv3x3_c256_ok(const dafne_conv_params* prm, const dafne_conv_seg* segs);
 int dafne_conv3x3_c256_num_tiles(const dafne_conv_params* prm, const dafne_conv_seg* segs);
 int dafne_conv3x3_c256_tiles_per_image(const dafne_conv_params* prm, const dafne_conv_seg* segs, int32_t* out);
-int dafne_conv3x3_c256_hip(const dafne_conv_params* prm, const dafne_conv_seg* segs, const void* d_wfrag, void* stream);
+size_t dafne_conv3x3_c256_scratch_bytes(void);
+int dafne_conv3x3_c256_hip(const dafne_conv_params* prm, const dafne_conv_seg* segs, const void* d_wfrag, void* d_scratch,
+                           size_t scratch_bytes, void* stream);
 /*
  * fp8-weight twin (BASELINE config 5: "fp8 weights, CDNA4 fp8 MFMA conv path"; SURVEY 8(b) item 5
  * dafne_conv2d_nhwc_{bf16,fp8w}_hip).  The reference has no fp8 path: this entry DEFINES it.

@@ -49,14 +49,14 @@ for name in names:
     print("%-14s %.1f us (median %.1f)  %.0f TFLOP/s   tiles %d" % (name, min(v) * 1e3, sorted(v)[1] * 1e3, flops / (min(v) * 1e-3) / 1e12,
                                                                    sets[0][names.index(name)].num_tiles()))
 if os.environ.get("DAFNE_RP_STAMPS"):
-    # a -DDAFNE_RP_TIMING library: per-workgroup stamps of the LAST launch of "rp plain" land in rows 4096.. of its partial buffer
+    # a -DDAFNE_RP_TIMING library: stamps of the THIRD tile of every workgroup (steady state) land in rows 4096.. of the partial buffer
     part = sets[(12 - 1) % NI][3].keep[2]
     torch.cuda.synchronize()
     part.zero_(); sets[(12 - 1) % NI][3](st); torch.cuda.synchronize()
-    s = part.view(-1)[4096 * 64:].view(torch.int64)[:1392 * 8].reshape(1392, 8).cpu()
-    d1 = (s[:, 1] - s[:, 0]).float(); d2 = (s[:, 2] - s[:, 1]).float(); d3 = (s[:, 3] - s[:, 2]).float()
-    d4 = (s[:, 4] - s[:, 3]).float(); d5 = (s[:, 5] - s[:, 4]).float()
-    print("cycles (median over 1392 workgroups): prologue->slab0 %d | main loop %d | barrier %d | epilogue %d | store drain %d | total %d"
-          % (d1.median(), d2.median(), d3.median(), d4.median(), d5.median(), (s[:, 5] - s[:, 0]).float().median()))
-    rt = s[:, 6]
-    print("launch span %.1f us (100 MHz realtime)" % ((rt.max() - rt.min()).item() / 100.0))
+    s = part.view(-1)[4096 * 64:].view(torch.int64)[:256 * 16].reshape(256, 16).cpu()
+    d = (s[:, 1:8] - s[:, 0:7]).float().median(dim=0).values.tolist()
+    tot = (s[:, 7] - s[:, 0]).float().median().item()
+    rt = (s[:, 9] - s[:, 8]).float().median().item()          # 100 MHz ticks
+    print("cycles, median over 256 workgroups (third tile): decode..step0 barrier %d | steps 0-35 %d | 36-71 %d | 72-107 %d | 108-143 %d | end barrier %d | slab3 DMA + epilogue %d | total %d"
+          % (d[0], d[1], d[2], d[3], d[4], d[5], d[6], tot))
+    print("tile wall time %.2f us -> shader clock %.2f GHz" % (rt / 100.0, tot / (rt * 10.0)))

@@ -743,7 +743,8 @@ def test_resident_patch_kernel_shape_rules():
     c = engine.ConvCall(wp, bp, 256, 256, 3, 1, 1, engine.F_RES, [(a.t, o.t, o.t, 8, 8, 8, 8)], 1)
     assert not c.rp_ok()                                  # residual epilogue
     with pytest.raises(_lib.DafneHipError):
-        _lib.check(_lib.load().dafne_conv3x3_c256_hip(ctypes.byref(c.prm), c.segs, _lib.ptr(wp), _lib.current_stream()), "c256")
+        scr = engine.rp_scratch(d)
+        _lib.check(_lib.load().dafne_conv3x3_c256_hip(ctypes.byref(c.prm), c.segs, _lib.ptr(wp), _lib.ptr(scr), scr.numel(), _lib.current_stream()), "c256")
 
 
 def _gsegs(outs, tpis, N):
