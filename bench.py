@@ -48,7 +48,7 @@ PEAK_HBM_GBPS = 8000.0        # HBM3E spec (6.29 TB/s measured float4 copy, same
 GFLOP_PER_IMG = {50: 505.97, 101: 661.13}   # SURVEY 8(d), 1024^2, C=15
 
 
-def seeded_state_dict(model, seed):
+def seeded_state_dict(model, seed, tower_std=None):
     """Random-init weights of the architecture: He-normal convs, FrozenBN scale
     U(0.5,1.5) / shift N(0,0.1), head towers N(0, 0.03), class prior -4.595
     (dafne.py:269-285).  He init (instead of the reference's N(0,0.01) towers /
@@ -61,8 +61,8 @@ def seeded_state_dict(model, seed):
         if v.dim() == 4:
             fan_in = v.shape[1] * v.shape[2] * v.shape[3]
             std = (2.0 / fan_in) ** 0.5
-            if "_tower" in k:
-                std = (2.0 / fan_in) ** 0.5
+            if "_tower" in k and tower_std is not None:
+                std = tower_std               # dafne.py:269-285: the reference initialises the head convolutions N(0, 0.01)
             if any(t in k for t in ("cls_logits", "ctrness", "corners_pred", "center_pred")):
                 std = 0.01
             sd[k] = torch.randn(v.shape, generator=g) * std
@@ -83,7 +83,7 @@ def seeded_state_dict(model, seed):
     return sd
 
 
-def build_model(depth, device, seed=0, cfgname=None, cls_prior=None):
+def build_model(depth, device, seed=0, cfgname=None, cls_prior=None, tower_std=None):
     """cls_prior: class-logit bias instead of the reference's -4.595.  The configs that threshold the RAW class score
     (THRESH_WITH_CTR false: DOTA-1.5, UCAS-AOD, HRSC) yield no candidates at -4.595 with random weights; the side
     metrics on those configs raise it so that decode / NMS see full candidate sets."""
@@ -92,7 +92,7 @@ def build_model(depth, device, seed=0, cfgname=None, cls_prior=None):
     from dafne_amd.registry import build_model as bm
     cfg = load_cfg(os.path.join(ROOT, "configs", cfgname or "dota-1.0_r%d.yaml" % depth))
     m = bm(cfg)
-    sd = seeded_state_dict(m, seed)
+    sd = seeded_state_dict(m, seed, tower_std=tower_std)
     if cls_prior is not None:
         kb = "proposal_generator.dafne_head.cls_logits.bias"
         sd[kb] = torch.full_like(sd[kb], float(cls_prior))

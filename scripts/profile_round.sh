@@ -21,7 +21,7 @@ for mode in serial pipelined; do
   rm -rf $OUT/prof_$mode
 done
 if [ "$2" != "nopmc" ]; then
-  BENCH_FLAGS="--mode serial" PMC_ROUND=r02b bash $ROOT/scripts/pmc_passes.sh ${TAG}_isolated > $OUT/pmc_isolated.log 2>&1
+  BENCH_FLAGS="--mode serial" PMC_ROUND=${PMC_ROUND:-r03} bash $ROOT/scripts/pmc_passes.sh ${TAG}_isolated > $OUT/pmc_isolated.log 2>&1
   cp $ROOT/gpurun_out/pmc_${TAG}_isolated/summary.txt $OUT/pmc_isolated_summary.txt 2>/dev/null
   cp $ROOT/gpurun_out/pmc_${TAG}_isolated/pmc_traffic.json $OUT/pmc_traffic_isolated.json 2>/dev/null
   rm -rf $ROOT/gpurun_out/pmc_${TAG}_isolated/FETCH_SIZE $ROOT/gpurun_out/pmc_${TAG}_isolated/WRITE_SIZE $ROOT/gpurun_out/pmc_${TAG}_isolated/SQ_VALU_MFMA_BUSY_CYCLES

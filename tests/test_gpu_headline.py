@@ -6,15 +6,18 @@ At this size the library picks kernels / tile shapes the small-image tests never
 persistent 1x1 kernels with several tiles per workgroup, conv_b2b at 64x64, the 2/3/3 sub-batch split).
 
 Checked, for both execution modes:
-  (1) per-level FPN features and head outputs of image 0 vs oracle/model.py (fp32 and bf16-emulated): relative L2 at the
-      bf16 noise floor -- same bounds as tests/test_gpu_model.py::test_backbone_and_head_vs_oracle;
+  (1) per-level FPN features and head outputs of ONE IMAGE OF EVERY SUB-BATCH (images 0, 2, 5: the 2-image and the two
+      3-image plans pick different kernels) vs oracle/model.py (fp32 and bf16-emulated): relative L2 at the bf16 noise
+      floor -- same bounds as tests/test_gpu_model.py::test_backbone_and_head_vs_oracle;
   (2) final detections of ALL 8 images vs the oracle's decode / top-k / rotated NMS / cap / detector_postprocess applied
       to the engine's own head outputs: detection keys (level, location, class) bit-exact, scores within 1e-6, corners /
       boxes within 1e-3 (BASELINE.json north_star: "bit-exact for NMS indices, within 1e-3 on box coordinates/scores");
   (3) REPORTED (gpurun_out/headline_parity.json, quoted in DESIGN.md section 5) and bounded: the end-to-end deviation of
-      image 0's detections from the fp32 oracle run from the same uint8 image -- fraction of detections matched by key,
+      those images' detections from the fp32 oracle run from the same uint8 image -- fraction of detections matched by key,
       percentiles of |score delta| and |corner delta| on the matched ones -- next to the same figures for the oracle's
-      own bf16 emulation (the noise floor of ANY bf16 implementation of this 100+-layer network).
+      own bf16 emulation (the noise floor of ANY bf16 implementation of this 100+-layer network): match rate within 3
+      points of the emulation's, score / corner percentiles within 1.5 x.
+Two weight regimes: the weights bench.py times (He-normal) and the reference's own head initialisation (towers N(0, 0.01)).
 
 Reference path: dafne/modeling/one_stage_detector.py:45-55, dafne/modeling/dafne/dafne.py:350-494,
 dafne/modeling/backbone/fpn.py:58-91, dafne/modeling/dafne/dafne_outputs.py:733-925.
@@ -101,70 +104,98 @@ def _deviation(got, ref):
             "match_rate": float(len(common) / max(len(rk), 1)), "abs_score_delta": pct(ds), "abs_corner_delta_px": pct(dc)}
 
 
-@pytest.fixture(scope="module")
-def headline():
-    sys.path.insert(0, ROOT)
-    import bench
-    dev = torch.device("cuda", 0)
-    cfg, model, sd = bench.build_model(101, dev, seed=0)           # the weights bench.py times
-    g = torch.Generator().manual_seed(0)                            # ... and rank 0's images
-    batch = torch.randint(0, 256, (BATCH, 3, SIZE, SIZE), generator=g, dtype=torch.uint8)
-    P = {k: v.float() for k, v in sd.items()}
-    t0 = time.perf_counter()
+REGIMES = {
+    # the weights bench.py times: He-normal everywhere (activations O(1): the bench does not time an all-zero network)
+    "bench_weights": {"images": (0, 2, 5), "modes": ("serial", "pipelined3"), "kw": {}},
+    # the reference's own initialisation of the head (dafne.py:269-285: tower / prediction convolutions N(0, 0.01), GroupNorm
+    # affine 1 / 0) -- the statistics a trained head starts from -- with the class prior raised so that candidates exist
+    "reference_init": {"images": (0, 5), "modes": ("pipelined3",), "kw": {"tower_std": 0.01, "cls_prior": -1.5}},
+}
+
+
+def _oracle_forward(cfg, P, img):
     with torch.no_grad():
-        x, _ = om.preprocess([batch[0]], cfg.MODEL.PIXEL_MEAN, cfg.MODEL.PIXEL_STD)
+        x, _ = om.preprocess([img], cfg.MODEL.PIXEL_MEAN, cfg.MODEL.PIXEL_STD)
         f32 = om.backbone_forward(P, x, 101)
         h32 = om.head_forward(P, [f32[k] for k in LEVELS])
         fe = om.backbone_forward(P, x, 101, emulate_bf16=True)
         he = om.head_forward(P, [fe[k] for k in LEVELS], emulate_bf16=True)
-    oracle_s = time.perf_counter() - t0
-    return {"cfg": cfg, "model": model, "batch": batch.to(dev), "f32": f32, "h32": h32, "fe": fe, "he": he,
-            "oracle_forward_s": oracle_s, "report": {}}
+    return {"f32": f32, "h32": h32, "fe": fe, "he": he}
+
+
+@pytest.fixture(scope="module", params=list(REGIMES))
+def headline(request):
+    sys.path.insert(0, ROOT)
+    import bench
+    regime = request.param
+    dev = torch.device("cuda", 0)
+    cfg, model, sd = bench.build_model(101, dev, seed=0, **REGIMES[regime]["kw"])     # bench_weights: the weights bench.py times
+    g = torch.Generator().manual_seed(0)                            # ... and rank 0's images
+    batch = torch.randint(0, 256, (BATCH, 3, SIZE, SIZE), generator=g, dtype=torch.uint8)
+    P = {k: v.float() for k, v in sd.items()}
+    t0 = time.perf_counter()
+    # one image of EVERY sub-batch of the timed layout (bounds 0 / 2 / 5: the 3-image plans pick other kernels than the
+    # 2-image plan), each through the fp32 oracle and its bf16 emulation
+    orc = {i: _oracle_forward(cfg, P, batch[i]) for i in REGIMES[regime]["images"]}
+    oracle_s = (time.perf_counter() - t0) / len(orc)
+    return {"regime": regime, "cfg": cfg, "model": model, "batch": batch.to(dev), "oracle": orc, "oracle_forward_s": oracle_s, "report": {}}
 
 
 def _run(model, batch, mode):
-    """-> (rows, counts, head-output holder, image-0 feature Acts)"""
+    """-> (rows, counts, head-output holder, features(i): the five FPN maps of image i as [1,C,H,W] float CPU tensors)"""
     if mode == "serial":
         rows, counts = model.detect_packed(batch)
         torch.cuda.synchronize()
         plan = model.plan(BATCH, SIZE, SIZE)
-        return rows, counts, plan.head, plan.features
+        return rows, counts, plan.head, lambda i: [a.nchw_float()[i:i + 1].cpu() for a in plan.features]
     for _ in range(3):                                      # steady state of the two alternating plan sets, as in bench.py
         rows, counts = model.detect_packed(batch, pipelined=True, splits=SPLITS)
     torch.cuda.synchronize()
     st = model._pipe[(BATCH, SIZE, SIZE, SPLITS)]
     slot = (st["i"] - 1) & 1
-    assert st["bounds"] == [0, 2, 5, 8]                     # the 2/3/3 sub-batch split of the timed region
-    return rows, counts, st["ho"][slot], st["plans"][slot][0].features
+    bounds = st["bounds"]
+    assert bounds == [0, 2, 5, 8]                           # the 2/3/3 sub-batch split of the timed region
+
+    def feats(i):
+        k = max(j for j in range(SPLITS) if bounds[j] <= i)
+        return [a.nchw_float()[i - bounds[k]:i - bounds[k] + 1].cpu() for a in st["plans"][slot][k].features]
+    return rows, counts, st["ho"][slot], feats
 
 
 @pytest.mark.parametrize("mode", ["serial", "pipelined3"])
 def test_headline_workload_vs_oracle(headline, mode):
     H = headline
+    if mode not in REGIMES[H["regime"]]["modes"]:
+        pytest.skip("regime %s runs %s only" % (H["regime"], REGIMES[H["regime"]]["modes"]))
     cfg, model = H["cfg"], H["model"]
     d = cfg.MODEL.DAFNE
     rows, counts, hp, feats = _run(model, H["batch"], mode)
-    rep = {"mode": mode, "features_rel_l2": {}, "head_rel_l2": {}}
+    rep = {"regime": H["regime"], "mode": mode, "images": {}}
+    if mode == "pipelined3":
+        st = model._pipe[(BATCH, SIZE, SIZE, SPLITS)]
+        rep["kernels_per_sub_batch"] = [sorted(set(c.kernel_name() for c in p.calls if hasattr(c, "kernel_name"))) for p in st["plans"][0]]
 
-    # (1) image 0: FPN features and head outputs vs the oracle
-    for k, a in zip(LEVELS, feats):
-        e = a.nchw_float()[0:1].cpu()
-        e_emu, e_32, floor = rel(e, H["fe"][k]), rel(e, H["f32"][k]), rel(H["fe"][k], H["f32"][k])
-        rep["features_rel_l2"][k] = {"vs_bf16_emulation": e_emu, "vs_fp32": e_32, "emulation_vs_fp32": floor}
-        assert e_emu < 2.5e-2 and e_32 < 2.5e-2 and e_32 < 1.5 * floor, (mode, k, e_emu, e_32, floor)
+    # (1) one image per sub-batch: FPN features and head outputs vs the oracle
     names = ("logits", "reg", "center", "ctrness")
-    for l in range(5):
-        lg = hp.logits[l][0:1].permute(0, 3, 1, 2).cpu()
-        dc = hp.delta_ctr[l][0:1].permute(0, 3, 1, 2).cpu()
-        ce = hp.center[l][0:1].permute(0, 3, 1, 2).cpu()
-        sc = float(hp.scales[l])
-        eng = (lg, (ce.repeat(1, 4, 1, 1) + dc[:, :8]) * sc, ce * sc, dc[:, 8:9])
-        for j, nme in enumerate(names):
-            e_emu, e_32, floor = rel(eng[j], H["he"][j][l]), rel(eng[j], H["h32"][j][l]), rel(H["he"][j][l], H["h32"][j][l])
-            rep["head_rel_l2"]["%s_l%d" % (nme, l)] = {"vs_bf16_emulation": e_emu, "vs_fp32": e_32, "emulation_vs_fp32": floor}
-            # end to end through backbone AND head (116 layers): the engine must sit at the noise floor the oracle's own
-            # bf16 emulation shows against fp32 (two bf16 pipelines are one floor apart from each other)
-            assert e_32 < max(2.0 * floor, 2.5e-2) and e_emu < max(2.0 * floor, 2.5e-2), (mode, nme, l, e_emu, e_32, floor)
+    for i, O in H["oracle"].items():
+        ri = {"features_rel_l2": {}, "head_rel_l2": {}}
+        for k, e in zip(LEVELS, feats(i)):
+            e_emu, e_32, floor = rel(e, O["fe"][k]), rel(e, O["f32"][k]), rel(O["fe"][k], O["f32"][k])
+            ri["features_rel_l2"][k] = {"vs_bf16_emulation": e_emu, "vs_fp32": e_32, "emulation_vs_fp32": floor}
+            assert e_emu < 2.5e-2 and e_32 < 2.5e-2 and e_32 < 1.5 * floor, (mode, i, k, e_emu, e_32, floor)
+        for l in range(5):
+            lg = hp.logits[l][i:i + 1].permute(0, 3, 1, 2).cpu()
+            dc = hp.delta_ctr[l][i:i + 1].permute(0, 3, 1, 2).cpu()
+            ce = hp.center[l][i:i + 1].permute(0, 3, 1, 2).cpu()
+            sc = float(hp.scales[l])
+            eng = (lg, (ce.repeat(1, 4, 1, 1) + dc[:, :8]) * sc, ce * sc, dc[:, 8:9])
+            for j, nme in enumerate(names):
+                e_emu, e_32, floor = rel(eng[j], O["he"][j][l]), rel(eng[j], O["h32"][j][l]), rel(O["he"][j][l], O["h32"][j][l])
+                ri["head_rel_l2"]["%s_l%d" % (nme, l)] = {"vs_bf16_emulation": e_emu, "vs_fp32": e_32, "emulation_vs_fp32": floor}
+                # end to end through backbone AND head (116 layers): the engine must sit at the noise floor the oracle's own
+                # bf16 emulation shows against fp32 (two bf16 pipelines are one floor apart from each other)
+                assert e_32 < max(2.0 * floor, 2.5e-2) and e_emu < max(2.0 * floor, 2.5e-2), (mode, i, nme, l, e_emu, e_32, floor)
+        rep["images"][i] = ri
 
     # (2) all 8 images: post-process exact given the engine's own head outputs
     engine_dets = []
@@ -175,27 +206,36 @@ def test_headline_workload_vs_oracle(headline, mode):
         engine_dets.append(got)
     rep["detections_per_image"] = [int(c) for c in counts.cpu()]
 
-    # (3) end-to-end deviation of image 0 from the fp32 oracle run from the uint8 image
+    # (3) end-to-end deviation from the fp32 oracle run from the uint8 image, per checked image
     def lv(h):
         return [(h[0][l][0].numpy(), h[1][l][0].numpy(), h[3][l][0].numpy()) for l in range(5)]
-    d32 = _oracle_detections(lv(H["h32"]), d)
-    dbf = _oracle_detections(lv(H["he"]), d)
-    rep["engine_vs_fp32_oracle"] = _deviation(engine_dets[0], d32)
-    rep["bf16_emulation_vs_fp32_oracle"] = _deviation(dbf, d32)
-    rep["engine_vs_bf16_emulation"] = _deviation(engine_dets[0], dbf)
+    for i, O in H["oracle"].items():
+        d32 = _oracle_detections(lv(O["h32"]), d)
+        dbf = _oracle_detections(lv(O["he"]), d)
+        ri = rep["images"][i]
+        ri["engine_vs_fp32_oracle"] = _deviation(engine_dets[i], d32)
+        ri["bf16_emulation_vs_fp32_oracle"] = _deviation(dbf, d32)
+        ri["engine_vs_bf16_emulation"] = _deviation(engine_dets[i], dbf)
     rep["oracle_forward_s"] = H["oracle_forward_s"]
     H["report"][mode] = rep
     out = os.path.join(ROOT, "gpurun_out")
     os.makedirs(out, exist_ok=True)
-    with open(os.path.join(out, "headline_parity.json"), "w") as f:
-        json.dump(H["report"], f, indent=1)
-    print("HEADLINE_PARITY " + json.dumps(rep))
-    e, b = rep["engine_vs_fp32_oracle"], rep["bf16_emulation_vs_fp32_oracle"]
-    # the engine may not lose materially more detections to bf16 noise than the oracle's own bf16 emulation does, and
-    # the matched detections must agree to well within the noise the emulation shows
-    assert e["match_rate"] >= b["match_rate"] - 0.10 and e["match_rate"] >= 0.5, (e, b)
-    assert e["abs_score_delta"]["p99"] <= max(2.0 * b["abs_score_delta"]["p99"], 1e-3), (e, b)
-    assert e["abs_corner_delta_px"]["p50"] <= max(2.0 * b["abs_corner_delta_px"]["p50"], 1e-3), (e, b)
+    path = os.path.join(out, "headline_parity.json")
+    allrep = json.load(open(path)) if os.path.exists(path) else {}
+    allrep = {k: v for k, v in allrep.items() if isinstance(v, dict) and "regime" in v}        # this layout only
+    allrep["%s/%s" % (H["regime"], mode)] = rep
+    with open(path, "w") as f:
+        json.dump(allrep, f, indent=1)
+    print("HEADLINE_PARITY " + json.dumps({"regime": H["regime"], "mode": mode,
+                                           "deviation": {i: rep["images"][i]["engine_vs_fp32_oracle"] for i in rep["images"]}}))
+    for i in rep["images"]:
+        e, b = rep["images"][i]["engine_vs_fp32_oracle"], rep["images"][i]["bf16_emulation_vs_fp32_oracle"]
+        # the engine may not lose materially more detections to bf16 noise than the oracle's own bf16 emulation does (3
+        # points: a real regression costs more), and the matched detections must agree as well as the emulation's do
+        assert e["match_rate"] >= b["match_rate"] - 0.03 and e["match_rate"] >= 0.5, (i, e, b)
+        assert e["abs_score_delta"]["p99"] <= max(1.5 * b["abs_score_delta"]["p99"], 1e-3), (i, e, b)
+        assert e["abs_corner_delta_px"]["p50"] <= max(1.5 * b["abs_corner_delta_px"]["p50"], 1e-3), (i, e, b)
+        assert e["abs_corner_delta_px"]["p99"] <= max(1.5 * b["abs_corner_delta_px"]["p99"], 1e-3), (i, e, b)
 
 
 # ------------------------------------------------------------------------------------------------------------------
@@ -226,7 +266,7 @@ def test_config1_r50_batch8_full_size_vs_oracle():
         f32 = om.backbone_forward(P, x, 50)
         fe = om.backbone_forward(P, x, 50, emulate_bf16=True)
     rows, counts, hp, feats = _run(model, batch.to(dev), "pipelined3")
-    _features_vs_oracle([a.nchw_float()[0:1] for a in feats], fe, f32, "r50")
+    _features_vs_oracle(feats(0), fe, f32, "r50")
     for i in range(BATCH):
         _check_postprocess_exact(_rows_to_dict(rows, counts, i), _oracle_detections(_levels_numpy(hp, i), cfg.MODEL.DAFNE), ("r50", i))
 
@@ -324,3 +364,54 @@ def test_config4_fp8_batch16_full_size_vs_oracle():
     d = cfg.MODEL.DAFNE
     for i in range(n):
         _check_postprocess_exact(_rows_to_dict(rows, counts, i), _oracle_detections(_levels_numpy(hp, i), d), ("fp8", i))
+
+
+def test_config3_whole_tta_full_size_vs_oracle():
+    """configs[3] as a whole: OneStageRCNNWithTTA on one 1024x1024 tile at the RELEASED 9 sizes x {none, hflip, vflip} = 27
+    views (dota-1.5_r101_ms.yaml:399-409; tta.py:199-268), through the packed / pipelined path the wrapper uses.  The
+    merged result must equal the oracle's inverse maps + merged rotated NMS + cap (oracle/postprocess.py) applied to the
+    ENGINE'S OWN per-view detections (all nine view sizes, i.e. every /32-padded shape and tile count of the config), and
+    the FPN features of a mid-size view that is not 1024-aligned (700 px -> 704) must sit at the oracle's bf16 noise floor."""
+    sys.path.insert(0, ROOT)
+    import bench
+    from dafne_amd.modeling.tta import DotaDatasetMapperTTA, OneStageRCNNWithTTA
+    dev = torch.device("cuda", 0)
+    cfg, model, sd = bench.build_model(101, dev, seed=0, cfgname="dota-1.5_r101.yaml", cls_prior=-1.5)
+    d = cfg.MODEL.DAFNE
+    assert list(cfg.TEST.AUG.MIN_SIZES) == [450, 500, 600, 700, 800, 900, 1000, 1100, 1200] and cfg.TEST.AUG.MAX_SIZE == 1200
+    g = torch.Generator().manual_seed(11)
+    tile = torch.randint(0, 256, (3, SIZE, SIZE), generator=g, dtype=torch.uint8)
+    inp = {"image": tile, "height": SIZE, "width": SIZE}
+    tta = OneStageRCNNWithTTA(cfg, model)
+    out = tta([inp])[0]["instances"]
+    torch.cuda.synchronize()
+    # expected: every view through the detector on its own (reference-style loop), inverted and merged by the oracle
+    views = DotaDatasetMapperTTA(cfg)({**inp, "image": tile.to(dev)})
+    assert len(views) == 27
+    dets, sizes_seen = [], set()
+    for k, v in enumerate(views):
+        r = model.inference([{kk: vv for kk, vv in v.items() if kk != "transforms"}], None, do_postprocess=False)[0]["instances"]
+        nh, nw = v["image"].shape[1:]
+        sizes_seen.add((int(nh), int(nw)))
+        hf, vf = (k % 3 == 1), (k % 3 == 2)
+        c = opp.tta_invert_corners(r.pred_corners.cpu().numpy(), (SIZE / nw, SIZE / nh), hf, vf, (nh, nw))
+        dets.append({"pred_corners": c, "scores": r.scores.cpu().numpy(), "centerness": r.centerness.cpu().numpy(),
+                     "pred_classes": r.pred_classes.cpu().numpy()})
+        assert len(r) > 0, k
+    assert sizes_seen == {(s, s) for s in cfg.TEST.AUG.MIN_SIZES}
+    exp = opp.select_over_all_levels(opp.cat(dets), d.NMS_TH, d.POST_NMS_TOPK_TEST, fast=True)
+    assert len(out) == exp["scores"].shape[0] and len(out) > 0
+    assert np.array_equal(out.pred_classes.cpu().numpy(), exp["pred_classes"])
+    assert np.abs(out.scores.cpu().numpy() - exp["scores"]).max() == 0
+    assert np.abs(out.pred_corners.cpu().numpy() - exp["pred_corners"]).max() < 1e-3
+    # a mid-size view (700 -> padded 704: 22 x 22 res5 map, ragged 4 x 32 / 8 x 32 tiles on every level) vs the oracle
+    v700 = [v for v in views if v["image"].shape[1] == 700][0]["image"]
+    P = {k: v.float() for k, v in sd.items()}
+    with torch.no_grad():
+        x, _ = om.preprocess([v700.cpu()], cfg.MODEL.PIXEL_MEAN, cfg.MODEL.PIXEL_STD)
+        f32 = om.backbone_forward(P, x, 101)
+        fe = om.backbone_forward(P, x, 101, emulate_bf16=True)
+    assert tuple(x.shape[2:]) == (704, 704)
+    model.detect_packed(v700[None], do_postprocess=False)
+    torch.cuda.synchronize()
+    _features_vs_oracle([a.nchw_float()[0:1] for a in model.plan(1, 704, 704).features], fe, f32, ("tta", 700))
