@@ -143,12 +143,11 @@ class DotaDatasetMapperTTA:
         if self.resize_type != "shortest-edge":
             raise NotImplementedError("INPUT.RESIZE_TYPE='both' is not used by any released config")
 
-    def __call__(self, dataset_dict):
-        image = dataset_dict["image"]
-        h, w = int(image.shape[1]), int(image.shape[2])
-        orig = (int(dataset_dict["height"]), int(dataset_dict["width"]))
-        pre = TransformList([ResizeT(orig[0], orig[1], h, w)] if (h, w) != orig else [])
-        ret = []
+    def view_specs(self, h, w, orig_hw):
+        """The views of an (h, w) image in the reference's order (tta.py:71-99: per size: plain, hflip, vflip):
+        [(new_h, new_w, TransformList)] -- no pixels (what a rank that only merges needs)."""
+        pre = TransformList([ResizeT(orig_hw[0], orig_hw[1], h, w)] if (h, w) != tuple(orig_hw) else [])
+        specs = []
         for s in self.min_sizes:
             nh, nw = shortest_edge_size(h, w, s, self.max_size)
             rs = ResizeT(h, w, nh, nw)
@@ -158,14 +157,28 @@ class DotaDatasetMapperTTA:
             if self.vflip:
                 cands.append([rs, VFlipT(nh)])
             for tf in cands:
-                # resize and flip of a view in one device call (flips are exact index reversals)
-                im = rs.apply_image(image, hflip=any(isinstance(t, HFlipT) for t in tf[1:]),
-                                    vflip=any(isinstance(t, VFlipT) for t in tf[1:]))
-                dic = {k: v for k, v in dataset_dict.items() if k != "image"}
-                dic = copy.deepcopy(dic)
-                dic["transforms"] = pre + TransformList(tf)
-                dic["image"] = im.contiguous()
-                ret.append(dic)
+                specs.append((nh, nw, pre + TransformList(tf)))
+        return specs
+
+    def __call__(self, dataset_dict, views=None):
+        """views: optional iterable of view indices to build (a rank's shard of the views); default all."""
+        image = dataset_dict["image"]
+        h, w = int(image.shape[1]), int(image.shape[2])
+        orig = (int(dataset_dict["height"]), int(dataset_dict["width"]))
+        specs = self.view_specs(h, w, orig)
+        ret = []
+        for k in (range(len(specs)) if views is None else views):
+            nh, nw, tfl = specs[k]
+            tf = tfl.tfms[-2:] if isinstance(tfl.tfms[-1], (HFlipT, VFlipT)) else tfl.tfms[-1:]
+            rs = tf[0]
+            # resize and flip of a view in one device call (flips are exact index reversals)
+            im = rs.apply_image(image, hflip=any(isinstance(t, HFlipT) for t in tf[1:]),
+                                vflip=any(isinstance(t, VFlipT) for t in tf[1:]))
+            dic = {kk: v for kk, v in dataset_dict.items() if kk != "image"}
+            dic = copy.deepcopy(dic)
+            dic["transforms"] = tfl
+            dic["image"] = im.contiguous()
+            ret.append(dic)
         return ret
 
 
@@ -193,6 +206,14 @@ class OneStageRCNNWithTTA(nn.Module):
         goes through the detector's pipelined path (three chunks in flight on the three compute streams, decode + NMS
         of a chunk on the side stream under the other chunks' convolutions; detections stay packed on the device) and
         the host waits once, after the last chunk."""
+        outputs = []
+        for rows, counts, out_hw in self._views_packed(batched_inputs):
+            outputs.extend({"instances": r} for r in pp.rows_to_instances(rows, counts, out_hw))
+        return outputs
+
+    def _views_packed(self, batched_inputs):
+        """-> [(rows [b, k_cap, 18], counts [b], out_hw)] per chunk of `batch_size` views, packed on the device (host
+        already synchronised with the side stream)."""
         m = self.model
         pending = []
         for i in range(0, len(batched_inputs), self.batch_size):
@@ -214,10 +235,45 @@ class OneStageRCNNWithTTA(nn.Module):
             pending.append((rows, counts, out_hw))
         if m.side_stream is not None:
             m.side_stream.synchronize()
-        outputs = []
-        for rows, counts, out_hw in pending:
-            outputs.extend({"instances": r} for r in pp.rows_to_instances(rows, counts, out_hw))
-        return outputs
+        return pending
+
+    # ---- the views of ONE image split over the GPUs of a node, merge NMS on rank 0 -----------------
+    def _detect_view_range(self, input, lo, hi):
+        """Packed detections (view coordinates, do_postprocess=False) of views [lo, hi) of `input`."""
+        views = self.tta_mapper(input, views=range(lo, hi))
+        for v in views:
+            v.pop("transforms")
+        chunks = self._views_packed(views)
+        return torch.cat([c[0] for c in chunks]), torch.cat([c[1] for c in chunks])
+
+    def inference_view_sharded(self, input, rank=0, world=1, group=None, device=None):
+        """One image, its TTA views sharded contiguously over the ranks (tta.py:173-197 runs them in chunks of 3 on one
+        GPU): every rank builds and runs ITS views, one gather_detections lands the packed per-view detections on rank
+        0 in view order, rank 0 inverts the transforms, concatenates and runs the merged rotated NMS + cap
+        (tta.py:237-268).  Every rank calls this (a collective); returns {"instances": ...} on rank 0, None elsewhere.
+        Same result as __call__ on one GPU (same kernels on the same views; only where they run differs)."""
+        from ..evaluation.driver import inference_on_images
+        input = dict(input)
+        if "height" not in input and "width" not in input:
+            input["height"], input["width"] = int(input["image"].shape[1]), int(input["image"].shape[2])
+        device = device if device is not None else self.model.device
+        if not input["image"].is_cuda and torch.device(device).type == "cuda":
+            input["image"] = input["image"].to(device)
+        h, w = int(input["image"].shape[1]), int(input["image"].shape[2])
+        specs = self.tta_mapper.view_specs(h, w, (int(input["height"]), int(input["width"])))
+        n = len(specs)
+        k_cap = self._view_k_cap()
+        out = inference_on_images(lambda lo, hi: self._detect_view_range(input, lo, hi), n, k_cap, batch_size=max(n, 1),
+                                  rank=rank, world=world, device=device, group=group)
+        if out is None:
+            return None
+        rows_all, counts_all = out
+        outputs = [{"instances": r} for r in pp.rows_to_instances(rows_all, counts_all, [(s[0], s[1]) for s in specs])]
+        instances = self._invert_and_concat(outputs, [s[2] for s in specs])
+        return {"instances": self._merge_detections(instances)}
+
+    def _view_k_cap(self):
+        return self.model.proposal_generator.dafne_outputs.packed_k_cap()
 
     def __call__(self, batched_inputs):
         def _fill(d):

@@ -202,3 +202,90 @@ def test_fp8_calibration_is_identical_on_every_rank():
 def test_reduce_amax_without_process_group_is_identity():
     from dafne_amd import engine
     assert engine.reduce_amax_over_ranks({"a": 1.5, "b": 0.0}) == {"a": 1.5, "b": 0.0}
+
+
+class _StubTTA:
+    """OneStageRCNNWithTTA's view-sharded driver with the detector stubbed (CPU, gloo): per-view packed detections are a
+    pure function of the view index, the merge is the identity -- what is exercised is the sharding of the 27 views, the
+    padded gather in view order, the per-view transforms of rank 0 and the reference's inverse maps."""
+
+    def __new__(cls, cfg, calls):
+        from dafne_amd.modeling.tta import DotaDatasetMapperTTA, OneStageRCNNWithTTA
+
+        class Stub(OneStageRCNNWithTTA):
+            def __init__(self, cfg, calls):
+                torch.nn.Module.__init__(self)
+                self.cfg, self.tta_mapper, self.batch_size, self.calls = cfg, DotaDatasetMapperTTA(cfg), 3, calls
+
+            def _view_k_cap(self):
+                return 8
+
+            def _detect_view_range(self, input, lo, hi):
+                self.calls.append((lo, hi))
+                rows = torch.zeros(hi - lo, 8, 18)
+                counts = torch.zeros(hi - lo, dtype=torch.int32)
+                for v in range(lo, hi):
+                    k = v % 5 + 1
+                    counts[v - lo] = k
+                    for j in range(k):
+                        rows[v - lo, j, 0:8] = torch.arange(8, dtype=torch.float32) * 7.0 + v + 0.25 * j      # view coordinates
+                        rows[v - lo, j, 8] = 1.0 - 0.01 * v - 0.001 * j
+                        rows[v - lo, j, 10] = v % 16
+                return rows, counts
+
+            def _merge_detections(self, instances):
+                return instances
+        return Stub(cfg, calls)
+
+
+def _tta_cfg():
+    from dafne_amd.config import get_cfg
+    cfg = get_cfg()
+    cfg.TEST.AUG.MIN_SIZES = [450, 500, 600, 700, 800, 900, 1000, 1100, 1200]
+    cfg.TEST.AUG.MAX_SIZE = 1200
+    return cfg
+
+
+def _tta_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    calls = []
+    tta = _StubTTA(_tta_cfg(), calls)
+    img = torch.zeros(3, 1024, 1024, dtype=torch.uint8)
+    out = tta.inference_view_sharded({"image": img, "height": 1024, "width": 1024}, rank=rank, world=world, device="cpu")
+    if rank == 0:
+        inst = out["instances"]
+        q.put((rank, calls, inst.pred_corners.clone(), inst.scores.clone(), inst.pred_classes.clone()))
+    else:
+        q.put((rank, calls, out))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_tta_views_sharded_over_two_ranks():
+    """SURVEY 8(e), configs[3]: the 27 views of one image split over the ranks (14 + 13), ONE gather, inverse transforms and
+    merge on rank 0 -- same result as one process running all 27 views (tta.py:173-197,237-268)."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_tta_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=180) for _ in range(2)), key=lambda r: r[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert res[0][1] == [(0, 14)] and res[1][1] == [(14, 27)] and res[1][2] is None
+    # one process, all views
+    calls = []
+    single = _StubTTA(_tta_cfg(), calls).inference_view_sharded(
+        {"image": torch.zeros(3, 1024, 1024, dtype=torch.uint8), "height": 1024, "width": 1024}, device="cpu")["instances"]
+    assert calls == [(0, 27)]
+    assert torch.equal(res[0][2], single.pred_corners) and torch.equal(res[0][3], single.scores) and torch.equal(res[0][4], single.pred_classes)
+    assert len(single) == sum(v % 5 + 1 for v in range(27))
+    # the inverse maps really ran: view 1 (450 px, hflip) maps x -> (450 - x) * 1024 / 450
+    x_view = 0 * 7.0 + 1 + 0.25 * 0
+    n0 = 0 % 5 + 1
+    assert abs(float(single.pred_corners[n0, 0]) - (450 - x_view) * (1024 / 450)) < 1e-3

@@ -351,3 +351,21 @@ def test_resize_kernel_is_pillow_exact():
         got = resize_u8(tb, s, s).cpu().numpy()
         ref = orz.resize_bilinear_u8(big[:, :, :], s, s)
         assert np.array_equal(got, ref)
+
+
+def test_tta_view_sharded_driver_equals_the_wrapper():
+    """OneStageRCNNWithTTA.inference_view_sharded (the multi-GPU form: views sharded over ranks, gather, merge on rank 0)
+    run by ONE process gives exactly the wrapper's __call__ result -- same kernels on the same views; the 2-rank sharding
+    and gather are covered on CPU by tests/test_gather_gloo.py::test_tta_views_sharded_over_two_ranks."""
+    from dafne_amd.modeling.tta import OneStageRCNNWithTTA
+    cfg, m, P = build("dota-1.5_r101.yaml", seed=9)
+    cfg.TEST.AUG.MIN_SIZES = [96, 128, 160]
+    cfg.TEST.AUG.MAX_SIZE = 192
+    g = torch.Generator().manual_seed(4)
+    img = torch.randint(0, 256, (3, 128, 160), generator=g, dtype=torch.uint8)
+    tta = OneStageRCNNWithTTA(cfg, m)
+    inp = {"image": img, "height": 128, "width": 160}
+    a = tta([inp])[0]["instances"]
+    b = tta.inference_view_sharded(inp)["instances"]
+    assert len(a) == len(b) > 0
+    assert torch.equal(a.pred_corners, b.pred_corners) and torch.equal(a.scores, b.scores) and torch.equal(a.pred_classes, b.pred_classes)

@@ -38,6 +38,9 @@ def parse_args(argv=None):
     ap.add_argument("--width", type=int, default=0)
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--tta", action="store_true", help="TEST.AUG multi-scale / flip inference")
+    ap.add_argument("--tta-shard-views", action="store_true",
+                    help="with --tta on several GPUs: shard the VIEWS of every image over the ranks (merge NMS on rank 0) instead "
+                         "of sharding the images -- the latency form: one image's 27 views take 1/N of the time")
     ap.add_argument("--output", default="")
     ap.add_argument("--task1-dir", default="", help="DOTA configs: write Task1_<class>.txt files here and merge the tiles "
                                                     "(Task1_merged/) with the device NMS (dota_evaluation.py:110-184)")
@@ -106,10 +109,20 @@ def run(args, rank=0, world=1, local_rank=0):
         rows, counts = model.detect_packed(batch, out_hw=[(x["height"], x["width"]) for x in chunk])
         return rows, counts
 
-    out = inference_on_images(detect_batch, n, k_cap, batch_size=args.batch, rank=rank, world=world, device=dev)
-    torch.cuda.synchronize()
-    if rank != 0:
-        return None
+    if tta is not None and args.tta_shard_views:
+        # SURVEY 8(e), configs[3]: every rank sees every image and runs ITS share of the image's views; one gather per image
+        # lands the per-view detections on rank 0, which inverts, concatenates and runs the merged NMS (tta.py:173-197,264-268)
+        everyone = synthetic_inputs(n, h, w, args.seed)
+        merged = [tta.inference_view_sharded(x, rank=rank, world=world, device=dev) for x in everyone]
+        torch.cuda.synchronize()
+        if rank != 0:
+            return None
+        out = instances_to_rows([o["instances"] for o in merged], k_cap, dev)
+    else:
+        out = inference_on_images(detect_batch, n, k_cap, batch_size=args.batch, rank=rank, world=world, device=dev)
+        torch.cuda.synchronize()
+        if rank != 0:
+            return None
     rows_all, counts_all = out
     meta = synthetic_inputs(n, h, w, args.seed, pixels=False)
     preds = to_predictions(rows_all, counts_all, image_ids=[m["image_id"] for m in meta])
