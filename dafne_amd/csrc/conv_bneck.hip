@@ -12,7 +12,7 @@
 //
 // Structure (8 waves, one workgroup per CU, a workgroup owns a 4 x 32 pixel tile and ALL channels):
 //   phase A (3x3): the (4+2) x (32+2) input patch is DMA'd into LDS for all 256 channels (four 64-channel slabs of
-//     26 KB, [pixel][128 B] with the 16-byte chunk XOR (pixel >> 1) & 7: conflict-free ds_read_b128 at any tap offset) and
+//     26 KB, [pixel][128 B] with the 16-byte chunk XOR (patch column >> 1) & 7: conflict-free ds_read_b128 at any tap offset) and
 //     STAYS there -- the nine taps read their B fragments from it at tap-dependent pixel offsets (LDS-staged im2col), so
 //     the 144 k16 steps of the layer run without a single barrier between them except one after the first slab.  The
 //     weights stream L2 -> REGISTERS exactly as in conv_b2b: a wave owns 32 output channels and all 128 pixels, so every
@@ -61,6 +61,7 @@ constexpr int kRing = 8;                               // k16 steps of A fragmen
 constexpr int kWABytes = kNW * kStepsA * 1024;         // phase A weights: [8 waves][144 steps][64 lanes][8]
 constexpr int kPhaseBytes = kNW * 16 * 1024;           // one phase of conv_b2b's weights: [8 waves][16 steps][64 lanes][8]
 constexpr int kTrickle = 12;                           // patch slabs 1..3: 12 pieces per wave, one per step 0..11
+constexpr int kRes0 = 60, kResStride = 4;              // slabs 0..2 of the first residual chunk: 6 pieces per wave at steps 60, 64, .., 80
 constexpr int kDumpBytes = kPx * kCB * 2;              // 256 KB: one Y row per tile pixel
 
 struct BneckDev {
@@ -95,8 +96,9 @@ __device__ __forceinline__ unsigned pack_bf16(float a, float b) {
 // Vector-memory program order of a wave: bias piece (1 DMA) | patch slab 0 (4 DMA) | A(0) .. A(7) | then for every k16
 // step s = 0 .. 271 (0..143 phase A; 144 + j = step j of conv_b2b's schedule):
 //   [wait A(s)] MFMAs | bn_st(s) row stores | A(s + 8) if it exists | bn_post(s) DMA pieces:
-//     phase A: one patch piece of slabs 1..3 at steps 0..11; the 8 pieces of the first residual chunk after step 143
-//              (behind the barrier that retires the patch);
+//     phase A: one patch piece of slabs 1..3 at steps 0..11; slabs 0..2 of the first residual chunk (their Y-buffer space
+//              does not overlap the patch) one piece at steps 60, 64, .., 80 -- HBM is idle while every CU is in phase A --,
+//              its slab 3 (2 pieces) after step 143, behind the barrier that retires the patch;
 //     phase B: 2 pieces of slab q of the next residual chunk after the last step of slab group q (conv_b2b.hip).
 // bn_wait(j) = number of those instructions issued after A(j) and before the wait for it: vmcnt retires in order, so
 // `s_waitcnt vmcnt(bn_wait(j))` is exactly "A(j) and everything older has landed".
@@ -106,7 +108,9 @@ constexpr int bn_st(int s) {
     return (i >= 16 && (i & 3) == 0) ? 2 : 0;
 }
 constexpr int bn_post(int s) {
-    if (s < kStepsA) return (s < kTrickle ? 1 : 0) + (s == kStepsA - 1 ? 8 : 0);
+    if (s < kStepsA)
+        return (s < kTrickle ? 1 : 0) + ((s >= kRes0 && s < kRes0 + 6 * kResStride && (s - kRes0) % kResStride == 0) ? 1 : 0) +
+               (s == kStepsA - 1 ? 2 : 0);
     const int j = s - kStepsA, i = j & 31;
     return (i >= 16 && (i & 3) == 3 && (j >> 5) < kChunks - 1) ? 2 : 0;
 }
@@ -123,7 +127,7 @@ constexpr int bn_wait(int j) {
 }
 // spot checks: steady state 7; the trickle adds one per step; conv_b2b's own values behind the 144-step shift
 static_assert(bn_wait(0) == 7 && bn_wait(1) == 8 && bn_wait(7) == 14 && bn_wait(8) == 15 && bn_wait(12) == 15 && bn_wait(13) == 14 && bn_wait(20) == 7 &&
-              bn_wait(100) == 7 && bn_wait(kStepsA + 7) == 15 && bn_wait(kStepsA + 8) == 7 && bn_wait(kStepsA + 127) == 4 &&
+              bn_wait(100) == 7 && bn_wait(68) == 9 && bn_wait(69) == 9 && bn_wait(61) == 8 && bn_wait(kStepsA + 7) == 9 && bn_wait(kStepsA + 8) == 7 && bn_wait(kStepsA + 127) == 4 &&
               bn_wait(kStepsA + 39) == 9 && bn_wait(kStepsA + 27) == 15 && bn_wait(kStepsA + 24) == 13, "vmcnt bookkeeping");
 
 template <int I, int N, class F>
@@ -147,6 +151,30 @@ __device__ __forceinline__ void bn_load(bf16x8 (&ar)[kRing], const char* wf, uns
         asm volatile("global_load_dwordx4 %0, %1, %2" : "=&v"(ar[J % kRing]) : "v"(voffB), "s"(sb) : "memory");
     }
 }
+// the four B fragments of phase-A step J (patch rows kh .. kh + 3 at tap column kw, chunk kc of slab sl): inline asm,
+// completion is awaited by the caller (lgkmcnt)
+template <int J>
+__device__ __forceinline__ void bn_bread(bf16x8 (&b)[kPF], const unsigned (&pb)[3], unsigned lds_base) {
+    constexpr int sl = J / 36, t = J % 36, kh = t / 12, kw = (t >> 2) % 3, kc = t & 3;
+    const unsigned ad = lds_base + ((pb[kw] ^ (unsigned)(kc << 5)) + (unsigned)(sl * kPSlab));
+    constexpr int o0 = (kh + 0) * kPC * 128, o1 = (kh + 1) * kPC * 128, o2 = (kh + 2) * kPC * 128, o3 = (kh + 3) * kPC * 128;
+    asm volatile("ds_read_b128 %0, %4 offset:%5\n\tds_read_b128 %1, %4 offset:%6\n\tds_read_b128 %2, %4 offset:%7\n\tds_read_b128 %3, %4 offset:%8"
+                 : "=&v"(b[0]), "=&v"(b[1]), "=&v"(b[2]), "=&v"(b[3])
+                 : "v"(ad), "n"(o0), "n"(o1), "n"(o2), "n"(o3)
+                 : "memory");
+}
+
+// phase B: the four B fragments (pixel fragments 4096 B apart) of k16 step ST of slab Q of the buffer at byte offset BUF
+template <int BUF, int Q, int ST>
+__device__ __forceinline__ void bn_bread_b(bf16x8 (&b)[kPF], const unsigned (&bs)[4], unsigned lds_base) {
+    const unsigned ad = lds_base + (unsigned)BUF + bs[ST];
+    constexpr int o = Q * kSlab;
+    asm volatile("ds_read_b128 %0, %4 offset:%5\n\tds_read_b128 %1, %4 offset:%6\n\tds_read_b128 %2, %4 offset:%7\n\tds_read_b128 %3, %4 offset:%8"
+                 : "=&v"(b[0]), "=&v"(b[1]), "=&v"(b[2]), "=&v"(b[3])
+                 : "v"(ad), "n"(o), "n"(o + 4096), "n"(o + 8192), "n"(o + 12288)
+                 : "memory");
+}
+
 template <int J>
 __device__ __forceinline__ void bn_wait_for(bf16x8 (&ar)[kRing]) {
     constexpr int kWaitN = bn_wait(J);
@@ -190,7 +218,7 @@ __global__ void __launch_bounds__(512, 2) conv_bneck_kernel(BneckDev P) {
         const int p = pp / kPC, q = pp - p * kPC;
         unsigned g = (unsigned)((img * (P.H + 2) + row0 + p) * Wp + col0 + q);
         g = g < P.max_pix ? g : P.max_pix;                       // ragged tiles reach past the image (and the buffer)
-        pofs[ii] = (size_t)g * (kCM * 2) + (unsigned)(((lane & 7) ^ ((pp >> 1) & 7)) * 16);
+        pofs[ii] = (size_t)g * (kCM * 2) + (unsigned)(((lane & 7) ^ ((q >> 1) & 7)) * 16);      // swizzle by patch COLUMN
         pdst[ii] = (unsigned)(kOffPatch + pc * 1024);
     }
     auto patch_piece = [&](int sl, int ii) {
@@ -205,11 +233,13 @@ __global__ void __launch_bounds__(512, 2) conv_bneck_kernel(BneckDev P) {
         dpix[ii] = pix_index(px);
         dq[ii] = (unsigned)(((lane & 7) ^ ((px >> 1) & 7)) * 16);
     }
+    auto dma_piece = [&](unsigned col0b, int sl, int ii) {
+        __builtin_amdgcn_global_load_lds((gvoid*)(P.res + (size_t)dpix[ii] * (kCB * 2) + col0b + sl * 128 + dq[ii]),
+                                         (lvoid*)(lds + kOffY + sl * kSlab + (wave + kNW * ii) * 1024), 16, 0, 0);
+    };
     auto dma_slab = [&](unsigned col0b, int sl) {                // 2 pieces per wave into slab sl of the Y buffer
-#pragma unroll
-        for (int ii = 0; ii < 2; ii++)
-            __builtin_amdgcn_global_load_lds((gvoid*)(P.res + (size_t)dpix[ii] * (kCB * 2) + col0b + sl * 128 + dq[ii]),
-                                             (lvoid*)(lds + kOffY + sl * kSlab + (wave + kNW * ii) * 1024), 16, 0, 0);
+        dma_piece(col0b, sl, 0);
+        dma_piece(col0b, sl, 1);
     };
 
     // ---- B fragment offsets
@@ -217,18 +247,17 @@ __global__ void __launch_bounds__(512, 2) conv_bneck_kernel(BneckDev P) {
     unsigned bs[4];
 #pragma unroll
     for (int s = 0; s < 4; s++) bs[s] = (unsigned)(frow * 128 + (((2 * s + half) ^ ((frow >> 1) & 7)) * 16));
-    // phase A: patch row p (0..5) at tap column kw (0..2): pixel pp = p * 34 + kw + frow, k16 step kc reads the 16-byte
-    // chunk (2 kc + half) ^ sw, sw = (pp >> 1) & 7.  That is  pb ^ (kc << 5)  with
-    // pb = pp * 128 | ((half ^ (sw & 1)) << 4) | ((sw >> 1) << 5)   (bits 5..6 of pp * 128 are zero)
-    unsigned pb[kPR * 3];
+    // phase A: patch row p (0..5) at tap column kw (0..2): pixel p * 34 + q, q = kw + frow; k16 step kc reads the 16-byte
+    // chunk (2 kc + half) ^ sw, sw = (q >> 1) & 7 (the row pitch is even: a swizzle by COLUMN is conflict-free like one by
+    // pixel index, and independent of the patch row).  That is  (pb[kw] ^ (kc << 5)) + p * 34 * 128  with
+    // pb[kw] = q * 128 | ((half ^ (sw & 1)) << 4) | ((sw >> 1) << 5)   (bits 5..6 of q * 128 are zero)
+    unsigned pb[3];
 #pragma unroll
-    for (int p = 0; p < kPR; p++)
-#pragma unroll
-        for (int kw = 0; kw < 3; kw++) {
-            const int pp = p * kPC + kw + frow;
-            const int sw = (pp >> 1) & 7;
-            pb[p * 3 + kw] = (unsigned)(kOffPatch + pp * 128 + ((half ^ (sw & 1)) << 4) + ((sw >> 1) << 5));
-        }
+    for (int kw = 0; kw < 3; kw++) {
+        const int q = kw + frow;
+        const int sw = (q >> 1) & 7;
+        pb[kw] = (unsigned)(kOffPatch + q * 128 + ((half ^ (sw & 1)) << 4) + ((sw >> 1) << 5));
+    }
 
     // ---- A operand: L2 -> registers through inline asm, ring of 8 k16 steps (conv_b2b.hip)
     const unsigned voffA = (unsigned)(wave * kStepsA * 1024 + lane * 16);
@@ -258,14 +287,6 @@ __global__ void __launch_bounds__(512, 2) conv_bneck_kernel(BneckDev P) {
         char* d = P.dump + (size_t)px * (kCB * 2);
         a = pix_valid(px) ? a : d;
         *(u32x4*)(a + col0b + sl * 128 + q * 16) = v;
-    };
-    // phase B k16 step: acc[b] += A . B[b]  (slab q of the buffer at byte offset buf, step st inside the slab)
-    auto consume = [&](const bf16x8& a, int q, int st, int buf, f32x16* acc) {
-        bf16x8 bfr[kPF];
-#pragma unroll
-        for (int b = 0; b < kPF; b++) bfr[b] = *(const bf16x8*)(lds + buf + q * kSlab + b * 4096 + bs[st]);
-#pragma unroll
-        for (int b = 0; b < kPF; b++) acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bfr[b], acc[b], 0, 0, 0);
     };
     // acc + bias (+ residual already in the buffer) -> ReLU -> bf16, in place in the buffer at byte offset buf
     // (conv_b2b.hip's epilogue; the expressions are those of the separate kernels)
@@ -344,26 +365,33 @@ __global__ void __launch_bounds__(512, 2) conv_bneck_kernel(BneckDev P) {
     for (int b = 0; b < kPF; b++)
 #pragma unroll
         for (int k = 0; k < 16; k++) acc1[b][k] = 0.f;
+    bf16x8 bfr[2][kPF];
     static_for<0, kStepsA>([&](auto J) {
         constexpr int j = decltype(J)::value;
-        constexpr int sl = j / 36, t = j % 36, kh = t / 12, kw = (t >> 2) % 3, kc = t & 3;
         wait_step(J);
         if constexpr (j == 0) barrier();             // slab 0 and the biases of every wave have landed
-        if constexpr (j == 36) barrier();            // slabs 1..3: every wave passed a wait covering its last piece at step 20
-        bf16x8 bfr[kPF];
+        if constexpr (j == 35) barrier();            // slabs 1..3: every wave passed a wait covering its last piece at step 20
+        // the B fragments of step j + 1 are requested before the MFMAs of step j (two register sets; the counted lgkmcnt leaves
+        // exactly those four reads in flight)
+        if constexpr (j == 0) bn_bread<0>(bfr[0], pb, lds_base);
+        if constexpr (j + 1 < kStepsA) {
+            bn_bread<j + 1>(bfr[(j + 1) & 1], pb, lds_base);
+            asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(bfr[j & 1][0]), "+v"(bfr[j & 1][1]), "+v"(bfr[j & 1][2]), "+v"(bfr[j & 1][3]) :: "memory");
+        } else {
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(bfr[j & 1][0]), "+v"(bfr[j & 1][1]), "+v"(bfr[j & 1][2]), "+v"(bfr[j & 1][3]) :: "memory");
+        }
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int r = 0; r < kPF; r++)
-            bfr[r] = *(const bf16x8*)(lds + ((pb[(r + kh) * 3 + kw] ^ (unsigned)(kc << 5)) + (unsigned)(sl * kPSlab)));
-#pragma unroll
-        for (int r = 0; r < kPF; r++) acc1[r] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ar[j % kRing], bfr[r], acc1[r], 0, 0, 0);
+        for (int r = 0; r < kPF; r++) acc1[r] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ar[j % kRing], bfr[j & 1][r], acc1[r], 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
         load_step(std::integral_constant<int, j + kRing>{});
         if constexpr (j < kTrickle) patch_piece(1 + j / 4, j & 3);
+        if constexpr (j >= kRes0 && j < kRes0 + 6 * kResStride && (j - kRes0) % kResStride == 0)
+            dma_piece(0u, ((j - kRes0) / kResStride) >> 1, ((j - kRes0) / kResStride) & 1);      // R(0), slabs 0..2
     });
     BN_STAMP();
     barrier();                                       // every wave is done with the patch: T and the residual may land on it
-#pragma unroll
-    for (int sl = 0; sl < 4; sl++) dma_slab(0u, sl);  // R(0): awaited through the weight waits of GEMM1(0)
+    dma_slab(0u, 3);                                 // R(0), slab 3: awaited through the weight waits of GEMM1(0)
     epilogue(acc1, 0, false, kOffT);
     barrier();
     BN_STAMP();
@@ -385,7 +413,16 @@ __global__ void __launch_bounds__(512, 2) conv_bneck_kernel(BneckDev P) {
             constexpr int i = decltype(I)::value;
             constexpr int j = j0 + i;
             wait_step(std::integral_constant<int, j>{});
-            consume(ar[j % kRing], i >> 2, i & 3, kOffT, acc1);
+            if constexpr (i == 0) bn_bread_b<kOffT, 0, 0>(bfr[j & 1], bs, lds_base);
+            if constexpr (i + 1 < 16) {
+                bn_bread_b<kOffT, ((i + 1) >> 2), ((i + 1) & 3)>(bfr[(j + 1) & 1], bs, lds_base);
+                asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(bfr[j & 1][0]), "+v"(bfr[j & 1][1]), "+v"(bfr[j & 1][2]), "+v"(bfr[j & 1][3]) :: "memory");
+            } else {
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(bfr[j & 1][0]), "+v"(bfr[j & 1][1]), "+v"(bfr[j & 1][2]), "+v"(bfr[j & 1][3]) :: "memory");
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int b = 0; b < kPF; b++) acc1[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ar[j % kRing], bfr[j & 1][b], acc1[b], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
             load_step(std::integral_constant<int, j + kRing>{});
         });
@@ -402,7 +439,16 @@ __global__ void __launch_bounds__(512, 2) conv_bneck_kernel(BneckDev P) {
                 constexpr int i = decltype(I)::value;
                 constexpr int j = j0 + 16 + 4 * q + i;
                 wait_step(std::integral_constant<int, j>{});
-                consume(ar[j % kRing], q, i, kOffY, acc2);
+                if constexpr (i == 0) bn_bread_b<kOffY, q, 0>(bfr[j & 1], bs, lds_base);
+                if constexpr (i + 1 < 4) {
+                    bn_bread_b<kOffY, q, i + 1>(bfr[(j + 1) & 1], bs, lds_base);
+                    asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(bfr[j & 1][0]), "+v"(bfr[j & 1][1]), "+v"(bfr[j & 1][2]), "+v"(bfr[j & 1][3]) :: "memory");
+                } else {
+                    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(bfr[j & 1][0]), "+v"(bfr[j & 1][1]), "+v"(bfr[j & 1][2]), "+v"(bfr[j & 1][3]) :: "memory");
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int b = 0; b < kPF; b++) acc2[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ar[j % kRing], bfr[j & 1][b], acc2[b], 0, 0, 0);
                 if constexpr (i == 0) {
                     store_slab(q, 0, P.out, kCB * 2, (unsigned)c * 512u);
                     store_slab(q, 1, P.out, kCB * 2, (unsigned)c * 512u);

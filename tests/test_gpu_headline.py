@@ -374,7 +374,7 @@ def test_config3_whole_tta_full_size_vs_oracle():
     the FPN features of a mid-size view that is not 1024-aligned (700 px -> 704) must sit at the oracle's bf16 noise floor."""
     sys.path.insert(0, ROOT)
     import bench
-    from dafne_amd.modeling.tta import DotaDatasetMapperTTA, OneStageRCNNWithTTA
+    from dafne_amd.modeling.tta import OneStageRCNNWithTTA
     dev = torch.device("cuda", 0)
     cfg, model, sd = bench.build_model(101, dev, seed=0, cfgname="dota-1.5_r101.yaml", cls_prior=-1.5)
     d = cfg.MODEL.DAFNE
@@ -385,12 +385,15 @@ def test_config3_whole_tta_full_size_vs_oracle():
     tta = OneStageRCNNWithTTA(cfg, model)
     out = tta([inp])[0]["instances"]
     torch.cuda.synchronize()
-    # expected: every view through the detector on its own (reference-style loop), inverted and merged by the oracle
-    views = DotaDatasetMapperTTA(cfg)({**inp, "image": tile.to(dev)})
+    # expected: the engine's own per-view detections -- the views through the detector in the chunks the wrapper uses (a
+    # view's result depends on its batch composition at the bf16 noise floor: other tile shapes, other grouping of the fp32
+    # GroupNorm partial sums; a given composition is bit-reproducible) -- inverted and merged by the ORACLE
+    views, _ = tta._get_augmented_inputs({**inp, "image": tile.to(dev)})
     assert len(views) == 27
+    per_view = tta._batch_inference_packed(views)
     dets, sizes_seen = [], set()
-    for k, v in enumerate(views):
-        r = model.inference([{kk: vv for kk, vv in v.items() if kk != "transforms"}], None, do_postprocess=False)[0]["instances"]
+    for k, (v, o) in enumerate(zip(views, per_view)):
+        r = o["instances"]
         nh, nw = v["image"].shape[1:]
         sizes_seen.add((int(nh), int(nw)))
         hf, vf = (k % 3 == 1), (k % 3 == 2)
