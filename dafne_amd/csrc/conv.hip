@@ -1833,8 +1833,8 @@ __global__ void __launch_bounds__(512) conv3x3_patch_kernel(ConvDev P) {
 //     barrier at steps 36 / 72 / 108 retires it and the next tile's slab s is DMA'd into its place in steps 40.. / 76.. /
 //     112.. (one piece per wave and step), slab 3 right behind the tile's last step;
 //   * GN_INPUT: a wave normalises the pieces IT loaded (GroupNorm + ReLU in place, out-of-image pixels stay zero) ~13
-//     steps after issuing them -- next tile's slabs 0..2 in steps 53.. / 89.. / 125.., its slab 3 in steps 13..16 of the
-//     next tile itself (first read at step 108) -- under the other waves' MFMAs; statistics of the next tile's image by
+//     steps after issuing them -- next tile's slabs 0..2 in steps 53.. / 89.. / 125.., its slab 3 in steps 13.. of the
+//     next tile itself (first read at step 108); the two waves of a SIMD four steps apart -- under the other waves' MFMAs; statistics of the next tile's image by
 //     one 256-B DMA piece (double-buffered);
 //   * the epilogue is short and asynchronous: at the end of a tile bias / ReLU / GroupNorm sums are applied in the
 //     accumulator layout (a wave holds all 128 pixels of its 32 channels: no cross-wave reduction), the bf16 values are
@@ -2093,6 +2093,7 @@ __global__ void __launch_bounds__(512, 2) conv3x3_rp_kernel(ConvDev P, char* dum
     const bool gn = P.flags & DAFNE_CONV_GN_STATS;
     const bool fin = gn && (P.flags & DAFNE_CONV_GN_FINALIZE);     // wave-uniform
     const int G8 = P.Cout / 8;
+    const int gnlate = wave >> 2;                                  // GN_INPUT: waves 4..7 convert their pieces four steps later
 
     // ---- prologue: layer constants -> LDS (plain loads: nothing asynchronous is in flight yet), first tile's patch
     RpTile cur = decode(pos);
@@ -2247,11 +2248,13 @@ __global__ void __launch_bounds__(512, 2) conv3x3_rp_kernel(ConvDev P, char* dum
                 if constexpr (j == 108) RP_STAMP(4);
             }
             // ---- GN_INPUT: pieces this wave loaded ~13 steps ago
+            // (waves w and w + 4 share a SIMD: the second half of the workgroup converts four steps later, so that one of the
+            // two always has MFMAs for the matrix pipe)
             if constexpr (GNIN) {
-                if constexpr (j >= 13 && j < 17) { if (!first) gn_piece(cur, 3, j - 13, sb_cur); }
-                if constexpr (j >= 53 && j < 57) gn_piece(nxt, 0, j - 53, sb_nxt);
-                if constexpr (j >= 89 && j < 93) gn_piece(nxt, 1, j - 89, sb_nxt);
-                if constexpr (j >= 125 && j < 129) gn_piece(nxt, 2, j - 125, sb_nxt);
+                if constexpr (j >= 13 && j < 21) { if (!first && ((j - 13) >> 2) == gnlate) gn_piece(cur, 3, (j - 13) & 3, sb_cur); }
+                if constexpr (j >= 53 && j < 61) { if (((j - 53) >> 2) == gnlate) gn_piece(nxt, 0, (j - 53) & 3, sb_nxt); }
+                if constexpr (j >= 89 && j < 97) { if (((j - 89) >> 2) == gnlate) gn_piece(nxt, 1, (j - 89) & 3, sb_nxt); }
+                if constexpr (j >= 125 && j < 133) { if (((j - 125) >> 2) == gnlate) gn_piece(nxt, 2, (j - 125) & 3, sb_nxt); }
             }
             if constexpr (j == 37) patch_map(nxt);
             // ---- the previous tile's GroupNorm sums

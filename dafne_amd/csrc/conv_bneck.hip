@@ -48,9 +48,10 @@ constexpr int kBuf = 4 * kSlab;                        // 256 channels: 64 KB
 constexpr int kOffY = 0;                               // Y chunk / residual chunk / Z staging
 constexpr int kOffT = kBuf;                            // T tile
 constexpr int kOffPatch = 3 * kSlab;                   // phase A only: [4 slabs][208 px][128 B]
+constexpr int kOffSide = kOffT + kBuf;                 // phase B: slab 3 of the NEXT residual chunk (16 KB; inside the dead patch)
 constexpr int kOffBias = kOffPatch + 4 * kPSlab;       // fp32 [256 conv2 | 1024 conv3 | 256 conv1 | 2 x 256 spare]
 constexpr int kSmemTotal = kOffBias + 8 * 1024;
-static_assert(kOffPatch + 4 * kPSlab >= kOffT + kBuf && kSmemTotal <= 160 * 1024, "LDS budget");
+static_assert(kOffPatch + 4 * kPSlab >= kOffSide + kSlab && kOffPatch <= kOffSide && kSmemTotal <= 160 * 1024, "LDS budget");
 constexpr int kCM = 256, kCB = 1024, kChunks = kCB / 256;
 constexpr int kNW = 8, kNT = 512;
 constexpr int kPF = kPx / 32;                          // pixel fragments per wave
@@ -98,8 +99,11 @@ __device__ __forceinline__ unsigned pack_bf16(float a, float b) {
 //   [wait A(s)] MFMAs | bn_st(s) row stores | A(s + 8) if it exists | bn_post(s) DMA pieces:
 //     phase A: one patch piece of slabs 1..3 at steps 0..11; slabs 0..2 of the first residual chunk (their Y-buffer space
 //              does not overlap the patch) one piece at steps 60, 64, .., 80 -- HBM is idle while every CU is in phase A --,
-//              its slab 3 (2 pieces) after step 143, behind the barrier that retires the patch;
-//     phase B: 2 pieces of slab q of the next residual chunk after the last step of slab group q (conv_b2b.hip).
+//              its slab 3 (2 pieces, into the side buffer) after step 143, behind the barrier that retires the patch;
+//     phase B: 2 pieces of slab q = 0..2 of the next residual chunk after the last step of slab group q of GEMM2 (into the
+//              Y buffer, as conv_b2b.hip); its slab 3 goes to a 16-KB SIDE buffer right after GEMM1 + epilogue of the
+//              current chunk, i.e. a whole GEMM2 + GEMM1 ahead of its use (in conv_b2b it is issued last and has one GEMM1,
+//              2.6 us, to arrive from HBM: chunks 1..2 took 18-25k cycles against 15k for chunk 0).
 // bn_wait(j) = number of those instructions issued after A(j) and before the wait for it: vmcnt retires in order, so
 // `s_waitcnt vmcnt(bn_wait(j))` is exactly "A(j) and everything older has landed".
 constexpr int bn_st(int s) {
@@ -112,7 +116,8 @@ constexpr int bn_post(int s) {
         return (s < kTrickle ? 1 : 0) + ((s >= kRes0 && s < kRes0 + 6 * kResStride && (s - kRes0) % kResStride == 0) ? 1 : 0) +
                (s == kStepsA - 1 ? 2 : 0);
     const int j = s - kStepsA, i = j & 31;
-    return (i >= 16 && (i & 3) == 3 && (j >> 5) < kChunks - 1) ? 2 : 0;
+    if ((j >> 5) >= kChunks - 1) return 0;
+    return ((i >= 16 && (i & 3) == 3 && i != 31) || i == 15) ? 2 : 0;
 }
 constexpr int bn_wait(int j) {
     int n = 0;
@@ -125,10 +130,11 @@ constexpr int bn_wait(int j) {
     }
     return n;
 }
-// spot checks: steady state 7; the trickle adds one per step; conv_b2b's own values behind the 144-step shift
-static_assert(bn_wait(0) == 7 && bn_wait(1) == 8 && bn_wait(7) == 14 && bn_wait(8) == 15 && bn_wait(12) == 15 && bn_wait(13) == 14 && bn_wait(20) == 7 &&
-              bn_wait(100) == 7 && bn_wait(68) == 9 && bn_wait(69) == 9 && bn_wait(61) == 8 && bn_wait(kStepsA + 7) == 9 && bn_wait(kStepsA + 8) == 7 && bn_wait(kStepsA + 127) == 4 &&
-              bn_wait(kStepsA + 39) == 9 && bn_wait(kStepsA + 27) == 15 && bn_wait(kStepsA + 24) == 13, "vmcnt bookkeeping");
+// spot checks (hand-counted): steady state 7; the trickle adds one per step; phase B around the side-buffer and slab pieces
+static_assert(bn_wait(0) == 7 && bn_wait(1) == 8 && bn_wait(7) == 14 && bn_wait(8) == 15 && bn_wait(12) == 15 && bn_wait(13) == 14 &&
+              bn_wait(20) == 7 && bn_wait(61) == 8 && bn_wait(68) == 9 && bn_wait(100) == 7 && bn_wait(kStepsA + 7) == 9 &&
+              bn_wait(kStepsA + 8) == 7 && bn_wait(kStepsA + 16) == 9 && bn_wait(kStepsA + 23) == 15 && bn_wait(kStepsA + 24) == 13 &&
+              bn_wait(kStepsA + 31) == 15 && bn_wait(kStepsA + 39) == 7 && bn_wait(kStepsA + 127) == 4, "vmcnt bookkeeping");
 
 template <int I, int N, class F>
 __device__ __forceinline__ void static_for(F&& f) {
@@ -233,9 +239,9 @@ __global__ void __launch_bounds__(512, 2) conv_bneck_kernel(BneckDev P) {
         dpix[ii] = pix_index(px);
         dq[ii] = (unsigned)(((lane & 7) ^ ((px >> 1) & 7)) * 16);
     }
-    auto dma_piece = [&](unsigned col0b, int sl, int ii) {
+    auto dma_piece = [&](unsigned col0b, int sl, int ii) {       // slabs 0..2 land in the Y buffer, slab 3 in the side buffer
         __builtin_amdgcn_global_load_lds((gvoid*)(P.res + (size_t)dpix[ii] * (kCB * 2) + col0b + sl * 128 + dq[ii]),
-                                         (lvoid*)(lds + kOffY + sl * kSlab + (wave + kNW * ii) * 1024), 16, 0, 0);
+                                         (lvoid*)(lds + (sl == 3 ? kOffSide : kOffY + sl * kSlab) + (wave + kNW * ii) * 1024), 16, 0, 0);
     };
     auto dma_slab = [&](unsigned col0b, int sl) {                // 2 pieces per wave into slab sl of the Y buffer
         dma_piece(col0b, sl, 0);
@@ -296,22 +302,25 @@ __global__ void __launch_bounds__(512, 2) conv_bneck_kernel(BneckDev P) {
         typedef __attribute__((ext_vector_type(2))) float f32x2;
         const unsigned rmask = with_res ? 0xffffffffu : 0u;
         const unsigned ebase = lds_base + (unsigned)(buf + (wave >> 1) * kSlab + frow * 128 + 8 * half);
+        // the residual of slab 3 (waves 6, 7) waits in the side buffer
+        const unsigned rbase = (with_res && (wave >> 1) == 3) ? lds_base + (unsigned)(kOffSide + frow * 128 + 8 * half) : ebase;
 #pragma unroll
         for (int gp = 0; gp < 2; gp++) {                 // two 8-channel groups at a time (register budget)
             f32x4 bv[2];
             u32x2 rc[2][kPF];
-            unsigned ead[2];
+            unsigned ead[2], rad[2];
             // LDS reads first, one wait.  Inline asm: a plain LDS read here makes the compiler drain
             // vmcnt (it cannot tell the read from the residual DMA's destination).  Pixel fragments sit 4096 B apart.
 #pragma unroll
             for (int gg = 0; gg < 2; gg++) {
                 const int g = 2 * gp + gg;
                 ead[gg] = ebase + (unsigned)(((((wave & 1) * 4 + g) ^ ((frow >> 1) & 7))) * 16);
+                rad[gg] = rbase + (unsigned)(((((wave & 1) * 4 + g) ^ ((frow >> 1) & 7))) * 16);
                 const unsigned bad = lbias_off + (unsigned)((bias0 + wave * 32 + 8 * g + 4 * half) * 4);
                 asm volatile("ds_read_b128 %4, %6\n\tds_read_b64 %0, %5\n\tds_read_b64 %1, %5 offset:4096\n\t"
                              "ds_read_b64 %2, %5 offset:8192\n\tds_read_b64 %3, %5 offset:12288"
                              : "=&v"(rc[gg][0]), "=&v"(rc[gg][1]), "=&v"(rc[gg][2]), "=&v"(rc[gg][3]), "=&v"(bv[gg])
-                             : "v"(ead[gg]), "v"(bad)
+                             : "v"(rad[gg]), "v"(bad)
                              : "memory");
             }
             asm volatile("s_waitcnt lgkmcnt(0)"
@@ -430,6 +439,7 @@ __global__ void __launch_bounds__(512, 2) conv_bneck_kernel(BneckDev P) {
         if constexpr (c == 0) BN_STAMP();
         epilogue(acc1, 256 + c * 256, true, kOffY);
         barrier();
+        if constexpr (c + 1 < kChunks) dma_slab((unsigned)(c + 1) * 512u, 3);       // side buffer: free since the epilogue read it
         if constexpr (c == 0) BN_STAMP();
         // GEMM2: Z += W1[:, chunk c] . Y chunk, slab by slab; then (every wave done with the slab, its row stores have
         // read it) the same slab of the NEXT residual chunk starts to land in its place
@@ -457,7 +467,7 @@ __global__ void __launch_bounds__(512, 2) conv_bneck_kernel(BneckDev P) {
                 load_step(std::integral_constant<int, j + kRing>{});
             });
             barrier();
-            if constexpr (c + 1 < kChunks) dma_slab((unsigned)(c + 1) * 512u, q);
+            if constexpr (c + 1 < kChunks && q < 3) dma_slab((unsigned)(c + 1) * 512u, q);
             __builtin_amdgcn_sched_barrier(0);
         });
         BN_STAMP();
