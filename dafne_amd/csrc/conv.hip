@@ -1854,9 +1854,9 @@ constexpr int kRCin = 256, kRSteps = 9 * kRCin / 16;    // 144 k16 steps
 constexpr int kRRing = 8;
 constexpr int kRMaxCout = 1024;
 constexpr int kROffStat = 4 * kRSlab;                   // GN_INPUT statistics of (segment, image): 2 x [32][2] fp32
-constexpr int kROffGB = kROffStat + 512;                // gamma [256], beta [256] fp32
-constexpr int kROffBias = kROffGB + 2048;               // bias fp32 [Cout <= 1024]
-constexpr int kROffRed = kROffBias + kRMaxCout * 4;     // [32 groups][2] fp32, finalize flag at +256
+constexpr int kROffGB = kROffStat + 512;                // per group: gamma [256], beta [256] fp32
+constexpr int kROffBias = kROffGB + 2 * 2048;           // per group: bias fp32 [Cout <= 1024]
+constexpr int kROffRed = kROffBias + 2 * kRMaxCout * 4; // [32 groups][2] fp32, finalize flag at +256
 constexpr int kROffFin = kROffRed + 512;                // GN_FINALIZE reduction scratch: 32 x 32 x 2 fp32
 constexpr int kRSmem = kROffFin + 32 * 32 * 2 * 4;
 static_assert(kRSmem <= 160 * 1024, "LDS budget");
@@ -1942,11 +1942,11 @@ __device__ __forceinline__ void rp_bread(bf16x8 (&b)[4], const unsigned (&pb)[3]
 }
 
 struct RpTile {
-    int nt, mt, si, img, Y0, X0, H, W, valid;
+    int nt, mt, si, img, Y0, X0, H, W, valid, grp;
 };
 
 template <bool GNIN>
-__global__ void __launch_bounds__(512, 2) conv3x3_rp_kernel(ConvDev P, char* dump) {
+__global__ void __launch_bounds__(512, 2) conv3x3_rp_kernel(ConvDev PA, ConvDev PB, int n_groups, char* dump) {
     constexpr int NT = 512, NW = 8;
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const int tid = threadIdx.x;
@@ -1956,7 +1956,12 @@ __global__ void __launch_bounds__(512, 2) conv3x3_rp_kernel(ConvDev P, char* dum
     const int lane_ = lane, frow_ = frow, half_ = half;
     const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) char*)lds;
 
-    const int T = P.mtiles * P.ntiles;
+    // up to two GROUPS of tiles in one launch (two layers of identical shape and flags with their own tensors, weights and
+    // GroupNorm state: cls_tower.i and center_tower.i): group 0's tiles first, then group 1's
+    auto PG = [&](int g) -> const ConvDev& { return g ? PB : PA; };
+    const ConvDev& P = PA;                                // launch-wide properties (flags, Cout, N, ntiles) are the same in both
+    const int T0 = PA.mtiles * PA.ntiles;
+    const int T = T0 + (n_groups > 1 ? PB.mtiles * PB.ntiles : 0);
     const int G = (int)gridDim.x;
     const int pos = xcd_remap(blockIdx.x, G);             // workgroups of one XCD take neighbouring tiles (shared halo rows in its L2)
     const int nmine = (T - pos + G - 1) / G;              // tiles pos, pos + G, ...   (G <= T: nmine >= 1)
@@ -1965,14 +1970,17 @@ __global__ void __launch_bounds__(512, 2) conv3x3_rp_kernel(ConvDev P, char* dum
         RpTile c;
         c.valid = t < T;
         t = t < T ? t : T - 1;
-        c.nt = t % P.ntiles;
-        c.mt = t / P.ntiles;
+        c.grp = t >= T0 ? 1 : 0;
+        t -= c.grp * T0;
+        const ConvDev& Q = PG(c.grp);
+        c.nt = t % Q.ntiles;
+        c.mt = t / Q.ntiles;
         int si = 0;
 #pragma unroll
         for (int k = 1; k < kMaxSegs; k++)
-            if (k < P.n_segs && c.mt >= P.seg[k].tile0) si = k;
+            if (k < Q.n_segs && c.mt >= Q.seg[k].tile0) si = k;
         c.si = si;
-        const SegDev& S = P.seg[si];
+        const SegDev& S = Q.seg[si];
         const int tloc = c.mt - S.tile0;
         c.img = tloc / S.tiles_per_img;
         const int tt = tloc - c.img * S.tiles_per_img;
@@ -2009,7 +2017,7 @@ __global__ void __launch_bounds__(512, 2) conv3x3_rp_kernel(ConvDev P, char* dum
             g = g < max_pix ? g : max_pix;                   // ragged tiles reach past the image (and the buffer)
             pofs[ii] = g * (unsigned)(kRCin * 2) + (unsigned)(((lane & 7) ^ ((q >> 1) & 7)) * 16);
         }
-        pin = P.seg[c.si].in;
+        pin = PG(c.grp).seg[c.si].in;
     };
     auto patch_piece = [&](int sl, int ii) {
         __builtin_amdgcn_global_load_lds((gvoid*)(pin + pofs[ii] + sl * 128), (lvoid*)(lds + sl * kRSlab + ppc[ii] * 1024), 16, 0, 0);
@@ -2029,7 +2037,7 @@ __global__ void __launch_bounds__(512, 2) conv3x3_rp_kernel(ConvDev P, char* dum
         const unsigned ad = lds_base + (unsigned)(sl * kRSlab + pc * 1024 + (lane >> 3) * 128 + phys * 16);
         const int ch = sl * kBK + (lane & 7) * 8;
         const unsigned ts = lds_base + (unsigned)(kROffStat + statbuf * 256 + (ch >> 3) * 8);
-        const unsigned tg = lds_base + (unsigned)(kROffGB + ch * 4);
+        const unsigned tg = lds_base + (unsigned)(kROffGB + c.grp * (2 * kRCin * 4) + ch * 4);
         const unsigned tb = tg + (unsigned)kRCin * 4u;
         // two halves of 4 channels (register budget: the constants of 8 channels at once spill inside the tile loop)
         u32x4 v;
@@ -2065,7 +2073,7 @@ __global__ void __launch_bounds__(512, 2) conv3x3_rp_kernel(ConvDev P, char* dum
     };
     // statistics (mean, rstd of the 32 groups) of tile c's image -> stat buffer b: one 256-byte DMA piece, issued by every wave
     auto stat_piece = [&](const RpTile& c, int b) {
-        const float* st = P.in_stats + ((size_t)c.si * P.N + c.img) * (kRCin / 8) * 2;
+        const float* st = PG(c.grp).in_stats + ((size_t)c.si * P.N + c.img) * (kRCin / 8) * 2;
         __builtin_amdgcn_global_load_lds((gvoid*)(st + lane), (lvoid*)(lds + kROffStat + b * 256), 4, 0, 0);
     };
 
@@ -2100,12 +2108,15 @@ __global__ void __launch_bounds__(512, 2) conv3x3_rp_kernel(ConvDev P, char* dum
     {
         float* gb = (float*)(lds + kROffGB);
         float* lb = (float*)(lds + kROffBias);
-        if (GNIN && tid < kRCin) {
-            gb[tid] = P.in_gamma[tid];
-            gb[kRCin + tid] = P.in_beta[tid];
+        for (int g = 0; g < n_groups; g++) {
+            if (GNIN && tid < kRCin) {
+                gb[g * 2 * kRCin + tid] = PG(g).in_gamma[tid];
+                gb[g * 2 * kRCin + kRCin + tid] = PG(g).in_beta[tid];
+            }
+            for (int k = tid; k < P.Cout; k += NT) lb[g * kRMaxCout + k] = PG(g).bias[k];
         }
-        for (int k = tid; k < P.Cout; k += NT) lb[k] = P.bias[k];
-        if (GNIN && tid < 64) ((float*)(lds + kROffStat))[tid] = (P.in_stats + ((size_t)cur.si * P.N + cur.img) * (kRCin / 8) * 2)[tid];
+        if (GNIN && tid < 64)
+            ((float*)(lds + kROffStat))[tid] = (PG(cur.grp).in_stats + ((size_t)cur.si * P.N + cur.img) * (kRCin / 8) * 2)[tid];
         __syncthreads();
     }
     patch_map(cur);
@@ -2114,7 +2125,7 @@ __global__ void __launch_bounds__(512, 2) conv3x3_rp_kernel(ConvDev P, char* dum
 #pragma unroll
         for (int ii = 0; ii < 4; ii++) patch_piece(sl, ii);
     {
-        const char* wf0 = P.w + (size_t)cur.nt * (NW * kRSteps * 1024);
+        const char* wf0 = PG(cur.grp).w + (size_t)cur.nt * (NW * kRSteps * 1024);
         rp_static_for<0, kRRing>([&](auto J) { rp_load<decltype(J)::value>(ar, wf0, wf0, voff); });
     }
     if (GNIN) {
@@ -2146,7 +2157,7 @@ __global__ void __launch_bounds__(512, 2) conv3x3_rp_kernel(ConvDev P, char* dum
             asm volatile("" : "+v"(td));              // (a hoisted tid * 8 spills: its reload would drain vmcnt)
             const float* redb = (const float*)(lds + kROffRed);
             const float sv = redb[td * 2 + 0], qv = redb[td * 2 + 1];
-            float* o = P.gn_partial + ((size_t)prv.mt * G8 + prv.nt * 32 + td) * 2;
+            float* o = PG(prv.grp).gn_partial + ((size_t)prv.mt * G8 + prv.nt * 32 + td) * 2;
             if (fin) {
                 typedef unsigned long long u64a;
                 const u64a vv = ((u64a)__float_as_uint(qv) << 32) | (u64a)__float_as_uint(sv);
@@ -2161,8 +2172,8 @@ __global__ void __launch_bounds__(512, 2) conv3x3_rp_kernel(ConvDev P, char* dum
         if (fin && tid == 0) {
             int last = 0;
             if (prv.valid) {
-                const int old = __hip_atomic_fetch_add(P.gn_counters + prv.si * P.N + prv.img, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                last = old == P.seg[prv.si].tiles_per_img - 1;
+                const int old = __hip_atomic_fetch_add(PG(prv.grp).gn_counters + prv.si * P.N + prv.img, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                last = old == PG(prv.grp).seg[prv.si].tiles_per_img - 1;
             }
             *(int*)(lds + kROffRed + 256) = last;
         }
@@ -2172,7 +2183,8 @@ __global__ void __launch_bounds__(512, 2) conv3x3_rp_kernel(ConvDev P, char* dum
     auto gn_last_tile = [&]() {
         if (fin && *(const int*)(lds + kROffRed + 256)) {
             typedef unsigned long long u64a;
-            const SegDev& S = P.seg[prv.si];
+            const ConvDev& Q = PG(prv.grp);
+            const SegDev& S = Q.seg[prv.si];
             float* scratch = (float*)(lds + kROffFin);
             const int t0 = S.tile0 + prv.img * S.tiles_per_img;
             const int g = tid & 31;
@@ -2182,7 +2194,7 @@ __global__ void __launch_bounds__(512, 2) conv3x3_rp_kernel(ConvDev P, char* dum
                 float sum = 0.f, sqs = 0.f;
                 if (g < G8)
                     for (int tt = sl2; tt < S.tiles_per_img; tt += 32) {
-                        const u64a vv = __hip_atomic_load((const u64a*)(P.gn_partial + ((size_t)(t0 + tt) * G8 + g) * 2), __ATOMIC_RELAXED,
+                        const u64a vv = __hip_atomic_load((const u64a*)(Q.gn_partial + ((size_t)(t0 + tt) * G8 + g) * 2), __ATOMIC_RELAXED,
                                                           __HIP_MEMORY_SCOPE_AGENT);
                         sum += __uint_as_float((unsigned)vv);
                         sqs += __uint_as_float((unsigned)(vv >> 32));
@@ -2202,11 +2214,11 @@ __global__ void __launch_bounds__(512, 2) conv3x3_rp_kernel(ConvDev P, char* dum
                 const float mean = a / cnt;
                 float var = b / cnt - mean * mean;
                 var = var > 0.f ? var : 0.f;
-                float* o = P.gn_stats_out + (((size_t)prv.si * P.N + prv.img) * G8 + tid) * 2;
+                float* o = Q.gn_stats_out + (((size_t)prv.si * P.N + prv.img) * G8 + tid) * 2;
                 o[0] = mean;
                 o[1] = rsqrtf(var + P.gn_eps);
             }
-            if (tid == 0) __hip_atomic_store(P.gn_counters + prv.si * P.N + prv.img, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (tid == 0) __hip_atomic_store(Q.gn_counters + prv.si * P.N + prv.img, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __syncthreads();
         }
     };
@@ -2228,8 +2240,8 @@ __global__ void __launch_bounds__(512, 2) conv3x3_rp_kernel(ConvDev P, char* dum
         const unsigned long long rp_rt0 = __builtin_amdgcn_s_memrealtime();
 #endif
         const RpTile nxt = decode(pos + (k + 1 < nmine ? k + 1 : k) * G);     // the last tile re-fetches itself (nobody reads it)
-        const char* wf_cur = P.w + (size_t)cur.nt * (NW * kRSteps * 1024);
-        const char* wf_nxt = P.w + (size_t)nxt.nt * (NW * kRSteps * 1024);
+        const char* wf_cur = PG(cur.grp).w + (size_t)cur.nt * (NW * kRSteps * 1024);
+        const char* wf_nxt = PG(nxt.grp).w + (size_t)nxt.nt * (NW * kRSteps * 1024);
         const int sb_cur = k & 1, sb_nxt = (k + 1) & 1;
 #pragma unroll
         for (int b = 0; b < 4; b++)
@@ -2299,7 +2311,7 @@ __global__ void __launch_bounds__(512, 2) conv3x3_rp_kernel(ConvDev P, char* dum
         for (int ii = 0; ii < 4; ii++) patch_piece(3, ii);
         {
             f32x4 bia4[4];
-            const unsigned bad = lds_base + (unsigned)(kROffBias + (cur.nt * 256 + wave * 32 + 4 * half) * 4);
+            const unsigned bad = lds_base + (unsigned)(kROffBias + (cur.grp * kRMaxCout + cur.nt * 256 + wave * 32 + 4 * half) * 4);
             asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:32\n\tds_read_b128 %2, %4 offset:64\n\tds_read_b128 %3, %4 offset:96\n\t"
                          "s_waitcnt lgkmcnt(0)"
                          : "=&v"(bia4[0]), "=&v"(bia4[1]), "=&v"(bia4[2]), "=&v"(bia4[3])
@@ -2310,7 +2322,7 @@ __global__ void __launch_bounds__(512, 2) conv3x3_rp_kernel(ConvDev P, char* dum
             // output row of this lane: pixel (Y0 + b, X0 + frow), 16 bytes at channel nt*256 + wave*32 + 8*(2 gp + half)
             const int Wp = cur.W + 2;
             const size_t rowpitch = (size_t)Wp * P.Cout * 2;
-            char* obase = P.seg[cur.si].out + ((size_t)(cur.img * (cur.H + 2) + cur.Y0 + 1) * Wp + cur.X0 + frow + 1) * P.Cout * 2
+            char* obase = PG(cur.grp).seg[cur.si].out + ((size_t)(cur.img * (cur.H + 2) + cur.Y0 + 1) * Wp + cur.X0 + frow + 1) * P.Cout * 2
                           + (cur.nt * 256 + wave * 32 + 8 * half) * 2;
             char* dbase = dump + (size_t)tid * 128;
             const bool colok = cur.valid && (cur.X0 + frow) < cur.W;
@@ -3234,11 +3246,13 @@ int launch_patch_fp8(const ConvDev& D, hipStream_t st) {
     return dafne::check_launch("conv3x3_patch_fp8");
 }
 
-int launch_rp(const ConvDev& D, char* dump, hipStream_t st) {
+int launch_rp(const ConvDev& D, const ConvDev* D2, char* dump, hipStream_t st) {
     DAFNE_MAX_LDS_ONCE(kRSmem, (const void*)conv3x3_rp_kernel<false>, (const void*)conv3x3_rp_kernel<true>);
     int cus = 0;                                           // persistent: at most one workgroup per CU, tiles dealt round-robin
     if (int rc = dafne::device_cus(&cus)) return rc;
-    const int T = D.mtiles * D.ntiles;
+    const int T = D.mtiles * D.ntiles + (D2 ? D2->mtiles * D2->ntiles : 0);
+    const int ng = D2 ? 2 : 1;
+    const ConvDev& E = D2 ? *D2 : D;
     // balanced: with R = ceil(T / CUs) rounds, ceil(T / R) workgroups do R (or R - 1) tiles each -- no half-empty last round
     // (348 tiles: 174 workgroups x 2, not 256 of which 92 do a second tile), and the CUs left over stay free for the
     // kernels of the other sub-batch streams
@@ -3247,8 +3261,8 @@ int launch_rp(const ConvDev& D, char* dump, hipStream_t st) {
     const int rounds = (T + lim - 1) / lim;
     const int G = (T + rounds - 1) / rounds;
     const dim3 grid(G), block(512);
-    if (D.flags & DAFNE_CONV_GN_INPUT) hipLaunchKernelGGL(conv3x3_rp_kernel<true>, grid, block, kRSmem, st, D, dump);
-    else hipLaunchKernelGGL(conv3x3_rp_kernel<false>, grid, block, kRSmem, st, D, dump);
+    if (D.flags & DAFNE_CONV_GN_INPUT) hipLaunchKernelGGL(conv3x3_rp_kernel<true>, grid, block, kRSmem, st, D, E, ng, dump);
+    else hipLaunchKernelGGL(conv3x3_rp_kernel<false>, grid, block, kRSmem, st, D, E, ng, dump);
     return dafne::check_launch("conv3x3_rp");
 }
 
@@ -3388,7 +3402,24 @@ int dafne_conv3x3_c256_hip(const dafne_conv_params* prm, const dafne_conv_seg* s
     if (!d_wfrag) return dafne::fail(DAFNE_E_INVALID, "conv3x3_c256: null fragment-major weights");
     if (!d_scratch || scratch_bytes < (size_t)kRDumpBytes) return dafne::fail(DAFNE_E_WORKSPACE, "conv3x3_c256: scratch %zu < %d", scratch_bytes, kRDumpBytes);
     D.w = (const char*)d_wfrag;
-    return launch_rp(D, (char*)d_scratch, (hipStream_t)stream);
+    return launch_rp(D, nullptr, (char*)d_scratch, (hipStream_t)stream);
+}
+
+int dafne_conv3x3_c256_pair_hip(const dafne_conv_params* prm_a, const dafne_conv_seg* segs_a, const void* d_wfrag_a,
+                                const dafne_conv_params* prm_b, const dafne_conv_seg* segs_b, const void* d_wfrag_b,
+                                void* d_scratch, size_t scratch_bytes, void* stream) {
+    ConvDev A, B;
+    int rc = build(A, prm_a, segs_a, false, true);
+    if (rc) return rc;
+    rc = build(B, prm_b, segs_b, false, true);
+    if (rc) return rc;
+    if (!d_wfrag_a || !d_wfrag_b) return dafne::fail(DAFNE_E_INVALID, "conv3x3_c256_pair: null fragment-major weights");
+    if (!d_scratch || scratch_bytes < (size_t)kRDumpBytes) return dafne::fail(DAFNE_E_WORKSPACE, "conv3x3_c256_pair: scratch %zu < %d", scratch_bytes, kRDumpBytes);
+    if (A.flags != B.flags || A.Cout != B.Cout || A.N != B.N || A.ntiles != B.ntiles || A.gn_eps != B.gn_eps)
+        return dafne::fail(DAFNE_E_INVALID, "conv3x3_c256_pair: the two layers must agree in flags, Cout, image count and gn_eps");
+    A.w = (const char*)d_wfrag_a;
+    B.w = (const char*)d_wfrag_b;
+    return launch_rp(A, &B, (char*)d_scratch, (hipStream_t)stream);
 }
 
 int dafne_conv2d_kernel_id(const dafne_conv_params* prm, const dafne_conv_seg* segs) {

@@ -348,6 +348,27 @@ class ConvCall:
             _lib.check(rc, "dafne_conv2d_nhwc_bf16_hip")
 
 
+class ConvPairCall:
+    """Two resident-patch ConvCalls of identical shape and flags (cls_tower.i, center_tower.i) as ONE launch of the persistent
+    kernel (dafne_conv3x3_c256_pair_hip): twice the tiles per launch, half the launch boundaries."""
+
+    def __init__(self, a, b):
+        assert a.wfrag is not None and b.wfrag is not None and a.prm.flags == b.prm.flags and a.prm.Cout == b.prm.Cout
+        self.a, self.b = a, b
+        self.flops, self.bytes = a.flops + b.flops, a.bytes + b.bytes
+
+    def kernel_name(self):
+        return "conv3x3_rp"
+
+    def __call__(self, stream):
+        a, b = self.a, self.b
+        scr = rp_scratch(a.wfrag.device)
+        rc = _lib.load().dafne_conv3x3_c256_pair_hip(ctypes.byref(a.prm), a.segs, _lib.ptr(a.wfrag), ctypes.byref(b.prm), b.segs,
+                                                     _lib.ptr(b.wfrag), _lib.ptr(scr), scr.numel(), stream)
+        if rc:
+            _lib.check(rc, "dafne_conv3x3_c256_pair_hip")
+
+
 class FnCall:
     def __init__(self, fn, args, keep, name, flops=0, nbytes=0):
         self.fn, self.args, self.keep, self.name = fn, args, keep, name
@@ -370,12 +391,17 @@ def conv_out_hw(h, w, k, stride, pad):
 class DensePlan:
     """Backbone + FPN + head for one (N, H, W): buffers + ordered launches."""
 
-    def __init__(self, weights, n, h, w, depth, num_classes, device, with_head=True, head_outputs=None, calib=None):
+    def __init__(self, weights, n, h, w, depth, num_classes, device, with_head=True, head_outputs=None, calib=None,
+                 shared_gpu=False):
         """calib (dict): build the CALIBRATION plan of an fp8 model -- every layer that could take its plain (not
         GroupNorm-fed) input in e4m3 runs on the bf16 kernel and records max |input| under its weight key; the scales derived
         from it (act_qscale_from_amax) go into weights["act_q8"], and plans built afterwards route those layers to the fp8
         MFMA kernel (dafne_conv2d_nhwc_fp8w_hip with in_qscale = the layer's scale)."""
         assert h % 32 == 0 and w % 32 == 0
+        # shared_gpu: the plan runs next to other plans on concurrent streams (the sub-batches of the pipelined step): launches
+        # stay small so that the streams interleave at a fine grain (no pairing of tower layers: measured -1..-4 % there,
+        # +1.1 % when every launch has the GPU to itself)
+        self.shared_gpu = shared_gpu
         self.calib = calib
         self.n, self.h, self.w = n, h, w
         self.device = device
@@ -670,6 +696,9 @@ class HeadPlan:
         def seg_list(ins, outs, f32=False):
             return [(i.t, (o if f32 else o.t), None, i.h, i.w, i.h, i.w) for i, o in zip(ins, outs)]
 
+        pair_towers = os.environ.get("DAFNE_RP_PAIR", "1") != "0" and not getattr(plan, "shared_gpu", False)
+        deferred = []              # intermediate maps of cls_tower / center_tower: released when BOTH towers are built (see below)
+
         def tower(name, ins, in_gn, consumers):
             """4 x [conv3x3 -> GroupNorm(32) -> ReLU].  When the library's 3x3 patch kernel takes the layer
             (kernel id 6 with F_GNIN), the GroupNorm + ReLU of layer i is applied by layer i+1 while it loads
@@ -734,6 +763,7 @@ class HeadPlan:
                 else:
                     c = ConvCall(wgt, bias, C, C, 3, 1, 1, flags, seg_list(cur, outs), n, gn_partial=partial, gn_in=cur_gn,
                                  gn_fin=fin, wfrag=wfrag)
+                c.tower_tag = (name, i)
                 calls.append(c)
                 plan.flops += c.flops
                 gsegs = (_lib.GnSeg * len(outs))()
@@ -757,7 +787,9 @@ class HeadPlan:
                     nxt_gn = None
                 if i > 0:
                     for a in cur:
-                        pool.put(a)
+                        # cls_tower.i and center_tower.i may run in ONE launch: a map the cls tower has released must not be
+                        # handed to the center tower while the pair that still reads it is in flight
+                        (deferred.append(a) if pair_towers and name != "corners_tower" else pool.put(a))
                 cur, cur_gn = outs, nxt_gn
             return cur, cur_gn
 
@@ -765,7 +797,22 @@ class HeadPlan:
         cls_t, cls_gn = tower("cls_tower", feats, None, [("cls_logits", num_classes, F_F32)] if fuse_pred else [])
         ctr_t, ctr_gn = tower("center_tower", feats, None,
                               [("center_pred", 2, F_F32), ("corners_tower.0", C, 0)] if fuse_pred else [])
+        for a in deferred:
+            pool.put(a)
         cor_t, cor_gn = tower("corners_tower", ctr_t, ctr_gn, [("corners_ctrness", 9, F_F32)] if fuse_pred else [])
+        # cls_tower.i and center_tower.i are independent chains of identical shape: one launch of the persistent kernel for
+        # both (the pair takes cls_tower.i's place in the launch list: center_tower.i only moves EARLIER, behind the pair that
+        # holds center_tower.i-1 -- legal when that layer's statistics are finalised inside its kernel, F_GNFIN)
+        if pair_towers:
+            tagged = {c.tower_tag: c for c in calls if isinstance(c, ConvCall) and hasattr(c, "tower_tag")}
+            for i in range(4):
+                a, b = tagged.get(("cls_tower", i)), tagged.get(("center_tower", i))
+                if a is None or b is None or a.wfrag is None or b.wfrag is None or a.prm.flags != b.prm.flags:
+                    break
+                if i > 0 and not (tagged[("cls_tower", i - 1)].prm.flags & tagged[("center_tower", i - 1)].prm.flags & F_GNFIN):
+                    break
+                calls[calls.index(a)] = ConvPairCall(a, b)
+                calls.remove(b)
 
         def pred(key, ins, cout, name, gn_in):
             wgt, bias = P[key]

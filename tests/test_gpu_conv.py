@@ -845,3 +845,56 @@ def test_resident_patch_kernel_gn_chain(fused_finalize):
         ref = bfr(F.conv2d(y1n, w2, b2, padding=1))
         got = a.nchw_float().cpu()
         assert (got - ref).abs().max() < 0.06 * ref.abs().max()
+
+
+@pytest.mark.parametrize("gnin", [False, True])
+def test_resident_patch_pair_launch_equals_two_launches(gnin):
+    """dafne_conv3x3_c256_pair_hip (two layers of identical shape -- cls_tower.i / center_tower.i -- as ONE launch of the
+    persistent kernel, each with its own tensors, weights and GroupNorm state) against two dafne_conv3x3_c256_hip launches:
+    outputs and finalised statistics bit for bit, with plain and GroupNorm-on-load inputs, ragged levels."""
+    from dafne_amd import engine, _lib
+    d = dev()
+    g = torch.Generator().manual_seed(123 + gnin)
+    C, N = 256, 3
+    sizes = [(40, 72), (17, 33), (8, 8)]
+    st = _lib.current_stream()
+    gamma = (1 + 0.2 * torch.randn(C, generator=g)).to(d)
+    beta = (0.3 * torch.randn(C, generator=g)).to(d)
+
+    def layer():
+        xs = [engine.Act.from_nchw(bfr(torch.randn(N, C, h, w, generator=g)).to(d)) for h, w in sizes]
+        wp, bp = engine.pack_conv(bfr(torch.randn(C, C, 3, 3, generator=g) / 48.0), torch.randn(C, generator=g) * 0.1, d)
+        in_stats = torch.zeros(len(sizes), N, C // 8, 2, device=d)
+        in_stats[..., 0] = (torch.randn(len(sizes), N, C // 8, generator=g) * 0.2).to(d)
+        in_stats[..., 1] = (1 + 0.3 * torch.rand(len(sizes), N, C // 8, generator=g)).to(d)
+        return xs, wp, bp, in_stats
+
+    def call(L, outs):
+        xs, wp, bp, in_stats = L
+        segs = [(i.t, o.t, None, i.h, i.w, i.h, i.w) for i, o in zip(xs, outs)]
+        kw = {"gn_in": (in_stats, gamma, beta)} if gnin else {}
+        probe = _rp_call(wp, bp, C, engine.F_GNIN if gnin else 0, segs, N, d, **kw)
+        partial = torch.zeros(probe.num_tiles(), C // 8, 2, dtype=torch.float32, device=d)
+        stats = torch.zeros(len(outs), N, C // 8, 2, dtype=torch.float32, device=d)
+        counters = torch.zeros(len(outs), N, dtype=torch.int32, device=d)
+        c = _rp_call(wp, bp, C, engine.F_GN | engine.F_GNFIN | (engine.F_GNIN if gnin else 0), segs, N, d, gn_partial=partial,
+                     gn_fin=(stats, counters, 1e-5), **kw)
+        return c, stats
+
+    LA, LB = layer(), layer()
+    single = [[engine.Act(N, h, w, C, d) for h, w in sizes] for _ in range(2)]
+    paired = [[engine.Act(N, h, w, C, d) for h, w in sizes] for _ in range(2)]
+    (ca, sa), (cb, sb) = call(LA, single[0]), call(LB, single[1])
+    ca(st)
+    cb(st)
+    (pa, psa), (pb_, psb) = call(LA, paired[0]), call(LB, paired[1])
+    pair = engine.ConvPairCall(pa, pb_)
+    assert pair.kernel_name() == "conv3x3_rp" and pair.flops == ca.flops + cb.flops
+    pair(st)
+    pair(st)                                          # the arrival counters were reset by the first launch
+    torch.cuda.synchronize()
+    for s_, p_ in zip(single[0] + single[1], paired[0] + paired[1]):
+        assert torch.equal(s_.t, p_.t)
+        assert float(p_.t[:, 0].abs().max()) == 0 and float(p_.t[:, :, -1].abs().max()) == 0
+    assert torch.equal(sa, psa) and torch.equal(sb, psb)
+    assert float(sa.abs().sum()) > 0
