@@ -244,7 +244,7 @@ class OneStageDetector(nn.Module):
                     hos.append(ho)
                     plan_sets.append([engine.DensePlan(self._weights(), bounds[k + 1] - bounds[k], hn, wn, self.depth,
                                                        nc, self.device, head_outputs=ho.views(bounds[k], bounds[k + 1]),
-                                                       shared_gpu=splits > 1)
+                                                       shared_gpu=True)
                                       for k in range(splits)])
                 # compute streams are high-priority: ROCm maps normal-priority streams onto a small shared set
                 # of hardware queues, and two sub-batches landing on one queue serialise (dense part alone,
