@@ -205,6 +205,38 @@ def pack_conv3x3_frag(w):
     return w.reshape(cout // 256, 8, 32, 144, 2, 8).permute(0, 1, 3, 4, 2, 5).contiguous().reshape(-1)   # nt, w, j, h, r, e
 
 
+def pack_conv3x3_frag8(qb):
+    """Fragment-major e4m3 weights of dafne_conv3x3_c256_fp8w_hip from pack_conv_fp8's bytes ([Cout, 2304] uint8, K order slab,
+    kh, kw, channel): [Cout/256][8 waves][36 steps][2][64 lanes][16]: rows nt*256 + wave*32 + (lane & 31), K bytes 64*step +
+    32*(lane >> 5) + 16*j .. +16."""
+    cout = qb.shape[0]
+    assert qb.dim() == 2 and qb.shape[1] == 2304 and cout % 256 == 0 and qb.dtype == torch.uint8
+    return qb.reshape(cout // 256, 8, 32, 36, 2, 2, 16).permute(0, 1, 3, 5, 4, 2, 6).contiguous().reshape(-1)   # nt, w, step, j, half, r, b
+
+
+_FRAG8 = {}
+
+
+def frag8_of(qb):
+    """pack_conv3x3_frag8 of an e4m3 weight tensor, built once per tensor."""
+    key = (qb.data_ptr(), str(qb.device))
+    if key not in _FRAG8:
+        _FRAG8[key] = (qb, pack_conv3x3_frag8(qb))          # keeps qb alive: the key is its address
+    return _FRAG8[key][1]
+
+
+_BUILDING_SHARED = [False]     # a DensePlan(shared_gpu=True) is being built (plans are built on one thread)
+
+
+def use_rp8_kernel():
+    """conv3x3_rp8_kernel (fp8 resident patch, persistent) for the fp8 layers with 256 input channels?  Default: when the plan
+    has the GPU to itself (tower layer at batch 8: 149 -> 134 us, config 5 serial +2 %); the sub-batch plans of the pipelined
+    step keep conv3x3_patch_fp8_kernel, whose small workgroups interleave with the other streams' launches (the persistent
+    kernel measured -3 % there).  DAFNE_CONV_RP8=1 / 0 forces it on / off everywhere (tests, A/B runs)."""
+    v = os.environ.get("DAFNE_CONV_RP8")
+    return (not _BUILDING_SHARED[0]) if v is None else v != "0"
+
+
 _RP_SCRATCH = {}
 
 
@@ -271,6 +303,7 @@ class ConvCall:
         self.fp8 = fp8
         self.wfrag = wfrag
         assert fp8 is None or wfrag is None
+        self.rp8 = None             # fp8 call on the resident-patch kernel: fragment-major e4m3 weights (decided below)
         self.keep = (w, b, gn_partial, [s for s in segs], gn_in, fp8, gn_fin, wfrag)
         gi = [t.data_ptr() for t in gn_in] if gn_in is not None else [None, None, None]
         gf = (gn_fin[0].data_ptr(), gn_fin[1].data_ptr(), float(gn_fin[2])) if gn_fin is not None else (None, None, 0.0)
@@ -284,6 +317,8 @@ class ConvCall:
                                   hin, win, hout, wout)
         self.segs = arr
         self.fn = L.dafne_conv2d_nhwc_bf16_hip
+        if fp8 is not None and cin == 256 and k == 3 and use_rp8_kernel() and L.dafne_conv3x3_c256_ok(ctypes.byref(self.prm), self.segs):
+            self.rp8 = frag8_of(w)
         self.flops = 0
         self.bytes = w.numel() * w.element_size()       # algorithmic HBM bytes: every operand once
         for (_, tout, tres, hin, win, hout, wout) in segs:
@@ -298,7 +333,7 @@ class ConvCall:
         return self.fp8 is None and bool(_lib.load().dafne_conv3x3_c256_ok(ctypes.byref(self.prm), self.segs))
 
     def num_tiles(self):
-        if self.wfrag is not None:
+        if self.wfrag is not None or self.rp8 is not None:
             return _lib.load().dafne_conv3x3_c256_num_tiles(ctypes.byref(self.prm), self.segs)
         if self.fp8 is not None:
             return _lib.load().dafne_conv2d_fp8w_num_tiles(ctypes.byref(self.prm), self.segs)
@@ -316,6 +351,8 @@ class ConvCall:
 
     def kernel_name(self):
         """The HIP kernel this call dispatches to (conv.hip), for per-kernel attribution in bench.py."""
+        if self.rp8 is not None:
+            return "conv3x3_rp8"
         if self.fp8 is not None:
             return "conv3x3_patch_fp8"
         if self.wfrag is not None:
@@ -325,12 +362,19 @@ class ConvCall:
     def tiles_per_image(self):
         out = (ctypes.c_int32 * self.prm.n_segs)()
         fn = _lib.load().dafne_conv2d_fp8w_tiles_per_image if self.fp8 is not None else _lib.load().dafne_conv2d_tiles_per_image
-        if self.wfrag is not None:
+        if self.wfrag is not None or self.rp8 is not None:
             fn = _lib.load().dafne_conv3x3_c256_tiles_per_image
         _lib.check(fn(ctypes.byref(self.prm), self.segs, out), "dafne_conv2d_tiles_per_image")
         return list(out)
 
     def __call__(self, stream):
+        if self.rp8 is not None:
+            scr = rp_scratch(self.rp8.device)
+            rc = _lib.load().dafne_conv3x3_c256_fp8w_hip(ctypes.byref(self.prm), self.segs, _lib.ptr(self.rp8), _lib.ptr(self.fp8[0]),
+                                                         ctypes.c_float(self.fp8[1]), _lib.ptr(scr), scr.numel(), stream)
+            if rc:
+                _lib.check(rc, "dafne_conv3x3_c256_fp8w_hip")
+            return
         if self.fp8 is not None:
             rc = _lib.load().dafne_conv2d_nhwc_fp8w_hip(ctypes.byref(self.prm), self.segs, _lib.ptr(self.fp8[0]),
                                                         ctypes.c_float(self.fp8[1]), stream)
@@ -402,6 +446,13 @@ class DensePlan:
         # stay small so that the streams interleave at a fine grain (no pairing of tower layers: measured -1..-4 % there,
         # +1.1 % when every launch has the GPU to itself)
         self.shared_gpu = shared_gpu
+        _BUILDING_SHARED[0] = bool(shared_gpu)
+        try:
+            self._build(weights, n, h, w, depth, num_classes, device, with_head, head_outputs, calib)
+        finally:
+            _BUILDING_SHARED[0] = False
+
+    def _build(self, weights, n, h, w, depth, num_classes, device, with_head, head_outputs, calib):
         self.calib = calib
         self.n, self.h, self.w = n, h, w
         self.device = device

@@ -26,12 +26,19 @@ for k in range(NI):
     partial = torch.zeros(4096, C // 8, 2, device=d)
     fl = engine.F_GN | engine.F_GNIN
     cb = engine.ConvCall(wp, bp, C, C, 3, 1, 1, fl, segs, B, gn_partial=partial, gn_in=(stats, gamma, beta))
+    os.environ["DAFNE_CONV_RP8"] = "0"
     cq = engine.ConvCall(wq, bp, C, C, 3, 1, 1, fl, segs, B, gn_partial=partial, gn_in=(stats, gamma, beta), fp8=(ws, 1.0))
+    os.environ["DAFNE_CONV_RP8"] = "1"
+    cr = engine.ConvCall(wq, bp, C, C, 3, 1, 1, fl, segs, B, gn_partial=partial, gn_in=(stats, gamma, beta), fp8=(ws, 1.0))
+    crn = engine.ConvCall(wq, bp, C, C, 3, 1, 1, engine.F_GN, segs, B, gn_partial=partial, fp8=(ws, 1.0))
+    cbr = engine.ConvCall(wp, bp, C, C, 3, 1, 1, fl, segs, B, gn_partial=partial, gn_in=(stats, gamma, beta), wfrag=engine.pack_conv3x3_frag(wp))
+    assert cq.kernel_name() == "conv3x3_patch_fp8" and cr.kernel_name() == "conv3x3_rp8" and cbr.kernel_name() == "conv3x3_rp"
     cn = engine.ConvCall(wp, bp, C, C, 3, 1, 1, engine.F_GN, segs, B, gn_partial=partial)
-    sets.append((cb, cq, cn, ins, outs))
+    sets.append((cb, cq, cn, cr, crn, cbr, ins, outs))
 st = _lib.current_stream()
 flops = sets[0][0].flops
-for name, idx in (("bf16 conv3x3_patch<GNIN>", 0), ("fp8 conv3x3_patch_fp8<GNIN>", 1), ("bf16 conv3x3_patch (no GN input)", 2)):
+for name, idx in (("bf16 conv3x3_patch<GNIN>", 0), ("fp8 conv3x3_patch_fp8<GNIN>", 1), ("bf16 conv3x3_patch (no GN input)", 2),
+                  ("fp8 conv3x3_rp8<GNIN>", 3), ("fp8 conv3x3_rp8 (no GN input)", 4), ("bf16 conv3x3_rp<GNIN>", 5)):
     for s in sets: s[idx](st)
     torch.cuda.synchronize()
     reps = 12

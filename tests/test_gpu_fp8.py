@@ -22,8 +22,9 @@ def q8(x, qscale=1.0):
     return (x * qscale).clamp(-448.0, 448.0).to(F8).float()
 
 
-def run_fp8(xs, w, b, in_qscale, flags=0, gn_in=None, gn_stats=False):
-    """xs: list of [N,C,H,W] float maps (levels sharing the weights).  Returns (outputs NCHW float on the CPU, partial, call)."""
+def run_fp8(xs, w, b, in_qscale, flags=0, gn_in=None, gn_stats=False, kernel=None):
+    """xs: list of [N,C,H,W] float maps (levels sharing the weights).  Returns (outputs NCHW float on the CPU, partial, call).
+    kernel: the kernel the call must land on (default: conv3x3_rp8 for 256 input channels, conv3x3_patch_fp8 otherwise)."""
     from dafne_amd import engine, _lib
     d = dev()
     n, cin = xs[0].shape[:2]
@@ -42,7 +43,7 @@ def run_fp8(xs, w, b, in_qscale, flags=0, gn_in=None, gn_stats=False):
         partial = torch.zeros(4096, cout // 8, 2, dtype=torch.float32, device=d)
         probe = engine.ConvCall(wq, bias, cin, cout, 3, 1, 1, flags | engine.F_GN, segs, n, gn_partial=partial,
                                 gn_in=gn_in, fp8=(oscale, in_qscale))
-    assert probe.kernel_name() == "conv3x3_patch_fp8"
+    assert probe.kernel_name() == (kernel or ("conv3x3_rp8" if cin == 256 else "conv3x3_patch_fp8"))
     probe(_lib.current_stream())
     torch.cuda.synchronize()
     for o in outs:      # the halo must still be zero
@@ -63,8 +64,37 @@ def test_e4m3_weight_quantiser_is_exact_in_bf16():
     assert float((deq - w).abs().max() / w.abs().max()) < 2.0 ** -4
 
 
+@pytest.fixture(params=["rp8", "patch_fp8"])
+def c256_kernel(request, monkeypatch):
+    """The fp8 layers with 256 input channels run on conv3x3_rp8 (default) or, with DAFNE_CONV_RP8=0, on conv3x3_patch_fp8."""
+    monkeypatch.setenv("DAFNE_CONV_RP8", "1" if request.param == "rp8" else "0")
+    return "conv3x3_" + request.param
+
+
+@pytest.mark.parametrize("H,W,N,cout,relu,qs", [
+    (64, 64, 5, 256, False, 1.0),            # FPN-output-like
+    (40, 100, 3, 256, True, 4.0),            # ragged in both directions
+    (33, 47, 3, 512, True, 0.5),             # two channel tiles, ragged rows and columns
+    (3, 5, 7, 256, False, 16.0),             # a single ragged tile per image
+    (128, 128, 2, 256, True, 2.0),           # more tiles than workgroups of the persistent grid: several rounds per workgroup
+])
+def test_fp8_c256_kernels_vs_torch(H, W, N, cout, relu, qs, c256_kernel):
+    from dafne_amd import engine
+    g = torch.Generator().manual_seed(cout + H + W)
+    x = bfr(torch.randn(N, 256, H, W, generator=g) * 3.0)
+    x[0, :, 0, 0] = 1000.0                    # saturates at 448 / qs
+    x[0, :, -1, -1] = -1000.0
+    w = torch.randn(cout, 256, 3, 3, generator=g) / (256 * 9) ** 0.5
+    b = torch.randn(cout, generator=g) * 0.1
+    _, wscale, wdeq = engine.quantize_weight_e4m3(w)
+    ref = F.conv2d(q8(x, qs), wdeq / qs, b, padding=1)
+    if relu:
+        ref = F.relu(ref)
+    (got,), _, _ = run_fp8([x], w, b, qs, flags=engine.F_RELU if relu else 0, kernel=c256_kernel)
+    close_bf16(got, bfr(ref))
+
+
 @pytest.mark.parametrize("cin,cout,H,W,N,relu,qs", [
-    (256, 256, 64, 64, 5, False, 1.0),       # FPN-output-like
     (64, 256, 40, 100, 3, True, 4.0),        # one slab, ragged in both directions
     (128, 512, 33, 47, 3, True, 0.5),        # two channel tiles, two slabs, ragged rows and columns
     (320, 256, 24, 64, 6, False, 16.0),      # five slabs
@@ -86,7 +116,7 @@ def test_fp8_patch_kernel_vs_torch(cin, cout, H, W, N, relu, qs):
     close_bf16(got, bfr(ref))
 
 
-def test_fp8_gn_input_chain_over_levels():
+def test_fp8_gn_input_chain_over_levels(c256_kernel):
     """Tower layer pair over three levels: layer 1 (bf16 patch kernel) emits the raw map + GroupNorm partial sums, the
     statistics are finalised, layer 2 is the fp8 kernel with GN_INPUT: GroupNorm + ReLU + e4m3 rounding while the patch
     is loaded, GroupNorm statistics of its own output.  The reference applies the same expression to the device's raw
@@ -122,7 +152,7 @@ def test_fp8_gn_input_chain_over_levels():
                                               ctypes.c_float(1e-5), st), "finalize")
     torch.cuda.synchronize()
     raw_maps = [r.nchw_float() for r in raw]           # device tensors, fp32 view of the bf16 maps
-    outs, partial2, c2 = run_fp8(raw_maps, w2, b2, 1.0, gn_in=(stats, gamma, beta), gn_stats=True)
+    outs, partial2, c2 = run_fp8(raw_maps, w2, b2, 1.0, gn_in=(stats, gamma, beta), gn_stats=True, kernel=c256_kernel)
     _, _, w2deq = engine.quantize_weight_e4m3(w2)
     t0 = 0
     for k, (rm, got) in enumerate(zip(raw_maps, outs)):
@@ -219,7 +249,7 @@ def test_fp8_model_backbone_and_head_vs_oracle():
 
 def test_fp8_model_uses_the_fp8_kernel_and_runs_end_to_end():
     """Config 5 end to end at a small size.  Without activation calibration the ten GroupNorm-fed tower layers go to
-    conv3x3_patch_fp8; after calibrate_fp8 pinned the plain-input layers' scales so do the 23 + 3 res4 / res5 3x3 layers,
+    the fp8 3x3 kernels; after calibrate_fp8 pinned the plain-input layers' scales so do the 23 + 3 res4 / res5 3x3 layers,
     the 3 FPN output convolutions and the 2 FPN-fed tower layers: 41.  Calibration is EXPLICIT by default: an fp8 model
     without scales raises instead of quantising by whatever batch comes first; scales can be installed and persisted with
     the weights.  Detections are well formed."""
@@ -235,7 +265,7 @@ def test_fp8_model_uses_the_fp8_kernel_and_runs_end_to_end():
     m([{"image": img, "height": h, "width": w}])
     assert m.fp8_act_scales() is None
     names = [c.kernel_name() for c in m.plan(1, h, w).calls if hasattr(c, "kernel_name")]
-    assert names.count("conv3x3_patch_fp8") == 10, names      # layers 1..3 of three towers + corners_tower.0
+    assert names.count("conv3x3_rp8") == 10, names            # layers 1..3 of three towers + corners_tower.0: 256 in, resident patch
     cfg.ENGINE.FP8_ACT_CALIBRATION = "explicit"
     m.calibrate_fp8(img.unsqueeze(0).to(dev()))
     out = m([{"image": img, "height": h, "width": w}])[0]["instances"]
@@ -255,7 +285,9 @@ def test_fp8_model_uses_the_fp8_kernel_and_runs_end_to_end():
     assert len(scales) == 31 and all(v > 0 and np.log2(v) == np.round(np.log2(v)) for v in scales.values()), scales
     plan = m.plan(1, h, w)
     names = [c.kernel_name() for c in plan.calls if hasattr(c, "kernel_name")]
-    assert names.count("conv3x3_patch_fp8") == 41, names      # 26 + 3 + 12: the same set of layers at every image size
+    # 26 + 3 + 12, the same set of layers at every image size; the 256-input ones (res4, FPN outputs, towers) on the resident-patch
+    # kernel, the three 512-input res5 layers on the generic fp8 patch kernel
+    assert names.count("conv3x3_rp8") == 38 and names.count("conv3x3_patch_fp8") == 3, names
     assert "amax_probe" not in names
     assert 0 < len(out) <= cfg.MODEL.DAFNE.POST_NMS_TOPK_TEST + 8
     s = out.scores.cpu().numpy()
@@ -263,9 +295,11 @@ def test_fp8_model_uses_the_fp8_kernel_and_runs_end_to_end():
     assert torch.isfinite(out.pred_corners).all() and int(out.pred_classes.max()) < 2
 
 
-def test_fp8_model_pipelined_equals_serial():
+def test_fp8_model_pipelined_equals_serial(c256_kernel):
     """The fp8 model through the pipelined path (sub-batches on concurrent streams, post-process on the side stream)
-    gives the detections of the serial path (same kernels on the same sub-batch composition: splits=1)."""
+    gives the detections of the serial path (same kernels on the same sub-batch composition: splits=1).  The kernel of the
+    256-input fp8 layers is pinned: left to the default, a plan that has the GPU to itself takes conv3x3_rp8 and the
+    pipelined step's sub-batch plans conv3x3_patch_fp8, two roundings of the same sums (2 bf16 ulps apart, the tests above)."""
     cfg, m, P = _build("ucas_aod_r101_fp8.yaml", seed=13)
     g = torch.Generator().manual_seed(6)
     batches = [torch.randint(0, 256, (3, 3, 128, 160), generator=g, dtype=torch.uint8).to(dev()) for _ in range(3)]
