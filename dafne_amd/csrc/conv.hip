@@ -3487,6 +3487,253 @@ __global__ void __launch_bounds__(512) conv3x3_slab_kernel(ConvDev P) {
     }
 }
 
+// ---------------------------------------------------------------------------------------
+// The slab kernel's persistent form for the head's own shapes: 256 input channels, <= 16 output channels (cls_logits 15 / 16,
+// corners_pred + ctrness 9, center_pred 2; dafne.py:318-344).  At 1/16 of a tower layer's matrix work these launches are
+// bound by the 512 B per input pixel they read, so everything else is taken off the critical path:
+//   * v_mfma_f32_16x16x32_bf16 (16 output channels per instruction: no padding to 32) with ALL weights resident in LDS,
+//     fragment-major (72 k32 steps x 1 KB), loaded once per workgroup instead of once per tile;
+//   * the workgroup walks its tiles (8 x 32 output pixels) as one stream of 64-channel slabs: raw pixels go global ->
+//     registers two slabs ahead (87 KB in flight per CU), are normalised (GN_INPUT: GroupNorm + ReLU, the expression of
+//     gn_apply_kernel) and written to one of two LDS slab buffers one slab ahead; one barrier per slab, the next tile's
+//     first slabs are on their way while the current tile's last ones are multiplied;
+//   * wave = (row pair, column half): 2 x 16 output pixels over the whole K, so the fp32 results leave from registers.
+// K order per output: (slab, kw, k32 half, kh) -- fp32 sums, compared with torch at 2e-3 like the slab kernel.
+constexpr int kVSlab = kPRows * 128;                // 43 520 B: 340 patch pixels x 64 channels
+constexpr int kVOffW = 2 * kVSlab;
+constexpr int kVSteps = 72;                         // k32 steps: (slab, tap, half)
+constexpr int kVSmem = kVOffW + kVSteps * 1024;     // 160 768 B
+constexpr int kVCin = 256;
+static_assert(kVSmem <= 160 * 1024, "LDS budget");
+
+struct QTile {
+    int si, img, Y0, X0, H, W;
+};
+
+template <bool GNIN>
+__global__ void __launch_bounds__(512) conv3x3_pred16_kernel(ConvDev P) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int rp = wave & 3, ch = wave >> 2;        // output rows 2rp, 2rp + 1; columns 16ch .. +16
+    const int fcol = lane & 15, kg = lane >> 4;     // fragment column / row, 8-element K group
+    const int q = tid & 7;                          // this thread's 16-byte chunk (8 channels) of every pixel it moves
+    const int T = P.mtiles, G = (int)gridDim.x;
+    const int ntl = (T - (int)blockIdx.x + G - 1) / G;      // tiles of this workgroup (>= 1: G <= T)
+
+    // ---- weights: k32 step st = (slab * 9 + tap) * 2 + half at 1 KB each, lane-linear (rows >= Cout repeat the last one:
+    // their results are never stored)
+    {
+        const int row = fcol < P.Cout ? fcol : P.Cout - 1;
+        const char* wsrc = P.w + (size_t)row * P.kbytes + kg * 16;
+        for (int st = wave; st < kVSteps; st += 8)
+            *(u32x4*)(lds + kVOffW + st * 1024 + lane * 16) = *(const u32x4*)(wsrc + (st >> 1) * 128 + (st & 1) * 64);
+    }
+
+    // ---- the six 16-byte pieces a thread moves per slab: patch pixel r = i * 64 + tid / 8, chunk q
+    int ppos[6];                                    // py | px << 8
+    unsigned wofs[6];
+#pragma unroll
+    for (int i = 0; i < 6; i++) {
+        int r = i * 64 + (tid >> 3);
+        r = r < kPRows ? r : kPRows - 1;
+        const int py = r / kPCols, px = r - py * kPCols;
+        ppos[i] = py | (px << 8);
+        wofs[i] = (unsigned)(r * 128 + ((q ^ ((px >> 1) & 7)) << 4));
+    }
+    const bool last_piece = tid < (kPRows - 5 * 64) * 8;    // piece 5 exists for patch pixels 320..339
+
+    float gam[4][8], bet[4][8];
+    if (GNIN) {
+#pragma unroll
+        for (int s = 0; s < 4; s++) {
+            const f32x4 g0 = *(const f32x4*)(P.in_gamma + s * 64 + q * 8), g1 = *(const f32x4*)(P.in_gamma + s * 64 + q * 8 + 4);
+            const f32x4 b0 = *(const f32x4*)(P.in_beta + s * 64 + q * 8), b1 = *(const f32x4*)(P.in_beta + s * 64 + q * 8 + 4);
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                gam[s][k] = g0[k]; gam[s][4 + k] = g1[k];
+                bet[s][k] = b0[k]; bet[s][4 + k] = b1[k];
+            }
+        }
+    }
+    float bias[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) bias[k] = (P.bias && 4 * kg + k < P.Cout) ? P.bias[4 * kg + k] : 0.f;
+
+    auto decode = [&](int v) {
+        const int mt = xcd_remap(v < T ? v : T - 1, T);
+        QTile c;
+        int si = 0;
+#pragma unroll
+        for (int k = 1; k < kMaxSegs; k++)
+            if (k < P.n_segs && mt >= P.seg[k].tile0) si = k;
+        c.si = si;
+        const SegDev& S = P.seg[si];
+        const int tloc = mt - S.tile0;
+        c.img = tloc / S.tiles_per_img;
+        const int tt = tloc - c.img * S.tiles_per_img;
+        const int ty = tt / S.tiles_x;
+        c.Y0 = ty * kPH;
+        c.X0 = (tt - ty * S.tiles_x) * kPW;
+        c.H = S.Hout;
+        c.W = S.Wout;
+        return c;
+    };
+
+    // per-lane source offsets of a tile's pieces (slab 0) and which of them are pixels of the image (GN_INPUT: the halo and
+    // the clamped overhang must stay zero after the normalisation)
+    unsigned pofs[6];
+    const char* pin = nullptr;
+    auto patch_map = [&](const QTile& c, unsigned& inside) {
+        const int Hp = c.H + 2, Wp = c.W + 2;
+        inside = 0;
+#pragma unroll
+        for (int i = 0; i < 6; i++) {
+            int gy = c.Y0 + (ppos[i] & 0xff), gx = c.X0 + (ppos[i] >> 8);
+            gy = gy < Hp ? gy : Hp - 1;
+            gx = gx < Wp ? gx : Wp - 1;
+            if (gy >= 1 && gy <= c.H && gx >= 1 && gx <= c.W) inside |= 1u << i;
+            pofs[i] = ((unsigned)(c.img * Hp + gy) * (unsigned)Wp + (unsigned)gx) * (unsigned)(kVCin * 2) + (unsigned)q * 16u;
+        }
+        pin = P.seg[c.si].in;
+    };
+    u32x4 raw[2][6];
+    auto load = [&](int set, int slab) {
+#pragma unroll
+        for (int i = 0; i < 6; i++) raw[set][i] = *(const u32x4*)(pin + pofs[i] + (unsigned)slab * 128u);
+    };
+    auto load_stats = [&](const QTile& c, f32x2 (&ms)[4]) {
+        const float* st = P.in_stats + ((size_t)c.si * P.N + c.img) * (kVCin / 8) * 2;
+#pragma unroll
+        for (int s = 0; s < 4; s++) ms[s] = *(const f32x2*)(st + (s * 8 + q) * 2);
+    };
+    auto convert = [&](int set, int slab, int buf, const f32x2& ms, unsigned inside) {
+        char* pb = lds + buf * kVSlab;
+#pragma unroll
+        for (int i = 0; i < 6; i++) {
+            u32x4 o = raw[set][i];
+            if (GNIN) {
+                const unsigned u[4] = {o.x, o.y, o.z, o.w};
+                float y[8];
+#pragma unroll
+                for (int k = 0; k < 8; k++) {
+                    const float x = bf2f((unsigned short)(k & 1 ? u[k >> 1] >> 16 : u[k >> 1] & 0xffff));
+                    y[k] = fmaxf((x - ms[0]) * ms[1] * gam[slab][k] + bet[slab][k], 0.f);      // expression of gn_apply_kernel
+                }
+                const bool in = (inside >> i) & 1u;
+                o.x = in ? pack_bf16(y[0], y[1]) : 0u;
+                o.y = in ? pack_bf16(y[2], y[3]) : 0u;
+                o.z = in ? pack_bf16(y[4], y[5]) : 0u;
+                o.w = in ? pack_bf16(y[6], y[7]) : 0u;
+            }
+            if (i < 5 || last_piece) *(u32x4*)(pb + wofs[i]) = o;
+        }
+    };
+    auto barrier = [&]() {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+    };
+
+    // fragment offsets: weights lane-linear; patch pixel (line, 16ch + kw + fcol), chunk 4 * half + kg, swizzled by the column
+    unsigned boff[3][2];
+#pragma unroll
+    for (int kw = 0; kw < 3; kw++)
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            const int pc = ch * 16 + kw + fcol;
+            boff[kw][h] = (unsigned)((2 * rp * kPCols + pc) * 128 + (((4 * h + kg) ^ ((pc >> 1) & 7)) << 4));
+        }
+    f32x4 acc[2];
+    auto compute = [&](int slab, int buf) {
+        const char* pb = lds + buf * kVSlab;
+        const char* wb = lds + kVOffW + slab * (18 * 1024) + lane * 16;
+#pragma unroll
+        for (int kw = 0; kw < 3; kw++)
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+                bf16x8 bfr[4], af[3];
+#pragma unroll
+                for (int l = 0; l < 4; l++) bfr[l] = *(const bf16x8*)(pb + l * (kPCols * 128) + boff[kw][h]);
+#pragma unroll
+                for (int kh = 0; kh < 3; kh++) af[kh] = *(const bf16x8*)(wb + ((kh * 3 + kw) * 2 + h) * 1024);
+#pragma unroll
+                for (int kh = 0; kh < 3; kh++)
+#pragma unroll
+                    for (int b = 0; b < 2; b++) acc[b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[kh], bfr[b + kh], acc[b], 0, 0, 0);
+            }
+    };
+    auto store_tile = [&](const QTile& c) {
+        float* out = (float*)P.seg[c.si].out;
+        const int gx = c.X0 + ch * 16 + fcol;
+#pragma unroll
+        for (int b = 0; b < 2; b++) {
+            const int gy = c.Y0 + 2 * rp + b;
+            if (gy < c.H && gx < c.W) {
+                float* o = out + ((size_t)(c.img * c.H + gy) * c.W + gx) * P.Cout + 4 * kg;
+#pragma unroll
+                for (int k = 0; k < 4; k++)
+                    if (4 * kg + k < P.Cout) o[k] = acc[b][k] + bias[k];
+            }
+        }
+    };
+
+    // ---- prologue: slabs 0 and 1 of the first tile on their way, slab 0 into buffer 0, slab 2 behind it
+    QTile cur = decode((int)blockIdx.x);
+    unsigned in_cur = 0, in_nxt = 0;
+    f32x2 ms_cur[4], ms_nxt[4];
+    patch_map(cur, in_cur);
+    load(0, 0);
+    load(1, 1);
+    if (GNIN) load_stats(cur, ms_cur);
+    convert(0, 0, 0, ms_cur[0], in_cur);
+    load(0, 2);
+
+    for (int it = 0; it < ntl; it++) {
+        const bool more = it + 1 < ntl;
+        const QTile nxt = decode((int)blockIdx.x + (it + 1) * G);
+#pragma unroll
+        for (int k = 0; k < 4; k++) acc[0][k] = acc[1][k] = 0.f;
+        // slab 0: slab 1 -> buffer 1, slab 3 leaves
+        barrier();
+        convert(1, 1, 1, ms_cur[1], in_cur);
+        load(1, 3);
+        // from here on the addresses are the next tile's.  After the last tile the loads still leave (every lane re-reads
+        // the first 16 bytes of the map: one cache line): a load under a branch would make the compiler count none of them
+        // when it waits for the older ones, and every wait would drain the whole queue
+        patch_map(nxt, in_nxt);
+        if (!more) {
+#pragma unroll
+            for (int i = 0; i < 6; i++) pofs[i] = 0;
+        }
+        if (GNIN) load_stats(nxt, ms_nxt);
+        compute(0, 0);
+        // slab 1: slab 2 -> buffer 0, the next tile's slab 0 leaves
+        barrier();
+        convert(0, 2, 0, ms_cur[2], in_cur);
+        load(0, 0);
+        compute(1, 1);
+        // slab 2: slab 3 -> buffer 1, the next tile's slab 1 leaves
+        barrier();
+        convert(1, 3, 1, ms_cur[3], in_cur);
+        load(1, 1);
+        compute(2, 0);
+        // slab 3: the next tile's slab 0 -> buffer 0 (after the last tile: sixteen bytes of nothing, never read), its slab 2
+        // leaves
+        barrier();
+        convert(0, 0, 0, ms_nxt[0], in_nxt);
+        load(0, 2);
+        compute(3, 1);
+        store_tile(cur);
+        cur = nxt;
+        in_cur = in_nxt;
+#pragma unroll
+        for (int s = 0; s < 4; s++) ms_cur[s] = ms_nxt[s];
+    }
+}
+
 struct Cfg {
     int bn, bm;
 };
@@ -3735,7 +3982,29 @@ int launch_rp8(const ConvDev& D, char* dump, hipStream_t st) {
     return dafne::check_launch("conv3x3_rp8");
 }
 
+// the slab kernel's persistent 16-channel form takes the head's prediction layers (256 -> <= 16 channels)
+bool pred16_ok(const ConvDev& D) {
+    const char* e = getenv("DAFNE_CONV_PRED16");            // read per call: the tests run both kernels in one process
+    if ((e && atoi(e) == 0) || !D.slab || D.Cin != kVCin || D.Cout > 16) return false;
+    for (int s = 0; s < D.n_segs; s++)
+        if ((long long)D.N * (D.seg[s].Hout + 2) * (D.seg[s].Wout + 2) * (kVCin * 2) > 0xffffffffll) return false;
+    return true;
+}
+
+int launch_pred16(const ConvDev& D, hipStream_t st) {
+    DAFNE_MAX_LDS_ONCE(kVSmem, (const void*)conv3x3_pred16_kernel<false>, (const void*)conv3x3_pred16_kernel<true>);
+    int cus = 0;
+    if (int rc = dafne::device_cus(&cus)) return rc;
+    const int T = D.mtiles;
+    const int rounds = (T + cus - 1) / cus;                // balanced persistent grid
+    const dim3 grid((T + rounds - 1) / rounds), block(512);
+    if (D.flags & DAFNE_CONV_GN_INPUT) hipLaunchKernelGGL(conv3x3_pred16_kernel<true>, grid, block, kVSmem, st, D);
+    else hipLaunchKernelGGL(conv3x3_pred16_kernel<false>, grid, block, kVSmem, st, D);
+    return dafne::check_launch("conv3x3_pred16");
+}
+
 int launch_slab(const ConvDev& D, hipStream_t st) {
+    if (pred16_ok(D)) return launch_pred16(D, st);
     DAFNE_MAX_LDS_ONCE(kSlabSmem, (const void*)conv3x3_slab_kernel<false>, (const void*)conv3x3_slab_kernel<true>);
     const dim3 grid(D.mtiles), block(512);
     if (D.flags & DAFNE_CONV_GN_INPUT) hipLaunchKernelGGL(conv3x3_slab_kernel<true>, grid, block, kSlabSmem, st, D);
@@ -3909,7 +4178,7 @@ int dafne_conv2d_kernel_id(const dafne_conv_params* prm, const dafne_conv_seg* s
     ConvDev D;
     if (build(D, prm, segs)) return -1;
     if (D.patch) return 6;
-    if (D.slab) return 7;
+    if (D.slab) return pred16_ok(D) ? 8 : 7;
     if (stream_eligible(D)) return ws_eligible(D) ? 5 : 4;
     return D.bn == 256 ? 3 : D.bn == 128 ? 2 : D.bn == 64 ? 1 : 0;
 }

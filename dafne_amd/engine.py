@@ -343,7 +343,7 @@ class ConvCall:
         return _lib.load().dafne_conv2d_tile_pixels(ctypes.byref(self.prm), self.segs)
 
     KERNEL_NAMES = ("conv_igemm<1,4,1,2>", "conv_igemm<1,4,2,2>", "conv_igemm<2,2,2,2>", "conv_igemm<4,2,2,4>",
-                    "conv_stream", "conv_ws", "conv3x3_patch", "conv3x3_slab")
+                    "conv_stream", "conv_ws", "conv3x3_patch", "conv3x3_slab", "conv3x3_pred16")
 
     def kernel_id(self):
         """-1 when the library cannot run this call (e.g. F_GNIN on a layer the patch kernel does not take)."""
@@ -800,7 +800,7 @@ class HeadPlan:
                     dst = [torch.empty(1, dtype=torch.float32, device=device)] * len(outs) if f32 else outs
                     nxt = ConvCall(wn, bn_, C, cout, 3, 1, 1, fl | F_GNIN, seg_list(outs, dst, f32=f32), n,
                                    gn_in=(stats, gamma, beta))
-                    fuse_next = fuse_next and (nxt.kernel_id() == (7 if f32 else 6) or (not f32 and rp_on and nxt.rp_ok()))
+                    fuse_next = fuse_next and (nxt.kernel_id() in ((7, 8) if f32 else (6,)) or (not f32 and rp_on and nxt.rp_ok()))
                 fuse_fin = fuse_next and fuse_gnfin and is_patch and C == 256
                 fin = (stats, torch.zeros(len(outs), n, dtype=torch.int32, device=device), 1e-5) if fuse_fin else None
                 if fuse_fin:

@@ -303,7 +303,8 @@ int dafne_conv2d_num_tiles(const dafne_conv_params* prm, const dafne_conv_seg* s
  * 2 conv_igemm_kernel<2,2,2,2> (128 x 128)           3 conv_igemm_kernel<4,2,2,4> (256 x 256, 8 waves)
  * 4 conv_stream_kernel (persistent, 1x1, Cin 512)    5 conv_ws_kernel (persistent, weights in registers, 1x1, Cin <= 256)
  * 6 conv3x3_patch_kernel (3x3 s1, 256 cout x 8x32 px tiles, input patch staged once per 64-channel slab)
- * 7 conv3x3_slab_kernel (3x3 s1, Cout <= 32, fp32 output: whole 64-channel slabs of both operands in LDS) */
+ * 7 conv3x3_slab_kernel (3x3 s1, Cout <= 32, fp32 output: whole 64-channel slabs of both operands in LDS)
+ * 8 conv3x3_pred16_kernel (the same layers with Cin = 256 and Cout <= 16: persistent, all weights resident in LDS) */
 int dafne_conv2d_kernel_id(const dafne_conv_params* prm, const dafne_conv_seg* segs);
 /* M tiles per image of every segment (out[n_segs]): where a segment's rows sit in d_gn_partial */
 int dafne_conv2d_tiles_per_image(const dafne_conv_params* prm, const dafne_conv_seg* segs, int32_t* out);

@@ -25,12 +25,13 @@ groups = {}
 for i, c in enumerate(plan.calls):
     ms = min(acc[i]); tot += ms
     if isinstance(c, engine.ConvCall):
+        kn = c.kernel_name()
         p = c.prm
         hw = [(c.segs[s].Hout, c.segs[s].Wout) for s in range(p.n_segs)]
-        key = "conv %dx%d s%d cin%-4d cout%-4d %s" % (p.KH, p.KW, p.stride, p.Cin, p.Cout, hw[0] if len(hw) == 1 else "5lvl")
+        key = "conv %dx%d s%d cin%-4d cout%-4d %s %s" % (p.KH, p.KW, p.stride, p.Cin, p.Cout, hw[0] if len(hw) == 1 else "5lvl", kn)
         g = groups.setdefault(key, [0, 0.0, 0.0]); g[0] += 1; g[1] += ms; g[2] += c.flops
     else:
-        g = groups.setdefault(c.name, [0, 0.0, 0.0]); g[0] += 1; g[1] += ms; g[2] += getattr(c, "flops", 0)
+        g = groups.setdefault(getattr(c, "name", None) or c.kernel_name() + " (pair)", [0, 0.0, 0.0]); g[0] += 1; g[1] += ms; g[2] += getattr(c, "flops", 0)
 print("batch", B, "total ms (event sum)", tot, "per image", tot / B)
 for k, (n, ms, fl) in sorted(groups.items(), key=lambda kv: -kv[1][1]):
-    print("%-55s n=%3d  %.3f ms  %7.1f TF  %5.1f%%" % (k, n, ms, fl / (ms * 1e-3) / 1e12 if fl else 0, 100 * ms / tot) + "  %.4f ms/img" % (ms / B))
+    print("%-80s n=%3d  %.3f ms  %7.1f TF  %5.1f%%" % (k, n, ms, fl / (ms * 1e-3) / 1e12 if fl else 0, 100 * ms / tot) + "  %.4f ms/img" % (ms / B))

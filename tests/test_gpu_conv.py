@@ -251,7 +251,7 @@ def test_slab_kernel_levels_and_gn_input(cout, cin):
         outs = [torch.full((N, h, w, cout), float("nan"), dtype=torch.float32, device=d) for h, w in sizes]
         segs = [(i.t, o, None, i.h, i.w, i.h, i.w) for i, o in zip(src, outs)]
         c = engine.ConvCall(wpq, bpq, C, cout, 3, 1, 1, engine.F_F32 | (engine.F_GNIN if gn_in else 0), segs, N, gn_in=gn_in)
-        assert c.kernel_name() == "conv3x3_slab"
+        assert c.kernel_name() == ("conv3x3_pred16" if cin == 256 and cout <= 16 else "conv3x3_slab")
         c(st)
         return outs
 
@@ -290,6 +290,56 @@ def test_slab_kernel_levels_and_gn_input(cout, cin):
     for a, b_ in zip(fused, unfused):
         assert torch.isfinite(a).all()
         assert torch.equal(a, b_)
+
+
+@pytest.mark.parametrize("cout,gn", [(15, True), (9, False), (16, True), (1, False)])
+def test_pred16_kernel_full_size_equals_slab_kernel(cout, gn, monkeypatch):
+    """The prediction layers at the headline shape (batch 8, five levels of a 1024^2 tile: 696 tiles, three per workgroup of
+    the persistent grid) on conv3x3_pred16 against the one-tile-per-workgroup slab kernel on the same buffers (GroupNorm + ReLU
+    on load included): the same products summed in another order -- fp32 rounding apart; level 0 also against torch."""
+    from dafne_amd import engine, _lib
+    d = dev()
+    g = torch.Generator().manual_seed(300 + cout)
+    C, N = 256, 8
+    sizes = [(128, 128), (64, 64), (32, 32), (16, 16), (8, 8)]
+    ins = []
+    for h, w in sizes:
+        a = engine.Act(N, h, w, C, d)
+        a.t[:, 1:-1, 1:-1, :] = (torch.randn(N, h, w, C, generator=g) * 2.0).to(torch.bfloat16).to(d)
+        ins.append(a)
+    wq = bfr(torch.randn(cout, C, 3, 3, generator=g) / (C * 9) ** 0.5)
+    bq = torch.randn(cout, generator=g)
+    wpq, bpq = engine.pack_conv(wq, bq, d)
+    gn_in = None
+    if gn:
+        stats = torch.empty(len(sizes), N, C // 8, 2, device=d)
+        stats[..., 0] = torch.randn(len(sizes), N, C // 8, generator=g).to(d) * 0.3
+        stats[..., 1] = (0.5 + torch.rand(len(sizes), N, C // 8, generator=g)).to(d)
+        gamma = (1 + 0.2 * torch.randn(C, generator=g)).to(d)
+        beta = (0.3 * torch.randn(C, generator=g)).to(d)
+        gn_in = (stats, gamma, beta)
+    st = _lib.current_stream()
+
+    def run(flag, name):
+        monkeypatch.setenv("DAFNE_CONV_PRED16", flag)
+        outs = [torch.full((N, h, w, cout), float("nan"), dtype=torch.float32, device=d) for h, w in sizes]
+        segs = [(i.t, o, None, i.h, i.w, i.h, i.w) for i, o in zip(ins, outs)]
+        c = engine.ConvCall(wpq, bpq, C, cout, 3, 1, 1, engine.F_F32 | (engine.F_GNIN if gn else 0), segs, N, gn_in=gn_in)
+        assert c.kernel_name() == name and c.num_tiles() == 696
+        c(st)
+        c(st)                # twice: nothing is left behind between launches
+        torch.cuda.synchronize()
+        return outs
+
+    new = run("1", "conv3x3_pred16")
+    old = run("0", "conv3x3_slab")
+    for a, b_ in zip(new, old):
+        assert torch.isfinite(a).all()
+        assert float((a - b_).abs().max()) <= 2e-5 * max(float(b_.abs().max()), 1.0)
+    if not gn:
+        x0 = ins[0].nchw_float()[:2].cpu()
+        ref = F.conv2d(x0, wq, bq, padding=1).permute(0, 2, 3, 1)
+        assert float((new[0][:2].cpu() - ref).abs().max()) < 2e-3 * max(float(ref.abs().max()), 1.0)
 
 
 @pytest.mark.parametrize("cout", [15, 9, 2, 1, 16])
