@@ -83,6 +83,8 @@ __device__ __forceinline__ unsigned short f2bf(float f) {
 // two fp32 -> packed bf16x2 with the hardware converter (v_cvt_pk_bf16_f32: round to nearest even,
 // the same rounding as f2bf for finite inputs); one instruction instead of eight
 typedef __attribute__((ext_vector_type(2))) float f32x2;
+typedef __attribute__((ext_vector_type(3))) float f32x3;
+typedef __attribute__((ext_vector_type(2))) short i16x2;
 typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
 __device__ __forceinline__ unsigned pack_bf16(float lo, float hi) {
     const f32x2 v = {lo, hi};
@@ -3522,15 +3524,6 @@ __global__ void __launch_bounds__(512) conv3x3_pred16_kernel(ConvDev P) {
     const int T = P.mtiles, G = (int)gridDim.x;
     const int ntl = (T - (int)blockIdx.x + G - 1) / G;      // tiles of this workgroup (>= 1: G <= T)
 
-    // ---- weights: k32 step st = (slab * 9 + tap) * 2 + half at 1 KB each, lane-linear (rows >= Cout repeat the last one:
-    // their results are never stored)
-    {
-        const int row = fcol < P.Cout ? fcol : P.Cout - 1;
-        const char* wsrc = P.w + (size_t)row * P.kbytes + kg * 16;
-        for (int st = wave; st < kVSteps; st += 8)
-            *(u32x4*)(lds + kVOffW + st * 1024 + lane * 16) = *(const u32x4*)(wsrc + (st >> 1) * 128 + (st & 1) * 64);
-    }
-
     // ---- the six 16-byte pieces a thread moves per slab: patch pixel r = i * 64 + tid / 8, chunk q
     int ppos[6];                                    // py | px << 8
     unsigned wofs[6];
@@ -3608,27 +3601,33 @@ __global__ void __launch_bounds__(512) conv3x3_pred16_kernel(ConvDev P) {
 #pragma unroll
         for (int s = 0; s < 4; s++) ms[s] = *(const f32x2*)(st + (s * 8 + q) * 2);
     };
-    auto convert = [&](int set, int slab, int buf, const f32x2& ms, unsigned inside) {
-        char* pb = lds + buf * kVSlab;
+    // piece i of a slab: registers -> (GroupNorm + ReLU) -> LDS slab buffer
+    auto convert_piece = [&](int i, int set, int slab, int buf, const f32x2& ms, unsigned inside) {
+        u32x4 o = raw[set][i];
+        if (GNIN) {
+            // the expression of gn_apply_kernel, two channels per instruction (v_pk_add / v_pk_mul / v_pk_fma_f32 round like
+            // their scalar forms); ReLU on the rounded pair as 16-bit integers (a negative bf16 is a negative int16; the
+            // rounding keeps the sign, so max before or after it is the same number)
+            const f32x2 m2 = {ms[0], ms[0]}, r2 = {ms[1], ms[1]};
+            const unsigned msk = (inside >> i) & 1u ? 0xffffffffu : 0u;
+            unsigned w[4] = {o.x, o.y, o.z, o.w};
 #pragma unroll
-        for (int i = 0; i < 6; i++) {
-            u32x4 o = raw[set][i];
-            if (GNIN) {
-                const unsigned u[4] = {o.x, o.y, o.z, o.w};
-                float y[8];
-#pragma unroll
-                for (int k = 0; k < 8; k++) {
-                    const float x = bf2f((unsigned short)(k & 1 ? u[k >> 1] >> 16 : u[k >> 1] & 0xffff));
-                    y[k] = fmaxf((x - ms[0]) * ms[1] * gam[slab][k] + bet[slab][k], 0.f);      // expression of gn_apply_kernel
-                }
-                const bool in = (inside >> i) & 1u;
-                o.x = in ? pack_bf16(y[0], y[1]) : 0u;
-                o.y = in ? pack_bf16(y[2], y[3]) : 0u;
-                o.z = in ? pack_bf16(y[4], y[5]) : 0u;
-                o.w = in ? pack_bf16(y[6], y[7]) : 0u;
+            for (int j = 0; j < 4; j++) {
+                const f32x2 x = {__uint_as_float(w[j] << 16), __uint_as_float(w[j] & 0xffff0000u)};
+                const f32x2 t = (x - m2) * r2;
+                const f32x2 g2 = {gam[slab][2 * j], gam[slab][2 * j + 1]}, b2 = {bet[slab][2 * j], bet[slab][2 * j + 1]};
+                const f32x2 y = t * g2 + b2;
+                const i16x2 pr = __builtin_bit_cast(i16x2, pack_bf16(y[0], y[1]));
+                const i16x2 zero = {0, 0};
+                w[j] = __builtin_bit_cast(unsigned, __builtin_elementwise_max(pr, zero)) & msk;
             }
-            if (i < 5 || last_piece) *(u32x4*)(pb + wofs[i]) = o;
+            o.x = w[0]; o.y = w[1]; o.z = w[2]; o.w = w[3];
         }
+        if (i < 5 || last_piece) *(u32x4*)(lds + buf * kVSlab + wofs[i]) = o;
+    };
+    auto convert = [&](int set, int slab, int buf, const f32x2& ms, unsigned inside) {
+#pragma unroll
+        for (int i = 0; i < 6; i++) convert_piece(i, set, slab, buf, ms, inside);
     };
     auto barrier = [&]() {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -3647,35 +3646,51 @@ __global__ void __launch_bounds__(512) conv3x3_pred16_kernel(ConvDev P) {
             boff[kw][h] = (unsigned)((2 * rp * kPCols + pc) * 128 + (((4 * h + kg) ^ ((pc >> 1) & 7)) << 4));
         }
     f32x4 acc[2];
+    // one slab: six groups (kw, k32 half) of 4 patch-line + 3 weight fragments feeding 6 MFMAs; the fragments of group g + 1
+    // are requested before the MFMAs of group g (pinned with sched_group_barrier: left alone the compiler keeps one or two
+    // reads in flight and the wave sits in LDS latency)
     auto compute = [&](int slab, int buf) {
         const char* pb = lds + buf * kVSlab;
         const char* wb = lds + kVOffW + slab * (18 * 1024) + lane * 16;
+        bf16x8 bfr[2][4], af[2][3];
+        auto fetch = [&](int g, int set) {
+            const int kw = g >> 1, h = g & 1;
 #pragma unroll
-        for (int kw = 0; kw < 3; kw++)
+            for (int l = 0; l < 4; l++) bfr[set][l] = *(const bf16x8*)(pb + l * (kPCols * 128) + boff[kw][h]);
 #pragma unroll
-            for (int h = 0; h < 2; h++) {
-                bf16x8 bfr[4], af[3];
+            for (int kh = 0; kh < 3; kh++) af[set][kh] = *(const bf16x8*)(wb + ((kh * 3 + kw) * 2 + h) * 1024);
+        };
+        fetch(0, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 7, 0);
 #pragma unroll
-                for (int l = 0; l < 4; l++) bfr[l] = *(const bf16x8*)(pb + l * (kPCols * 128) + boff[kw][h]);
-#pragma unroll
-                for (int kh = 0; kh < 3; kh++) af[kh] = *(const bf16x8*)(wb + ((kh * 3 + kw) * 2 + h) * 1024);
-#pragma unroll
-                for (int kh = 0; kh < 3; kh++)
-#pragma unroll
-                    for (int b = 0; b < 2; b++) acc[b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[kh], bfr[b + kh], acc[b], 0, 0, 0);
+        for (int g = 0; g < 6; g++) {
+            if (g + 1 < 6) {
+                fetch(g + 1, (g + 1) & 1);
+                __builtin_amdgcn_sched_group_barrier(0x100, 7, 0);
             }
+#pragma unroll
+            for (int kh = 0; kh < 3; kh++)
+#pragma unroll
+                for (int b = 0; b < 2; b++)
+                    acc[b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[g & 1][kh], bfr[g & 1][b + kh], acc[b], 0, 0, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);
+        }
     };
+    const int nco = P.Cout - 4 * kg < 0 ? 0 : (P.Cout - 4 * kg > 4 ? 4 : P.Cout - 4 * kg);     // this lane's channels 4kg .. 4kg + nco
     auto store_tile = [&](const QTile& c) {
         float* out = (float*)P.seg[c.si].out;
         const int gx = c.X0 + ch * 16 + fcol;
 #pragma unroll
         for (int b = 0; b < 2; b++) {
             const int gy = c.Y0 + 2 * rp + b;
-            if (gy < c.H && gx < c.W) {
+            if (gy < c.H && gx < c.W && nco > 0) {
                 float* o = out + ((size_t)(c.img * c.H + gy) * c.W + gx) * P.Cout + 4 * kg;
-#pragma unroll
-                for (int k = 0; k < 4; k++)
-                    if (4 * kg + k < P.Cout) o[k] = acc[b][k] + bias[k];
+                const float v0 = acc[b][0] + bias[0], v1 = acc[b][1] + bias[1], v2 = acc[b][2] + bias[2], v3 = acc[b][3] + bias[3];
+                // one store per pixel row: the address is 4-byte aligned only (Cout = 15, 9), which global stores allow
+                if (nco == 4) asm volatile("global_store_dwordx4 %0, %1, off" ::"v"(o), "v"((f32x4){v0, v1, v2, v3}) : "memory");
+                else if (nco == 3) asm volatile("global_store_dwordx3 %0, %1, off" ::"v"(o), "v"((f32x3){v0, v1, v2}) : "memory");
+                else if (nco == 2) asm volatile("global_store_dwordx2 %0, %1, off" ::"v"(o), "v"((f32x2){v0, v1}) : "memory");
+                else asm volatile("global_store_dword %0, %1, off" ::"v"(o), "v"(v0) : "memory");
             }
         }
     };
@@ -3688,6 +3703,14 @@ __global__ void __launch_bounds__(512) conv3x3_pred16_kernel(ConvDev P) {
     load(0, 0);
     load(1, 1);
     if (GNIN) load_stats(cur, ms_cur);
+    // ---- weights: k32 step st = (slab * 9 + tap) * 2 + half at 1 KB each, lane-linear (rows >= Cout repeat the last one:
+    // their results are never stored); requested behind the first tile's pixels
+    {
+        const int row = fcol < P.Cout ? fcol : P.Cout - 1;
+        const char* wsrc = P.w + (size_t)row * P.kbytes + kg * 16;
+        for (int st = wave; st < kVSteps; st += 8)
+            *(u32x4*)(lds + kVOffW + st * 1024 + lane * 16) = *(const u32x4*)(wsrc + (st >> 1) * 128 + (st & 1) * 64);
+    }
     convert(0, 0, 0, ms_cur[0], in_cur);
     load(0, 2);
 
