@@ -504,8 +504,9 @@ def _run_worker(args, make_step, rank, world, distributed, device):
             try:
                 pmc = json.load(open(os.path.join(ROOT, "profiles", fname)))
                 cands = [v for k, v in pmc["kernels"].items() if k == kname or k.startswith(kname + "<")]
-                if cands:
-                    return 1e6 * sum(c["hbm_mb_per_launch"] for c in cands) / len(cands), pmc["source"]
+                if cands:       # the kernel's template instantiations, weighted by their launches
+                    nl = sum(c.get("launches", 1) for c in cands)
+                    return 1e6 * sum(c["hbm_mb_per_launch"] * c.get("launches", 1) for c in cands) / nl, pmc["source"]
             except (OSError, KeyError, ValueError):
                 pass
             return None, None

@@ -261,6 +261,13 @@ class OneStageDetector(nn.Module):
             inputs_ready = torch.cuda.Event()
             inputs_ready.record(main)
             vts = []
+            dbg = getattr(self, "_dbg_events", None)        # scratch/pipe_events.py: timestamps of the step's phases
+
+            def mark(tag, k, stream):
+                if dbg is not None:
+                    e = torch.cuda.Event(enable_timing=True)
+                    e.record(stream)
+                    dbg.append((st["i"], tag, k, e))
             for k in range(splits):
                 lo, hi = bounds[k], bounds[k + 1]
                 cs[k].wait_event(inputs_ready)
@@ -276,6 +283,7 @@ class OneStageDetector(nn.Module):
                     _lib.check(L.dafne_preprocess_image_hip(_lib.ptr(sub), int(layout_hwc), hi - lo, h, w, _lib.ptr(vt),
                                                             mean, std, hn, wn, _lib.ptr(plans[k].stem_in),
                                                             _lib.current_stream()), "dafne_preprocess_image_hip")
+                mark("pre", k, cs[k])
             # layer-interleaved enqueue: launch j of every sub-batch before launch j+1, so that the
             # prologue / epilogue bubbles of one sub-batch's kernel are filled by another's
             sp = [ctypes.c_void_p(s.cuda_stream) for s in cs]
@@ -285,14 +293,19 @@ class OneStageDetector(nn.Module):
                 for k in range(splits):
                     if j < len(plans[k].calls):
                         plans[k].calls[j](sp[k])
+            for k in range(splits):
+                mark("end", k, cs[k])
             with torch.cuda.stream(self.side_stream):
                 for k in range(splits):
                     ev = torch.cuda.Event()
                     ev.record(cs[k])
                     self.side_stream.wait_event(ev)
+                mark("dec0", 0, self.side_stream)
                 cand = outs.decode_packed(head_levels(st["ho"][slot], strides), out=st["cand"][slot])
                 st["cand"][slot] = cand
+                mark("dec1", 0, self.side_stream)
                 res = outs.select_packed(cand, sizes=sizes, scale_corners=do_postprocess)
+                mark("nms1", 0, self.side_stream)
                 done = torch.cuda.Event()
                 done.record(self.side_stream)
             st["done"][slot] = done

@@ -74,7 +74,7 @@ def main():
         lines.append("%-40s %7d %9.2f %9.2f %9.2f | %9.3g %8.3f %8.3f" % (k[:40], n, f, w, hbm, mb, u_clk, u_nom))
         if f == f:
             traffic[k] = {"fetch_size_mb_per_launch": round(f, 2), "write_size_mb_per_launch": round(w, 2),
-                          "hbm_mb_per_launch": round(hbm, 2)}
+                          "hbm_mb_per_launch": round(hbm, 2), "launches": n}
             if u_clk == u_clk:
                 traffic[k]["mfma_util_at_nominal_clock"] = round(u_nom, 4)
     txt = "\n".join(lines) + "\n"
