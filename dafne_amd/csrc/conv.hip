@@ -111,7 +111,11 @@ __device__ __forceinline__ void divmod_small(int m, int W, float invW, int& q, i
     r = m - q * W;
 }
 
-template <int WC, int WP, int TC, int TP>
+// NS: operand stages in LDS of the 4-wave loop.  2 = double buffer with a drain per K step (two workgroups per CU hide each
+// other's load latency when the launch has the tiles for it); 4 = ring with counted waits for launches with at most one
+// tile per CU (res5, the top FPN levels, every small layer of a sub-batch plan), whose K loop was one L2 round trip per
+// step: res5 conv2 (K = 4608, 72 steps) 0.9 -> 0.3 us per step.  Same K order, same results.
+template <int WC, int WP, int TC, int TP, int NS = 2>
 __global__ void __launch_bounds__(WC * WP * 64) conv_igemm_kernel(ConvDev P) {
     constexpr int NW = WC * WP;            // waves per block
     constexpr int NT = NW * 64;
@@ -391,6 +395,53 @@ __global__ void __launch_bounds__(WC * WP * 64) conv_igemm_kernel(ConvDev P) {
                 mma_half_ld(j + 2, 1, 0);                      // t = 4j+4  : M1
                 if (j + 1 < K) phase_end(false, 4 * j + 4);
             }
+        }
+    } else if constexpr (NS > 2) {
+        // ---- ring of NS stages: stage s + NS - 1 is requested when stage s is about to be multiplied; the wait for stage s
+        // leaves the NS - 2 younger stages (NL loads each per wave) in flight; one raw barrier per step (everybody's pieces
+        // of stage s have landed, everybody is done with stage s - 1, whose buffer the new request overwrites)
+        static_assert(NS == 3 || NS == 4, "ring depth");
+        const int K = P.ksteps;
+        for (int s0 = 0; s0 < NS - 1 && s0 < K; s0++) issue(s0, s0);
+        int cur = 0, nxt = NS - 1;
+        for (int step = 0; step < K; step++) {
+            const int ahead = K - 1 - step;
+            if (ahead >= NS - 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 2) * NL) : "memory");
+            else if (ahead == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NL) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            if (step == 0) { TSTAMP(1); }
+            if (step + NS - 1 < K) issue(nxt, step + NS - 1);
+            const char* sb = lds + cur * STAGE;
+            // one wave per SIMD here: the fragments of k16 sub-step ks + 1 are requested before the MFMAs of sub-step ks
+            // (pinned: left alone the compiler waits for every read group right in front of its MFMAs)
+            bf16x8 af[2][TC], bfr[2][TP];
+            auto fetch = [&](int ks, int set) {
+#pragma unroll
+                for (int a = 0; a < TC; a++) af[set][a] = *(const bf16x8*)(sb + (arow0 + a * 32) * kRowBytes + roff[ks]);
+#pragma unroll
+                for (int b = 0; b < TP; b++) bfr[set][b] = *(const bf16x8*)(sb + (brow0 + b * 32) * kRowBytes + roff[ks]);
+            };
+            fetch(0, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, TC + TP, 0);
+#pragma unroll
+            for (int ks = 0; ks < 4; ks++) {
+                if (ks < 3) {
+                    fetch(ks + 1, (ks + 1) & 1);
+                    __builtin_amdgcn_sched_group_barrier(0x100, TC + TP, 0);
+                }
+#pragma unroll
+                for (int a = 0; a < TC; a++)
+#pragma unroll
+                    for (int b = 0; b < TP; b++)
+                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks & 1][a], bfr[ks & 1][b], acc[a][b], 0, 0, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, TC * TP, 0);
+            }
+            cur = cur + 1 == NS ? 0 : cur + 1;
+            nxt = nxt + 1 == NS ? 0 : nxt + 1;
         }
     } else {
     issue(0, 0);
@@ -3927,18 +3978,18 @@ int build(ConvDev& D, const dafne_conv_params* p, const dafne_conv_seg* segs, bo
     return DAFNE_OK;
 }
 
-template <int WC, int WP, int TC, int TP>
+template <int WC, int WP, int TC, int TP, int NS = 2>
 int launch(const ConvDev& D, hipStream_t st) {
     constexpr int ROWS = (WC * TC + WP * TP) * 32;
     constexpr int BN = WC * TC * 32, BM = WP * TP * 32, NW = WC * WP;
     constexpr int EN = BN > 128 ? 128 : BN;
-    constexpr int stage2 = 2 * ROWS * kRowBytes;
+    constexpr int stage2 = NS * ROWS * kRowBytes;
     constexpr int epi_f32 = BM * (EN * 4 + 16) + NW * (EN / 8) * 2 * 4;
     constexpr int epi_b16 = BM * (BN * 2 + 16) + NW * (WC * TC * 32 / 8) * 2 * 4;
     constexpr int epi = epi_f32 > epi_b16 ? epi_f32 : epi_b16;
     constexpr int smem = stage2 > epi ? stage2 : epi;
-    DAFNE_MAX_LDS_ONCE(smem, (const void*)conv_igemm_kernel<WC, WP, TC, TP>);
-    hipLaunchKernelGGL((conv_igemm_kernel<WC, WP, TC, TP>), dim3(D.mtiles * D.ntiles), dim3(WC * WP * 64), smem, st, D);
+    DAFNE_MAX_LDS_ONCE(smem, (const void*)conv_igemm_kernel<WC, WP, TC, TP, NS>);
+    hipLaunchKernelGGL((conv_igemm_kernel<WC, WP, TC, TP, NS>), dim3(D.mtiles * D.ntiles), dim3(WC * WP * 64), smem, st, D);
     return dafne::check_launch("conv_igemm");
 }
 
@@ -4221,7 +4272,17 @@ int dafne_conv2d_nhwc_bf16_hip(const dafne_conv_params* prm, const dafne_conv_se
     if (D.bn == 256) return launch<2, 2, 4, 4>(D, st);
 #endif
     if (D.bn == 256) return launch<4, 2, 2, 4>(D, st);
-    if (D.bn == 128) return launch<2, 2, 2, 2>(D, st);
+    if (D.bn == 128) {
+        // at most one tile per CU and a long K loop: the 4-stage ring (one workgroup per CU, no drain per step)
+        const char* e = getenv("DAFNE_CONV_RING");          // read per call: the tests run both forms in one process
+        int cus = 0;
+        if (int rc = dafne::device_cus(&cus)) return rc;
+        // DAFNE_CONV_RING: 0 never, 1 always (tests, A/B runs); default: when the caller says the launch is alone on the GPU
+        // (+1 % in the serial layout; next to other streams' launches the 128 KB of LDS cost 0.5 %)
+        const bool ring = e ? atoi(e) != 0 : (D.flags & DAFNE_CONV_EXCLUSIVE) != 0;
+        if (ring && D.mtiles * D.ntiles <= cus && D.ksteps >= 8) return launch<2, 2, 2, 2, 4>(D, st);
+        return launch<2, 2, 2, 2>(D, st);
+    }
     if (D.bn == 64) return launch<1, 4, 2, 2>(D, st);
     return launch<1, 4, 1, 2>(D, st);
 }

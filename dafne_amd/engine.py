@@ -20,7 +20,7 @@ from . import _lib
 BF16 = torch.bfloat16
 STAGE_BLOCKS = {50: (3, 4, 6, 3), 101: (3, 4, 23, 3)}
 
-F_RELU, F_RES, F_UP, F_F32, F_GN, F_GNIN, F_GNFIN = 1, 2, 4, 8, 16, 32, 64
+F_RELU, F_RES, F_UP, F_F32, F_GN, F_GNIN, F_GNFIN, F_EXCL = 1, 2, 4, 8, 16, 32, 64, 128
 
 
 # ------------------------------------------------------------------ activations
@@ -307,6 +307,8 @@ class ConvCall:
         self.keep = (w, b, gn_partial, [s for s in segs], gn_in, fp8, gn_fin, wfrag)
         gi = [t.data_ptr() for t in gn_in] if gn_in is not None else [None, None, None]
         gf = (gn_fin[0].data_ptr(), gn_fin[1].data_ptr(), float(gn_fin[2])) if gn_fin is not None else (None, None, 0.0)
+        if not _BUILDING_SHARED[0]:
+            flags |= F_EXCL             # hint (results unchanged): the plan this call belongs to has the GPU to itself
         self.prm = _lib.ConvParams(n_images, len(segs), cin, cout, k, k, stride, pad, flags,
                                    w.data_ptr(), b.data_ptr() if b is not None else None,
                                    gn_partial.data_ptr() if gn_partial is not None else None, gi[0], gi[1], gi[2],

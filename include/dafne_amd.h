@@ -202,6 +202,10 @@ int dafne_gather_detections_hip(const float* d_corners, const float* d_scores, c
 #define DAFNE_CONV_GN_FINALIZE 64u /* with GN_STATS, 3x3 patch-kernel layers with Cout == 256 (kernel id 6): the last tile
                                     * of every image finalises mean / rstd into d_gn_stats_out -- same values, bit for bit, as
                                     * dafne_groupnorm_finalize_hip on d_gn_partial, without the extra launch */
+#define DAFNE_CONV_EXCLUSIVE 128u  /* scheduling hint, results unchanged: nothing else runs on the GPU next to this launch (one
+                                    * stream, whole batch).  Small launches (<= one 128 x 128 tile per CU) then take the whole
+                                    * LDS of their CU for a 4-stage operand ring (K loop without a drain per step); launches of
+                                    * plans that share the GPU with other streams keep the small footprint */
 
 typedef struct dafne_conv_seg {
     const void* d_in;   /* bf16 [N, Hin+2, Win+2, Cin]; stem: [N, Hin, Win, 4] pre-padded */

@@ -292,6 +292,42 @@ def test_slab_kernel_levels_and_gn_input(cout, cin):
         assert torch.equal(a, b_)
 
 
+@pytest.mark.parametrize("cin,cout,k,stride,H,W,N,relu,res", [
+    (512, 512, 3, 1, 32, 32, 3, True, False),       # res5 conv2 of a 3-image sub-batch: 96 tiles, 72 K steps
+    (2048, 512, 1, 1, 32, 32, 8, True, False),      # res5 conv1 at batch 8: 256 tiles
+    (256, 256, 3, 2, 32, 32, 2, False, False),      # P6: 3x3 stride 2, 8 tiles
+    (256, 256, 3, 2, 16, 16, 1, False, False),      # P7 of one image: a single ragged tile per channel half
+    (1024, 512, 1, 2, 64, 64, 3, True, False),      # stride-2 1x1
+    (1024, 128, 1, 1, 24, 40, 2, True, True),       # residual epilogue, ragged last tile, K = 16 steps
+    (128, 128, 3, 1, 20, 20, 1, True, False),       # 18 steps, 4 tiles
+])
+def test_igemm_ring_equals_two_stage_loop(cin, cout, k, stride, H, W, N, relu, res, monkeypatch):
+    """Launches with at most one 128 x 128 tile per CU run conv_igemm_kernel<2,2,2,2> with a 4-stage operand ring (counted
+    waits) instead of the double buffer with a drain per K step: same K order, bit-identical outputs; both against torch."""
+    from dafne_amd import engine
+    g = torch.Generator().manual_seed(cin + cout + H)
+    x = bfr(torch.randn(N, cin, H, W, generator=g))
+    w = bfr(torch.randn(cout, cin, k, k, generator=g) / (cin * k * k) ** 0.5)
+    b = torch.randn(cout, generator=g) * 0.1
+    pad = 1 if k == 3 else 0
+    ho, wo = engine.conv_out_hw(H, W, k, stride, pad)
+    r = bfr(torch.randn(N, cout, ho, wo, generator=g)) if res else None
+    flags = (engine.F_RELU if relu else 0) | (engine.F_RES if res else 0)
+    outs = []
+    for ring in ("1", "0"):
+        monkeypatch.setenv("DAFNE_CONV_RING", ring)
+        got, _, call = run_conv(x, w, b, k, stride, pad, flags=flags, res=r)
+        assert call.kernel_name() == "conv_igemm<2,2,2,2>"
+        outs.append(got)
+    assert torch.equal(outs[0], outs[1])
+    ref = F.conv2d(x, w, b, stride=stride, padding=pad)
+    if res:
+        ref = ref + r
+    if relu:
+        ref = F.relu(ref)
+    close_bf16(outs[0], bfr(ref))
+
+
 @pytest.mark.parametrize("cout,gn", [(15, True), (9, False), (16, True), (1, False)])
 def test_pred16_kernel_full_size_equals_slab_kernel(cout, gn, monkeypatch):
     """The prediction layers at the headline shape (batch 8, five levels of a 1024^2 tile: 696 tiles, three per workgroup of
