@@ -31,13 +31,7 @@ def _shared_stream(device, kind, k):
     is already in use, and two sub-batches on one queue serialise."""
     key = (str(device), kind, k)
     if key not in _STREAMS:
-        import os as _os
-        pr = -1 if kind == "compute" else 0
-        _e = _os.environ.get("DAFNE_EXP_PRIO")
-        if _e:
-            tab = [int(x) for x in _e.split(",")]
-            pr = tab[k] if kind == "compute" else tab[-1]
-        _STREAMS[key] = torch.cuda.Stream(device=device, priority=pr)
+        _STREAMS[key] = torch.cuda.Stream(device=device, priority=-1 if kind == "compute" else 0)
     return _STREAMS[key]
 
 
@@ -295,13 +289,9 @@ class OneStageDetector(nn.Module):
             sp = [ctypes.c_void_p(s.cuda_stream) for s in cs]
             # (sub-batches of different sizes may differ by a launch: the library picks kernels by tile count)
             ncalls = max(len(p.calls) for p in plans)
-            import os as _os
-            _thr = float(_os.environ.get("DAFNE_EXP_SKIP_GF", "0")) * 1e9
             for j in range(ncalls):
                 for k in range(splits):
                     if j < len(plans[k].calls):
-                        if _thr and 0 < getattr(plans[k].calls[j], "flops", 0) < _thr:
-                            continue
                         plans[k].calls[j](sp[k])
             for k in range(splits):
                 mark("end", k, cs[k])
