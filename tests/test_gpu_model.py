@@ -299,6 +299,13 @@ def test_pipelined_side_stream_equals_serial():
         for i in range(3):
             k = int(c0[i])
             assert torch.equal(r0[i, :k], r1[i, :k])
+    # scheduling hint: the launches of a plan that has the GPU to itself carry DAFNE_CONV_EXCLUSIVE (small launches then take a
+    # whole CU's LDS for an operand ring), the sub-batch plans of the pipelined step do not; results are the same (above)
+    from dafne_amd import engine
+    alone = [c for c in m.plan(3, 128, 160).calls if isinstance(c, engine.ConvCall)]
+    shared = [c for p in m._pipe[(3, 128, 160, 2)]["plans"][0] for c in p.calls if isinstance(c, engine.ConvCall)]
+    assert alone and all(c.prm.flags & engine.F_EXCL for c in alone)
+    assert shared and not any(c.prm.flags & engine.F_EXCL for c in shared)
 
 
 @pytest.mark.parametrize("cfgname,h,w", [("hrsc_r50.yaml", 800, 1216), ("ucas_aod_r101.yaml", 256, 320),
