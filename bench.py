@@ -102,7 +102,7 @@ def build_model(depth, device, seed=0, cfgname=None, cls_prior=None, tower_std=N
     return cfg, m, sd
 
 
-def time_steps(step_fn, steps, warmup, distributed, device="cuda"):
+def time_steps(step_fn, steps, warmup, distributed, device="cuda", per_rank=None):
     """W untimed steps, then EXACTLY `steps` steps bracketed by barrier + device synchronize on both sides; the
     result is the MAX over ranks (the slowest rank's time).  device "cpu" is the gloo test's layout (no GPU)."""
     sync = torch.cuda.synchronize if str(device).startswith("cuda") else (lambda: None)
@@ -119,9 +119,16 @@ def time_steps(step_fn, steps, warmup, distributed, device="cuda"):
     sync()
     dt = time.perf_counter() - t0
     if distributed:
-        t = torch.tensor([dt], dtype=torch.float64, device=device)
+        mine = torch.tensor([dt], dtype=torch.float64, device=device)
+        t = mine.clone()
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        if per_rank is not None:                 # every rank's own time, for the line's self-check (min / max over ranks)
+            every = [torch.zeros_like(mine) for _ in range(dist.get_world_size())]
+            dist.all_gather(every, mine)
+            per_rank[:] = [float(e.item()) for e in every]
         dt = float(t.item())
+    elif per_rank is not None:
+        per_rank[:] = [dt]
     return dt
 
 
@@ -358,6 +365,23 @@ def headline(args, world, dt, det_mean):
     return out
 
 
+def distributed_record(args, world, distributed, per_rank_s, gathered):
+    """What the collective DELIVERED, so that an N > 1 line proves itself: `n_gpus` in the headline is the launcher's
+    WORLD_SIZE; this records the process group's own size and backend, the number of images the last step's detection
+    gather landed on rank 0 (must be per_gpu_batch x world) with their detection count, and every rank's own timed-region
+    time (value is computed from the MAX).  gathered: (rows_all, counts_all) on rank 0, None elsewhere / at N = 1."""
+    rec = {"world_size_from_env": world, "process_group_size": dist.get_world_size() if distributed else 1,
+           "backend": dist.get_backend() if distributed else None,
+           "per_rank_ms_per_step": {"min": 1e3 * min(per_rank_s) / args.steps, "max": 1e3 * max(per_rank_s) / args.steps,
+                                    "ranks": len(per_rank_s)} if per_rank_s else None}
+    if distributed and gathered is not None:
+        rows_all, counts_all = gathered
+        rec["gathered_images"] = int(rows_all.shape[0])
+        rec["gathered_detections"] = int(counts_all.sum().item())
+        rec["expected_images"] = args.batch * world
+    return rec
+
+
 def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -447,8 +471,11 @@ def run(args, make_step=None, backend="nccl", device_kind="cuda"):
 def _run_worker(args, make_step, rank, world, distributed, device):
     if make_step is not None:
         step, finish = make_step(args, rank, world, device)
-        dt = time_steps(step, args.steps, args.warmup, distributed, device)
+        per_rank = []
+        dt = time_steps(step, args.steps, args.warmup, distributed, device, per_rank=per_rank)
         out = headline(args, world, dt, None)
+        last = step()
+        out["distributed"] = distributed_record(args, world, distributed, per_rank, last)
         if rank == 0 and finish is not None:
             finish(out)
         return out
@@ -458,6 +485,8 @@ def _run_worker(args, make_step, rank, world, distributed, device):
     g = torch.Generator().manual_seed(rank)
     batch = torch.randint(0, 256, (args.batch, 3, args.size, args.size), generator=g, dtype=torch.uint8).to(device)
 
+    gathered = {"out": None}
+
     def step():
         # decode + NMS + gather (+ the RCCL detection gather) ride a side stream and overlap the
         # next step's convolutions; the dense part runs as --splits sub-batches on concurrent
@@ -465,19 +494,21 @@ def _run_worker(args, make_step, rank, world, distributed, device):
         if args.mode == "serial":
             rows, counts = model.detect_packed(batch)
             if distributed:
-                gather_detections(rows, counts, dst=0)
+                gathered["out"] = gather_detections(rows, counts, dst=0)
             return rows, counts
         rows, counts = model.detect_packed(batch, pipelined=True, splits=args.splits)
         if distributed:
             with torch.cuda.stream(model.side_stream):
-                gather_detections(rows, counts, dst=0)
+                gathered["out"] = gather_detections(rows, counts, dst=0)
         return rows, counts
 
-    dt = time_steps(step, args.steps, args.warmup, distributed, device)
+    per_rank = []
+    dt = time_steps(step, args.steps, args.warmup, distributed, device, per_rank=per_rank)
     rows, counts = step()
     torch.cuda.synchronize()
     out = headline(args, world, dt, float(counts.float().mean().item()))
     out["config"]["mode"] = args.mode
+    out["distributed"] = distributed_record(args, world, distributed, per_rank, gathered["out"])
     # extras only at N=1: at N>1 the other ranks would sit in the final barrier while rank 0 measures side metrics
     if rank == 0 and world == 1 and not args.no_extras:
       try:
@@ -618,7 +649,31 @@ def _run_worker(args, make_step, rank, world, distributed, device):
                                                         % (list(cfg15.TEST.AUG.MIN_SIZES),)}
                 del tta, m15
 
-            for fn in (side_r50, side_fp8, side_tta):
+            def side_forward():
+                # the SAME model through the reference-shaped entry point: inference_on_dataset(model, loader, evaluator)
+                # (tools/plain_train_net.py:316-336) -> OneStageDetector.forward_streamed, list[dict] in, list[{"instances"}] out,
+                # Instances built on the host for every image.  Device-resident tiles (as the headline) and host tiles (pageable
+                # CPU tensors as a data loader yields them: pinned staging + upload under the previous batch).
+                from dafne_amd.evaluation.inference import DafneEvaluator, inference_on_dataset
+                nb = max(args.steps // 4, 6)
+                res = {}
+                for where in ("device", "host"):
+                    imgs = batch if where == "device" else batch.cpu()
+                    loader = [[{"image": imgs[k], "height": args.size, "width": args.size, "image_id": j * args.batch + k}
+                               for k in range(args.batch)] for j in range(nb)]
+                    ev = DafneEvaluator("synthetic", cfg, distributed=False)
+                    inference_on_dataset(model, loader[:2], ev)                     # warm-up: plans, pinned buffers
+                    st = {}
+                    r = inference_on_dataset(model, loader, ev, st)
+                    assert r["num_images"] == nb * args.batch
+                    res[where] = st["images_per_sec"]
+                out["through_forward_images_per_sec"] = res["device"]
+                out["through_forward"] = {"images_per_sec_device_tiles": res["device"], "images_per_sec_host_tiles": res["host"],
+                                          "fraction_of_value": res["device"] / out["value"], "batches": nb,
+                                          "entry": "evaluation.inference.inference_on_dataset -> OneStageDetector.forward_streamed "
+                                                   "(ENGINE.PIPELINE_SPLITS %d), DafneEvaluator.process per batch" % cfg.ENGINE.PIPELINE_SPLITS}
+
+            for fn in (side_forward, side_r50, side_fp8, side_tta):
                 try:
                     fn()
                 except Exception as e:      # noqa: BLE001

@@ -100,6 +100,10 @@ SIGNATURES = {
                                             c_void_p]),
     "dafne_conv3x3_c256_scratch_bytes": (c_size_t, []),
     "dafne_conv3x3_c256_hip": (c_int, [ctypes.POINTER(ConvParams), ctypes.POINTER(ConvSeg), c_void_p, c_void_p, c_size_t, c_void_p]),
+    "dafne_conv2d_wr_ok": (c_int, [ctypes.POINTER(ConvParams), ctypes.POINTER(ConvSeg)]),
+    "dafne_conv2d_wr_splits": (c_int, [ctypes.POINTER(ConvParams), ctypes.POINTER(ConvSeg)]),
+    "dafne_conv2d_wr_workspace_bytes": (c_size_t, [ctypes.POINTER(ConvParams), ctypes.POINTER(ConvSeg)]),
+    "dafne_conv2d_wr_hip": (c_int, [ctypes.POINTER(ConvParams), ctypes.POINTER(ConvSeg), c_void_p, c_void_p, c_size_t, c_void_p]),
     "dafne_bottleneck_body_scratch_bytes": (c_size_t, []),
     "dafne_bottleneck_body_hip": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
                                           c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),

@@ -154,7 +154,14 @@ def _defaults():
                     # detect_packed RAISES until calibrate_fp8(batch) or set_fp8_act_scales(scales) has been called -- results
                     # never depend on image order, batch size or world size; "off" = only the GroupNorm-fed tower layers take e4m3
                     # activations; "first_batch" = opt-in convenience: calibrate on the first batch detect_packed sees
-                    FP8_ACT_CALIBRATION="explicit"),
+                    FP8_ACT_CALIBRATION="explicit",
+                    # fp8 model: the kernel of its 3x3 layers with 256 input channels -- "patch" (conv3x3_patch_fp8_kernel) or "rp8"
+                    # (conv3x3_rp8_kernel).  The two round the same sums differently (2 bf16 ulps), so the choice is part of the
+                    # model: every plan (whole batch, pipelined sub-batches, TTA chunks) of one model uses the same kernel
+                    FP8_CONV3X3_KERNEL="patch",
+                    # sub-batches on concurrent streams in the streamed evaluation loop (OneStageDetector.forward_streamed /
+                    # evaluation.inference.inference_on_dataset): the layout bench.py times
+                    PIPELINE_SPLITS=3),
     )
 
 

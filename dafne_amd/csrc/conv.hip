@@ -293,9 +293,6 @@ __global__ void __launch_bounds__(WC * WP * 64) conv_igemm_kernel(ConvDev P) {
         };
         auto piece = [&](int sidx, int h, int i) {    // i is a compile-time constant at every call site
             if (sidx >= K) return;
-#ifdef DAFNE_EXP_HALF_GLDS
-            if (i >= 2) sidx = 0;       // experiment: pixel-side pieces always re-fetch step 0 (L2/L1-hot lines)
-#endif
             const bool isW = (i * NW + wave) * 16 < BN;
             const char* base = isW ? P.w : S.in;
             const unsigned koff = isW ? (unsigned)sidx * (unsigned)kRowBytes : offX[sidx & 1];
@@ -311,13 +308,8 @@ __global__ void __launch_bounds__(WC * WP * 64) conv_igemm_kernel(ConvDev P) {
         bf16x8 af[2][TC], bfr[2][TP];
         auto read_half = [&](int stage, int h) {
             const char* sb = lds + stage * STAGE + h * HSTAGE;
-#ifdef DAFNE_EXP_HALF_LDS
-#pragma unroll
-            for (int k2 = 0; k2 < 1; k2++) {
-#else
 #pragma unroll
             for (int k2 = 0; k2 < 2; k2++) {
-#endif
 #pragma unroll
                 for (int a = 0; a < TC; a++) af[k2][a] = *(const bf16x8*)(sb + (arow0 + a * 32) * 64 + hroff[k2]);
 #pragma unroll
@@ -4268,9 +4260,6 @@ int dafne_conv2d_nhwc_bf16_hip(const dafne_conv_params* prm, const dafne_conv_se
         if (ws_eligible(D)) return launch_ws(D, st);
         return launch_stream(D, st);
     }
-#ifdef DAFNE_EXP_BIGWAVE
-    if (D.bn == 256) return launch<2, 2, 4, 4>(D, st);
-#endif
     if (D.bn == 256) return launch<4, 2, 2, 4>(D, st);
     if (D.bn == 128) {
         // at most one tile per CU and a long K loop: the 4-stage ring (one workgroup per CU, no drain per step)

@@ -38,9 +38,6 @@ constexpr int kStage = kTH * kTW * 128;
 constexpr int kOffBias = kOffStage + 2 * kStage;
 constexpr int kSmemTotal = kOffBias + 64 * 4;
 constexpr int kNT = 512;
-#ifndef DAFNE_C64_ABL
-#define DAFNE_C64_ABL 0      // timing ablations (wrong results): 1 no patch DMA, 2 no stores
-#endif
 static_assert(kSmemTotal <= 160 * 1024, "LDS budget");
 
 struct C64Dev {
@@ -97,7 +94,6 @@ __global__ void __launch_bounds__(512, 2) conv3x3_c64_kernel(C64Dev P) {
         return r;
     };
     auto issue_piece = [&](const TileXY& T, int buf, int ii) {
-        if (DAFNE_C64_ABL & 1) return;
         int piece = wave + 8 * ii;
         piece = piece < kPieces ? piece : kPieces - 1;
         int ln = lane;
@@ -124,7 +120,7 @@ __global__ void __launch_bounds__(512, 2) conv3x3_c64_kernel(C64Dev P) {
         pxx = pxx < xmax ? pxx : xmax;
         const int px = py * kTW + pxx, q = idx & 7;
         const u32x4 v = *(const u32x4*)(lds + kOffStage + sbuf * kStage + px * 128 + ((q ^ ((px >> 1) & 7)) * 16));
-        if (!(DAFNE_C64_ABL & 2)) *(u32x4*)(P.out + ((size_t)(T.img * Hp + T.y0 + py + 1) * Wp + T.x0 + pxx + 1) * 128 + q * 16) = v;
+        *(u32x4*)(P.out + ((size_t)(T.img * Hp + T.y0 + py + 1) * Wp + T.x0 + pxx + 1) * 128 + q * 16) = v;
     };
     auto barrier = [&]() {
         __builtin_amdgcn_sched_barrier(0);

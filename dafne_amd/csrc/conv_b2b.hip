@@ -307,27 +307,11 @@ __global__ void __launch_bounds__(512, 2) conv_b2b_kernel(B2bDev P) {
     barrier();
     B2B_STAMP();
 
-// timing ablations (scratch/build_variant.sh; wrong results): -DDAFNE_B2B_NOSTORE / _NOBAR / _NORES
-#ifdef DAFNE_B2B_NOSTORE
-#define B2B_ABL_STORE 0
-#else
-#define B2B_ABL_STORE 1
-#endif
-#ifdef DAFNE_B2B_NOBAR
-#define B2B_ABL_BAR 0
-#else
-#define B2B_ABL_BAR 1
-#endif
-#ifdef DAFNE_B2B_NORES
-#define B2B_ABL_RES 0
-#else
-#define B2B_ABL_RES 1
-#endif
 #define B2B_STEP(j, ACC)                                                                                        \
     {                                                                                                           \
         B2B_WAIT_STEP(j);                                                                                       \
         consume(ar[(j) % kRing], ((j) & 15) >> 2, (j) & 3, ((j) >> 4) & 1, ACC);                                    \
-        if (!kStRow && B2B_ABL_STORE && ((j) & 31) >= 16 && (((j) & 31) & 3) == 0) {                            \
+        if (!kStRow && ((j) & 31) >= 16 && (((j) & 31) & 3) == 0) {                            \
             store_slab((((j) & 31) - 16) >> 2, 0, P.out, kCB * 2, (unsigned)((j) >> 5) * 512u);                 \
             store_slab((((j) & 31) - 16) >> 2, 1, P.out, kCB * 2, (unsigned)((j) >> 5) * 512u);                 \
         }                                                                                                       \
@@ -344,8 +328,8 @@ __global__ void __launch_bounds__(512, 2) conv_b2b_kernel(B2bDev P) {
 #define B2B_G2SLAB(C, Q)                                                                                        \
     {                                                                                                           \
         B2B_STEP4(32 * (C) + 16 + 4 * (Q), acc2)                                                                \
-        if ((B2B_ABL_BAR && !kResWhole) || (Q) == 3) barrier();                                                 \
-        if (!kResWhole && B2B_ABL_RES && (C) + 1 < kChunks) dma_slab(P.res, kCB * 2, (unsigned)((C) + 1) * 512u, 1, (Q));      \
+        if (!kResWhole || (Q) == 3) barrier();                                                 \
+        if (!kResWhole && (C) + 1 < kChunks) dma_slab(P.res, kCB * 2, (unsigned)((C) + 1) * 512u, 1, (Q));      \
         if (kResWhole && (Q) == 3 && (C) + 1 < kChunks) dma_tile(P.res, kCB * 2, (unsigned)((C) + 1) * 512u, 1);               \
         __builtin_amdgcn_sched_barrier(0);                                                                      \
     }

@@ -47,9 +47,6 @@ constexpr int kOffBias = kOffW + 4 * kQB;          // fp32 [512 conv3 | 128 conv
 constexpr int kSmemTotal = kOffBias + (kCB + kCM) * 4;
 constexpr int kNT = 512;
 constexpr int kQPT = 16;                 // quarter blocks per tile
-#ifndef DAFNE_MID_ABL
-#define DAFNE_MID_ABL 0                  // timing ablations (wrong results): 1 no weight stream, 2 no HBM loads, 4 no stores
-#endif
 static_assert(kSmemTotal <= 160 * 1024, "LDS budget");
 
 struct MidDev {
@@ -118,7 +115,6 @@ __global__ void __launch_bounds__(512, 2) conv_b2b_mid_kernel(MidDev P) {
 #pragma unroll
     for (int i = 0; i < 8; i++) rr[0][i] = rr[1][i] = u32x4{0u, 0u, 0u, 0u};
     auto issue_T = [&](int t, int buf) {
-        if (DAFNE_MID_ABL & 2) return;
 #pragma unroll
         for (int ii = 0; ii < 4; ii++) {
             const int piece = wave + 4 * ii;
@@ -131,7 +127,6 @@ __global__ void __launch_bounds__(512, 2) conv_b2b_mid_kernel(MidDev P) {
         }
     };
     auto issue_rows = [&](int t, int c, u32x4 (&r)[8]) {
-        if (DAFNE_MID_ABL & 2) return;
 #pragma unroll
         for (int i = 0; i < 8; i++) {
             int idx = mt + 256 * i;
@@ -155,7 +150,6 @@ __global__ void __launch_bounds__(512, 2) conv_b2b_mid_kernel(MidDev P) {
     };
     // ---- weight waves: quarter block q (global sequence) -> ring slot q & 3; 16 pieces of 1 KB, 4 per wave
     auto issue_qb = [&](int q) {                                   // q = block number inside a tile (any tile: same weights)
-        if (DAFNE_MID_ABL & 1) return;
         unsigned voff = (unsigned)lane * 16u;
         asm volatile("" : "+v"(voff));           // opaque per call: otherwise all 64 source addresses are hoisted out of the tile loop and spilled
         const char* src = P.wf + (size_t)(q & (kQPT - 1)) * kQB;
@@ -241,7 +235,7 @@ __global__ void __launch_bounds__(512, 2) conv_b2b_mid_kernel(MidDev P) {
                             px = px < plastp ? px : plastp;
                             const int j = idx & 15;
                             const u32x4 v = *(const u32x4*)(lds + kOffZ + (j >> 3) * kSlab + px * 128 + (((j & 7) ^ ((px >> 1) & 7)) * 16));
-                            if (!(DAFNE_MID_ABL & 4)) *(u32x4*)(P.next + (size_t)halo_index(tp, px) * (kCM * 2) + j * 16) = v;
+                            *(u32x4*)(P.next + (size_t)halo_index(tp, px) * (kCM * 2) + j * 16) = v;
                         }
                     }
                     rows_to_lds(rr[0]);
@@ -263,7 +257,7 @@ __global__ void __launch_bounds__(512, 2) conv_b2b_mid_kernel(MidDev P) {
                         px = px < plast ? px : plast;
                         const int j = idx & 31;
                         const u32x4 v = *(const u32x4*)(lds + kOffY + (j >> 3) * kSlab + px * 128 + (((j & 7) ^ ((px >> 1) & 7)) * 16));
-                        if (!(DAFNE_MID_ABL & 4)) __builtin_nontemporal_store(v, (u32x4*)(P.out + (size_t)halo_index(t, px) * (kCB * 2) + c * 512 + j * 16));
+                        __builtin_nontemporal_store(v, (u32x4*)(P.out + (size_t)halo_index(t, px) * (kCB * 2) + c * 512 + j * 16));
                     }
                 }
             }

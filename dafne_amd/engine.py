@@ -205,6 +205,15 @@ def pack_conv3x3_frag(w):
     return w.reshape(cout // 256, 8, 32, 144, 2, 8).permute(0, 1, 3, 4, 2, 5).contiguous().reshape(-1)   # nt, w, j, h, r, e
 
 
+def pack_conv_frag(w):
+    """Fragment-major weights of dafne_conv2d_wr_hip from a packed weight ([Cout, K] bf16 in pack_conv's K order, Cout % 256 ==
+    0, K % 64 == 0): bf16 [Cout/256][8 waves][K/16 steps][64 lanes][8]: rows nt*256 + wave*32 + (lane & 31), K columns
+    16*step + 8*(lane >> 5) .. +8  (pack_conv3x3_frag for any K)."""
+    cout, k = w.shape
+    assert w.dim() == 2 and cout % 256 == 0 and k % 64 == 0 and w.dtype == BF16
+    return w.reshape(cout // 256, 8, 32, k // 16, 2, 8).permute(0, 1, 3, 4, 2, 5).contiguous().reshape(-1)   # nt, w, j, h, r, e
+
+
 def pack_conv3x3_frag8(qb):
     """Fragment-major e4m3 weights of dafne_conv3x3_c256_fp8w_hip from pack_conv_fp8's bytes ([Cout, 2304] uint8, K order slab,
     kh, kw, channel): [Cout/256][8 waves][36 steps][2][64 lanes][16]: rows nt*256 + wave*32 + (lane & 31), K bytes 64*step +
@@ -214,27 +223,28 @@ def pack_conv3x3_frag8(qb):
     return qb.reshape(cout // 256, 8, 32, 36, 2, 2, 16).permute(0, 1, 3, 5, 4, 2, 6).contiguous().reshape(-1)   # nt, w, step, j, half, r, b
 
 
-_FRAG8 = {}
+def frag8_of(P, key):
+    """pack_conv3x3_frag8 of the e4m3 weight P[key + ".fp8"], built once and stored NEXT TO it in the packed-weights dict
+    (key + ".fp8.frag", like the bf16 ".frag" copies): it dies with the weights on invalidate() / a re-pack."""
+    fk = key + ".fp8.frag"
+    if fk not in P:
+        P[fk] = pack_conv3x3_frag8(P[key + ".fp8"][0])
+    return P[fk]
 
 
-def frag8_of(qb):
-    """pack_conv3x3_frag8 of an e4m3 weight tensor, built once per tensor."""
-    key = (qb.data_ptr(), str(qb.device))
-    if key not in _FRAG8:
-        _FRAG8[key] = (qb, pack_conv3x3_frag8(qb))          # keeps qb alive: the key is its address
-    return _FRAG8[key][1]
+FP8_KERNELS = ("patch", "rp8")
 
 
-_BUILDING_SHARED = [False]     # a DensePlan(shared_gpu=True) is being built (plans are built on one thread)
-
-
-def use_rp8_kernel():
-    """conv3x3_rp8_kernel (fp8 resident patch, persistent) for the fp8 layers with 256 input channels?  Default: when the plan
-    has the GPU to itself (tower layer at batch 8: 149 -> 134 us, config 5 serial +2 %); the sub-batch plans of the pipelined
-    step keep conv3x3_patch_fp8_kernel, whose small workgroups interleave with the other streams' launches (the persistent
-    kernel measured -3 % there).  DAFNE_CONV_RP8=1 / 0 forces it on / off everywhere (tests, A/B runs)."""
+def fp8_conv3x3_kernel(P):
+    """Which kernel runs the fp8 model's 3x3 layers with 256 input channels: "patch" (conv3x3_patch_fp8_kernel) or "rp8"
+    (conv3x3_rp8_kernel: persistent, fp8 resident patch).  The two round the same sums differently (2 bf16 ulps), so the choice
+    is PART OF THE MODEL (cfg.ENGINE.FP8_CONV3X3_KERNEL -> P["fp8_kernel"], fixed when the weights are packed): every plan of a
+    model -- whole batch, sub-batches of the pipelined step, TTA chunks -- uses the same one and serial == pipelined holds.
+    DAFNE_CONV_RP8=1 / 0 overrides it for the whole process (A/B runs)."""
     v = os.environ.get("DAFNE_CONV_RP8")
-    return (not _BUILDING_SHARED[0]) if v is None else v != "0"
+    if v is not None:
+        return "rp8" if v != "0" else "patch"
+    return P.get("fp8_kernel", "patch")
 
 
 _RP_SCRATCH = {}
@@ -290,7 +300,7 @@ class ConvCall:
     """One dafne_conv2d_nhwc_bf16_hip launch with its argument structs kept alive."""
 
     def __init__(self, w, b, cin, cout, k, stride, pad, flags, segs, n_images, gn_partial=None, gn_in=None, fp8=None,
-                 gn_fin=None, wfrag=None):
+                 gn_fin=None, wfrag=None, shared_gpu=False, frag8=None):
         """gn_in: (stats [n_segs,N,Cin/8,2], gamma [Cin], beta [Cin]) of the INPUT maps when they hold the raw
         output of the previous tower convolution (flag F_GNIN: GroupNorm + ReLU applied on load).
         fp8: (oscale fp32 [Cout], in_qscale) -> `w` holds e4m3 bytes (pack_conv_fp8) and the call goes to
@@ -298,7 +308,10 @@ class ConvCall:
         gn_fin: (stats out [n_segs,N,Cout/8,2] fp32, counters [n_segs,N] int32 zeros, eps) with flag F_GNFIN: the last
         tile of every image finalises the GroupNorm statistics of the OUTPUT (no dafne_groupnorm_finalize_hip launch).
         wfrag: fragment-major bf16 weights (pack_conv3x3_frag) -> the call goes to dafne_conv3x3_c256_hip (resident-patch
-        kernel: 3x3 s1 p1, Cin 256, Cout % 256 == 0; its own tile geometry)."""
+        kernel: 3x3 s1 p1, Cin 256, Cout % 256 == 0; its own tile geometry).
+        shared_gpu: the plan this call belongs to runs next to other plans on concurrent streams (no F_EXCL hint).
+        frag8: fragment-major e4m3 weights (frag8_of) -> an fp8 call the resident-patch kernel can take goes to
+        dafne_conv3x3_c256_fp8w_hip (the model's FP8_CONV3X3_KERNEL == "rp8")."""
         L = _lib.load()
         self.fp8 = fp8
         self.wfrag = wfrag
@@ -307,7 +320,7 @@ class ConvCall:
         self.keep = (w, b, gn_partial, [s for s in segs], gn_in, fp8, gn_fin, wfrag)
         gi = [t.data_ptr() for t in gn_in] if gn_in is not None else [None, None, None]
         gf = (gn_fin[0].data_ptr(), gn_fin[1].data_ptr(), float(gn_fin[2])) if gn_fin is not None else (None, None, 0.0)
-        if not _BUILDING_SHARED[0]:
+        if not shared_gpu:
             flags |= F_EXCL             # hint (results unchanged): the plan this call belongs to has the GPU to itself
         self.prm = _lib.ConvParams(n_images, len(segs), cin, cout, k, k, stride, pad, flags,
                                    w.data_ptr(), b.data_ptr() if b is not None else None,
@@ -319,8 +332,8 @@ class ConvCall:
                                   hin, win, hout, wout)
         self.segs = arr
         self.fn = L.dafne_conv2d_nhwc_bf16_hip
-        if fp8 is not None and cin == 256 and k == 3 and use_rp8_kernel() and L.dafne_conv3x3_c256_ok(ctypes.byref(self.prm), self.segs):
-            self.rp8 = frag8_of(w)
+        if fp8 is not None and frag8 is not None and cin == 256 and k == 3 and L.dafne_conv3x3_c256_ok(ctypes.byref(self.prm), self.segs):
+            self.rp8 = frag8
         self.flops = 0
         self.bytes = w.numel() * w.element_size()       # algorithmic HBM bytes: every operand once
         for (_, tout, tres, hin, win, hout, wout) in segs:
@@ -415,6 +428,66 @@ class ConvPairCall:
             _lib.check(rc, "dafne_conv3x3_c256_pair_hip")
 
 
+def use_wr_kernel():
+    """conv_wr_kernel (128 px x 256 ch tiles, weights -> registers, deterministic split-K) for the small-M layers it takes
+    (res5, FPN laterals / P4-P5 outputs / P6 / P7, the stride-2 projections); DAFNE_CONV_WR=0 keeps them on conv_igemm /
+    conv_stream (A/B runs)."""
+    return os.environ.get("DAFNE_CONV_WR", "1") != "0"
+
+
+def wr_takes(k, stride, cin, cout, npx):
+    """Which small-M layers go to conv_wr: the shapes where it measured faster than the kernel dafne_conv2d_nhwc_bf16_hip picks,
+    both as a whole batch of 8 alone on the GPU and as a 3-image sub-batch beside two others (scratch/wr_micro.py,
+    profiles/NOTES_r04.md): res5 conv2 (3x3, 512 -> 512: x1.09 / x1.23), res5 conv3 (512 -> 2048 + residual: x1.02 / x1.11),
+    FPN lateral 5 / 4 (x1.05-1.17), FPN output 5, P6, P7 (3x3 on <= 8192 pixels: x1.05-1.14), res4.0 conv1 (512 -> 256, stride
+    2: x1.28 / x1.09).  Not: res5.0 conv1 / shortcut, res5 conv1 (2048 -> 512), the 64 x 64 3x3 layers (x0.75-1.0)."""
+    if k == 3:
+        return stride in (1, 2) and npx <= 10000 and cin in (256, 512) and cout == cin
+    if stride == 1:
+        return (cin == 512 and cout == 2048 and npx <= 10000) or (cout == 256 and cin >= 1024 and npx <= 40000)
+    return cin == 512 and cout == 256 and npx <= 40000
+
+
+class WrWorkspace:
+    """Split-K workspace of a plan's dafne_conv2d_wr_hip calls (arrival tickets + fp32 partial slabs).  One per plan: its calls
+    run on ONE stream, back to back, and each leaves the tickets zero.  Grown while the plan is built, allocated (zeroed) at
+    the first launch."""
+
+    def __init__(self, device):
+        self.device, self.bytes, self.t = device, 0, None
+
+    def need(self, nbytes):
+        assert self.t is None
+        self.bytes = max(self.bytes, int(nbytes))
+
+    def tensor(self):
+        if self.t is None:
+            self.t = torch.zeros(max(self.bytes, 1 << 16), dtype=torch.uint8, device=self.device)
+        return self.t
+
+
+class WrCall:
+    """One dafne_conv2d_wr_hip launch built from a ConvCall's parameter block."""
+
+    def __init__(self, conv, wfrag, ws):
+        self.conv, self.wfrag, self.ws = conv, wfrag, ws
+        self.prm, self.segs = conv.prm, conv.segs
+        self.flops, self.bytes = conv.flops, conv.bytes
+        L = _lib.load()
+        self.splits = L.dafne_conv2d_wr_splits(ctypes.byref(self.prm), self.segs)
+        assert self.splits >= 1
+        ws.need(L.dafne_conv2d_wr_workspace_bytes(ctypes.byref(self.prm), self.segs))
+
+    def kernel_name(self):
+        return "conv_wr"
+
+    def __call__(self, stream):
+        w = self.ws.tensor()
+        rc = _lib.load().dafne_conv2d_wr_hip(ctypes.byref(self.prm), self.segs, _lib.ptr(self.wfrag), _lib.ptr(w), w.numel(), stream)
+        if rc:
+            _lib.check(rc, "dafne_conv2d_wr_hip")
+
+
 class FnCall:
     def __init__(self, fn, args, keep, name, flops=0, nbytes=0):
         self.fn, self.args, self.keep, self.name = fn, args, keep, name
@@ -447,12 +520,8 @@ class DensePlan:
         # shared_gpu: the plan runs next to other plans on concurrent streams (the sub-batches of the pipelined step): launches
         # stay small so that the streams interleave at a fine grain (no pairing of tower layers: measured -1..-4 % there,
         # +1.1 % when every launch has the GPU to itself)
-        self.shared_gpu = shared_gpu
-        _BUILDING_SHARED[0] = bool(shared_gpu)
-        try:
-            self._build(weights, n, h, w, depth, num_classes, device, with_head, head_outputs, calib)
-        finally:
-            _BUILDING_SHARED[0] = False
+        self.shared_gpu = bool(shared_gpu)
+        self._build(weights, n, h, w, depth, num_classes, device, with_head, head_outputs, calib)
 
     def _build(self, weights, n, h, w, depth, num_classes, device, with_head, head_outputs, calib):
         self.calib = calib
@@ -467,6 +536,9 @@ class DensePlan:
         self.pool = pool
 
         act_q8 = P.get("act_q8") or {}
+        rp8_on = fp8_conv3x3_kernel(P) == "rp8"
+        wr_on = use_wr_kernel()
+        self.wr_ws = WrWorkspace(device)
         # conv3x3_c64.hip: 65 -> 49 us per launch when it has the GPU to itself, but nothing in the timed 3-stream layout (its
         # persistent workgroups hold every CU's LDS, so the other sub-batches' kernels cannot share the chip with it): opt-in
         use_c64 = os.environ.get("DAFNE_CONV_C64", "0") == "1"
@@ -495,13 +567,23 @@ class DensePlan:
                 elif key in act_q8:
                     fp8 = (q8[1] / act_q8[key], act_q8[key])       # oscale = weight scale / in_qscale
             c = ConvCall(q8[0] if fp8 else wgt, bias, cin, cout, k, stride, pad, flags,
-                         [(tin.t, o.t, res.t if res is not None else None, tin.h, tin.w, ho, wo)], n, fp8=fp8)
+                         [(tin.t, o.t, res.t if res is not None else None, tin.h, tin.w, ho, wo)], n, fp8=fp8,
+                         shared_gpu=self.shared_gpu, frag8=frag8_of(P, key) if (fp8 and rp8_on and cin == 256 and k == 3) else None)
+            if (fp8 is None and wr_on and wr_takes(k, stride, cin, cout, n * ho * wo) and bias is not None
+                    and L.dafne_conv2d_wr_ok(ctypes.byref(c.prm), c.segs)):
+                # small-M layer (res5, FPN top): 128 px x 256 ch tiles, weights -> registers, split-K
+                if key + ".wr" not in P:
+                    P[key + ".wr"] = pack_conv_frag(wgt)
+                w = WrCall(c, P[key + ".wr"], self.wr_ws)
+                self.calls.append(w)
+                self.flops += w.flops
+                return o
             if fp8 is None and k == 3 and cin == 256 and use_rp_kernel() and c.kernel_id() == 6 and c.rp_ok():
                 # 256-channel 3x3 layers the patch kernel would take (FPN outputs): resident-patch kernel
                 if key + ".frag" not in P:
                     P[key + ".frag"] = pack_conv3x3_frag(wgt)
                 c = ConvCall(wgt, bias, cin, cout, k, stride, pad, flags,
-                             [(tin.t, o.t, None, tin.h, tin.w, ho, wo)], n, wfrag=P[key + ".frag"])
+                             [(tin.t, o.t, None, tin.h, tin.w, ho, wo)], n, wfrag=P[key + ".frag"], shared_gpu=self.shared_gpu)
             self.calls.append(c)
             self.flops += c.flops
             return o
@@ -521,7 +603,7 @@ class DensePlan:
         else:
             stem_out = pool.get(n, h // 2, w // 2, 64)
             c = ConvCall(wgt, bias, 4, 64, 7, 2, 3, F_RELU,
-                         [(self.stem_in, stem_out.t, None, h + 6, w + 6, h // 2, w // 2)], n)
+                         [(self.stem_in, stem_out.t, None, h + 6, w + 6, h // 2, w // 2)], n, shared_gpu=self.shared_gpu)
             self.calls.append(c)
             self.flops += c.flops
             self.calls.append(FnCall(L.dafne_maxpool3x3s2_nhwc_bf16_hip,
@@ -743,6 +825,8 @@ class HeadPlan:
         C = feats[0].c
         self.num_classes = num_classes
         calls = plan.calls
+        sg = bool(getattr(plan, "shared_gpu", False))
+        rp8_on = fp8_conv3x3_kernel(P) == "rp8"
         fuse_gn = os.environ.get("DAFNE_FUSE_GN", "1") != "0"
         fuse_gnfin = os.environ.get("DAFNE_FUSE_GNFIN", "1") != "0"
 
@@ -775,7 +859,7 @@ class HeadPlan:
                     aq = None                                            # ... and bf16 while calibrating
                 # M-tile geometry comes from the library (the kernel choice fixes the tile shape; the fp8 kernel always
                 # uses the patch kernel's tiles, the bf16 one only when the launch has enough of them)
-                probe = ConvCall(wgt, bias, C, C, 3, 1, 1, flags & ~F_GN, seg_list(cur, outs), n, gn_in=cur_gn)
+                probe = ConvCall(wgt, bias, C, C, 3, 1, 1, flags & ~F_GN, seg_list(cur, outs), n, gn_in=cur_gn, shared_gpu=sg)
                 rp_on = use_rp_kernel() and C == 256
                 use_fp8 = q8 is not None and aq is not None and (cur_gn is None or probe.kernel_id() == 6 or (rp_on and probe.rp_ok()))
                 use_rp = rp_on and not use_fp8 and probe.rp_ok() and (cur_gn is not None or probe.kernel_id() == 6)
@@ -784,10 +868,10 @@ class HeadPlan:
                     if lkey + ".frag" not in P:
                         P[lkey + ".frag"] = pack_conv3x3_frag(wgt)
                     wfrag = P[lkey + ".frag"]
-                    probe = ConvCall(wgt, bias, C, C, 3, 1, 1, flags & ~F_GN, seg_list(cur, outs), n, gn_in=cur_gn, wfrag=wfrag)
+                    probe = ConvCall(wgt, bias, C, C, 3, 1, 1, flags & ~F_GN, seg_list(cur, outs), n, gn_in=cur_gn, wfrag=wfrag, shared_gpu=sg)
                 if use_fp8:
                     probe = ConvCall(q8[0], bias, C, C, 3, 1, 1, flags & ~F_GN, seg_list(cur, outs), n, gn_in=cur_gn,
-                                     fp8=(q8[1] / aq, aq))
+                                     fp8=(q8[1] / aq, aq), shared_gpu=sg, frag8=frag8_of(P, lkey) if rp8_on else None)
                 is_patch = use_fp8 or use_rp or probe.kernel_id() == 6
                 nt = probe.num_tiles()
                 partial = torch.empty(nt, C // 8, 2, dtype=torch.float32, device=device)
@@ -801,7 +885,7 @@ class HeadPlan:
                     f32 = bool(fl & F_F32)
                     dst = [torch.empty(1, dtype=torch.float32, device=device)] * len(outs) if f32 else outs
                     nxt = ConvCall(wn, bn_, C, cout, 3, 1, 1, fl | F_GNIN, seg_list(outs, dst, f32=f32), n,
-                                   gn_in=(stats, gamma, beta))
+                                   gn_in=(stats, gamma, beta), shared_gpu=sg)
                     fuse_next = fuse_next and (nxt.kernel_id() in ((7, 8) if f32 else (6,)) or (not f32 and rp_on and nxt.rp_ok()))
                 fuse_fin = fuse_next and fuse_gnfin and is_patch and C == 256
                 fin = (stats, torch.zeros(len(outs), n, dtype=torch.int32, device=device), 1e-5) if fuse_fin else None
@@ -812,10 +896,11 @@ class HeadPlan:
                     # quantised on load (in_qscale 1: a normalised, rectified map sits well inside e4m3's range); the two
                     # layers that read FPN features use the calibrated scale of their input
                     c = ConvCall(q8[0], bias, C, C, 3, 1, 1, flags, seg_list(cur, outs), n, gn_partial=partial,
-                                 gn_in=cur_gn, fp8=(q8[1] / aq, aq), gn_fin=fin)
+                                 gn_in=cur_gn, fp8=(q8[1] / aq, aq), gn_fin=fin, shared_gpu=sg,
+                                 frag8=frag8_of(P, lkey) if rp8_on else None)
                 else:
                     c = ConvCall(wgt, bias, C, C, 3, 1, 1, flags, seg_list(cur, outs), n, gn_partial=partial, gn_in=cur_gn,
-                                 gn_fin=fin, wfrag=wfrag)
+                                 gn_fin=fin, wfrag=wfrag, shared_gpu=sg)
                 c.tower_tag = (name, i)
                 calls.append(c)
                 plan.flops += c.flops
@@ -875,7 +960,7 @@ class HeadPlan:
             else:
                 outs = [torch.empty(n, f.h, f.w, cout, dtype=torch.float32, device=device) for f in ins]
             c = ConvCall(wgt, bias, C, cout, 3, 1, 1, F_F32 | (F_GNIN if gn_in is not None else 0),
-                         seg_list(ins, outs, f32=True), n, gn_in=gn_in)
+                         seg_list(ins, outs, f32=True), n, gn_in=gn_in, shared_gpu=sg)
             calls.append(c)
             plan.flops += c.flops
             return outs
@@ -953,11 +1038,15 @@ def pack_head_weights(sd, device, prefix="proposal_generator.dafne_head.", fp8=F
     return P
 
 
-def pack_model_weights(sd, depth, device, weight_dtype="bf16"):
-    """weight_dtype: "bf16" or "fp8_e4m3" (cfg.ENGINE.WEIGHT_DTYPE; BASELINE config 5)."""
+def pack_model_weights(sd, depth, device, weight_dtype="bf16", fp8_kernel="patch"):
+    """weight_dtype: "bf16" or "fp8_e4m3" (cfg.ENGINE.WEIGHT_DTYPE; BASELINE config 5); fp8_kernel: cfg.ENGINE.FP8_CONV3X3_KERNEL
+    (fp8_conv3x3_kernel)."""
     if weight_dtype not in ("bf16", "fp8_e4m3"):
         raise NotImplementedError("ENGINE.WEIGHT_DTYPE %r (bf16 or fp8_e4m3)" % (weight_dtype,))
+    if fp8_kernel not in FP8_KERNELS:
+        raise NotImplementedError("ENGINE.FP8_CONV3X3_KERNEL %r (%s)" % (fp8_kernel, " or ".join(FP8_KERNELS)))
     fp8 = weight_dtype == "fp8_e4m3"
     P = pack_backbone_weights(sd, depth, device, fp8=fp8)
     P.update(pack_head_weights(sd, device, fp8=fp8))
+    P["fp8_kernel"] = fp8_kernel
     return P

@@ -1,0 +1,143 @@
+"""`inference_on_dataset(model, data_loader, evaluator)` for the MI355X engine.
+
+Reference: `do_test` hands every test set to detectron2's `inference_on_dataset` (tools/plain_train_net.py:316-336), whose
+loop is [recalled]  `evaluator.reset(); for inputs in data_loader: outputs = model(inputs); evaluator.process(inputs,
+outputs)`, then `evaluator.evaluate()`; `DafneEvaluator.process` moves every image's fields to the host
+(dafne/evaluation/dafne_evaluator.py:44-58) and `evaluate()` gathers the per-rank lists on rank 0 (:60-64).
+
+Here the loop is STREAMED: `model.forward_streamed(inputs)` enqueues batch i on the layout bench.py times (sub-batches on
+concurrent streams, post-process on a side stream under the next batch's convolutions) and hands back the outputs of
+batch i - 1, which go to `evaluator.process` while batch i runs; `model.flush()` drains the last one.  The evaluator sees
+exactly the (inputs, outputs) pairs of the synchronous loop, in the same order.  A model without `forward_streamed` (the TTA
+wrapper) is called synchronously.
+"""
+import time
+
+import torch
+
+from .gather import gather_detections, to_predictions
+from .driver import instances_to_rows
+
+
+class DatasetEvaluator:
+    """detectron2's evaluator protocol [recalled]: reset() / process(inputs, outputs) / evaluate()."""
+
+    def reset(self):
+        pass
+
+    def process(self, inputs, outputs):
+        pass
+
+    def evaluate(self):
+        return {}
+
+
+class DafneEvaluator(DatasetEvaluator):
+    """The collecting part of the reference's DafneEvaluator (dafne_evaluator.py:18-69): per image {image_id, file_name,
+    height, width, labels, scores, corners, centerness} on the host; `evaluate()` lands every rank's predictions on rank 0 in
+    global image order.  distributed: ONE collective pair over fixed-layout device buffers (gather.gather_detections: RCCL
+    on the MI355X, gloo in the CPU tests) instead of the reference's pickled lists -- every rank must have processed the same
+    number of images (the driver pads shards; `pad_to`).  The dataset-specific scoring (`_eval_predictions`: Task1 files, tile
+    merge, voc_eval) lives in evaluation/dota_evaluation.py."""
+
+    def __init__(self, dataset_name, cfg, distributed, output_dir=None, k_cap=None, device=None, pad_to=None):
+        self._dataset_name, self._cfg, self._distributed, self._output_dir = dataset_name, cfg, distributed, output_dir
+        self._k_cap = k_cap
+        self._device = device
+        self._pad_to = pad_to            # images every rank contributes to the gather (ceil(n / world): shards may be ragged)
+        self._predictions = []
+        self._meta = []
+        self._insts = []
+
+    def reset(self):
+        self._predictions, self._meta, self._insts = [], [], []
+
+    def process(self, inputs, outputs):
+        for inp, out in zip(inputs, outputs):
+            meta = {"image_id": inp["image_id"], "file_name": inp.get("file_name", ""), "height": inp["height"], "width": inp["width"]}
+            self._meta.append(meta)
+            pred = dict(meta)
+            if "instances" in out:
+                inst = out["instances"]
+                if self._distributed:
+                    self._insts.append(inst)          # stays on the device: gathered as packed rows in evaluate()
+                inst = inst.to(torch.device("cpu"))
+                pred["labels"], pred["scores"] = inst.pred_classes, inst.scores
+                pred["corners"], pred["centerness"] = inst.pred_corners, inst.centerness
+            self._predictions.append(pred)
+
+    def evaluate(self):
+        pad_to = self._pad_to
+        import torch.distributed as dist
+        if self._distributed and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            if self._k_cap is None:
+                raise RuntimeError("DafneEvaluator(distributed=True) needs k_cap (DAFNeOutputs.packed_k_cap())")
+            dev = self._device if self._device is not None else (self._insts[0].scores.device if self._insts else torch.device("cpu"))
+            rows, counts = instances_to_rows(self._insts, self._k_cap, dev)
+            ids = torch.tensor([m["image_id"] for m in self._meta], dtype=torch.int64, device=dev)
+            n = pad_to if pad_to is not None else len(self._insts)
+            if n > rows.shape[0]:                     # equal shapes on every rank: pad with empty images (id -1)
+                pad = n - rows.shape[0]
+                rows = torch.cat([rows, rows.new_zeros((pad,) + tuple(rows.shape[1:]))])
+                counts = torch.cat([counts, counts.new_zeros(pad)])
+                ids = torch.cat([ids, ids.new_full((pad,), -1)])
+            out = gather_detections(rows, counts, dst=0)
+            idl = [torch.empty_like(ids) for _ in range(dist.get_world_size())] if dist.get_rank() == 0 else None
+            dist.gather(ids, idl, dst=0)
+            if out is None:
+                return {}
+            ids_all = torch.cat(idl).cpu().tolist()
+            preds = to_predictions(out[0], out[1], image_ids=ids_all)
+            predictions = [p for p in preds if p["image_id"] >= 0]
+        else:
+            predictions = self._predictions
+        self._results = {"predictions": predictions, "num_images": len(predictions)}
+        return self._results
+
+
+def inference_on_dataset(model, data_loader, evaluator=None, stats=None):
+    """Run `model` over `data_loader` (an iterable of batches: list[dict] with "image" uint8 CHW BGR, "height", "width", ...)
+    and feed `evaluator` (reset / process / evaluate).  Returns evaluator.evaluate() (or the list of (inputs, outputs) pairs'
+    outputs when there is no evaluator).  stats (dict, optional) receives images, seconds and images_per_sec of the loop
+    (wall clock around the loop + the final drain, device synchronised on both sides)."""
+    if evaluator is not None:
+        evaluator.reset()
+    streamed = hasattr(model, "forward_streamed")
+    collected = []
+
+    def deliver(inputs, outputs):
+        if evaluator is not None:
+            evaluator.process(inputs, outputs)
+        else:
+            collected.extend(outputs)
+    cuda = torch.cuda.is_available()
+    if cuda:
+        torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    n = 0
+    prev_inputs = None
+    was_training = getattr(model, "training", False)
+    if hasattr(model, "eval"):
+        model.eval()
+    with torch.no_grad():
+        for inputs in data_loader:
+            n += len(inputs)
+            if streamed:
+                out_prev = model.forward_streamed(inputs)
+                if out_prev is not None:
+                    deliver(prev_inputs, out_prev)
+                prev_inputs = inputs
+            else:
+                deliver(inputs, model(inputs))
+        if streamed:
+            last = model.flush()
+            if last is not None:
+                deliver(prev_inputs, last)
+    if cuda:
+        torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if was_training and hasattr(model, "train"):
+        model.train()
+    if stats is not None:
+        stats.update(images=n, seconds=dt, images_per_sec=n / dt if dt > 0 else float("inf"))
+    return evaluator.evaluate() if evaluator is not None else collected

@@ -45,8 +45,6 @@ class DAFNeOutputs(nn.Module):
         """levels: list[postprocess.LevelInput] (NHWC fp32).  Returns (rows, counts):
         [N,k_cap,18] float32 detections and their per-image counts, on the GPU."""
         if not self.stride_norm:
-            levels = [pp.LevelInput(l.logits, l.delta, l.center, l.ctrness, 1, l.scale,
-                                    l.delta_ps, l.center_ps, l.ctrness_ps, l.logits_ps) for l in levels]
             raise NotImplementedError("ENABLE_FPN_STRIDE_NORM=False is not used by any released config")
         cand = self.decode_packed(levels)
         return self.select_packed(cand, sizes=sizes, k_cap=k_cap, scale_corners=scale_corners)

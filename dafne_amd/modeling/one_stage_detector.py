@@ -70,6 +70,7 @@ class OneStageDetector(nn.Module):
         self._plans = {}
         self._graphs = {}
         self._act_q8 = None
+        self._pending = None
         if hasattr(self, "_pipe"):
             self._pipe = {}
         self.backbone.invalidate()
@@ -83,7 +84,8 @@ class OneStageDetector(nn.Module):
     def _weights(self):
         if self._packed is None:
             self._packed = engine.pack_model_weights(self.state_dict(), self.depth, self.device,
-                                                     weight_dtype=self.cfg.ENGINE.WEIGHT_DTYPE)
+                                                     weight_dtype=self.cfg.ENGINE.WEIGHT_DTYPE,
+                                                     fp8_kernel=self.cfg.ENGINE.FP8_CONV3X3_KERNEL)
         return self._packed
 
     # ------------------------------------------------------------ fp8 activation scales (BASELINE config 5)
@@ -313,29 +315,105 @@ class OneStageDetector(nn.Module):
                 t.record_stream(main)
             return res
 
-    def forward(self, batched_inputs, do_postprocess=True):
-        if self.training:
-            raise NotImplementedError("training is outside the scope of the MI355X inference engine")
+    def _pack_inputs(self, batched_inputs, staged=False):
+        """list[{"image": uint8 CHW BGR, "height", "width"}] -> (device uint8 batch [n,3,H,W], valid (h, w) per image, requested
+        output (height, width) per image): ImageList.from_tensors' zero padding to the batch maximum (one_stage_detector.py:
+        100-107); the normalisation and the /32 padding happen in the engine's load kernel.
+        staged: host images go through a pinned staging buffer and an asynchronous copy on the upload stream (two buffers
+        alternate; the caller's stream waits for the copy, the host does not), so that the upload of batch i + 1 runs under
+        the network of batch i.  Images that already live on the device are stacked there."""
         dev = self.device
         imgs = [x["image"] for x in batched_inputs]
         n = len(imgs)
+        if not all(i.dtype == torch.uint8 for i in imgs):
+            raise NotImplementedError("the engine takes uint8 images, as the reference's data loader yields them")
         hs = [int(i.shape[1]) for i in imgs]
         ws = [int(i.shape[2]) for i in imgs]
         H, W = max(hs), max(ws)
-        if all(i.dtype == torch.uint8 for i in imgs):
-            if n == 1:
-                batch = imgs[0].to(dev, non_blocking=True).unsqueeze(0)
-            else:
-                batch = torch.zeros(n, 3, H, W, dtype=torch.uint8, device=dev)
+        same = all(h == H and w == W for h, w in zip(hs, ws))
+        if all(i.is_cuda for i in imgs):
+            batch = torch.stack(imgs) if same else torch.zeros(n, 3, H, W, dtype=torch.uint8, device=dev)
+            if not same:
                 for k, im in enumerate(imgs):
-                    batch[k, :, : hs[k], : ws[k]] = im.to(dev, non_blocking=True)
+                    batch[k, :, : hs[k], : ws[k]] = im
+        elif staged:
+            st = self.__dict__.setdefault("_staging", {"i": 0, "buf": {}, "stream": None, "free": {}})
+            if st["stream"] is None:
+                st["stream"] = torch.cuda.Stream(device=dev)
+            slot = st["i"] & 1
+            st["i"] += 1
+            key = (slot, n, H, W)
+            if key not in st["buf"]:
+                st["buf"][key] = torch.zeros(n, 3, H, W, dtype=torch.uint8).pin_memory()
+            pinned = st["buf"][key]
+            if st["free"].get(key) is not None:
+                st["free"][key].synchronize()            # the copy that last read this buffer (two calls ago) is done
+            if not same:
+                pinned.zero_()
+            for k, im in enumerate(imgs):
+                pinned[k, :, : hs[k], : ws[k]].copy_(im)
+            batch = torch.empty(n, 3, H, W, dtype=torch.uint8, device=dev)
+            with torch.cuda.stream(st["stream"]):
+                batch.copy_(pinned, non_blocking=True)
+                done = torch.cuda.Event()
+                done.record(st["stream"])
+            st["free"][key] = done
+            batch.record_stream(st["stream"])
+            torch.cuda.current_stream(dev).wait_event(done)
+        elif n == 1:
+            batch = imgs[0].to(dev, non_blocking=True).unsqueeze(0)
         else:
-            raise NotImplementedError("the engine takes uint8 images, as the reference's data loader yields them")
+            batch = torch.zeros(n, 3, H, W, dtype=torch.uint8, device=dev)
+            for k, im in enumerate(imgs):
+                batch[k, :, : hs[k], : ws[k]] = im.to(dev, non_blocking=True)
         valid = list(zip(hs, ws))
         out_hw = [(int(x.get("height", hs[k])), int(x.get("width", ws[k]))) for k, x in enumerate(batched_inputs)]
+        return batch, valid, out_hw
+
+    def forward(self, batched_inputs, do_postprocess=True):
+        if self.training:
+            raise NotImplementedError("training is outside the scope of the MI355X inference engine")
+        batch, valid, out_hw = self._pack_inputs(batched_inputs)
         rows, counts = self.detect_packed(batch, valid_hw=valid, out_hw=out_hw, do_postprocess=do_postprocess)
         insts = pp.rows_to_instances(rows, counts, out_hw)
         return [{"instances": r} for r in insts]
+
+    # ------------------------------------------------------------ streamed form of forward()
+    def forward_streamed(self, batched_inputs, do_postprocess=True):
+        """forward() for an evaluation LOOP (detectron2's inference_on_dataset: `for inputs in loader: outputs = model(inputs);
+        evaluator.process(inputs, outputs)`, called from tools/plain_train_net.py:316-336): ENQUEUES this batch on the layout
+        bench.py times -- cfg.ENGINE.PIPELINE_SPLITS sub-batches on concurrent streams, decode / rotated NMS / rescale on the
+        side stream under the next batch's convolutions -- and returns the outputs of the PREVIOUS call (None on the first
+        one); flush() returns the last batch's.  Same per-image results as forward() up to the bf16 noise floor of another batch
+        composition (identical when PIPELINE_SPLITS == 1).  The host never waits for the GPU except for the
+        previous batch's detection counts (a pinned 4-byte-per-image copy behind its NMS).
+        evaluation.inference.inference_on_dataset drives this."""
+        if self.training:
+            raise NotImplementedError("training is outside the scope of the MI355X inference engine")
+        splits = max(1, int(self.cfg.ENGINE.PIPELINE_SPLITS))
+        batch, valid, out_hw = self._pack_inputs(batched_inputs, staged=True)
+        rows, counts = self.detect_packed(batch, valid_hw=valid, out_hw=out_hw, do_postprocess=do_postprocess,
+                                          pipelined=True, splits=splits)
+        with torch.cuda.stream(self.side_stream):
+            counts_h = torch.empty(counts.shape, dtype=counts.dtype).pin_memory()
+            counts_h.copy_(counts, non_blocking=True)
+            ready = torch.cuda.Event()
+            ready.record(self.side_stream)
+        prev, self._pending = getattr(self, "_pending", None), (rows, counts_h, out_hw, ready)
+        return self._finish_streamed(prev)
+
+    def flush(self):
+        """Outputs of the last forward_streamed() call (None if there is none pending)."""
+        prev, self._pending = getattr(self, "_pending", None), None
+        return self._finish_streamed(prev)
+
+    @staticmethod
+    def _finish_streamed(p):
+        if p is None:
+            return None
+        rows, counts_h, out_hw, ready = p
+        ready.synchronize()                      # that batch's post-process (side stream) is done; later batches keep running
+        return [{"instances": r} for r in pp.rows_to_instances(rows, counts_h, out_hw)]
 
     def inference(self, batched_inputs, detected_instances=None, do_postprocess=True):
         assert not self.training

@@ -276,6 +276,27 @@ size_t dafne_conv3x3_c256_scratch_bytes(void);
 int dafne_conv3x3_c256_hip(const dafne_conv_params* prm, const dafne_conv_seg* segs, const void* d_wfrag, void* d_scratch,
                            size_t scratch_bytes, void* stream);
 /*
+ * Small-M layers -- res5 (1x1 / 3x3 / stride-2 projections on 32 x 32 maps), the FPN laterals, the P4 / P5 outputs and
+ * LastLevelP6P7's stride-2 convolutions (backbone/fpn.py:16-37,58-91; d2 ResNet / FPN [recalled]) -- on conv_wr_kernel
+ * (conv_wr.hip): 128-pixel x 256-channel tiles over the flat (image, row, column) pixel order, weights streamed L2 ->
+ * registers, pixel operand staged by DMA, and a DETERMINISTIC split-K: dafne_conv2d_wr_splits() workgroups share a tile,
+ * each writes its fp32 partial (128 KB) to d_workspace, the last arriver sums them in slice order and runs the epilogue.
+ * Same parameter block and result definition as dafne_conv2d_nhwc_bf16_hip for one segment with flags RELU / RESIDUAL /
+ * UPSAMPLE_ADD (EXCLUSIVE is the scheduling hint: it enters the slice count); 1x1 pad 0 or 3x3 pad 1, stride 1 / 2,
+ * Cin % 64 == 0, Cout % 256 == 0, bias required; else DAFNE_E_UNSUPPORTED (dafne_conv2d_wr_ok: 1 / 0).  One slice: K order
+ * and epilogue expressions are dafne_conv2d_nhwc_bf16_hip's -> bit-identical output.  Several slices: the fp32 sum is
+ * grouped by slices (fp32 rounding apart from the unsplit sum; run-to-run identical).  prm->d_weight is ignored;
+ * d_wfrag: bf16 [Cout/256][8 waves][K/16 steps][64 lanes][8] = rows nt*256 + wave*32 + (lane & 31), K columns 16*step +
+ * 8*(lane >> 5) .. +8 of the packed weight [Cout][Cin/64][KH][KW][64]  (engine.pack_conv_frag).
+ * d_workspace: >= dafne_conv2d_wr_workspace_bytes() (0 for one slice: may be NULL); its first 64 KB are arrival tickets
+ * and MUST BE ZERO before the first call (the kernel leaves them zero); calls on ONE stream may share it.
+ */
+int dafne_conv2d_wr_ok(const dafne_conv_params* prm, const dafne_conv_seg* segs);
+int dafne_conv2d_wr_splits(const dafne_conv_params* prm, const dafne_conv_seg* segs);
+size_t dafne_conv2d_wr_workspace_bytes(const dafne_conv_params* prm, const dafne_conv_seg* segs);
+int dafne_conv2d_wr_hip(const dafne_conv_params* prm, const dafne_conv_seg* segs, const void* d_wfrag, void* d_workspace,
+                        size_t workspace_bytes, void* stream);
+/*
  * fp8-weight twin (BASELINE config 5: "fp8 weights, CDNA4 fp8 MFMA conv path"; SURVEY 8(b) item 5
  * dafne_conv2d_nhwc_{bf16,fp8w}_hip).  The reference has no fp8 path: this entry DEFINES it.
  *   d_weight   OCP e4m3 bytes [Cout][Cin/64][KH][KW][64] (same K order as the bf16 layout, 1 byte per element)

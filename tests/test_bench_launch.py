@@ -26,7 +26,8 @@ def _stub_make_step(args, rank, world, device):
         calls["n"] += 1
         time.sleep(0.02 * (rank + 1))            # rank 1 is the slow one: the MAX reduction must report ITS time
         if world > 1:
-            gather_detections(rows, counts, dst=0)   # the per-step detection gather of the real step
+            return gather_detections(rows, counts, dst=0)   # the per-step detection gather of the real step
+        return None
 
     def finish(out):
         out["stub"] = {"calls_rank0": calls["n"], "env": {k: os.environ.get(k) for k in
@@ -70,18 +71,27 @@ def test_plain_command_self_launches_two_ranks():
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["steps"] == 3 and out["warmup"] == 1 and out["scaling"] == "weak"
     assert out["config"]["global_batch"] == 8 and out["config"]["per_gpu_batch"] == 4
-    assert out["stub"]["calls_rank0"] == 4                 # W + K steps, exactly
+    assert out["stub"]["calls_rank0"] == 5                 # W + K steps, exactly, + the one recorded step behind the timed region
     assert out["stub"]["env"]["WORLD_SIZE"] == "2" and out["stub"]["env"]["RANK"] == "0"
     assert out["stub"]["env"]["MASTER_ADDR"] == "127.0.0.1" and out["stub"]["dist_initialized"]
     # 3 steps of the SLOW rank (40 ms each): max over ranks, not rank 0's own 20 ms
     assert out["ms_per_step"] >= 39.0
+    # the line proves what the collective delivered: group size and backend from the process group itself, the images and
+    # detections the last gather landed on rank 0 (rank r contributes 4 images with r + 1 detections each), every rank's time
+    d = out["distributed"]
+    assert d["process_group_size"] == 2 and d["world_size_from_env"] == 2 and d["backend"] == "gloo"
+    assert d["gathered_images"] == 8 == d["expected_images"] and d["gathered_detections"] == 4 * 1 + 4 * 2
+    pr = d["per_rank_ms_per_step"]
+    # (the per-step gather makes the fast rank wait for the slow one: both clocks read ~40 ms)
+    assert pr["ranks"] == 2 and 19.0 <= pr["min"] <= pr["max"] and pr["max"] >= 39.0 and abs(pr["max"] - out["ms_per_step"]) < 1e-6
     assert abs(out["value"] - 8 * 3 / (out["ms_per_step"] * 3e-3)) < 1e-6 * out["value"]
 
 
 def test_single_gpu_runs_in_process():
     lines = _run(["--gpus", "1", "--steps", "2", "--warmup", "0"])
     out = json.loads(lines[0])
-    assert out["n_gpus"] == 1 and out["stub"]["calls_rank0"] == 2 and not out["stub"]["dist_initialized"]
+    assert out["n_gpus"] == 1 and out["stub"]["calls_rank0"] == 3 and not out["stub"]["dist_initialized"]     # W + K + the recorded step
+    assert out["distributed"]["process_group_size"] == 1 and out["distributed"]["backend"] is None and "gathered_images" not in out["distributed"]
     assert out["stub"]["env"]["WORLD_SIZE"] is None
 
 
@@ -97,7 +107,8 @@ def test_under_torch_distributed_run():
                            "--master-port", str(port)])
     assert len(lines) == 1
     out = json.loads(lines[0])
-    assert out["n_gpus"] == 2 and out["stub"]["calls_rank0"] == 3 and out["stub"]["env"]["MASTER_PORT"] == str(port)
+    assert out["n_gpus"] == 2 and out["stub"]["calls_rank0"] == 4 and out["stub"]["env"]["MASTER_PORT"] == str(port)
+    assert out["distributed"]["gathered_images"] == out["config"]["global_batch"]
 
 
 def test_world_size_mismatch_is_an_error_not_an_assert():

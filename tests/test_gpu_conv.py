@@ -984,3 +984,118 @@ def test_resident_patch_pair_launch_equals_two_launches(gnin):
         assert float(p_.t[:, 0].abs().max()) == 0 and float(p_.t[:, :, -1].abs().max()) == 0
     assert torch.equal(sa, psa) and torch.equal(sb, psb)
     assert float(sa.abs().sum()) > 0
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# conv_wr.hip: small-M layers (res5, FPN laterals / top outputs, P6 / P7) -- 128 px x 256 ch tiles, weights -> registers,
+# deterministic split-K.  Reference blocks: detectron2 BottleneckBlock / FPN [recalled], backbone/fpn.py:16-37,58-91.
+def _run_wr(x, w, b, k, stride, pad, flags=0, res=None, excl=True, reps=1):
+    """-> (conv_wr output NCHW float CPU, conv_igemm output of the same call, slices)"""
+    from dafne_amd import engine, _lib
+    d = dev()
+    L = _lib.load()
+    n, cin, h, wd = x.shape
+    cout = w.shape[0]
+    a = engine.Act.from_nchw(x.to(d))
+    wp, bp = engine.pack_conv(w, b, d)
+    ho, wo = engine.conv_out_hw(h, wd, k, stride, pad)
+    r = engine.Act.from_nchw(res.to(d)) if res is not None else None
+    o_ref = engine.Act(n, ho, wo, cout, d)
+    ref_call = engine.ConvCall(wp, bp, cin, cout, k, stride, pad, flags, [(a.t, o_ref.t, r.t if r is not None else None, h, wd, ho, wo)], n,
+                               shared_gpu=not excl)
+    ref_call(_lib.current_stream())
+    outs = []
+    ws = engine.WrWorkspace(d)
+    for _ in range(reps):
+        o = engine.Act(n, ho, wo, cout, d)
+        c = engine.ConvCall(wp, bp, cin, cout, k, stride, pad, flags, [(a.t, o.t, r.t if r is not None else None, h, wd, ho, wo)], n,
+                            shared_gpu=not excl)
+        assert L.dafne_conv2d_wr_ok(ctypes.byref(c.prm), c.segs) == 1
+        call = engine.WrCall(c, engine.pack_conv_frag(wp), ws)
+        outs.append((o, call))
+    for o, call in outs:
+        call(_lib.current_stream())
+    torch.cuda.synchronize()
+    for o, _ in outs:
+        assert float(o.t[:, 0].abs().max()) == 0 and float(o.t[:, -1].abs().max()) == 0
+        assert float(o.t[:, :, 0].abs().max()) == 0 and float(o.t[:, :, -1].abs().max()) == 0
+        assert torch.equal(o.t, outs[0][0].t)                           # the shared workspace leaves its tickets zero; run-to-run identical
+    return outs[0][0].nchw_float().cpu(), o_ref.nchw_float().cpu(), outs[0][1].splits
+
+
+WR_CASES = [
+    # cin, cout, k, stride, H, W, N, flags ("r" relu, "s" residual, "u" top-down add), exclusive
+    (512, 512, 3, 1, 32, 32, 2, "r", True),         # res5 conv2: 16 pixel tiles x 2 channel tiles -> 8 slices
+    (512, 512, 3, 1, 32, 32, 8, "r", True),         # ... at batch 8: 2 slices of 36 steps
+    (512, 2048, 1, 1, 32, 32, 8, "rs", True),       # res5 conv3: 512 tiles, one slice, residual
+    (2048, 512, 1, 1, 32, 32, 3, "r", False),       # res5 conv1 in a sub-batch plan
+    (1024, 2048, 1, 2, 64, 64, 2, "", True),        # res5 projection shortcut (stride 2)
+    (1024, 512, 1, 2, 64, 64, 2, "r", True),        # res5.0 conv1 (STRIDE_IN_1X1)
+    (2048, 256, 1, 1, 32, 32, 8, "", True),         # FPN lateral 5: 64 tiles -> 4 slices
+    (1024, 256, 1, 1, 64, 64, 3, "u", True),        # FPN lateral 4 + nearest-2x top-down add
+    (256, 256, 3, 1, 32, 32, 8, "", True),          # FPN output 5
+    (256, 256, 3, 2, 32, 32, 8, "", True),          # P6
+    (256, 256, 3, 2, 16, 16, 8, "", True),          # P7 (input = relu(P6)): 4 tiles x 8 slices
+    (256, 256, 3, 2, 16, 16, 1, "", False),         # ... one image: a single half-empty tile
+    (128, 256, 3, 1, 25, 38, 1, "r", True),         # ragged: 950 pixels (7.4 tiles), rows cross tile boundaries
+    (64, 256, 1, 1, 7, 9, 3, "rs", True),           # one K64 step, 189 pixels
+    (320, 768, 3, 2, 21, 27, 2, "u", False),        # odd input, 3 channel tiles, stride 2 + top-down add (output 11 x 14 is even in W only -> skipped below)
+]
+
+
+@pytest.mark.parametrize("cin,cout,k,stride,H,W,N,fl,excl", WR_CASES)
+def test_conv_wr_vs_igemm_and_torch(cin, cout, k, stride, H, W, N, fl, excl):
+    """dafne_conv2d_wr_hip vs torch (2 bf16 ulps, the conv tests' tolerance) and vs dafne_conv2d_nhwc_bf16_hip on the same
+    operands: BIT-IDENTICAL with one slice (same K order, same epilogue expressions); with several slices the fp32 sum is
+    grouped by slices -- a different rounding of the same sum, so the two kernels may differ by one bf16 ulp where the fp32
+    value sits at a rounding boundary (checked: <= 1 ulp everywhere, equal for > 99 %)."""
+    from dafne_amd import engine
+    pad = 1 if k == 3 else 0
+    ho, wo = engine.conv_out_hw(H, W, k, stride, pad)
+    if "u" in fl and (ho % 2 or wo % 2):
+        pytest.skip("top-down add needs an even map")
+    g = torch.Generator().manual_seed(cin + cout + H + W + N)
+    x = bfr(torch.randn(N, cin, H, W, generator=g))
+    w = bfr(torch.randn(cout, cin, k, k, generator=g) / (cin * k * k) ** 0.5)
+    b = torch.randn(cout, generator=g) * 0.1
+    flags = (engine.F_RELU if "r" in fl else 0) | (engine.F_RES if "s" in fl else 0) | (engine.F_UP if "u" in fl else 0)
+    res = None
+    ref = F.conv2d(x, w, b, stride=stride, padding=pad)
+    if "s" in fl:
+        res = bfr(torch.randn(N, cout, ho, wo, generator=g))
+        ref = ref + res
+    if "u" in fl:
+        res = bfr(torch.randn(N, cout, ho // 2, wo // 2, generator=g))
+        ref = ref + F.interpolate(res, scale_factor=2, mode="nearest")
+    if "r" in fl:
+        ref = F.relu(ref)
+    got, ig, splits = _run_wr(x, w, b, k, stride, pad, flags=flags, res=res, excl=excl, reps=3)
+    close_bf16(got, bfr(ref))
+    if splits == 1:
+        assert torch.equal(got, ig), float((got - ig).abs().max())
+    else:
+        d = (got - ig).abs()
+        ulp = 2.0 ** -7 * ig.abs().clamp_min(2.0 ** -10)        # one bf16 ulp is <= 2^-7 relative (absolute floor: outputs that
+        assert bool((d <= ulp).all()), float((d / ulp).max())    # cancel to ~0 or sit at the ReLU edge differ by the fp32 noise)
+        assert float((d == 0).float().mean()) > 0.99
+
+
+def test_conv_wr_slices_follow_the_shape():
+    """The slice count is a function of the shape, the EXCLUSIVE hint and the CU count: res5 conv2 at batch 8 -> 128 tiles x 2,
+    lateral5 -> 64 tiles x 4, P7 -> 4 tiles x 8 (at most 8 slabs for the reducer, at least 4 K64 steps per slice)."""
+    from dafne_amd import engine, _lib
+    L = _lib.load()
+    d = dev()
+
+    def splits(cin, cout, k, stride, H, N, excl=True):
+        pad = 1 if k == 3 else 0
+        ho, wo = engine.conv_out_hw(H, H, k, stride, pad)
+        a, o = engine.Act(N, H, H, cin, d), engine.Act(N, ho, wo, cout, d)
+        wp, bp = engine.pack_conv(torch.zeros(cout, cin, k, k), torch.zeros(cout), d)
+        c = engine.ConvCall(wp, bp, cin, cout, k, stride, pad, 0, [(a.t, o.t, None, H, H, ho, wo)], N, shared_gpu=not excl)
+        return L.dafne_conv2d_wr_splits(ctypes.byref(c.prm), c.segs)
+    assert splits(512, 512, 3, 1, 32, 8) == 2
+    assert splits(2048, 256, 1, 1, 32, 8) == 4
+    assert splits(256, 256, 3, 2, 16, 8) == 8
+    assert splits(512, 2048, 1, 1, 32, 8) == 1
+    assert splits(512, 512, 3, 1, 32, 3, excl=False) == 2        # sub-batch plan: half the chip

@@ -24,7 +24,8 @@ def q8(x, qscale=1.0):
 
 def run_fp8(xs, w, b, in_qscale, flags=0, gn_in=None, gn_stats=False, kernel=None):
     """xs: list of [N,C,H,W] float maps (levels sharing the weights).  Returns (outputs NCHW float on the CPU, partial, call).
-    kernel: the kernel the call must land on (default: conv3x3_rp8 for 256 input channels, conv3x3_patch_fp8 otherwise)."""
+    kernel: the kernel the call must land on: "conv3x3_rp8" (256 input channels only: the call gets the fragment-major weights,
+    as a model with ENGINE.FP8_CONV3X3_KERNEL "rp8" builds it) or conv3x3_patch_fp8 (default)."""
     from dafne_amd import engine, _lib
     d = dev()
     n, cin = xs[0].shape[:2]
@@ -37,13 +38,14 @@ def run_fp8(xs, w, b, in_qscale, flags=0, gn_in=None, gn_stats=False, kernel=Non
     oscale = (wscale / in_qscale).contiguous()
     if gn_in is not None:
         flags |= engine.F_GNIN
-    probe = engine.ConvCall(wq, bias, cin, cout, 3, 1, 1, flags, segs, n, gn_in=gn_in, fp8=(oscale, in_qscale))
+    frag8 = engine.pack_conv3x3_frag8(wq) if kernel == "conv3x3_rp8" else None
+    probe = engine.ConvCall(wq, bias, cin, cout, 3, 1, 1, flags, segs, n, gn_in=gn_in, fp8=(oscale, in_qscale), frag8=frag8)
     partial = None
     if gn_stats:
         partial = torch.zeros(4096, cout // 8, 2, dtype=torch.float32, device=d)
         probe = engine.ConvCall(wq, bias, cin, cout, 3, 1, 1, flags | engine.F_GN, segs, n, gn_partial=partial,
-                                gn_in=gn_in, fp8=(oscale, in_qscale))
-    assert probe.kernel_name() == (kernel or ("conv3x3_rp8" if cin == 256 else "conv3x3_patch_fp8"))
+                                gn_in=gn_in, fp8=(oscale, in_qscale), frag8=frag8)
+    assert probe.kernel_name() == (kernel or "conv3x3_patch_fp8")
     probe(_lib.current_stream())
     torch.cuda.synchronize()
     for o in outs:      # the halo must still be zero
@@ -66,9 +68,17 @@ def test_e4m3_weight_quantiser_is_exact_in_bf16():
 
 @pytest.fixture(params=["rp8", "patch_fp8"])
 def c256_kernel(request, monkeypatch):
-    """The fp8 layers with 256 input channels run on conv3x3_rp8 (default) or, with DAFNE_CONV_RP8=0, on conv3x3_patch_fp8."""
+    """The fp8 layers with 256 input channels run on conv3x3_patch_fp8 (ENGINE.FP8_CONV3X3_KERNEL "patch", the default) or on
+    conv3x3_rp8 ("rp8"); DAFNE_CONV_RP8=1 / 0 overrides the model's choice for the whole process."""
     monkeypatch.setenv("DAFNE_CONV_RP8", "1" if request.param == "rp8" else "0")
     return "conv3x3_" + request.param
+
+
+@pytest.fixture(params=["cfg_patch", "cfg_rp8"])
+def fp8_kernel_cfg(request, monkeypatch):
+    """The kernel choice as a model property (no environment override): cfg.ENGINE.FP8_CONV3X3_KERNEL."""
+    monkeypatch.delenv("DAFNE_CONV_RP8", raising=False)
+    return {"cfg_patch": "patch", "cfg_rp8": "rp8"}[request.param]
 
 
 @pytest.mark.parametrize("H,W,N,cout,relu,qs", [
@@ -187,7 +197,7 @@ def test_fp8w_rejects_unsupported_shapes():
 
 
 # ---------------------------------------------------------------------------------- config 5 model (fp8 weights)
-def _build(cfgname, seed):
+def _build(cfgname, seed, fp8_kernel=None):
     import os
     import dafne_amd.modeling  # noqa: F401
     from dafne_amd.config import load_cfg
@@ -195,6 +205,8 @@ def _build(cfgname, seed):
     from oracle import model as om
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     cfg = load_cfg(os.path.join(root, "configs", cfgname))
+    if fp8_kernel is not None:
+        cfg.ENGINE.FP8_CONV3X3_KERNEL = fp8_kernel
     m = build_model(cfg)
     P = om.make_params(cfg.MODEL.RESNETS.DEPTH, cfg.MODEL.DAFNE.NUM_CLASSES, seed=seed)
     m.load_state_dict(P)
@@ -247,7 +259,7 @@ def test_fp8_model_backbone_and_head_vs_oracle():
             assert e_b > e_q, (name, l, e_q, e_b)
 
 
-def test_fp8_model_uses_the_fp8_kernel_and_runs_end_to_end():
+def test_fp8_model_uses_the_fp8_kernel_and_runs_end_to_end(c256_kernel):
     """Config 5 end to end at a small size.  Without activation calibration the ten GroupNorm-fed tower layers go to
     the fp8 3x3 kernels; after calibrate_fp8 pinned the plain-input layers' scales so do the 23 + 3 res4 / res5 3x3 layers,
     the 3 FPN output convolutions and the 2 FPN-fed tower layers: 41.  Calibration is EXPLICIT by default: an fp8 model
@@ -265,7 +277,7 @@ def test_fp8_model_uses_the_fp8_kernel_and_runs_end_to_end():
     m([{"image": img, "height": h, "width": w}])
     assert m.fp8_act_scales() is None
     names = [c.kernel_name() for c in m.plan(1, h, w).calls if hasattr(c, "kernel_name")]
-    assert names.count("conv3x3_rp8") == 10, names            # layers 1..3 of three towers + corners_tower.0: 256 in, resident patch
+    assert names.count(c256_kernel) == 10, names              # layers 1..3 of three towers + corners_tower.0: 256 input channels
     cfg.ENGINE.FP8_ACT_CALIBRATION = "explicit"
     m.calibrate_fp8(img.unsqueeze(0).to(dev()))
     out = m([{"image": img, "height": h, "width": w}])[0]["instances"]
@@ -285,9 +297,12 @@ def test_fp8_model_uses_the_fp8_kernel_and_runs_end_to_end():
     assert len(scales) == 31 and all(v > 0 and np.log2(v) == np.round(np.log2(v)) for v in scales.values()), scales
     plan = m.plan(1, h, w)
     names = [c.kernel_name() for c in plan.calls if hasattr(c, "kernel_name")]
-    # 26 + 3 + 12, the same set of layers at every image size; the 256-input ones (res4, FPN outputs, towers) on the resident-patch
-    # kernel, the three 512-input res5 layers on the generic fp8 patch kernel
-    assert names.count("conv3x3_rp8") == 38 and names.count("conv3x3_patch_fp8") == 3, names
+    # 26 + 3 + 12, the same set of layers at every image size; the 38 256-input ones (res4, FPN outputs, towers) on the model's
+    # FP8_CONV3X3_KERNEL, the three 512-input res5 layers always on the generic fp8 patch kernel
+    if c256_kernel == "conv3x3_rp8":
+        assert names.count("conv3x3_rp8") == 38 and names.count("conv3x3_patch_fp8") == 3, names
+    else:
+        assert names.count("conv3x3_patch_fp8") == 41 and "conv3x3_rp8" not in names, names
     assert "amax_probe" not in names
     assert 0 < len(out) <= cfg.MODEL.DAFNE.POST_NMS_TOPK_TEST + 8
     s = out.scores.cpu().numpy()
@@ -295,12 +310,14 @@ def test_fp8_model_uses_the_fp8_kernel_and_runs_end_to_end():
     assert torch.isfinite(out.pred_corners).all() and int(out.pred_classes.max()) < 2
 
 
-def test_fp8_model_pipelined_equals_serial(c256_kernel):
+def test_fp8_model_pipelined_equals_serial(fp8_kernel_cfg):
     """The fp8 model through the pipelined path (sub-batches on concurrent streams, post-process on the side stream)
-    gives the detections of the serial path (same kernels on the same sub-batch composition: splits=1).  The kernel of the
-    256-input fp8 layers is pinned: left to the default, a plan that has the GPU to itself takes conv3x3_rp8 and the
-    pipelined step's sub-batch plans conv3x3_patch_fp8, two roundings of the same sums (2 bf16 ulps apart, the tests above)."""
-    cfg, m, P = _build("ucas_aod_r101_fp8.yaml", seed=13)
+    gives the detections of the serial path (same kernels on the same sub-batch composition: splits=1) -- with NO environment
+    pin: the kernel of the 256-input fp8 layers is a property of the model (cfg.ENGINE.FP8_CONV3X3_KERNEL, both values), so
+    the plan that has the GPU to itself and the pipelined step's sub-batch plans use the same one (round 3 chose per plan:
+    two roundings of the same sums, 2 bf16 ulps apart)."""
+    cfg, m, P = _build("ucas_aod_r101_fp8.yaml", seed=13, fp8_kernel=fp8_kernel_cfg)
+    want = {"patch": "conv3x3_patch_fp8", "rp8": "conv3x3_rp8"}[fp8_kernel_cfg]
     g = torch.Generator().manual_seed(6)
     batches = [torch.randint(0, 256, (3, 3, 128, 160), generator=g, dtype=torch.uint8).to(dev()) for _ in range(3)]
     m.calibrate_fp8(batches[0])
@@ -309,6 +326,10 @@ def test_fp8_model_pipelined_equals_serial(c256_kernel):
     serial = [(r.clone(), c.clone()) for r, c in serial]
     piped = [m.detect_packed(b, pipelined=True, splits=1) for b in batches]
     torch.cuda.synchronize()
+    other = {"conv3x3_patch_fp8": "conv3x3_rp8", "conv3x3_rp8": "conv3x3_patch_fp8"}[want]
+    for plan in [m.plan(3, 128, 160)] + [p for ps in m._pipe[(3, 128, 160, 1)]["plans"] for p in ps]:
+        names = [c.kernel_name() for c in plan.calls if hasattr(c, "kernel_name")]
+        assert names.count(want) >= 38 and (other not in names or want == "conv3x3_rp8"), (plan.shared_gpu, names)
     for (r0, c0), (r1, c1) in zip(serial, piped):
         assert torch.equal(c0, c1)
         for i in range(3):

@@ -228,14 +228,19 @@ def test_headline_workload_vs_oracle(headline, mode):
         json.dump(allrep, f, indent=1)
     print("HEADLINE_PARITY " + json.dumps({"regime": H["regime"], "mode": mode,
                                            "deviation": {i: rep["images"][i]["engine_vs_fp32_oracle"] for i in rep["images"]}}))
+    # the single worst matched detection is one sample of a heavy tail (round 3: engine 14-41 px, emulation 18-38 px, on
+    # different images), so it is bounded by the emulation's worst over ALL checked images, not image by image
+    emu_max = max(rep["images"][i]["bf16_emulation_vs_fp32_oracle"]["abs_corner_delta_px"]["max"] for i in rep["images"])
     for i in rep["images"]:
         e, b = rep["images"][i]["engine_vs_fp32_oracle"], rep["images"][i]["bf16_emulation_vs_fp32_oracle"]
         # the engine may not lose materially more detections to bf16 noise than the oracle's own bf16 emulation does (3
-        # points: a real regression costs more), and the matched detections must agree as well as the emulation's do
+        # points: a real regression costs more), and the matched detections must agree as well as the emulation's do:
+        # percentiles within 1.25 x the emulation's (round 3 measured 0.61-1.10 x), the maximum within 1.5 x its worst
         assert e["match_rate"] >= b["match_rate"] - 0.03 and e["match_rate"] >= 0.5, (i, e, b)
-        assert e["abs_score_delta"]["p99"] <= max(1.5 * b["abs_score_delta"]["p99"], 1e-3), (i, e, b)
-        assert e["abs_corner_delta_px"]["p50"] <= max(1.5 * b["abs_corner_delta_px"]["p50"], 1e-3), (i, e, b)
-        assert e["abs_corner_delta_px"]["p99"] <= max(1.5 * b["abs_corner_delta_px"]["p99"], 1e-3), (i, e, b)
+        assert e["abs_score_delta"]["p99"] <= max(1.25 * b["abs_score_delta"]["p99"], 1e-3), (i, e, b)
+        assert e["abs_corner_delta_px"]["p50"] <= max(1.25 * b["abs_corner_delta_px"]["p50"], 1e-3), (i, e, b)
+        assert e["abs_corner_delta_px"]["p99"] <= max(1.25 * b["abs_corner_delta_px"]["p99"], 1e-3), (i, e, b)
+        assert e["abs_corner_delta_px"]["max"] <= 1.5 * emu_max, (i, e, emu_max)
 
 
 # ------------------------------------------------------------------------------------------------------------------
@@ -269,6 +274,49 @@ def test_config1_r50_batch8_full_size_vs_oracle():
     _features_vs_oracle(feats(0), fe, f32, "r50")
     for i in range(BATCH):
         _check_postprocess_exact(_rows_to_dict(rows, counts, i), _oracle_detections(_levels_numpy(hp, i), cfg.MODEL.DAFNE), ("r50", i))
+
+
+def test_config0_hrsc_r50_800x1216_vs_oracle():
+    """configs[0]: HRSC2016 R50-FPN single-scale, ONE image at the released test size (MIN_SIZE_TEST 800 / MAX_SIZE_TEST
+    1333: an HRSC image lands at 800 x 1216 -- configs/pre-trained/hrsc_r50_ms.yaml:33,37), one class (:140), SORT_CORNERS
+    true (:154), THRESH_WITH_CTR false (:156), through the reference-shaped entry point model([{"image", "height",
+    "width"}]) (one_stage_detector.py:45-55).  The same two comparisons every other config has at its own size: the FPN
+    features of the image vs oracle/model.py (fp32 and bf16 emulation), and the final detections vs the oracle's decode /
+    top-k / corner sort / rotated NMS / cap / detector_postprocess on the engine's own head outputs (keys bit-exact, scores
+    1e-6, corners / boxes 1e-3).  25 x 38 res5 map: ragged tiles on every level, batch 1 (the exclusive-launch kernel
+    choices).  The class prior is raised as for the other raw-class-score configs (random weights give no candidates at
+    -4.595)."""
+    sys.path.insert(0, ROOT)
+    import bench
+    dev = torch.device("cuda", 0)
+    cfg, model, sd = bench.build_model(50, dev, seed=0, cfgname="hrsc_r50.yaml", cls_prior=-1.5)
+    d = cfg.MODEL.DAFNE
+    assert d.NUM_CLASSES == 1 and d.SORT_CORNERS and not d.THRESH_WITH_CTR and cfg.MODEL.RESNETS.DEPTH == 50
+    assert cfg.INPUT.MIN_SIZE_TEST == 800 and cfg.INPUT.MAX_SIZE_TEST == 1333
+    h, w = 800, 1216
+    g = torch.Generator().manual_seed(3)
+    img = torch.randint(0, 256, (3, h, w), generator=g, dtype=torch.uint8)
+    P = {k: v.float() for k, v in sd.items()}
+    with torch.no_grad():
+        x, _ = om.preprocess([img], cfg.MODEL.PIXEL_MEAN, cfg.MODEL.PIXEL_STD)
+        assert tuple(x.shape[2:]) == (h, w)
+        f32 = om.backbone_forward(P, x, 50)
+        fe = om.backbone_forward(P, x, 50, emulate_bf16=True)
+    out = model([{"image": img, "height": h, "width": w}])[0]["instances"]
+    torch.cuda.synchronize()
+    plan = model.plan(1, h, w)
+    _features_vs_oracle([a.nchw_float()[0:1] for a in plan.features], fe, f32, "hrsc_r50")
+    det = opp.predict_proposals(_levels_numpy(plan.head, 0), d.FPN_STRIDES, thresh=d.INFERENCE_TH_TEST, topk=d.PRE_NMS_TOPK_TEST,
+                                nms_thresh=d.NMS_TH, post_topk=d.POST_NMS_TOPK_TEST, thresh_with_ctr=d.THRESH_WITH_CTR,
+                                sort_corners=d.SORT_CORNERS, fast=True)
+    exp = opp.detector_postprocess(det, (h, w), (h, w), (h, w))
+    got = {"pred_corners": out.pred_corners.cpu().numpy(), "scores": out.scores.cpu().numpy(),
+           "centerness": out.centerness.cpu().numpy(), "pred_classes": out.pred_classes.cpu().numpy().astype(np.int64),
+           "fpn_levels": out.fpn_levels.cpu().numpy().astype(np.int64), "pred_boxes": out.pred_boxes.tensor.cpu().numpy(),
+           "locations": out.locations.cpu().numpy()}
+    assert got["scores"].shape[0] > 100, got["scores"].shape
+    assert out.image_size == (h, w)
+    _check_postprocess_exact(got, exp, "hrsc_r50")
 
 
 @pytest.mark.parametrize("size", [450, 1200])

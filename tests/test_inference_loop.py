@@ -1,0 +1,228 @@
+"""The streamed evaluation loop (dafne_amd/evaluation/inference.py): the counterpart of detectron2's
+inference_on_dataset(model, data_loader, evaluator) as tools/plain_train_net.py:316-336 calls it, with the reference's
+DafneEvaluator protocol (dafne/evaluation/dafne_evaluator.py:39-69).  CPU tests with a stub detector (the loop's order /
+drain logic, the evaluator's 2-rank gather over gloo); the GPU tests compare the streamed results with forward()'s."""
+import os
+import socket
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _inst(g, k):
+    from dafne_amd.structures import Boxes, Instances
+    inst = Instances((64, 64))
+    inst.pred_corners = torch.full((k, 8), float(g))
+    inst.scores = torch.arange(k, 0, -1).float() / 10
+    inst.centerness = torch.ones(k)
+    inst.pred_classes = torch.full((k,), g, dtype=torch.int64)
+    inst.pred_boxes = Boxes(torch.zeros(k, 4))
+    return inst
+
+
+class _StubStreamed:
+    """forward_streamed / flush with the engine's contract: call i returns the outputs of call i - 1."""
+
+    def __init__(self):
+        self.pending = None
+        self.calls = []
+        self.training = False
+
+    def eval(self):
+        return self
+
+    def _run(self, inputs):
+        return [{"instances": _inst(x["image_id"], x["image_id"] % 5 + 1)} for x in inputs]
+
+    def __call__(self, inputs):
+        self.calls.append(("sync", [x["image_id"] for x in inputs]))
+        return self._run(inputs)
+
+    def forward_streamed(self, inputs):
+        self.calls.append(("stream", [x["image_id"] for x in inputs]))
+        prev, self.pending = self.pending, self._run(inputs)
+        return prev
+
+    def flush(self):
+        prev, self.pending = self.pending, None
+        return prev
+
+
+class _Recorder:
+    def __init__(self):
+        self.pairs = []
+
+    def reset(self):
+        self.pairs = []
+
+    def process(self, inputs, outputs):
+        assert len(inputs) == len(outputs)
+        self.pairs.extend((x["image_id"], int(o["instances"].pred_classes[0]), len(o["instances"])) for x, o in zip(inputs, outputs))
+
+    def evaluate(self):
+        return {"n": len(self.pairs)}
+
+
+def _loader(n, b, lo=0):
+    items = [{"image_id": lo + i, "file_name": "f%d" % (lo + i), "height": 64, "width": 64} for i in range(n)]
+    return [items[i:i + b] for i in range(0, n, b)]
+
+
+@pytest.mark.parametrize("n,b", [(7, 3), (1, 4), (8, 8), (0, 2)])
+def test_streamed_loop_pairs_inputs_with_their_outputs(n, b):
+    from dafne_amd.evaluation.inference import inference_on_dataset
+    m, ev, stats = _StubStreamed(), _Recorder(), {}
+    res = inference_on_dataset(m, _loader(n, b), ev, stats)
+    assert res == {"n": n} and stats["images"] == n
+    assert ev.pairs == [(g, g, g % 5 + 1) for g in range(n)]            # every image once, in order, with ITS outputs
+    assert all(c[0] == "stream" for c in m.calls) and m.pending is None   # drained
+
+    class Sync:                                                            # a model without the streamed form (the TTA wrapper)
+        def __call__(self, inputs):
+            return m._run(inputs)
+    ev2 = _Recorder()
+    inference_on_dataset(Sync(), _loader(n, b), ev2)
+    assert ev2.pairs == ev.pairs
+    outs = inference_on_dataset(m, _loader(n, b))                          # no evaluator: the outputs themselves
+    assert [int(o["instances"].pred_classes[0]) for o in outs] == list(range(n))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _eval_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from dafne_amd.evaluation.gather import shard_range
+    from dafne_amd.evaluation.inference import DafneEvaluator, inference_on_dataset
+    ok = True
+    for n_total, b in ((7, 3), (1, 2), (6, 2)):              # ragged shards, an EMPTY shard on rank 1, even shards
+        lo, hi = shard_range(n_total, rank, world)
+        ev = DafneEvaluator("stub", None, distributed=True, k_cap=16, device=torch.device("cpu"), pad_to=(n_total + world - 1) // world)
+        res = inference_on_dataset(_StubStreamed(), _loader(hi - lo, b, lo), ev)
+        if rank == 0:
+            preds = sorted(res["predictions"], key=lambda p: p["image_id"])
+            ok = ok and [p["image_id"] for p in preds] == list(range(n_total))
+            ok = ok and all(p["labels"].tolist() == [g] * (g % 5 + 1) and float(p["corners"][0, 0]) == g for g, p in enumerate(preds))
+        else:
+            ok = ok and res == {}
+    q.put((rank, ok))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_dafne_evaluator_gathers_two_ranks_over_gloo():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_eval_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(2)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(r[1] for r in res), res
+
+
+def test_single_process_evaluator_keeps_the_reference_fields():
+    from dafne_amd.evaluation.inference import DafneEvaluator, inference_on_dataset
+    ev = DafneEvaluator("stub", None, distributed=False)
+    res = inference_on_dataset(_StubStreamed(), _loader(5, 2), ev)
+    assert res["num_images"] == 5
+    for g, p in enumerate(res["predictions"]):
+        assert set(p) == {"image_id", "file_name", "height", "width", "labels", "scores", "corners", "centerness"}   # dafne_evaluator.py:46-57
+        assert p["image_id"] == g and p["file_name"] == "f%d" % g and p["labels"].tolist() == [g] * (g % 5 + 1)
+
+
+# ------------------------------------------------------------------------------------------------------------------ GPU
+def _gpu_model(cfgname="dota-1.0_r50.yaml", splits=None, seed=11):
+    import dafne_amd.modeling  # noqa: F401
+    from dafne_amd.config import load_cfg
+    from dafne_amd.registry import build_model
+    from oracle import model as om
+    cfg = load_cfg(os.path.join(ROOT, "configs", cfgname))
+    if splits is not None:
+        cfg.ENGINE.PIPELINE_SPLITS = splits
+    m = build_model(cfg)
+    m.load_state_dict(om.make_params(cfg.MODEL.RESNETS.DEPTH, cfg.MODEL.DAFNE.NUM_CLASSES, seed=seed))
+    m.to(torch.device("cuda", 0))
+    m.invalidate()
+    return cfg, m
+
+
+def _same(a, b):
+    ia, ib = a["instances"], b["instances"]
+    return (len(ia) == len(ib) and ia.image_size == ib.image_size and torch.equal(ia.pred_corners, ib.pred_corners)
+            and torch.equal(ia.scores, ib.scores) and torch.equal(ia.pred_classes, ib.pred_classes)
+            and torch.equal(ia.pred_boxes.tensor, ib.pred_boxes.tensor))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("where", ["host", "device"])
+def test_streamed_loop_equals_forward_per_image(where):
+    """inference_on_dataset over 7 images of three sizes, one image per batch (detectron2's test loader) and in batches of
+    2 with ONE sub-batch stream: every image's streamed result EQUALS model([input]) / model(batch) -- same kernels on the
+    same batch composition; only the enqueue order and the streams differ.  Host images go through the pinned staging."""
+    from dafne_amd.evaluation.inference import inference_on_dataset
+    cfg, m = _gpu_model(splits=1)
+    g = torch.Generator().manual_seed(4)
+    sizes = [(128, 160), (128, 160), (96, 224), (128, 160), (160, 128), (96, 224), (128, 160)]
+    items = []
+    for i, (h, w) in enumerate(sizes):
+        img = torch.randint(0, 256, (3, h, w), generator=g, dtype=torch.uint8)
+        items.append({"image": img.cuda() if where == "device" else img, "height": h + 7, "width": w + 3, "image_id": i})
+    for b in (1, 2):
+        loader = [items[i:i + b] for i in range(0, len(items), b)]
+        expected = [o for batch in loader for o in m(batch)]
+        torch.cuda.synchronize()
+        stats = {}
+        got = inference_on_dataset(m, loader, None, stats)
+        assert len(got) == len(items) and stats["images"] == len(items)
+        assert all(len(o["instances"]) > 0 for o in got)
+        for i, (a, e) in enumerate(zip(got, expected)):
+            assert _same(a, e), (b, i, len(a["instances"]), len(e["instances"]))
+        assert m.flush() is None
+
+
+@pytest.mark.gpu
+def test_streamed_loop_on_the_benchmarked_layout():
+    """The default layout (ENGINE.PIPELINE_SPLITS 3: bench.py's): batches of 8 through forward_streamed give exactly what
+    detect_packed(pipelined=True, splits=3) gives for the same batch (the call bench.py times), in order, and -- sub-batch
+    composition 2 / 3 / 3 instead of one batch of 8 -- the same detections as forward() up to the bf16 noise floor (most
+    detection keys equal)."""
+    from dafne_amd import postprocess as pp
+    from dafne_amd.evaluation.inference import inference_on_dataset
+    cfg, m = _gpu_model()
+    assert cfg.ENGINE.PIPELINE_SPLITS == 3
+    g = torch.Generator().manual_seed(9)
+    items = [{"image": torch.randint(0, 256, (3, 128, 160), generator=g, dtype=torch.uint8), "height": 128, "width": 160, "image_id": i}
+             for i in range(24)]
+    loader = [items[i:i + 8] for i in range(0, 24, 8)]
+    got = inference_on_dataset(m, loader)
+    assert len(got) == 24
+    for k, batch in enumerate(loader):
+        bd = torch.stack([x["image"] for x in batch]).cuda()
+        rows, counts = m.detect_packed(bd, pipelined=True, splits=3)
+        torch.cuda.synchronize()
+        direct = pp.rows_to_instances(rows, counts, [(128, 160)] * 8)
+        for i in range(8):
+            assert _same(got[8 * k + i], {"instances": direct[i]}), (k, i)
+        sync = m(batch)
+        for i in range(8):
+            a, e = got[8 * k + i]["instances"], sync[i]["instances"]
+            ka = set(zip(a.fpn_levels.tolist(), a.locations[:, 0].tolist(), a.locations[:, 1].tolist(), a.pred_classes.tolist()))
+            ke = set(zip(e.fpn_levels.tolist(), e.locations[:, 0].tolist(), e.locations[:, 1].tolist(), e.pred_classes.tolist()))
+            assert len(ka & ke) >= 0.8 * len(ke), (k, i, len(ka & ke), len(ke))

@@ -41,6 +41,10 @@ def parse_args(argv=None):
     ap.add_argument("--tta-shard-views", action="store_true",
                     help="with --tta on several GPUs: shard the VIEWS of every image over the ranks (merge NMS on rank 0) instead "
                          "of sharding the images -- the latency form: one image's 27 views take 1/N of the time")
+    ap.add_argument("--images-on", choices=["host", "device"], default="host",
+                    help="where the synthetic tiles live when the loop starts: host (pageable CPU tensors, as a data loader yields them; "
+                         "uploaded through pinned staging under the previous batch) or device (resident in HBM, as bench.py times)")
+    ap.add_argument("--serial", action="store_true", help="synchronous model(inputs) per batch instead of the streamed loop")
     ap.add_argument("--output", default="")
     ap.add_argument("--task1-dir", default="", help="DOTA configs: write Task1_<class>.txt files here and merge the tiles "
                                                     "(Task1_merged/) with the device NMS (dota_evaluation.py:110-184)")
@@ -100,15 +104,12 @@ def run(args, rank=0, world=1, local_rank=0):
         if cal:
             model.calibrate_fp8(torch.stack([x["image"] for x in cal]).to(dev))
 
-    def detect_batch(b0, b1):
+    def detect_batch(b0, b1):                # TTA: one merged Instances per image -> packed rows for the gather
         chunk = mine[b0 - lo:b1 - lo]
-        if tta is not None:                  # one merged Instances per image -> packed rows for the gather
-            insts = [o["instances"] for o in tta(chunk)]
-            return instances_to_rows(insts, k_cap, dev)
-        batch = torch.stack([x["image"] for x in chunk]).to(dev)
-        rows, counts = model.detect_packed(batch, out_hw=[(x["height"], x["width"]) for x in chunk])
-        return rows, counts
+        insts = [o["instances"] for o in tta(chunk)]
+        return instances_to_rows(insts, k_cap, dev)
 
+    meta = synthetic_inputs(n, h, w, args.seed, pixels=False)
     if tta is not None and args.tta_shard_views:
         # SURVEY 8(e), configs[3]: every rank sees every image and runs ITS share of the image's views; one gather per image
         # lands the per-view detections on rank 0, which inverts, concatenates and runs the merged NMS (tta.py:173-197,264-268)
@@ -118,17 +119,52 @@ def run(args, rank=0, world=1, local_rank=0):
         if rank != 0:
             return None
         out = instances_to_rows([o["instances"] for o in merged], k_cap, dev)
-    else:
+    elif tta is not None:
         out = inference_on_images(detect_batch, n, k_cap, batch_size=args.batch, rank=rank, world=world, device=dev)
         torch.cuda.synchronize()
         if rank != 0:
             return None
-    rows_all, counts_all = out
-    meta = synthetic_inputs(n, h, w, args.seed, pixels=False)
-    preds = to_predictions(rows_all, counts_all, image_ids=[m["image_id"] for m in meta])
-    for p, m in zip(preds, meta):
-        p.update(file_name=m["file_name"], height=m["height"], width=m["width"])
-        print("image %d: %d detections, best score %.4f" % (m["image_id"], len(p["scores"]),
+    else:
+        # the reference's loop: inference_on_dataset(model, data_loader, evaluator) (plain_train_net.py:316-336), streamed --
+        # batch i runs on the benchmarked layout while batch i - 1's outputs go to the evaluator
+        from dafne_amd.evaluation.inference import DafneEvaluator, inference_on_dataset
+        if args.images_on == "device":
+            for x in mine:
+                x["image"] = x["image"].to(dev)
+            torch.cuda.synchronize()
+        b = max(args.batch, 1)
+        loader = [mine[i:i + b] for i in range(0, len(mine), b)]
+        ev = DafneEvaluator("synthetic", cfg, distributed=world > 1, k_cap=k_cap, device=dev, pad_to=(n + world - 1) // world)
+        stats = {}
+        if args.serial:
+            class _Sync:                      # the synchronous form: model(inputs) per batch
+                def __init__(self, m):
+                    self.m = m
+
+                def __call__(self, inputs):
+                    return self.m(inputs)
+            res = inference_on_dataset(_Sync(model), loader, ev, stats)
+        else:
+            res = inference_on_dataset(model, loader, ev, stats)
+        print("rank %d: inference_on_dataset %d images in %.3f s = %.1f images/s (batch %d, %s, images on the %s)"
+              % (rank, stats["images"], stats["seconds"], stats["images_per_sec"], b,
+                 "synchronous" if args.serial else "streamed, %d sub-batch streams" % cfg.ENGINE.PIPELINE_SPLITS, args.images_on), flush=True)
+        if rank != 0:
+            return None
+        preds = res["predictions"]
+        by_id = {m["image_id"]: m for m in meta}
+        for p in preds:
+            m = by_id[p["image_id"]]
+            p.update(file_name=m["file_name"], height=m["height"], width=m["width"])
+        preds.sort(key=lambda p: p["image_id"])
+        out = None
+    if out is not None:
+        rows_all, counts_all = out
+        preds = to_predictions(rows_all, counts_all, image_ids=[m["image_id"] for m in meta])
+        for p, m in zip(preds, meta):
+            p.update(file_name=m["file_name"], height=m["height"], width=m["width"])
+    for p in preds:
+        print("image %d: %d detections, best score %.4f" % (p["image_id"], len(p["scores"]),
                                                              float(p["scores"].max()) if len(p["scores"]) else 0.0))
     if args.output:
         torch.save(preds, args.output)
