@@ -373,13 +373,13 @@ int wr_build(WrDev& D, const dafne_conv_params* prm, const dafne_conv_seg* segs,
     D.ctiles = D.Cout / kCT;
     D.flags = prm->flags;
     if ((long long)D.ptiles * D.ctiles > kCounterBytes / 4) { *why = "too many tiles"; return 0; }
-    // slices: fill the chip (a launch that shares the GPU with the other sub-batch streams: half of it), at least 4 K64 steps
-    // per slice, at most 8 slabs for the reducer.  A function of the shape, the hint and the CU count only.
+    // slices: fill the chip, at least 4 K64 steps per slice, at most 8 slabs for the reducer.  A function of the shape and the
+    // CU count ONLY (not of the EXCLUSIVE hint): the slice count enters the fp32 grouping of the sum, and a batch must give the
+    // same bits whether its plan has the GPU to itself or shares it with other streams.
     int cus = 0;
     if (dafne::device_cus(&cus)) cus = 256;
-    const int target = (prm->flags & DAFNE_CONV_EXCLUSIVE) ? cus : cus / 2;
     const int tiles = D.ptiles * D.ctiles;
-    int s = target / tiles;
+    int s = cus / tiles;
     if (s > D.nsteps / 4) s = D.nsteps / 4;
     if (s > 8) s = 8;
     if (s < 1) s = 1;

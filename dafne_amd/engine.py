@@ -278,6 +278,29 @@ def pack_b2b_narrow(w3, w1, wsc=None):
     return torch.cat(parts).contiguous()
 
 
+def pack_blk_narrow(w2, w3, w1=None, wsc=None):
+    """Weights of dafne_bottleneck_block_narrow_hip (a whole res2 block) from the packed weights of conv2 ([64, 576] bf16, K
+    order kh, kw, channel), conv3 ([256, 64]), optionally the next block's conv1 ([64, 256]) and the projection shortcut
+    ([256, 64]): conv2 [2 channel halves][36 k16 steps][64 lanes][8] | conv3 [2 halves of 128][4 quarters][4 steps][64][8] |
+    conv1' [2 halves][16 steps][64][8] | projection in conv3's layout; absent matrices are zeros (fixed section offsets)."""
+    assert tuple(w2.shape) == (64, 576) and tuple(w3.shape) == (256, 64) and w2.dtype == BF16 and w3.dtype == BF16
+    a2 = w2.reshape(2, 32, 36, 2, 8).permute(0, 2, 3, 1, 4).reshape(-1)                    # ct, j, hl, r, e
+
+    def quarters(w):                                                                       # [256, 64] -> h, cq, s, hl, r, e
+        return w.reshape(2, 4, 32, 4, 2, 8).permute(0, 1, 3, 4, 2, 5).reshape(-1)
+    if w1 is not None:
+        assert tuple(w1.shape) == (64, 256) and w1.dtype == BF16
+        a1 = w1.reshape(2, 32, 16, 2, 8).permute(0, 2, 3, 1, 4).reshape(-1)                # ct, step, hl, r, e
+    else:
+        a1 = torch.zeros(2 * 16 * 64 * 8, dtype=BF16, device=w2.device)
+    if wsc is not None:
+        assert tuple(wsc.shape) == (256, 64) and wsc.dtype == BF16
+        asc = quarters(wsc)
+    else:
+        asc = torch.zeros(256 * 64, dtype=BF16, device=w2.device)
+    return torch.cat([a2, quarters(w3), a1, asc]).contiguous()
+
+
 def pack_b2b_mid(w3, w1):
     """Weights of dafne_bottleneck_tail_head_mid_hip (res3) from the packed 1x1 weights of conv3 ([512, 128] bf16) and the next
     block's conv1 ([128, 512] bf16): bf16 [16 quarter blocks][4 channel quarters][4 k16 steps][64 lanes][8], in the order the
@@ -617,6 +640,8 @@ class DensePlan:
         fuse_mid = fuse_b2b and os.environ.get("DAFNE_FUSE_B2B_MID", "1") != "0"
         fuse_bneck = fuse_b2b and os.environ.get("DAFNE_FUSE_BNECK", "1") != "0"
         bneck_scratch = None
+        blk_scratch = None
+        fuse_blk_narrow = fuse_narrow and os.environ.get("DAFNE_FUSE_BLK_NARROW", "1") != "0"
         for si, nb in enumerate(STAGE_BLOCKS[depth]):
             y1_next = None
             for b in range(nb):
@@ -627,6 +652,7 @@ class DensePlan:
                 # res2.0: the projection shortcut is computed inside the fused tail (conv_b2b_narrow.hip, PROJ)
                 proj_fused = (fuse_narrow and b == 0 and stride == 1 and nb > 1 and tuple(w3.shape) == (256, 64)
                               and tuple(P[p + "shortcut"][0].shape) == (256, 64) and tuple(P[nxt][0].shape) == (64, 256))
+                # (the whole-block kernel below takes block 0 under the same conditions: its projection is fused as well)
                 if b == 0:
                     sc = None if proj_fused else conv(p + "shortcut", x, 1, stride, 0, 0)
                 else:
@@ -663,6 +689,38 @@ class DensePlan:
                     pool.put(y1)
                     if b == 0 and sc is not None:
                         pool.put(sc)
+                    if not any(x is f for k, f in feats.items() if k != "res2"):
+                        pool.put(x)
+                    x = y3
+                    continue
+                if (fuse_blk_narrow and tuple(w2.shape) == (64, 576) and tuple(w3.shape) == (256, 64) and y1.c == 64 and stride == 1
+                        and (b > 0 or proj_fused) and (b + 1 >= nb or tuple(P[nxt][0].shape) == (64, 256))):
+                    # res2: the whole block -- conv2 (3x3) + conv3 + shortcut (identity / projection) + ReLU, and the next
+                    # block's conv1 + ReLU when there is one -- in ONE kernel (conv_blk_narrow.hip): the 64-channel map between
+                    # the 3x3 and the tail is never written or read
+                    head = b + 1 < nb
+                    proj = b == 0
+                    w1, b1 = P[nxt] if head else (None, None)
+                    wsc, bsc = P[p + "shortcut"] if proj else (None, None)
+                    key = p + "blk"
+                    if key not in P:
+                        P[key] = pack_blk_narrow(w2, w3, w1, wsc)
+                    if blk_scratch is None:
+                        blk_scratch = torch.empty(L.dafne_bottleneck_block_narrow_scratch_bytes(), dtype=torch.uint8, device=device)
+                    src = x if proj else sc               # projection: the block input; identity: the previous block's output
+                    y3 = pool.get(n, y1.h, y1.w, 256)
+                    y1_next = pool.get(n, y1.h, y1.w, 64) if head else None
+                    px = n * y1.h * y1.w
+                    fl = 2 * px * (64 * 576 + 64 * 256 + (256 * 64 if head else 0) + (64 * 256 if proj else 0))
+                    nb_ = px * (64 + (64 if proj else 256) + 256 + (64 if head else 0)) * 2 + P[key].numel() * 2
+                    self.calls.append(FnCall(L.dafne_bottleneck_block_narrow_hip,
+                                             (_lib.ptr(y1.t), _lib.ptr(src.t), _lib.ptr(P[key]), _lib.ptr(b2), _lib.ptr(b3), _lib.ptr(bsc),
+                                              _lib.ptr(b1), n, y1.h, y1.w, _lib.ptr(y3.t), _lib.ptr(y1_next.t) if head else None,
+                                              _lib.ptr(blk_scratch), blk_scratch.numel()),
+                                             (y1, src, P[key], b2, b3, bsc, b1, y3, y1_next, blk_scratch),
+                                             "conv_blk_narrow" + ("_proj" if proj else "") + ("" if head else "_last"), flops=fl, nbytes=nb_))
+                    self.flops += fl
+                    pool.put(y1)
                     if not any(x is f for k, f in feats.items() if k != "res2"):
                         pool.put(x)
                     x = y3

@@ -282,7 +282,7 @@ int dafne_conv3x3_c256_hip(const dafne_conv_params* prm, const dafne_conv_seg* s
  * registers, pixel operand staged by DMA, and a DETERMINISTIC split-K: dafne_conv2d_wr_splits() workgroups share a tile,
  * each writes its fp32 partial (128 KB) to d_workspace, the last arriver sums them in slice order and runs the epilogue.
  * Same parameter block and result definition as dafne_conv2d_nhwc_bf16_hip for one segment with flags RELU / RESIDUAL /
- * UPSAMPLE_ADD (EXCLUSIVE is the scheduling hint: it enters the slice count); 1x1 pad 0 or 3x3 pad 1, stride 1 / 2,
+ * UPSAMPLE_ADD (EXCLUSIVE is accepted and ignored: the slice count depends on the shape and the CU count only); 1x1 pad 0 or 3x3 pad 1, stride 1 / 2,
  * Cin % 64 == 0, Cout % 256 == 0, bias required; else DAFNE_E_UNSUPPORTED (dafne_conv2d_wr_ok: 1 / 0).  One slice: K order
  * and epilogue expressions are dafne_conv2d_nhwc_bf16_hip's -> bit-identical output.  Several slices: the fp32 sum is
  * grouped by slices (fp32 rounding apart from the unsplit sum; run-to-run identical).  prm->d_weight is ignored;
@@ -430,6 +430,25 @@ int dafne_bottleneck_tail_head_mid_hip(const void* d_in, const void* d_res, cons
 int dafne_bottleneck_proj_tail_head_narrow_hip(const void* d_in, const void* d_x0, const void* d_wfrag, const float* d_bias3,
                                                const float* d_bias_sc, const float* d_bias1, int n_images, int H, int W,
                                                void* d_out, void* d_next, void* stream);
+/*
+ * A WHOLE res2 bottleneck body, optionally with the head of the next block, in one kernel (same reference block;
+ * conv_blk_narrow.hip):  T = relu(conv2(d_in) + bias2)  (3x3, 64 -> 64, pad 1; d_in = the block's conv1 output),
+ * d_out = relu(conv3(T) + bias3 + X)  (1x1, 64 -> 256) and, when d_next is given, d_next = relu(conv1'(d_out) + bias1)
+ * (1x1, 256 -> 64).  X = d_res [N,H+2,W+2,256] (identity shortcut) or, when d_bias_sc is given (block 0), the projection
+ * shortcut conv_sc(d_res) + bias_sc of the block's 64-channel input d_res [N,H+2,W+2,64], rounded to bf16 as the separate
+ * launch stores it.  T never reaches HBM (per block at batch 8: 67 MB written + read).  d_wfrag (engine.pack_blk_narrow):
+ * conv2 fragment-major [2 channel halves][36 k16 steps][64 lanes][8] (rows half*32 + (lane & 31), K columns 16*step +
+ * 8*(lane >> 5) .. +8 of dafne_conv2d_nhwc_bf16_hip's packed weight: kh, kw, channel), conv3 [2 halves of 128][4 quarters]
+ * [4 steps][64][8], conv1' [2 halves][16 steps][64][8] (zeros without d_next), the projection in conv3's layout (zeros
+ * without d_bias_sc).  4 x 32 pixel tiles, any H, W: rows of out-of-image tile pixels are written to d_scratch
+ * (>= dafne_bottleneck_block_narrow_scratch_bytes(); holds nothing afterwards).  Bit-identical to
+ * dafne_conv2d_nhwc_bf16_hip(conv2, RELU) followed by dafne_bottleneck_[proj_]tail_head_narrow_hip (or by
+ * dafne_conv2d_nhwc_bf16_hip(conv3, RELU|RESIDUAL) without d_next).
+ */
+size_t dafne_bottleneck_block_narrow_scratch_bytes(void);
+int dafne_bottleneck_block_narrow_hip(const void* d_in, const void* d_res, const void* d_wfrag, const float* d_bias2,
+                                      const float* d_bias3, const float* d_bias_sc, const float* d_bias1, int n_images, int H, int W,
+                                      void* d_out, void* d_next, void* d_scratch, size_t scratch_bytes, void* stream);
 /*
  * detectron2 BasicStem in one kernel [recalled; the backbone of backbone/fpn.py:58-91]: conv 7x7 / s2 / p3
  * (FrozenBN folded into d_weight / d_bias) + ReLU + max-pool 3x3 / s2 / p1.  d_in: the layout

@@ -1081,8 +1081,9 @@ def test_conv_wr_vs_igemm_and_torch(cin, cout, k, stride, H, W, N, fl, excl):
 
 
 def test_conv_wr_slices_follow_the_shape():
-    """The slice count is a function of the shape, the EXCLUSIVE hint and the CU count: res5 conv2 at batch 8 -> 128 tiles x 2,
-    lateral5 -> 64 tiles x 4, P7 -> 4 tiles x 8 (at most 8 slabs for the reducer, at least 4 K64 steps per slice)."""
+    """The slice count is a function of the shape and the CU count only (NOT of the EXCLUSIVE hint: a batch gives the same
+    bits alone on the GPU and beside other streams): res5 conv2 at batch 8 -> 128 tiles x 2, lateral5 -> 64 tiles x 4, P7 -> 4
+    tiles x 8 (at most 8 slabs for the reducer, at least 4 K64 steps per slice)."""
     from dafne_amd import engine, _lib
     L = _lib.load()
     d = dev()
@@ -1098,4 +1099,71 @@ def test_conv_wr_slices_follow_the_shape():
     assert splits(2048, 256, 1, 1, 32, 8) == 4
     assert splits(256, 256, 3, 2, 16, 8) == 8
     assert splits(512, 2048, 1, 1, 32, 8) == 1
-    assert splits(512, 512, 3, 1, 32, 3, excl=False) == 2        # sub-batch plan: half the chip
+    assert splits(512, 512, 3, 1, 32, 3, excl=False) == splits(512, 512, 3, 1, 32, 3, excl=True) == 5
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# conv_blk_narrow.hip: a WHOLE res2 bottleneck body (3x3 + conv3 + shortcut + ReLU [+ next conv1 + ReLU]) in one kernel
+@pytest.mark.parametrize("proj", [False, True])
+@pytest.mark.parametrize("head", [True, False])
+@pytest.mark.parametrize("N,H,W", [(1, 8, 32), (2, 64, 64), (3, 13, 21), (1, 1, 1), (1, 40, 410), (2, 256, 256), (5, 72, 104)])
+def test_bottleneck_block_narrow_equals_the_separate_launches(N, H, W, head, proj):
+    """dafne_bottleneck_block_narrow_hip (res2: conv2 3x3 64 -> 64 + ReLU, conv3 64 -> 256 + shortcut + ReLU, optionally the
+    next block's conv1 256 -> 64 + ReLU; shortcut = identity rows or the projection of the block input, rounded to bf16 like
+    the separate launch) against the generic launches: BIT FOR BIT on both outputs -- ragged tiles in both directions
+    (out-of-image rows go to the dump area), 1 .. 16 tiles per workgroup (4096 tiles at 2 x 256 x 256), halo untouched,
+    launched twice -- and against torch within bf16 rounding."""
+    from dafne_amd import engine, _lib
+    L = _lib.load()
+    d = dev()
+    g = torch.Generator().manual_seed(7000 + H * W + 2 * head + proj)
+    u = bfr(torch.relu(torch.randn(N, 64, H, W, generator=g)))
+    w2 = bfr(torch.randn(64, 64, 3, 3, generator=g) / 24.0)
+    b2 = torch.randn(64, generator=g) * 0.2
+    w3 = bfr(torch.randn(256, 64, 1, 1, generator=g) / 8.0)
+    b3 = torch.randn(256, generator=g) * 0.2
+    w1 = bfr(torch.randn(64, 256, 1, 1, generator=g) / 16.0)
+    b1 = torch.randn(64, generator=g) * 0.2
+    ws = bfr(torch.randn(256, 64, 1, 1, generator=g) / 8.0)
+    bs_ = torch.randn(256, generator=g) * 0.2
+    x = bfr(torch.relu(torch.randn(N, 64 if proj else 256, H, W, generator=g)))
+    st = _lib.current_stream()
+    ua, xa = engine.Act.from_nchw(u.to(d)), engine.Act.from_nchw(x.to(d))
+    w2p, b2p = engine.pack_conv(w2, b2, d)
+    w3p, b3p = engine.pack_conv(w3, b3, d)
+    w1p, b1p = engine.pack_conv(w1, b1, d)
+    wsp, bsp = engine.pack_conv(ws, bs_, d)
+    # the separate launches
+    t_u, y_u, z_u = engine.Act(N, H, W, 64, d), engine.Act(N, H, W, 256, d), engine.Act(N, H, W, 64, d)
+    engine.ConvCall(w2p, b2p, 64, 64, 3, 1, 1, engine.F_RELU, [(ua.t, t_u.t, None, H, W, H, W)], N)(st)
+    if proj:
+        sc_u = engine.Act(N, H, W, 256, d)
+        engine.ConvCall(wsp, bsp, 64, 256, 1, 1, 0, 0, [(xa.t, sc_u.t, None, H, W, H, W)], N)(st)
+    else:
+        sc_u = xa
+    engine.ConvCall(w3p, b3p, 64, 256, 1, 1, 0, engine.F_RELU | engine.F_RES, [(t_u.t, y_u.t, sc_u.t, H, W, H, W)], N)(st)
+    if head:
+        engine.ConvCall(w1p, b1p, 256, 64, 1, 1, 0, engine.F_RELU, [(y_u.t, z_u.t, None, H, W, H, W)], N)(st)
+    # one kernel
+    wf = engine.pack_blk_narrow(w2p, w3p, w1p if head else None, wsp if proj else None)
+    scratch = torch.empty(L.dafne_bottleneck_block_narrow_scratch_bytes(), dtype=torch.uint8, device=d)
+    y_f, z_f = engine.Act(N, H, W, 256, d), engine.Act(N, H, W, 64, d)
+    for _ in range(2):
+        _lib.check(L.dafne_bottleneck_block_narrow_hip(_lib.ptr(ua.t), _lib.ptr(xa.t), _lib.ptr(wf), _lib.ptr(b2p), _lib.ptr(b3p),
+                                                       _lib.ptr(bsp) if proj else None, _lib.ptr(b1p) if head else None, N, H, W,
+                                                       _lib.ptr(y_f.t), _lib.ptr(z_f.t) if head else None, _lib.ptr(scratch),
+                                                       scratch.numel(), st), "blk_narrow")
+    torch.cuda.synchronize()
+    assert float(y_f.t.float().abs().max()) > 0
+    assert torch.equal(y_f.t, y_u.t)
+    if head:
+        assert torch.equal(z_f.t, z_u.t)
+    else:
+        assert float(z_f.t.float().abs().max()) == 0           # untouched
+    assert float(y_f.t[:, 0].abs().max()) == 0 and float(y_f.t[:, :, -1].abs().max()) == 0 and float(y_f.t[:, -1].abs().max()) == 0
+    if N * H * W <= 3 * 64 * 64:
+        t_ref = bfr(F.relu(F.conv2d(u, w2, b2, padding=1)))
+        sc = bfr(F.conv2d(x, ws, bs_)) if proj else x
+        y_ref = bfr(F.relu(F.conv2d(t_ref, w3, b3) + sc))
+        got = y_f.nchw_float().cpu()
+        assert float((got - y_ref).abs().max()) < 0.03 * float(y_ref.abs().max())

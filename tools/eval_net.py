@@ -45,6 +45,9 @@ def parse_args(argv=None):
                     help="where the synthetic tiles live when the loop starts: host (pageable CPU tensors, as a data loader yields them; "
                          "uploaded through pinned staging under the previous batch) or device (resident in HBM, as bench.py times)")
     ap.add_argument("--serial", action="store_true", help="synchronous model(inputs) per batch instead of the streamed loop")
+    ap.add_argument("--warmup-batches", type=int, default=2,
+                    help="batches run through the detector before the loop is timed (launch plans, packed weights, pinned buffers "
+                         "are built on first use); their results are discarded")
     ap.add_argument("--output", default="")
     ap.add_argument("--task1-dir", default="", help="DOTA configs: write Task1_<class>.txt files here and merge the tiles "
                                                     "(Task1_merged/) with the device NMS (dota_evaluation.py:110-184)")
@@ -136,6 +139,8 @@ def run(args, rank=0, world=1, local_rank=0):
         loader = [mine[i:i + b] for i in range(0, len(mine), b)]
         ev = DafneEvaluator("synthetic", cfg, distributed=world > 1, k_cap=k_cap, device=dev, pad_to=(n + world - 1) // world)
         stats = {}
+        if args.warmup_batches > 0 and loader:
+            inference_on_dataset(model, (loader * args.warmup_batches)[:args.warmup_batches], None)
         if args.serial:
             class _Sync:                      # the synchronous form: model(inputs) per batch
                 def __init__(self, m):
