@@ -64,13 +64,23 @@ def load_checkpoint_file(path):
 FP8_SCALES_KEY = "fp8_act_scales"       # engine-specific entry beside "model" in a .pth checkpoint
 
 
+def load_checkpoint_with_scales(path):
+    """ONE read of the file -> (state dict, fp8 activation scales or None): the scales an fp8 model was calibrated with travel
+    beside "model" in the .pth ({weight key: in_qscale})."""
+    if path.endswith(".pkl"):
+        return load_checkpoint_file(path), None
+    data = torch.load(path, map_location="cpu", weights_only=False)
+    sd = data["model"] if isinstance(data, dict) and "model" in data else data
+    sd = {k: (v if isinstance(v, torch.Tensor) else torch.from_numpy(np.asarray(v))) for k, v in sd.items()}
+    sc = data.get(FP8_SCALES_KEY) if isinstance(data, dict) else None
+    return sd, (None if sc is None else {str(k): float(v) for k, v in dict(sc).items()})
+
+
 def load_fp8_act_scales(path):
     """The fp8 model's calibrated activation scales stored beside the weights ({weight key: in_qscale}), or None."""
     if not isinstance(path, str) or path.endswith(".pkl"):
         return None
-    data = torch.load(path, map_location="cpu", weights_only=False)
-    sc = data.get(FP8_SCALES_KEY) if isinstance(data, dict) else None
-    return None if sc is None else {str(k): float(v) for k, v in dict(sc).items()}
+    return load_checkpoint_with_scales(path)[1]
 
 
 def save_checkpoint(model, path):
@@ -87,7 +97,11 @@ def load_weights(model, path_or_state, strict=False):
     """Copy matching tensors into `model`; returns (missing, unexpected) key lists.
     Caffe2-style BGR stems etc. are taken as they are (the released DAFNe configs use
     INPUT.FORMAT BGR with d2's ImageNet trunks)."""
-    sd = load_checkpoint_file(path_or_state) if isinstance(path_or_state, str) else dict(path_or_state)
+    sc = None
+    if isinstance(path_or_state, str):
+        sd, sc = load_checkpoint_with_scales(path_or_state)          # one read: weights and the scales calibrated for them
+    else:
+        sd = dict(path_or_state)
     own = model.state_dict()
     missing = [k for k in own if k not in sd]
     unexpected = [k for k in sd if k not in own]
@@ -102,8 +116,11 @@ def load_weights(model, path_or_state, strict=False):
                 v.copy_(sd[k].to(v.dtype))
     if hasattr(model, "invalidate"):
         model.invalidate()
-    sc = load_fp8_act_scales(path_or_state)
     if sc is not None and getattr(getattr(model, "cfg", None), "ENGINE", None) is not None \
             and model.cfg.ENGINE.WEIGHT_DTYPE == "fp8_e4m3" and model.device.type == "cuda":
+        if missing or bad:
+            # the scales were calibrated for the checkpoint's weights: a partial load serves other weights
+            raise ValueError("fp8 activation scales in the checkpoint, but %d model keys are missing from it: the scales belong to "
+                             "ITS weights (load them explicitly with set_fp8_act_scales if that is intended)" % len(missing))
         model.set_fp8_act_scales(sc)
     return missing, unexpected

@@ -3867,6 +3867,11 @@ int build(ConvDev& D, const dafne_conv_params* p, const dafne_conv_seg* segs, bo
     D.oscale = nullptr;
     D.in_qscale = 1.f;
     if (p->n_segs < 1 || p->n_segs > kMaxSegs || p->n_images < 1) return dafne::fail(DAFNE_E_INVALID, "conv: bad segment/image count");
+    {
+        const unsigned known = DAFNE_CONV_RELU | DAFNE_CONV_RESIDUAL | DAFNE_CONV_UPSAMPLE_ADD | DAFNE_CONV_OUT_F32 | DAFNE_CONV_GN_STATS |
+                               DAFNE_CONV_GN_INPUT | DAFNE_CONV_GN_FINALIZE | DAFNE_CONV_EXCLUSIVE;
+        if (p->flags & ~known) return dafne::fail(DAFNE_E_INVALID, "conv: unknown flag bits 0x%x", p->flags & ~known);
+    }
     const bool stem = p->Cin == 4 && p->KH == 7 && p->KW == 7 && p->stride == 2;
     if (!stem) {
         if (p->Cin % kBK) return dafne::fail(DAFNE_E_UNSUPPORTED, "conv: Cin %d not a multiple of 64", p->Cin);

@@ -187,6 +187,9 @@ __device__ __forceinline__ void bn_wait_for(bf16x8 (&ar)[kRing]) {
     asm volatile("s_waitcnt vmcnt(%1)" : "+v"(ar[J % kRing]) : "n"(kWaitN) : "memory");
 }
 
+// HEAD = false (the stage's last block: no next conv1): GEMM2, its epilogue and the Z rows are skipped; the weight stream still
+// walks the (zero) conv1' fragments -- the vmcnt bookkeeping is one schedule for both forms.
+template <bool HEAD>
 __global__ void __launch_bounds__(512, 2) conv_bneck_kernel(BneckDev P) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const int tid = threadIdx.x;
@@ -457,8 +460,10 @@ __global__ void __launch_bounds__(512, 2) conv_bneck_kernel(BneckDev P) {
                     asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(bfr[j & 1][0]), "+v"(bfr[j & 1][1]), "+v"(bfr[j & 1][2]), "+v"(bfr[j & 1][3]) :: "memory");
                 }
                 __builtin_amdgcn_sched_barrier(0);
+                if constexpr (HEAD) {
 #pragma unroll
-                for (int b = 0; b < kPF; b++) acc2[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ar[j % kRing], bfr[j & 1][b], acc2[b], 0, 0, 0);
+                    for (int b = 0; b < kPF; b++) acc2[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ar[j % kRing], bfr[j & 1][b], acc2[b], 0, 0, 0);
+                }
                 if constexpr (i == 0) {
                     store_slab(q, 0, P.out, kCB * 2, (unsigned)c * 512u);
                     store_slab(q, 1, P.out, kCB * 2, (unsigned)c * 512u);
@@ -472,11 +477,13 @@ __global__ void __launch_bounds__(512, 2) conv_bneck_kernel(BneckDev P) {
         });
         BN_STAMP();
     });
-    epilogue(acc2, 256 + kCB, false, kOffY);
-    barrier();
-    BN_STAMP();
+    if constexpr (HEAD) {
+        epilogue(acc2, 256 + kCB, false, kOffY);
+        barrier();
+        BN_STAMP();
 #pragma unroll
-    for (int i = 0; i < 8; i++) store_slab(i >> 1, i & 1, P.next, kCM * 2, 0);
+        for (int i = 0; i < 8; i++) store_slab(i >> 1, i & 1, P.next, kCM * 2, 0);
+    }
 #ifdef DAFNE_BNECK_TIMING
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     BN_STAMP();
@@ -496,13 +503,14 @@ size_t dafne_bottleneck_body_scratch_bytes(void) { return (size_t)kDumpBytes; }
 int dafne_bottleneck_body_hip(const void* d_in, const void* d_res, const void* d_wfrag, const float* d_bias2,
                               const float* d_bias3, const float* d_bias1, int n_images, int H, int W, void* d_out,
                               void* d_next, void* d_scratch, size_t scratch_bytes, void* stream) {
-    if (!d_in || !d_res || !d_wfrag || !d_bias2 || !d_bias3 || !d_bias1 || !d_out || !d_next || !d_scratch)
+    const bool head = d_next != nullptr;
+    if (!d_in || !d_res || !d_wfrag || !d_bias2 || !d_bias3 || (head && !d_bias1) || !d_out || !d_scratch)
         return dafne::fail(DAFNE_E_INVALID, "bottleneck_body: null argument");
     if (n_images < 1 || H < 1 || W < 1 || (long long)H * W > (1 << 20)) return dafne::fail(DAFNE_E_INVALID, "bottleneck_body: bad size");
     if (scratch_bytes < (size_t)kDumpBytes) return dafne::fail(DAFNE_E_WORKSPACE, "bottleneck_body: scratch %zu < %d", scratch_bytes, kDumpBytes);
     BneckDev D;
     D.in = (const char*)d_in; D.res = (const char*)d_res; D.wf = (const char*)d_wfrag;
-    D.b2 = d_bias2; D.b3 = d_bias3; D.b1 = d_bias1;
+    D.b2 = d_bias2; D.b3 = d_bias3; D.b1 = head ? d_bias1 : d_bias2;      // (a valid 1-KB source for the bias DMA; unused without the head)
     D.out = (char*)d_out; D.next = (char*)d_next; D.dump = (char*)d_scratch;
     D.N = n_images; D.H = H; D.W = W;
     D.tiles_x = (W + kTW - 1) / kTW;
@@ -512,8 +520,9 @@ int dafne_bottleneck_body_hip(const void* d_in, const void* d_res, const void* d
     if (tiles > (1ll << 24) || pix * (kCB * 2) > 0xffffffffll) return dafne::fail(DAFNE_E_UNSUPPORTED, "bottleneck_body: too large");
     D.tiles = (int)tiles;
     D.max_pix = (unsigned)(pix - 1);
-    DAFNE_MAX_LDS_ONCE(kSmemTotal, (const void*)conv_bneck_kernel);
-    hipLaunchKernelGGL(conv_bneck_kernel, dim3(D.tiles), dim3(kNT), kSmemTotal, (hipStream_t)stream, D);
+    DAFNE_MAX_LDS_ONCE(kSmemTotal, (const void*)conv_bneck_kernel<true>, (const void*)conv_bneck_kernel<false>);
+    if (head) hipLaunchKernelGGL(conv_bneck_kernel<true>, dim3(D.tiles), dim3(kNT), kSmemTotal, (hipStream_t)stream, D);
+    else hipLaunchKernelGGL(conv_bneck_kernel<false>, dim3(D.tiles), dim3(kNT), kSmemTotal, (hipStream_t)stream, D);
     return dafne::check_launch("conv_bneck");
 }
 

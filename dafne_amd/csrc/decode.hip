@@ -288,16 +288,39 @@ __device__ int radix_step(const u64* E, int n, int nbits, unsigned* h, KeyFn key
     }
     __syncthreads();
     __shared__ int s_bin, s_need;
-    if (threadIdx.x == 0) {
-        int acc = 0, bin = descending ? nb - 1 : 0;
-        for (int t = 0; t < nb; t++) {
-            int b = descending ? nb - 1 - t : t;
-            int hv = (int)h[b];
-            if (acc + hv >= need) { bin = b; break; }
-            acc += hv;
+    // the bin in which the running count (from the top when `descending`) reaches `need`: wave 0, lane l owns `per`
+    // consecutive bins in walk order; a wave scan finds the lane that holds the crossing, which then walks its own bins.
+    // (Round 3 walked all 2048 bins on ONE thread -- dependent LDS reads, ~60 us per step, four steps per (image, level):
+    // the whole 245 us of this kernel.)
+    if (threadIdx.x < 64) {
+        const int lane = threadIdx.x;
+        const int per = nb >= 64 ? nb / 64 : 1;
+        const int t0 = lane * per;                               // first walk position of this lane
+        int mine = 0;
+        if (t0 < nb)
+            for (int t = 0; t < per; t++) mine += (int)h[descending ? nb - 1 - (t0 + t) : t0 + t];
+        int incl = mine;                                         // inclusive prefix over lanes in walk order
+        for (int o = 1; o < 64; o <<= 1) {
+            const int v = __shfl_up(incl, o, 64);
+            if (lane >= o) incl += v;
         }
-        s_bin = bin;
-        s_need = need - acc;
+        const int before = incl - mine;
+        const int total = __shfl(incl, 63, 64);
+        if (need <= 0) {                                         // (not reached by the callers) the serial walk stops at once
+            if (lane == 0) { s_bin = descending ? nb - 1 : 0; s_need = need; }
+        } else if (total < need) {                               // never reached: the walk's defaults
+            if (lane == 0) { s_bin = descending ? nb - 1 : 0; s_need = need - total; }
+        } else if (before < need && incl >= need) {              // exactly one lane (need >= 1)
+            int acc = before, bin = descending ? nb - 1 - t0 : t0;
+            for (int t = 0; t < per; t++) {
+                const int b = descending ? nb - 1 - (t0 + t) : t0 + t;
+                const int hv = (int)h[b];
+                if (acc + hv >= need) { bin = b; break; }
+                acc += hv;
+            }
+            s_bin = bin;
+            s_need = need - acc;
+        }
     }
     __syncthreads();
     need = s_need;

@@ -118,7 +118,7 @@ def act_qscale_from_amax(amax, margin=2.0):
     return float(2.0 ** math.floor(math.log2(E4M3_MAX / (margin * amax))))
 
 
-def reduce_amax_over_ranks(calib, group=None):
+def reduce_amax_over_ranks(calib, group=None, device=None):
     """fp8 calibration in a multi-process job: every rank must end up with the SAME activation scales, whatever images its
     shard holds -- element-wise MAX of the per-layer amax values over the ranks (one all-reduce of a small float64 vector
     in sorted-key order; RCCL on the GPU, gloo in the CPU tests).  Returns the reduced dict; a no-op without a process
@@ -129,7 +129,8 @@ def reduce_amax_over_ranks(calib, group=None):
     keys = sorted(calib)
     # every rank calibrates the same architecture: same keys.  A mismatch would silently pair different layers.
     sig = [len(keys), sum(hash_str(k) for k in keys) % (1 << 52)]
-    dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend(group) == "nccl" else torch.device("cpu")
+    dev = (device if device is not None else torch.device("cuda", torch.cuda.current_device())) if dist.get_backend(group) == "nccl" \
+        else torch.device("cpu")
     t = torch.tensor([float(calib[k]) for k in keys] + [float(s) for s in sig] + [-float(s) for s in sig],
                      dtype=torch.float64, device=dev)
     dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
@@ -663,28 +664,31 @@ class DensePlan:
                     y1 = conv(p + "conv1", x, 1, stride, 0, F_RELU)       # STRIDE_IN_1X1
                 w2, b2 = P[p + "conv2"]
                 q8_2 = P.get(p + "conv2.fp8")
-                body_fused = (fuse_bneck and b + 1 < nb and tuple(w3.shape) == (1024, 256) and tuple(P[nxt][0].shape) == (256, 1024)
+                bn_head = b + 1 < nb                  # the stage's last block has no next conv1: the kernel's no-head form
+                body_fused = (fuse_bneck and tuple(w3.shape) == (1024, 256) and (not bn_head or tuple(P[nxt][0].shape) == (256, 1024))
+                              and (bn_head or os.environ.get("DAFNE_FUSE_BNECK_LAST", "1") != "0")
                               and tuple(w2.shape) == (256, 2304) and y1.c == 256
                               # an fp8 model's conv2 takes e4m3 activations on the fp8 MFMA kernel (its definition): not fused
                               and not (q8_2 is not None and (calib is not None or (p + "conv2") in act_q8)))
                 if body_fused:
                     # res4: conv2 (3x3) + conv3 + residual + ReLU + the next block's conv1 + ReLU in ONE kernel
                     # (conv_bneck.hip): neither the 3x3's output nor conv3's is read back from HBM
-                    w1, b1 = P[nxt]
+                    w1, b1 = P[nxt] if bn_head else (torch.zeros(256, 1024, dtype=BF16, device=w2.device), None)
                     key = p + "bneck"
                     if key not in P:
                         P[key] = pack_bneck(w2, w3, w1)
                     if bneck_scratch is None:
                         bneck_scratch = torch.empty(L.dafne_bottleneck_body_scratch_bytes(), dtype=torch.uint8, device=device)
                     y3 = pool.get(n, y1.h, y1.w, 1024)
-                    y1_next = pool.get(n, y1.h, y1.w, 256)
-                    fl = 2 * n * y1.h * y1.w * (256 * 2304 + 256 * 1024 + 1024 * 256)
-                    nb_ = n * y1.h * y1.w * (256 + 1024 + 1024 + 256) * 2 + (256 * 2304 + 2 * 1024 * 256) * 2
+                    y1_next = pool.get(n, y1.h, y1.w, 256) if bn_head else None
+                    fl = 2 * n * y1.h * y1.w * (256 * 2304 + 256 * 1024 + (1024 * 256 if bn_head else 0))
+                    nb_ = n * y1.h * y1.w * (256 + 1024 + 1024 + (256 if bn_head else 0)) * 2 + (256 * 2304 + 2 * 1024 * 256) * 2
                     self.calls.append(FnCall(L.dafne_bottleneck_body_hip,
                                              (_lib.ptr(y1.t), _lib.ptr(sc.t), _lib.ptr(P[key]), _lib.ptr(b2), _lib.ptr(b3), _lib.ptr(b1),
-                                              n, y1.h, y1.w, _lib.ptr(y3.t), _lib.ptr(y1_next.t), _lib.ptr(bneck_scratch),
+                                              n, y1.h, y1.w, _lib.ptr(y3.t), _lib.ptr(y1_next.t) if bn_head else None, _lib.ptr(bneck_scratch),
                                               bneck_scratch.numel()),
-                                             (y1, sc, P[key], b2, b3, b1, y3, y1_next, bneck_scratch), "conv_bneck", flops=fl, nbytes=nb_))
+                                             (y1, sc, P[key], b2, b3, b1, y3, y1_next, bneck_scratch),
+                                             "conv_bneck" if bn_head else "conv_bneck_last", flops=fl, nbytes=nb_))
                     self.flops += fl
                     pool.put(y1)
                     if b == 0 and sc is not None:

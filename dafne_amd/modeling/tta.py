@@ -268,7 +268,9 @@ class OneStageRCNNWithTTA(nn.Module):
         if out is None:
             return None
         rows_all, counts_all = out
-        outputs = [{"instances": r} for r in pp.rows_to_instances(rows_all, counts_all, [(s[0], s[1]) for s in specs])]
+        # image_size of every view's Instances = the ORIGINAL image's (height, width), as _views_packed builds them: the merged
+        # result of the sharded path then carries the same image_size as __call__'s
+        outputs = [{"instances": r} for r in pp.rows_to_instances(rows_all, counts_all, [(int(input["height"]), int(input["width"]))] * n)]
         instances = self._invert_and_concat(outputs, [s[2] for s in specs])
         return {"instances": self._merge_detections(instances)}
 

@@ -388,7 +388,9 @@ int dafne_bottleneck_tail_head_hip(const void* d_in, const void* d_res, const vo
  * [8 waves][144 k16 steps][64 lanes][8] (rows wave*32 + (lane & 31); K columns 16*step + 8*(lane >> 5) .. +8 of
  * dafne_conv2d_nhwc_bf16_hip's packed weight: 64-channel slab, kh, kw, channel), followed by
  * dafne_bottleneck_tail_head_hip's d_wfrag  (engine.pack_bneck).  Bit-identical to dafne_conv2d_nhwc_bf16_hip(conv2, RELU)
- * followed by dafne_bottleneck_tail_head_hip.
+ * followed by dafne_bottleneck_tail_head_hip.  d_next == NULL (the stage's last block: no next conv1): only d_out is
+ * produced (d_bias1 may be NULL; the conv1' section of d_wfrag is still read: pack zeros), bit-identical to
+ * dafne_conv2d_nhwc_bf16_hip(conv2, RELU) followed by (conv3, RELU|RESIDUAL).
  */
 size_t dafne_bottleneck_body_scratch_bytes(void);
 int dafne_bottleneck_body_hip(const void* d_in, const void* d_res, const void* d_wfrag, const float* d_bias2,

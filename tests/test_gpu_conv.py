@@ -764,6 +764,16 @@ def test_bottleneck_body_fused_equals_three_convs(N, H, W):
     assert float(z_t[:, 0].abs().max()) == 0 and float(y_t[:, :, -1].abs().max()) == 0
     for lo, hi in ((0, guard), (guard + ny, 2 * guard + ny), (2 * guard + ny + nz, 3 * guard + ny + nz)):
         assert bool((slab[lo:hi] == 7.0).all())
+    # the no-head form (the stage's last block: d_next NULL, zero conv1' section): d_out alone, bit for bit, nothing else written
+    wf0 = engine.pack_bneck(w2p, w3p, torch.zeros_like(w1p))
+    y_t.zero_()
+    z_t.fill_(5.0)
+    _lib.check(L.dafne_bottleneck_body_hip(_lib.ptr(ua.t), _lib.ptr(xa.t), _lib.ptr(wf0), _lib.ptr(b2p), _lib.ptr(b3p), None, N, H, W,
+                                           _lib.ptr(y_t), None, _lib.ptr(scr), nscr, st), "bneck (no head)")
+    torch.cuda.synchronize()
+    assert torch.equal(y_t, y_u.t) and bool((z_t == 5.0).all())
+    for lo, hi in ((0, guard), (guard + ny, 2 * guard + ny), (2 * guard + ny + nz, 3 * guard + ny + nz)):
+        assert bool((slab[lo:hi] == 7.0).all())
     t_ref = bfr(F.relu(F.conv2d(u, w2, b2, padding=1)))
     close_bf16(t_u.nchw_float().cpu(), t_ref)
     y_ref = bfr(F.relu(F.conv2d(t_u.nchw_float().cpu(), w3, b3) + x))

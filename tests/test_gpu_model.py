@@ -375,4 +375,5 @@ def test_tta_view_sharded_driver_equals_the_wrapper():
     a = tta([inp])[0]["instances"]
     b = tta.inference_view_sharded(inp)["instances"]
     assert len(a) == len(b) > 0
+    assert a.image_size == b.image_size == (128, 160)          # the ORIGINAL image's size, not the first view's
     assert torch.equal(a.pred_corners, b.pred_corners) and torch.equal(a.scores, b.scores) and torch.equal(a.pred_classes, b.pred_classes)
