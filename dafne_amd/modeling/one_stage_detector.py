@@ -31,7 +31,7 @@ def _shared_stream(device, kind, k):
     is already in use, and two sub-batches on one queue serialise."""
     key = (str(device), kind, k)
     if key not in _STREAMS:
-        _STREAMS[key] = torch.cuda.Stream(device=device, priority=-1 if kind == "compute" else 0)
+        _STREAMS[key] = torch.cuda.Stream(device=device, priority=-1 if kind in ("compute", "upload") else 0)
     return _STREAMS[key]
 
 
@@ -355,7 +355,15 @@ class OneStageDetector(nn.Module):
                 for k, im in enumerate(imgs):
                     batch[k, :, : hs[k], : ws[k]] = im
         elif staged:
-            st = self.__dict__.setdefault("_staging", {"i": 0, "buf": {}, "free": {}})
+            st = self.__dict__.get("_staging")
+            if st is None:
+                st = self.__dict__.setdefault("_staging", {"i": 0, "buf": {}, "free": {}})
+                # the staging copies below run on torch's intra-op pool; with one worker per core (128 on the MI355X hosts)
+                # the workers' spin-wait after every copy starves the HIP runtime's completion threads: the streamed loop
+                # then stalls for 50-200 ms every few batches (measured 107-170 images/s; 1085 with 4 workers).  The loop's
+                # host side is latency work, not throughput work: cap the pool (process-wide, once).
+                if torch.get_num_threads() > 8:
+                    torch.set_num_threads(8)
             slot = st["i"] & 1
             st["i"] += 1
             key = (slot, n, H, W)
@@ -368,14 +376,23 @@ class OneStageDetector(nn.Module):
                 pinned.zero_()
             for k, im in enumerate(imgs):
                 pinned[k, :, : hs[k], : ws[k]].copy_(im)
-            # the copy rides the CALLER's stream, which carries nothing else in the streamed loop (the network runs on the
-            # sub-batch streams, the post-process on the side stream): it overlaps the previous batch and needs no extra
-            # stream -- a further normal-priority stream shares a hardware queue with one of those and its copy would wait
-            # behind that queue's kernels (measured: 221 instead of ~1200 images/s)
-            batch = torch.empty(n, 3, H, W, dtype=torch.uint8, device=dev)
-            batch.copy_(pinned, non_blocking=True)
-            done = torch.cuda.Event()
-            done.record(torch.cuda.current_stream(dev))
+            # the copy rides a HIGH-PRIORITY stream of its own.  The sub-batch streams are high-priority and the host runs
+            # many steps ahead of the GPU, so they never idle: a copy on a normal-priority stream (or on the caller's) is a
+            # blit that only gets the chip when they drain -- measured 107-221 images/s instead of ~1250.
+            up = _shared_stream(dev, "upload", 0)
+            # device batches from a ring of three persistent buffers (this call's, the batch in flight, the one whose results
+            # the previous call handed back: forward_streamed waits for batch i - 1's post-process before it returns, so the
+            # buffer of batch i - 2 is free).  A fresh torch.empty per call, used on three more streams, made the caching
+            # allocator fall back to hipMalloc (device-wide stalls of 50-200 ms: 107 images/s).
+            dkey = (st["i"] % 3, n, H, W)
+            if dkey not in st.setdefault("dev", {}):
+                st["dev"][dkey] = torch.empty(n, 3, H, W, dtype=torch.uint8, device=dev)
+            batch = st["dev"][dkey]
+            with torch.cuda.stream(up):
+                batch.copy_(pinned, non_blocking=True)
+                done = torch.cuda.Event()
+                done.record(up)
+            torch.cuda.current_stream(dev).wait_event(done)
             st["free"][key] = done
         elif n == 1:
             batch = imgs[0].to(dev, non_blocking=True).unsqueeze(0)
