@@ -31,7 +31,7 @@ def _shared_stream(device, kind, k):
     is already in use, and two sub-batches on one queue serialise."""
     key = (str(device), kind, k)
     if key not in _STREAMS:
-        _STREAMS[key] = torch.cuda.Stream(device=device, priority=-1 if kind in ("compute", "upload") else 0)
+        _STREAMS[key] = torch.cuda.Stream(device=device, priority=-1 if kind == "compute" else 0)
     return _STREAMS[key]
 
 
@@ -184,7 +184,7 @@ class OneStageDetector(nn.Module):
 
     # ------------------------------------------------------------ fused path
     def detect_packed(self, images_u8, valid_hw=None, out_hw=None, layout_hwc=False, do_postprocess=True,
-                      pipelined=False, splits=1, stream_offset=0):
+                      pipelined=False, splits=1, stream_offset=0, graphs=None):
         """images_u8: device uint8 [N,3,H,W] (or [N,H,W,3] with layout_hwc) BGR.
         valid_hw: optional per-image (h, w) true sizes; out_hw: optional per-image
         requested output (height, width).  Returns (rows [N,k_cap,18], counts [N])
@@ -197,7 +197,10 @@ class OneStageDetector(nn.Module):
         convolutions (two plan sets / head-output buffers alternate).
         The returned tensors are then produced on `self.side_stream`: wait on it (or
         torch.cuda.synchronize()) before reading them.  stream_offset rotates the compute streams the
-        sub-batches use: consecutive calls with different offsets (the TTA wrapper's chunks) run concurrently."""
+        sub-batches use: consecutive calls with different offsets (the TTA wrapper's chunks) run concurrently.
+        graphs: replay the sub-batches' dense launches from HIP graphs (None: cfg.ENGINE.HIP_GRAPHS).  Worth it for a loop over
+        one shape (host enqueue 1.9 -> 0.4 ms per step); the TTA wrapper's 27 views of 9 shapes pass False (GPU-bound at 26.7
+        ms per image either way, and every shape's capture costs ~10 ms)."""
         if not images_u8.is_cuda or images_u8.dtype != torch.uint8:
             raise RuntimeError("detect_packed needs a uint8 CUDA tensor (the MI355X engine has no CPU path)")
         if self.cfg.ENGINE.WEIGHT_DTYPE == "fp8_e4m3" and self._act_q8 is None:
@@ -308,11 +311,37 @@ class OneStageDetector(nn.Module):
             # prologue / epilogue bubbles of one sub-batch's kernel are filled by another's
             sp = [ctypes.c_void_p(s.cuda_stream) for s in cs]
             # (sub-batches of different sizes may differ by a launch: the library picks kernels by tile count)
-            ncalls = max(len(p.calls) for p in plans)
-            for j in range(ncalls):
-                for k in range(splits):
-                    if j < len(plans[k].calls):
-                        plans[k].calls[j](sp[k])
+            genv = os.environ.get("DAFNE_HIP_GRAPHS")                # A/B runs: 1 / 0 overrides the config
+            want_graphs = self.cfg.ENGINE.HIP_GRAPHS if graphs is None else bool(graphs)
+            if (self.use_graphs or want_graphs or genv == "1") and genv != "0" and graphs is not False:
+                # every sub-batch's ~200 dense launches replayed from ONE HIP graph per stream (captured on first use: kernels,
+                # arguments and buffers of a plan are static): ~10 host calls per step instead of ~600.  The launch order
+                # inside a stream is the plan's; across streams the hardware queues interleave as before (the host runs
+                # many steps ahead either way).
+                # A plan set's FIRST step always runs eagerly and graphs are captured from its second use on: ROCm binds a
+                # stream to a hardware queue at its first submission, and torch's capture stream, created first, took one of
+                # the few queues the three sub-batch streams need for themselves (measured: capture in the very first step
+                # left the whole process at 1010-1050 images/s, eager and graph steps alike; eager first: 1300 both ways).
+                eager_first = st.setdefault("runs", [0, 0])
+                if eager_first[slot] == 0:
+                    for j in range(max(len(p.calls) for p in plans)):
+                        for k in range(splits):
+                            if j < len(plans[k].calls):
+                                plans[k].calls[j](sp[k])
+                else:
+                    for k in range(splits):
+                        if plans[k].graph is None:
+                            with torch.cuda.stream(cs[k]):
+                                plans[k].capture()
+                        with torch.cuda.stream(cs[k]):
+                            plans[k].graph.replay()
+                eager_first[slot] += 1
+            else:
+                ncalls = max(len(p.calls) for p in plans)
+                for j in range(ncalls):
+                    for k in range(splits):
+                        if j < len(plans[k].calls):
+                            plans[k].calls[j](sp[k])
             for k in range(splits):
                 mark("end", k, cs[k])
             with torch.cuda.stream(self.side_stream):
@@ -376,23 +405,19 @@ class OneStageDetector(nn.Module):
                 pinned.zero_()
             for k, im in enumerate(imgs):
                 pinned[k, :, : hs[k], : ws[k]].copy_(im)
-            # the copy rides a HIGH-PRIORITY stream of its own.  The sub-batch streams are high-priority and the host runs
-            # many steps ahead of the GPU, so they never idle: a copy on a normal-priority stream (or on the caller's) is a
-            # blit that only gets the chip when they drain -- measured 107-221 images/s instead of ~1250.
-            up = _shared_stream(dev, "upload", 0)
-            # device batches from a ring of three persistent buffers (this call's, the batch in flight, the one whose results
-            # the previous call handed back: forward_streamed waits for batch i - 1's post-process before it returns, so the
-            # buffer of batch i - 2 is free).  A fresh torch.empty per call, used on three more streams, made the caching
-            # allocator fall back to hipMalloc (device-wide stalls of 50-200 ms: 107 images/s).
+            # the copy rides the CALLER's stream, which carries nothing else in the streamed loop (the network runs on the
+            # sub-batch streams, the post-process on the side stream), so it overlaps the previous batch; a stream of its own
+            # would be the fifth one on four hardware queues (two of them then share a queue and serialise).
+            # Device batches come from a ring of three persistent buffers (this call's, the batch in flight, the one whose
+            # results the previous call handed back: forward_streamed waits for batch i - 1's post-process before it
+            # returns, so the buffer of batch i - 2 is free).
             dkey = (st["i"] % 3, n, H, W)
             if dkey not in st.setdefault("dev", {}):
                 st["dev"][dkey] = torch.empty(n, 3, H, W, dtype=torch.uint8, device=dev)
             batch = st["dev"][dkey]
-            with torch.cuda.stream(up):
-                batch.copy_(pinned, non_blocking=True)
-                done = torch.cuda.Event()
-                done.record(up)
-            torch.cuda.current_stream(dev).wait_event(done)
+            batch.copy_(pinned, non_blocking=True)
+            done = torch.cuda.Event()
+            done.record(torch.cuda.current_stream(dev))
             st["free"][key] = done
         elif n == 1:
             batch = imgs[0].to(dev, non_blocking=True).unsqueeze(0)

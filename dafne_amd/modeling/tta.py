@@ -230,7 +230,7 @@ class OneStageRCNNWithTTA(nn.Module):
                 for k, im in enumerate(imgs):
                     batch[k, :, : hs[k], : ws[k]] = im
             out_hw = [(int(x.get("height", hs[k])), int(x.get("width", ws[k]))) for k, x in enumerate(chunk)]
-            rows, counts = m.detect_packed(batch, valid_hw=list(zip(hs, ws)), out_hw=out_hw, do_postprocess=False,
+            rows, counts = m.detect_packed(batch, valid_hw=list(zip(hs, ws)), out_hw=out_hw, do_postprocess=False, graphs=False,
                                            pipelined=True, splits=1, stream_offset=len(pending) % 3)
             pending.append((rows, counts, out_hw))
         if m.side_stream is not None:

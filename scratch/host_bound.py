@@ -9,7 +9,9 @@ d = torch.device("cuda", 0)
 cfg, m, _ = bench.build_model(101, d, seed=0)
 g = torch.Generator().manual_seed(0)
 batch = torch.randint(0, 256, (8, 3, 1024, 1024), generator=g, dtype=torch.uint8).to(d)
-for mode, kw in (("pipelined x3", dict(pipelined=True, splits=3)), ("pipelined x1", dict(pipelined=True, splits=1)), ("serial", dict())):
+for mode, kw in (("pipelined x3", dict(pipelined=True, splits=3)), ("pipelined x3 graphs", dict(pipelined=True, splits=3)),
+                 ("pipelined x1", dict(pipelined=True, splits=1)), ("serial", dict())):
+    m.use_graphs = "graphs" in mode
     f = lambda: m.detect_packed(batch, **kw)
     for _ in range(5): f()
     torch.cuda.synchronize()

@@ -226,3 +226,31 @@ def test_streamed_loop_on_the_benchmarked_layout():
             ka = set(zip(a.fpn_levels.tolist(), a.locations[:, 0].tolist(), a.locations[:, 1].tolist(), a.pred_classes.tolist()))
             ke = set(zip(e.fpn_levels.tolist(), e.locations[:, 0].tolist(), e.locations[:, 1].tolist(), e.pred_classes.tolist()))
             assert len(ka & ke) >= 0.8 * len(ke), (k, i, len(ka & ke), len(ke))
+
+
+@pytest.mark.gpu
+def test_graph_replay_equals_eager_launches(monkeypatch):
+    """ENGINE.HIP_GRAPHS (default on): from a plan set's second use the pipelined step replays every sub-batch's dense
+    launches from a HIP graph (one host call per stream instead of ~200).  Same kernels, same arguments, same buffers:
+    the detections are bit-identical to the eagerly launched step, call after call (both plan sets, graph capture in the
+    middle of the sequence)."""
+    cfg, m = _gpu_model()
+    assert cfg.ENGINE.HIP_GRAPHS
+    g = torch.Generator().manual_seed(21)
+    batches = [torch.randint(0, 256, (8, 3, 128, 160), generator=g, dtype=torch.uint8).cuda() for _ in range(6)]
+    monkeypatch.setenv("DAFNE_HIP_GRAPHS", "0")
+    eager = []
+    for b in batches:
+        r, c = m.detect_packed(b, pipelined=True, splits=3)
+        torch.cuda.synchronize()
+        eager.append((r.clone(), c.clone()))
+    st = m._pipe[(8, 128, 160, 3)]
+    assert all(p.graph is None for ps in st["plans"] for p in ps)
+    monkeypatch.setenv("DAFNE_HIP_GRAPHS", "1")
+    for b, (r0, c0) in zip(batches, eager):
+        r, c = m.detect_packed(b, pipelined=True, splits=3)
+        torch.cuda.synchronize()
+        assert torch.equal(c, c0)
+        for i in range(8):
+            assert torch.equal(r[i, :int(c0[i])], r0[i, :int(c0[i])])
+    assert all(p.graph is not None for ps in st["plans"] for p in ps)          # both plan sets were captured and replayed

@@ -45,8 +45,8 @@ def parse_args(argv=None):
                     help="where the synthetic tiles live when the loop starts: host (pageable CPU tensors, as a data loader yields them; "
                          "uploaded through pinned staging under the previous batch) or device (resident in HBM, as bench.py times)")
     ap.add_argument("--serial", action="store_true", help="synchronous model(inputs) per batch instead of the streamed loop")
-    ap.add_argument("--warmup-batches", type=int, default=2,
-                    help="batches run through the detector before the loop is timed (launch plans, packed weights, pinned buffers "
+    ap.add_argument("--warmup-batches", type=int, default=4,
+                    help="batches run through the detector before the loop is timed (launch plans, packed weights, HIP graphs, pinned buffers "
                          "are built on first use); their results are discarded")
     ap.add_argument("--output", default="")
     ap.add_argument("--task1-dir", default="", help="DOTA configs: write Task1_<class>.txt files here and merge the tiles "
@@ -140,7 +140,7 @@ def run(args, rank=0, world=1, local_rank=0):
         ev = DafneEvaluator("synthetic", cfg, distributed=world > 1, k_cap=k_cap, device=dev, pad_to=(n + world - 1) // world)
         stats = {}
         if args.warmup_batches > 0 and loader:
-            inference_on_dataset(model, (loader * args.warmup_batches)[:args.warmup_batches], None)
+            inference_on_dataset(model, (loader * args.warmup_batches)[:args.warmup_batches], None)     # (two per plan set: eager, then graph capture)
         if args.serial:
             class _Sync:                      # the synchronous form: model(inputs) per batch
                 def __init__(self, m):
