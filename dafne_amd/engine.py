@@ -924,7 +924,12 @@ class HeadPlan:
                 probe = ConvCall(wgt, bias, C, C, 3, 1, 1, flags & ~F_GN, seg_list(cur, outs), n, gn_in=cur_gn, shared_gpu=sg)
                 rp_on = use_rp_kernel() and C == 256
                 use_fp8 = q8 is not None and aq is not None and (cur_gn is None or probe.kernel_id() == 6 or (rp_on and probe.rp_ok()))
-                use_rp = rp_on and not use_fp8 and probe.rp_ok() and (cur_gn is not None or probe.kernel_id() == 6)
+                # (the FPN-fed layer 0 of a SMALL plan -- the 2-image sub-batch of the timed layout -- takes the generic tile, kernel
+                # id != 6, and is then followed by ONE dafne_groupnorm_finalize_hip launch per tower: the two gn_finalize launches
+                # per step in the pipelined rocprof stats.  DAFNE_RP_LAYER0=1 puts it on the persistent kernel with fused finalize:
+                # measured -0.3 .. 0 % in the timed layout (round 4), so it stays opt-in)
+                rp_small = os.environ.get("DAFNE_RP_LAYER0", "0") == "1"
+                use_rp = rp_on and not use_fp8 and probe.rp_ok() and (cur_gn is not None or probe.kernel_id() == 6 or rp_small)
                 wfrag = None
                 if use_rp:
                     if lkey + ".frag" not in P:
