@@ -302,6 +302,22 @@ def pack_blk_narrow(w2, w3, w1=None, wsc=None):
     return torch.cat([a2, quarters(w3), a1, asc]).contiguous()
 
 
+def pack_blk_mid(w2, w3, w1=None):
+    """Weights of dafne_bottleneck_block_mid_hip (a whole res3 block) from the packed weights of conv2 ([128, 1152] bf16, K
+    order 64-channel slab, kh, kw, channel), conv3 ([512, 128]) and optionally the next block's conv1 ([128, 512]): conv2 [4
+    channel groups][72 k16 steps][64 lanes][8] | conv3 [2 halves of 256][8 groups][8 steps][64][8] | conv1' [4 groups][32
+    steps][64][8] (zeros when absent: the kernel still walks the section)."""
+    assert tuple(w2.shape) == (128, 1152) and tuple(w3.shape) == (512, 128) and w2.dtype == BF16 and w3.dtype == BF16
+    a2 = w2.reshape(4, 32, 72, 2, 8).permute(0, 2, 3, 1, 4).reshape(-1)                    # cg, j, hl, r, e
+    a3 = w3.reshape(2, 8, 32, 8, 2, 8).permute(0, 1, 3, 4, 2, 5).reshape(-1)               # h, w, s, hl, r, e
+    if w1 is not None:
+        assert tuple(w1.shape) == (128, 512) and w1.dtype == BF16
+        a1 = w1.reshape(4, 32, 32, 2, 8).permute(0, 2, 3, 1, 4).reshape(-1)                # cg, step, hl, r, e
+    else:
+        a1 = torch.zeros(128 * 512, dtype=BF16, device=w2.device)
+    return torch.cat([a2, a3, a1]).contiguous()
+
+
 def pack_b2b_mid(w3, w1):
     """Weights of dafne_bottleneck_tail_head_mid_hip (res3) from the packed 1x1 weights of conv3 ([512, 128] bf16) and the next
     block's conv1 ([128, 512] bf16): bf16 [16 quarter blocks][4 channel quarters][4 k16 steps][64 lanes][8], in the order the
@@ -642,6 +658,8 @@ class DensePlan:
         fuse_bneck = fuse_b2b and os.environ.get("DAFNE_FUSE_BNECK", "1") != "0"
         bneck_scratch = None
         blk_scratch = None
+        blk_mid_scratch = None
+        fuse_blk_mid = fuse_mid and os.environ.get("DAFNE_FUSE_BLK_MID", "1") != "0"
         fuse_blk_narrow = fuse_narrow and os.environ.get("DAFNE_FUSE_BLK_NARROW", "1") != "0"
         for si, nb in enumerate(STAGE_BLOCKS[depth]):
             y1_next = None
@@ -725,6 +743,36 @@ class DensePlan:
                                              "conv_blk_narrow" + ("_proj" if proj else "") + ("" if head else "_last"), flops=fl, nbytes=nb_))
                     self.flops += fl
                     pool.put(y1)
+                    if not any(x is f for k, f in feats.items() if k != "res2"):
+                        pool.put(x)
+                    x = y3
+                    continue
+                if (fuse_blk_mid and tuple(w2.shape) == (128, 1152) and tuple(w3.shape) == (512, 128) and y1.c == 128
+                        and (b + 1 >= nb or tuple(P[nxt][0].shape) == (128, 512))):
+                    # res3: the whole block -- conv2 (3x3) + conv3 + shortcut + ReLU, and the next block's conv1 + ReLU when
+                    # there is one -- in ONE kernel (conv_blk_mid.hip)
+                    head = b + 1 < nb
+                    w1, b1 = P[nxt] if head else (None, None)
+                    key = p + "blk"
+                    if key not in P:
+                        P[key] = pack_blk_mid(w2, w3, w1)
+                    if blk_mid_scratch is None:
+                        blk_mid_scratch = torch.empty(L.dafne_bottleneck_block_mid_scratch_bytes(), dtype=torch.uint8, device=device)
+                    y3 = pool.get(n, y1.h, y1.w, 512)
+                    y1_next = pool.get(n, y1.h, y1.w, 128) if head else None
+                    px = n * y1.h * y1.w
+                    fl = 2 * px * (128 * 1152 + 128 * 512 + (512 * 128 if head else 0))
+                    nb_ = px * (128 + 512 + 512 + (128 if head else 0)) * 2 + P[key].numel() * 2
+                    self.calls.append(FnCall(L.dafne_bottleneck_block_mid_hip,
+                                             (_lib.ptr(y1.t), _lib.ptr(sc.t), _lib.ptr(P[key]), _lib.ptr(b2), _lib.ptr(b3), _lib.ptr(b1),
+                                              n, y1.h, y1.w, _lib.ptr(y3.t), _lib.ptr(y1_next.t) if head else None,
+                                              _lib.ptr(blk_mid_scratch), blk_mid_scratch.numel()),
+                                             (y1, sc, P[key], b2, b3, b1, y3, y1_next, blk_mid_scratch),
+                                             "conv_blk_mid" + ("" if head else "_last"), flops=fl, nbytes=nb_))
+                    self.flops += fl
+                    pool.put(y1)
+                    if b == 0 and sc is not None:
+                        pool.put(sc)
                     if not any(x is f for k, f in feats.items() if k != "res2"):
                         pool.put(x)
                     x = y3
@@ -895,7 +943,8 @@ class HeadPlan:
         def seg_list(ins, outs, f32=False):
             return [(i.t, (o if f32 else o.t), None, i.h, i.w, i.h, i.w) for i, o in zip(ins, outs)]
 
-        pair_towers = os.environ.get("DAFNE_RP_PAIR", "1") != "0" and not getattr(plan, "shared_gpu", False)
+        pair_towers = os.environ.get("DAFNE_RP_PAIR", "1") != "0" and (not getattr(plan, "shared_gpu", False)
+                                                                       or os.environ.get("DAFNE_RP_PAIR_SHARED", "0") == "1")
         deferred = []              # intermediate maps of cls_tower / center_tower: released when BOTH towers are built (see below)
 
         def tower(name, ins, in_gn, consumers):

@@ -452,6 +452,24 @@ int dafne_bottleneck_block_narrow_hip(const void* d_in, const void* d_res, const
                                       const float* d_bias3, const float* d_bias_sc, const float* d_bias1, int n_images, int H, int W,
                                       void* d_out, void* d_next, void* d_scratch, size_t scratch_bytes, void* stream);
 /*
+ * A WHOLE res3 bottleneck body, optionally with the head of the next block, in one kernel (same reference block;
+ * conv_blk_mid.hip):  T = relu(conv2(d_in) + bias2)  (3x3, 128 -> 128, pad 1; d_in = the block's conv1 output),
+ * d_out = relu(conv3(T) + bias3 + d_res)  (1x1, 128 -> 512; d_res = the block's shortcut: identity input or projection
+ * output) and, when d_next is given, d_next = relu(conv1'(d_out) + bias1)  (1x1, 512 -> 128).  d_in / d_next
+ * [N,H+2,W+2,128], d_res / d_out [N,H+2,W+2,512].  T never reaches HBM and every weight byte is fetched once per 128 pixels
+ * (dafne_bottleneck_tail_head_mid_hip: once per 64).  d_wfrag (engine.pack_blk_mid): conv2 fragment-major [4 channel
+ * groups][72 k16 steps][64 lanes][8] (rows group*32 + (lane & 31), K columns 16*step + 8*(lane >> 5) .. +8 of
+ * dafne_conv2d_nhwc_bf16_hip's packed weight: 64-channel slab, kh, kw, channel), conv3 [2 halves of 256][8 groups][8 steps]
+ * [64][8], conv1' [4 groups][32 steps][64][8] (zeros without d_next: the section is still read).  4 x 32 pixel tiles, any
+ * H, W: rows of out-of-image tile pixels are written to d_scratch (>= dafne_bottleneck_block_mid_scratch_bytes(); holds
+ * nothing afterwards).  Bit-identical to dafne_conv2d_nhwc_bf16_hip(conv2, RELU) followed by
+ * dafne_bottleneck_tail_head_mid_hip (or by dafne_conv2d_nhwc_bf16_hip(conv3, RELU|RESIDUAL) without d_next).
+ */
+size_t dafne_bottleneck_block_mid_scratch_bytes(void);
+int dafne_bottleneck_block_mid_hip(const void* d_in, const void* d_res, const void* d_wfrag, const float* d_bias2,
+                                   const float* d_bias3, const float* d_bias1, int n_images, int H, int W, void* d_out,
+                                   void* d_next, void* d_scratch, size_t scratch_bytes, void* stream);
+/*
  * detectron2 BasicStem in one kernel [recalled; the backbone of backbone/fpn.py:58-91]: conv 7x7 / s2 / p3
  * (FrozenBN folded into d_weight / d_bias) + ReLU + max-pool 3x3 / s2 / p1.  d_in: the layout
  * dafne_preprocess_image_hip writes, bf16 [N, H+6, W+6, 4]; d_weight: bf16 [64, 256] with k = (kh 0..7, kw 0..7,

@@ -1177,3 +1177,56 @@ def test_bottleneck_block_narrow_equals_the_separate_launches(N, H, W, head, pro
         y_ref = bfr(F.relu(F.conv2d(t_ref, w3, b3) + sc))
         got = y_f.nchw_float().cpu()
         assert float((got - y_ref).abs().max()) < 0.03 * float(y_ref.abs().max())
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# conv_blk_mid.hip: a WHOLE res3 bottleneck body (3x3 + conv3 + shortcut + ReLU [+ next conv1 + ReLU]) in one kernel
+@pytest.mark.parametrize("head", [True, False])
+@pytest.mark.parametrize("N,H,W", [(1, 8, 32), (2, 32, 64), (3, 13, 21), (1, 1, 1), (1, 20, 210), (8, 128, 128), (5, 36, 52)])
+def test_bottleneck_block_mid_equals_the_separate_launches(N, H, W, head):
+    """dafne_bottleneck_block_mid_hip (res3: conv2 3x3 128 -> 128 + ReLU, conv3 128 -> 512 + shortcut + ReLU, optionally the
+    next block's conv1 512 -> 128 + ReLU) against the generic launches: BIT FOR BIT on both outputs -- the headline shape
+    (8 x 128 x 128: 1024 tiles, four per workgroup), ragged tiles in both directions (out-of-image rows go to the dump area),
+    one tile per workgroup and fewer tiles than CUs, halo untouched, launched twice -- and against torch within bf16 rounding."""
+    from dafne_amd import engine, _lib
+    L = _lib.load()
+    d = dev()
+    g = torch.Generator().manual_seed(9000 + H * W + head)
+    u = bfr(torch.relu(torch.randn(N, 128, H, W, generator=g)))
+    x = bfr(torch.relu(torch.randn(N, 512, H, W, generator=g)))
+    w2 = bfr(torch.randn(128, 128, 3, 3, generator=g) / 34.0)
+    b2 = torch.randn(128, generator=g) * 0.2
+    w3 = bfr(torch.randn(512, 128, 1, 1, generator=g) / 11.0)
+    b3 = torch.randn(512, generator=g) * 0.2
+    w1 = bfr(torch.randn(128, 512, 1, 1, generator=g) / 22.0)
+    b1 = torch.randn(128, generator=g) * 0.2
+    st = _lib.current_stream()
+    ua, xa = engine.Act.from_nchw(u.to(d)), engine.Act.from_nchw(x.to(d))
+    w2p, b2p = engine.pack_conv(w2, b2, d)
+    w3p, b3p = engine.pack_conv(w3, b3, d)
+    w1p, b1p = engine.pack_conv(w1, b1, d)
+    t_u, y_u, z_u = engine.Act(N, H, W, 128, d), engine.Act(N, H, W, 512, d), engine.Act(N, H, W, 128, d)
+    engine.ConvCall(w2p, b2p, 128, 128, 3, 1, 1, engine.F_RELU, [(ua.t, t_u.t, None, H, W, H, W)], N)(st)
+    engine.ConvCall(w3p, b3p, 128, 512, 1, 1, 0, engine.F_RELU | engine.F_RES, [(t_u.t, y_u.t, xa.t, H, W, H, W)], N)(st)
+    if head:
+        engine.ConvCall(w1p, b1p, 512, 128, 1, 1, 0, engine.F_RELU, [(y_u.t, z_u.t, None, H, W, H, W)], N)(st)
+    wf = engine.pack_blk_mid(w2p, w3p, w1p if head else None)
+    scratch = torch.empty(L.dafne_bottleneck_block_mid_scratch_bytes(), dtype=torch.uint8, device=d)
+    y_f, z_f = engine.Act(N, H, W, 512, d), engine.Act(N, H, W, 128, d)
+    for _ in range(2):
+        _lib.check(L.dafne_bottleneck_block_mid_hip(_lib.ptr(ua.t), _lib.ptr(xa.t), _lib.ptr(wf), _lib.ptr(b2p), _lib.ptr(b3p),
+                                                    _lib.ptr(b1p) if head else None, N, H, W, _lib.ptr(y_f.t),
+                                                    _lib.ptr(z_f.t) if head else None, _lib.ptr(scratch), scratch.numel(), st), "blk_mid")
+    torch.cuda.synchronize()
+    assert float(y_f.t.float().abs().max()) > 0
+    assert torch.equal(y_f.t, y_u.t)
+    if head:
+        assert torch.equal(z_f.t, z_u.t)
+    else:
+        assert float(z_f.t.float().abs().max()) == 0           # untouched
+    assert float(y_f.t[:, 0].abs().max()) == 0 and float(y_f.t[:, :, -1].abs().max()) == 0 and float(y_f.t[:, -1].abs().max()) == 0
+    if N * H * W <= 3 * 64 * 64:
+        t_ref = bfr(F.relu(F.conv2d(u, w2, b2, padding=1)))
+        y_ref = bfr(F.relu(F.conv2d(t_ref, w3, b3) + x))
+        got = y_f.nchw_float().cpu()
+        assert float((got - y_ref).abs().max()) < 0.03 * float(y_ref.abs().max())
