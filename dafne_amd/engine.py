@@ -360,7 +360,7 @@ class ConvCall:
         self.keep = (w, b, gn_partial, [s for s in segs], gn_in, fp8, gn_fin, wfrag)
         gi = [t.data_ptr() for t in gn_in] if gn_in is not None else [None, None, None]
         gf = (gn_fin[0].data_ptr(), gn_fin[1].data_ptr(), float(gn_fin[2])) if gn_fin is not None else (None, None, 0.0)
-        if not shared_gpu:
+        if not shared_gpu or os.environ.get("DAFNE_SHARED_EXCL", "0") == "1":
             flags |= F_EXCL             # hint (results unchanged): the plan this call belongs to has the GPU to itself
         self.prm = _lib.ConvParams(n_images, len(segs), cin, cout, k, k, stride, pad, flags,
                                    w.data_ptr(), b.data_ptr() if b is not None else None,
