@@ -19,10 +19,12 @@ batch 8, one GPU) is measured in the same run at N=1 and reported under
 
 Extra objects on the JSON line:
   roofline      dominant kernel = the kernel with the most GPU time per step (whole batch on one stream: every launch
-                has the GPU to itself, the layout `--mode serial` runs and profiles/r02_kernel_stats_isolated.txt
+                has the GPU to itself, the layout `--mode serial` runs and profiles/r04b_kernel_stats_isolated.txt
                 profiles with rocprofv3): algorithmic FLOPs of its launches / their HIP-event time vs the dense bf16
-                MFMA peak (2.5 PFLOP/s).  Its sibling "roofline_timed" repeats the bookkeeping for the timed region's
-                layout (3 sub-batches on concurrent streams, where a launch's duration includes sharing the GPU);
+                MFMA peak (2.5 PFLOP/s); roofline.library_gemm = what torch.matmul (hipBLASLt) sustains in the same run on
+                that kernel's GEMM shape and on an 8192^3 bf16 GEMM (the practical ceiling: the matrix pipe's clock follows
+                its power draw).  Its sibling "roofline_timed" repeats the bookkeeping for the timed region's
+                layout (2 sub-batches on concurrent streams, where a launch's duration includes sharing the GPU);
                 every instantiation is listed under "kernels" (timed layout) and "kernels_isolated".  Rounds 1's
                 "roofline" was the timed layout, round 2 nested it as roofline.shared_stream: compare like with like
   roofline_nms  the rotated NMS on the SURVEY 8(d) candidate sets: class-filtered pairs per second and algorithmic bytes
@@ -368,6 +370,31 @@ def headline(args, world, dt, det_mean):
     return out
 
 
+def library_gemm_reference(device, batch):
+    """What the vendor GEMM (hipBLASLt through torch.matmul) sustains on THIS box, measured live: (a) the dominant kernel's
+    own GEMM shape with the im2col already done (M = batch x 21 824 tower pixels of a 1024^2 image, N = 256, K = 2304),
+    (b) a large square bf16 GEMM, both with random operands.  The matrix pipe's clock follows its power draw (the same
+    8192^3 GEMM runs 30 % faster on all-zero operands), so (b) is the practical ceiling `roofline.frac` is to be read
+    against; `peak` stays the guide's nominal 2.5 PFLOP/s."""
+    def run(M, N, K):
+        a = torch.randn(M, K, device=device).to(torch.bfloat16)
+        b = torch.randn(K, N, device=device).to(torch.bfloat16)
+        for _ in range(3):
+            a @ b
+        torch.cuda.synchronize()
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        for _ in range(10):
+            a @ b
+        e.record()
+        torch.cuda.synchronize()
+        return 2.0 * M * N * K * 10 / (s.elapsed_time(e) * 1e-3) / 1e12
+    M = batch * 21824
+    return {"same_gemm_shape_tflops": run(M, 256, 2304), "same_gemm_shape": [M, 256, 2304],
+            "square_8192_tflops": run(8192, 8192, 8192), "operands": "randn bf16",
+            "note": "torch.matmul (hipBLASLt), im2col not included; measured in this run"}
+
+
 def distributed_record(args, world, distributed, per_rank_s, gathered):
     """What the collective DELIVERED, so that an N > 1 line proves itself: `n_gpus` in the headline is the launcher's
     WORLD_SIZE; this records the process group's own size and backend, the number of images the last step's detection
@@ -546,6 +573,11 @@ def _run_worker(args, make_step, rank, world, distributed, device):
             except (OSError, KeyError, ValueError):
                 pass
             return None, None
+        try:
+            out["roofline"]["library_gemm"] = library_gemm_reference(device, args.batch)
+            out["roofline"]["frac_of_library_square_gemm"] = di["tflops"] / out["roofline"]["library_gemm"]["square_8192_tflops"]
+        except Exception as ex:                      # a reference figure must never cost the line
+            out["roofline"]["library_gemm"] = {"error": repr(ex)[:200]}
         tr, src = pmc_traffic("pmc_traffic_isolated.json")
         if tr is not None:
             out["roofline"]["traffic"] = tr

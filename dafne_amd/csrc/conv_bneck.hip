@@ -244,7 +244,7 @@ __global__ void __launch_bounds__(512, 2) conv_bneck_kernel(BneckDev P) {
     }
     auto dma_piece = [&](unsigned col0b, int sl, int ii) {       // slabs 0..2 land in the Y buffer, slab 3 in the side buffer
         __builtin_amdgcn_global_load_lds((gvoid*)(P.res + (size_t)dpix[ii] * (kCB * 2) + col0b + sl * 128 + dq[ii]),
-                                         (lvoid*)(lds + (sl == 3 ? kOffSide : kOffY + sl * kSlab) + (wave + kNW * ii) * 1024), 16, 0, 0);
+                                         (lvoid*)(lds + (sl == 3 ? kOffSide : kOffY + sl * kSlab) + (wave + kNW * ii) * 1024), 16, 0, 2);      // aux 2 = nt: X is read once per block (the Y rows, not-nt, are the next block's X)
     };
     auto dma_slab = [&](unsigned col0b, int sl) {                // 2 pieces per wave into slab sl of the Y buffer
         dma_piece(col0b, sl, 0);

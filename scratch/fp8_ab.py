@@ -1,5 +1,5 @@
 """Config 5 (UCAS-AOD head, R101-FPN, batch 16, fp8 weights) in one process: bf16 model, fp8 model with the 256-input layers on
-conv3x3_patch_fp8 (DAFNE_CONV_RP8=0 while its plans are built) and on conv3x3_rp8; alternating timed blocks.
+conv3x3_patch_fp8 (ENGINE.FP8_CONV3X3_KERNEL "patch") and on conv3x3_rp8 ("rp8"); alternating timed blocks.
 usage: fp8_ab.py [steps]"""
 import os, sys
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, R)
@@ -10,13 +10,17 @@ d = torch.device("cuda", 0)
 g = torch.Generator().manual_seed(0)
 b16 = torch.randint(0, 256, (16, 3, 1024, 1024), generator=g, dtype=torch.uint8).to(d)
 models = {}
-for name, cfgname, env in (("bf16", "ucas_aod_r101.yaml", "1"), ("fp8 patch", "ucas_aod_r101_fp8.yaml", "0"), ("fp8 rp8", "ucas_aod_r101_fp8.yaml", "1")):
-    os.environ["DAFNE_CONV_RP8"] = env
+SPL = int(os.environ.get("SPLITS", "2"))
+for name, cfgname, kern in (("bf16", "ucas_aod_r101.yaml", None), ("fp8 patch", "ucas_aod_r101_fp8.yaml", "patch"), ("fp8 rp8", "ucas_aod_r101_fp8.yaml", "rp8")):
     m = bench.build_model(101, d, seed=0, cfgname=cfgname, cls_prior=-1.5)[1]
+    if kern:
+        if hasattr(m.cfg, "defrost"): m.cfg.defrost()
+        m.cfg.ENGINE.FP8_CONV3X3_KERNEL = kern
+        m.invalidate()
     if "fp8" in name:
         m.calibrate_fp8(b16)
-    f = (lambda m: (lambda: m.detect_packed(b16, pipelined=True, splits=3)))(m)
-    for _ in range(3):
+    f = (lambda m: (lambda: m.detect_packed(b16, pipelined=True, splits=SPL)))(m)
+    for _ in range(6):
         f()
     torch.cuda.synchronize()
     models[name] = f

@@ -26,11 +26,10 @@ for k in range(NI):
     partial = torch.zeros(4096, C // 8, 2, device=d)
     fl = engine.F_GN | engine.F_GNIN
     cb = engine.ConvCall(wp, bp, C, C, 3, 1, 1, fl, segs, B, gn_partial=partial, gn_in=(stats, gamma, beta))
-    os.environ["DAFNE_CONV_RP8"] = "0"
+    f8 = engine.pack_conv3x3_frag8(wq)
     cq = engine.ConvCall(wq, bp, C, C, 3, 1, 1, fl, segs, B, gn_partial=partial, gn_in=(stats, gamma, beta), fp8=(ws, 1.0))
-    os.environ["DAFNE_CONV_RP8"] = "1"
-    cr = engine.ConvCall(wq, bp, C, C, 3, 1, 1, fl, segs, B, gn_partial=partial, gn_in=(stats, gamma, beta), fp8=(ws, 1.0))
-    crn = engine.ConvCall(wq, bp, C, C, 3, 1, 1, engine.F_GN, segs, B, gn_partial=partial, fp8=(ws, 1.0))
+    cr = engine.ConvCall(wq, bp, C, C, 3, 1, 1, fl, segs, B, gn_partial=partial, gn_in=(stats, gamma, beta), fp8=(ws, 1.0), frag8=f8)
+    crn = engine.ConvCall(wq, bp, C, C, 3, 1, 1, engine.F_GN, segs, B, gn_partial=partial, fp8=(ws, 1.0), frag8=f8)
     cbr = engine.ConvCall(wp, bp, C, C, 3, 1, 1, fl, segs, B, gn_partial=partial, gn_in=(stats, gamma, beta), wfrag=engine.pack_conv3x3_frag(wp))
     assert cq.kernel_name() == "conv3x3_patch_fp8" and cr.kernel_name() == "conv3x3_rp8" and cbr.kernel_name() == "conv3x3_rp"
     cn = engine.ConvCall(wp, bp, C, C, 3, 1, 1, engine.F_GN, segs, B, gn_partial=partial)
