@@ -298,7 +298,12 @@ def cpu_baseline(cfg, sd, depth, budget_s=4.0):
     d = cfg.MODEL.DAFNE
     P = {k: v.float() for k, v in sd.items()}
     g = torch.Generator().manual_seed(0)
-    cores = torch.get_num_threads()
+    # threads the host can really run: the scheduler affinity capped by the cgroup CPU quota (256 visible CPUs under a quota of
+    # 16 on this project's MI355X boxes; a 128-thread pool there is throttled as a group and measures the throttle)
+    from dafne_amd.utils.host import usable_cpus
+    threads_before = torch.get_num_threads()
+    cores = min(threads_before, usable_cpus())
+    torch.set_num_threads(cores)
 
     def full_path(imgs):
         with torch.no_grad():
@@ -335,7 +340,7 @@ def cpu_baseline(cfg, sd, depth, budget_s=4.0):
     nms_all = {}
     try:
         import multiprocessing as mp
-        nproc = max(1, min(8, os.cpu_count() or 1))
+        nproc = max(1, min(8, usable_cpus()))
         with mp.get_context("spawn").Pool(nproc) as pool:      # spawn: never fork a process that holds a HIP context
             pool.map(_nms_one, sets[:nproc])                    # warm (imports, page-in)
             t0 = time.perf_counter()
@@ -344,8 +349,9 @@ def cpu_baseline(cfg, sd, depth, budget_s=4.0):
                        "rotated_nms_all_cores_processes": nproc}
     except Exception as e:      # noqa: BLE001
         nms_all = {"rotated_nms_all_cores_error": "%s: %s" % (type(e).__name__, e)}
+    torch.set_num_threads(threads_before)
     out = {"rotated_nms_ms_per_img_m10000": nms_cpu_ms, "rotated_nms_cores": 1, "rotated_nms_kept": int(len(kq)),
-           "value": n_done / t_total, "unit": "images/sec", "cores": cores, "kind": "port",
+           "value": n_done / t_total, "unit": "images/sec", "cores": cores, "cpus_visible": os.cpu_count(), "kind": "port",
            "batch8_images_per_sec": 8 / t_b8,
            "sample": "%d x 1024x1024 image(s) at batch 1 (%.1f s) + one batch of 8 (%.1f s), R%d-FPN fp32 torch-CPU + "
                      "C/numpy post-process" % (n_done, t_total, t_b8, depth)}
@@ -471,6 +477,12 @@ def run(args, make_step=None, backend="nccl", device_kind="cuda"):
     if distributed:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    # host threads: never more than this worker's share of the CPUs the process group may use (affinity, cgroup quota): a
+    # pool sized by the visible CPU count is throttled as a group and stalls the HIP runtime's threads with it
+    from dafne_amd.utils.host import usable_cpus
+    share = max(1, usable_cpus() // max(world, 1))
+    if torch.get_num_threads() > share:
+        torch.set_num_threads(share)
     if args.gpus != world:
         raise SystemExit("bench.py: --gpus %d but the launched world size is %d (torch.distributed.run --nproc-per-node "
                          "must equal --gpus)" % (args.gpus, world))

@@ -16,6 +16,7 @@ import torch
 from torch import nn
 
 from .. import _lib, engine
+from ..utils.host import usable_cpus
 from .. import postprocess as pp
 from ..registry import BACKBONE_REGISTRY, META_ARCH_REGISTRY, PROPOSAL_GENERATOR_REGISTRY
 from ..structures import ImageList
@@ -391,8 +392,9 @@ class OneStageDetector(nn.Module):
                 # the workers' spin-wait after every copy starves the HIP runtime's completion threads: the streamed loop
                 # then stalls for 50-200 ms every few batches (measured 107-170 images/s; 1085 with 4 workers).  The loop's
                 # host side is latency work, not throughput work: cap the pool (process-wide, once).
-                if torch.get_num_threads() > 8:
-                    torch.set_num_threads(8)
+                cap = min(8, usable_cpus())
+                if torch.get_num_threads() > cap:
+                    torch.set_num_threads(cap)
             slot = st["i"] & 1
             st["i"] += 1
             key = (slot, n, H, W)

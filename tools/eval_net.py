@@ -37,6 +37,16 @@ def parse_args(argv=None):
     ap.add_argument("--height", type=int, default=0, help="synthetic image height (default INPUT.MIN_SIZE_TEST)")
     ap.add_argument("--width", type=int, default=0)
     ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--image-dir", default="",
+                    help="read the images from this directory (PNG / JPEG / BMP / TIFF) through dafne_amd.data.build_test_loader -- the "
+                         "reference's build_test_loader: PIL decode on worker threads, INPUT.RESIZE_TYPE resize on the GPU -- instead "
+                         "of synthetic tiles; --num-images caps the count (0: all)")
+    ap.add_argument("--write-synthetic-dir", default="",
+                    help="first write --num-images synthetic tiles (smooth content + noise: PNGs that compress like aerial tiles) into "
+                         "this directory, then use it as --image-dir: the file-fed loop on a box without a dataset")
+    ap.add_argument("--decode-workers", type=int, default=32,
+                    help="host workers decoding image files ahead of the GPU (capped at the CPUs this process may use, less two)")
+    ap.add_argument("--decode-backend", choices=["thread", "process"], default="thread")
     ap.add_argument("--tta", action="store_true", help="TEST.AUG multi-scale / flip inference")
     ap.add_argument("--tta-shard-views", action="store_true",
                     help="with --tta on several GPUs: shard the VIEWS of every image over the ranks (merge NMS on rank 0) instead "
@@ -68,6 +78,21 @@ def synthetic_inputs(n, h, w, seed, lo=0, hi=None, pixels=True):
     return out
 
 
+def write_synthetic_tiles(root, n, h, w, seed):
+    """n PNG tiles named like DOTA's split tiles; smooth low-frequency content plus noise, so that the files compress (and
+    decode) like photographs rather than like random bytes."""
+    import numpy as np
+    from PIL import Image
+    os.makedirs(root, exist_ok=True)
+    for i in range(n):
+        g = torch.Generator().manual_seed(seed * 1000003 + i)
+        low = torch.rand(1, 3, max(h // 32, 2), max(w // 32, 2), generator=g)
+        img = torch.nn.functional.interpolate(low, size=(h, w), mode="bilinear", align_corners=False)[0]
+        img = (img * 220 + torch.rand(3, h, w, generator=g) * 12).clamp_(0, 255).to(torch.uint8)
+        Image.fromarray(np.ascontiguousarray(img.permute(1, 2, 0).numpy())).save(
+            os.path.join(root, "P%04d__1__0___%d.png" % (i // 4, 824 * (i % 4))), compress_level=3)
+
+
 def run(args, rank=0, world=1, local_rank=0):
     import dafne_amd.modeling  # noqa: F401  (registers the classes)
     from dafne_amd.checkpoint import load_weights
@@ -95,24 +120,49 @@ def run(args, rank=0, world=1, local_rank=0):
     h = args.height or cfg.INPUT.MIN_SIZE_TEST
     w = args.width or cfg.INPUT.MIN_SIZE_TEST
     n = args.num_images
+    records = None
+    if args.write_synthetic_dir:
+        if args.tta:
+            raise SystemExit("--write-synthetic-dir / --image-dir feed the single-scale loop (the TTA wrapper builds its own views)")
+        if rank == 0 and not os.path.isdir(args.write_synthetic_dir):
+            write_synthetic_tiles(args.write_synthetic_dir, n, h, w, args.seed)
+        if world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+        args.image_dir = args.write_synthetic_dir
+    if args.image_dir:
+        if args.tta:
+            raise SystemExit("--image-dir feeds the single-scale loop (the TTA wrapper builds its own views)")
+        from dafne_amd.data import list_image_records
+        records = list_image_records(args.image_dir)
+        if n > 0:
+            records = records[:n]
+        n = len(records)
     lo, hi = shard_range(n, rank, world)
-    mine = synthetic_inputs(n, h, w, args.seed, lo, hi)
+    mine = synthetic_inputs(n, h, w, args.seed, lo, hi) if records is None else []
     k_cap = model.proposal_generator.dafne_outputs.packed_k_cap()      # the detector's own capacity rule
     tta = OneStageRCNNWithTTA(cfg, model) if args.tta else None
     if cfg.ENGINE.WEIGHT_DTYPE == "fp8_e4m3" and model.fp8_act_scales() is None and cfg.ENGINE.FP8_ACT_CALIBRATION == "explicit":
         # no scales came with the weights: calibrate on the first batch of every rank's shard; calibrate_fp8 MAX-reduces the
         # amax values over the ranks (a collective), so all ranks serve the same quantised model at any world size.  A rank
         # with an empty shard contributes the batch of image 0.
-        cal = mine[:args.batch] if mine else synthetic_inputs(n, h, w, args.seed, 0, min(1, n))
-        if cal:
-            model.calibrate_fp8(torch.stack([x["image"] for x in cal]).to(dev))
+        if records is not None:
+            from dafne_amd.data import DAFNeTestMapper
+            mp = DAFNeTestMapper(cfg, dev)
+            cal = [mp(r) for r in (records[lo:hi][:args.batch] or records[:1])]
+            if cal:
+                model.calibrate_fp8(model._pack_inputs(cal)[0])
+        else:
+            cal = mine[:args.batch] if mine else synthetic_inputs(n, h, w, args.seed, 0, min(1, n))
+            if cal:
+                model.calibrate_fp8(torch.stack([x["image"] for x in cal]).to(dev))
 
     def detect_batch(b0, b1):                # TTA: one merged Instances per image -> packed rows for the gather
         chunk = mine[b0 - lo:b1 - lo]
         insts = [o["instances"] for o in tta(chunk)]
         return instances_to_rows(insts, k_cap, dev)
 
-    meta = synthetic_inputs(n, h, w, args.seed, pixels=False)
+    meta = synthetic_inputs(n, h, w, args.seed, pixels=False) if records is None else None
     if tta is not None and args.tta_shard_views:
         # SURVEY 8(e), configs[3]: every rank sees every image and runs ITS share of the image's views; one gather per image
         # lands the per-view detections on rank 0, which inverts, concatenates and runs the merged NMS (tta.py:173-197,264-268)
@@ -136,11 +186,19 @@ def run(args, rank=0, world=1, local_rank=0):
                 x["image"] = x["image"].to(dev)
             torch.cuda.synchronize()
         b = max(args.batch, 1)
-        loader = [mine[i:i + b] for i in range(0, len(mine), b)]
+        if records is not None:
+            from dafne_amd.data.loader import InferenceLoader
+            loader = InferenceLoader(cfg, records, batch_size=b, device=dev, num_workers=args.decode_workers, shard=(rank, world),
+                                     backend=args.decode_backend, prefetch_batches=4)
+        else:
+            loader = [mine[i:i + b] for i in range(0, len(mine), b)]
         ev = DafneEvaluator("synthetic", cfg, distributed=world > 1, k_cap=k_cap, device=dev, pad_to=(n + world - 1) // world)
         stats = {}
-        if args.warmup_batches > 0 and loader:
-            inference_on_dataset(model, (loader * args.warmup_batches)[:args.warmup_batches], None)     # (two per plan set: eager, then graph capture)
+        if args.warmup_batches > 0 and len(loader):
+            import itertools
+            warm = (loader * args.warmup_batches)[:args.warmup_batches] if isinstance(loader, list) else \
+                list(itertools.islice(itertools.cycle(list(itertools.islice(iter(loader), 2))), args.warmup_batches))
+            inference_on_dataset(model, warm, None)     # (two per plan set: eager, then graph capture)
         if args.serial:
             class _Sync:                      # the synchronous form: model(inputs) per batch
                 def __init__(self, m):
@@ -153,14 +211,16 @@ def run(args, rank=0, world=1, local_rank=0):
             res = inference_on_dataset(model, loader, ev, stats)
         print("rank %d: inference_on_dataset %d images in %.3f s = %.1f images/s (batch %d, %s, images on the %s)"
               % (rank, stats["images"], stats["seconds"], stats["images_per_sec"], b,
-                 "synchronous" if args.serial else "streamed, %d sub-batch streams" % cfg.ENGINE.PIPELINE_SPLITS, args.images_on), flush=True)
+                 "synchronous" if args.serial else "streamed, %d sub-batch streams" % cfg.ENGINE.PIPELINE_SPLITS,
+                 args.images_on if records is None else "disk (%s, %d decode %s workers)" % (args.image_dir, args.decode_workers, args.decode_backend)), flush=True)
         if rank != 0:
             return None
         preds = res["predictions"]
-        by_id = {m["image_id"]: m for m in meta}
-        for p in preds:
-            m = by_id[p["image_id"]]
-            p.update(file_name=m["file_name"], height=m["height"], width=m["width"])
+        if meta is not None:
+            by_id = {m["image_id"]: m for m in meta}
+            for p in preds:
+                m = by_id[p["image_id"]]
+                p.update(file_name=m["file_name"], height=m["height"], width=m["width"])
         preds.sort(key=lambda p: p["image_id"])
         out = None
     if out is not None:
@@ -169,7 +229,7 @@ def run(args, rank=0, world=1, local_rank=0):
         for p, m in zip(preds, meta):
             p.update(file_name=m["file_name"], height=m["height"], width=m["width"])
     for p in preds:
-        print("image %d: %d detections, best score %.4f" % (p["image_id"], len(p["scores"]),
+        print("image %s: %d detections, best score %.4f" % (p["image_id"], len(p["scores"]),
                                                              float(p["scores"].max()) if len(p["scores"]) else 0.0))
     if args.output:
         torch.save(preds, args.output)
