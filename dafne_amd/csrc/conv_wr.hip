@@ -33,6 +33,7 @@ typedef __attribute__((address_space(1))) void gvoid;
 typedef __attribute__((address_space(3))) void lvoid;
 
 constexpr int kPx = 128, kCT = 256;                 // tile: pixels x output channels
+constexpr int kNominalBatch = 4;                    // images the split-K slice count is sized for (the timed layout's sub-batch)
 constexpr int kNW = 8, kNT = 512;
 constexpr int kPF = kPx / 32;                       // pixel fragments per wave
 constexpr int kStage = kPx * 128;                   // one K64 step of the pixel operand: [128 px][128 B]
@@ -373,12 +374,15 @@ int wr_build(WrDev& D, const dafne_conv_params* prm, const dafne_conv_seg* segs,
     D.ctiles = D.Cout / kCT;
     D.flags = prm->flags;
     if ((long long)D.ptiles * D.ctiles > kCounterBytes / 4) { *why = "too many tiles"; return 0; }
-    // slices: fill the chip, at least 4 K64 steps per slice, at most 8 slabs for the reducer.  A function of the shape and the
-    // CU count ONLY (not of the EXCLUSIVE hint): the slice count enters the fp32 grouping of the sum, and a batch must give the
-    // same bits whether its plan has the GPU to itself or shares it with other streams.
+    // slices: fill the chip, at least 4 K64 steps per slice, at most 8 slabs for the reducer.  The slice count enters the fp32
+    // grouping of the sum, so it is a function of the PER-IMAGE shape and the CU count only: not of the EXCLUSIVE hint (a batch
+    // gives the same bits whether its plan has the GPU to itself or shares it) and not of the batch size (an image gives the same
+    // bits whichever images share its batch: the TTA wrapper's grouped views, tests/test_gpu_model.py).  It is sized for the
+    // sub-batch the timed layout runs (kNominalBatch images); other batch sizes get that count.
     int cus = 0;
     if (dafne::device_cus(&cus)) cus = 256;
-    const int tiles = D.ptiles * D.ctiles;
+    const long long px_nom = (long long)kNominalBatch * S.Hout * S.Wout;
+    const int tiles = (int)((px_nom + kPx - 1) / kPx) * D.ctiles;
     int s = cus / tiles;
     if (s > D.nsteps / 4) s = D.nsteps / 4;
     if (s > 8) s = 8;

@@ -475,8 +475,13 @@ def use_wr_kernel():
     return os.environ.get("DAFNE_CONV_WR", "1") != "0"
 
 
+WR_NOMINAL_BATCH = 4      # conv_wr.hip kNominalBatch: the choice below and the kernel's slice count look at 4 images' worth of pixels,
+
+
 def wr_takes(k, stride, cin, cout, npx):
-    """Which small-M layers go to conv_wr: the shapes where it measured faster than the kernel dafne_conv2d_nhwc_bf16_hip picks,
+    """npx: WR_NOMINAL_BATCH x the output pixels of ONE image -- not the batch's: which kernel runs a layer (and how conv_wr groups
+    its fp32 sum) must not depend on the batch an image sits in, or its detections would (tta.py's grouped views).
+    Which small-M layers go to conv_wr: the shapes where it measured faster than the kernel dafne_conv2d_nhwc_bf16_hip picks,
     both as a whole batch of 8 alone on the GPU and as a 3-image sub-batch beside two others (scratch/wr_micro.py,
     profiles/NOTES_r04.md): res5 conv2 (3x3, 512 -> 512: x1.09 / x1.23), res5 conv3 (512 -> 2048 + residual: x1.02 / x1.11),
     FPN lateral 5 / 4 (x1.05-1.17), FPN output 5, P6, P7 (3x3 on <= 8192 pixels: x1.05-1.14), res4.0 conv1 (512 -> 256, stride
@@ -609,7 +614,7 @@ class DensePlan:
             c = ConvCall(q8[0] if fp8 else wgt, bias, cin, cout, k, stride, pad, flags,
                          [(tin.t, o.t, res.t if res is not None else None, tin.h, tin.w, ho, wo)], n, fp8=fp8,
                          shared_gpu=self.shared_gpu, frag8=frag8_of(P, key) if (fp8 and rp8_on and cin == 256 and k == 3) else None)
-            if (fp8 is None and wr_on and wr_takes(k, stride, cin, cout, n * ho * wo) and bias is not None
+            if (fp8 is None and wr_on and wr_takes(k, stride, cin, cout, WR_NOMINAL_BATCH * ho * wo) and bias is not None
                     and L.dafne_conv2d_wr_ok(ctypes.byref(c.prm), c.segs)):
                 # small-M layer (res5, FPN top): 128 px x 256 ch tiles, weights -> registers, split-K
                 if key + ".wr" not in P:

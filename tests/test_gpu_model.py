@@ -285,6 +285,59 @@ def test_tta_packed_chunks_equal_the_reference_style_loop():
         assert torch.equal(ix.pred_classes, iy.pred_classes)
 
 
+def test_tta_groups_of_images_match_the_per_image_calls():
+    """OneStageRCNNWithTTA.__call__ on several images of one size runs the same-shape views of up to images_per_group images as
+    one detector call (the reference augments image by image: a scheduling choice).  Per image the result EQUALS the per-image
+    call's: the same kernels on the same views, and no kernel's arithmetic depends on the batch an image sits in (conv_wr's
+    split-K slice count is sized per image, test_conv_wr_slices_follow_the_shape)."""
+    from dafne_amd.modeling.tta import OneStageRCNNWithTTA
+    cfg, m, P = build("dota-1.5_r101.yaml", seed=21)
+    cfg.TEST.AUG.MIN_SIZES = [96, 128, 160]
+    cfg.TEST.AUG.MAX_SIZE = 256
+    g = torch.Generator().manual_seed(12)
+    imgs = [torch.randint(0, 256, (3, 128, 160), generator=g, dtype=torch.uint8).to(dev()) for _ in range(4)]
+    imgs.append(torch.randint(0, 256, (3, 96, 128), generator=g, dtype=torch.uint8).to(dev()))
+    inputs = [{"image": im, "height": int(im.shape[1]) + 5, "width": int(im.shape[2]) + 3} for im in imgs]
+    one = OneStageRCNNWithTTA(cfg, m, images_per_group=1)
+    grp = OneStageRCNNWithTTA(cfg, m, images_per_group=3)
+    calls = []
+    orig = grp._views_packed
+    grp._views_packed = lambda views, sizes=None, sync=True: calls.append(list(sizes) if sizes else None) or orig(views, sizes, sync)
+    a = one(inputs)
+    b = grp(inputs)
+    # images 0-2 form one group (3 sizes x 3 variants x 3 images: chunks of 9), image 3 and the smaller image 4 go alone
+    assert calls == [[9, 9, 9], [3, 3, 3], [3, 3, 3]]
+    assert len(a) == len(b) == 5
+    for k, (x, y) in enumerate(zip(a, b)):
+        ix, iy = x["instances"], y["instances"]
+        assert ix.image_size == iy.image_size == (inputs[k]["height"], inputs[k]["width"])
+        assert len(ix) == len(iy) > 0, k
+        assert torch.equal(ix.pred_corners, iy.pred_corners) and torch.equal(ix.scores, iy.scores), k
+        assert torch.equal(ix.pred_classes, iy.pred_classes) and torch.equal(ix.centerness, iy.centerness), k
+
+
+def test_an_image_gets_the_same_detections_in_any_batch():
+    """Batch invariance of the whole path: image k's packed detections are the same bits at batch 1, in a batch of 3 and in a
+    batch of 8 (serial layout and sub-batch streams).  Holds because every kernel's per-output arithmetic is a function of the
+    image's own shape (tile mapping, K order, split-K slice count), never of the batch."""
+    cfg, m, P = build("dota-1.0_r101.yaml", seed=23)
+    g = torch.Generator().manual_seed(5)
+    b8 = torch.randint(0, 256, (8, 3, 160, 192), generator=g, dtype=torch.uint8).to(dev())
+    r8, c8 = m.detect_packed(b8)
+    torch.cuda.synchronize()
+    r8, c8 = r8.clone(), c8.clone()
+    for lo, hi in ((0, 1), (2, 5), (5, 8), (7, 8)):
+        r, c = m.detect_packed(b8[lo:hi].contiguous())
+        torch.cuda.synchronize()
+        assert torch.equal(c, c8[lo:hi]), (lo, hi)
+        for i in range(hi - lo):
+            k = int(c[i])
+            assert k > 0 and torch.equal(r[i, :k], r8[lo + i, :k]), (lo, hi, i)
+    rp, cp = m.detect_packed(b8, pipelined=True, splits=2)
+    torch.cuda.synchronize()
+    assert torch.equal(cp, c8) and all(torch.equal(rp[i, :int(c8[i])], r8[i, :int(c8[i])]) for i in range(8))
+
+
 def test_pipelined_side_stream_equals_serial():
     cfg, m, P = build("dota-1.0_r50.yaml", seed=13)
     g = torch.Generator().manual_seed(6)
