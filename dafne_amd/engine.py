@@ -475,7 +475,7 @@ def use_wr_kernel():
     return os.environ.get("DAFNE_CONV_WR", "1") != "0"
 
 
-WR_NOMINAL_BATCH = 4      # conv_wr.hip kNominalBatch: the choice below and the kernel's slice count look at 4 images' worth of pixels,
+WR_NOMINAL_BATCH = 8      # conv_wr.hip kNominalBatch: the choice below and the kernel's slice count look at 8 images' worth of pixels,
 
 
 def wr_takes(k, stride, cin, cout, npx):

@@ -1093,7 +1093,7 @@ def test_conv_wr_vs_igemm_and_torch(cin, cout, k, stride, H, W, N, fl, excl):
 def test_conv_wr_slices_follow_the_shape():
     """The slice count is a function of the PER-IMAGE shape and the CU count only -- NOT of the EXCLUSIVE hint (a batch gives the
     same bits alone on the GPU and beside other streams) and NOT of the batch size (an image gives the same bits whatever shares
-    its batch); it is sized for the timed layout's sub-batch of 4: res5 conv2 -> 64 tiles x 4, lateral5 -> 32 tiles x 8, P7 -> 8
+    its batch); it is sized for the headline batch of 8: res5 conv2 -> 128 tiles x 2, lateral5 -> 64 tiles x 4, P7 -> 8
     (at most 8 slabs for the reducer, at least 4 K64 steps per slice)."""
     from dafne_amd import engine, _lib
     L = _lib.load()
@@ -1106,11 +1106,11 @@ def test_conv_wr_slices_follow_the_shape():
         wp, bp = engine.pack_conv(torch.zeros(cout, cin, k, k), torch.zeros(cout), d)
         c = engine.ConvCall(wp, bp, cin, cout, k, stride, pad, 0, [(a.t, o.t, None, H, H, ho, wo)], N, shared_gpu=not excl)
         return L.dafne_conv2d_wr_splits(ctypes.byref(c.prm), c.segs)
-    assert splits(512, 512, 3, 1, 32, 8) == splits(512, 512, 3, 1, 32, 1) == splits(512, 512, 3, 1, 32, 16) == 4
-    assert splits(2048, 256, 1, 1, 32, 8) == 8
+    assert splits(512, 512, 3, 1, 32, 8) == splits(512, 512, 3, 1, 32, 1) == splits(512, 512, 3, 1, 32, 16) == 2
+    assert splits(2048, 256, 1, 1, 32, 8) == 4
     assert splits(256, 256, 3, 2, 16, 8) == 8
     assert splits(512, 2048, 1, 1, 32, 8) == 1
-    assert splits(512, 512, 3, 1, 32, 3, excl=False) == splits(512, 512, 3, 1, 32, 3, excl=True) == 4
+    assert splits(512, 512, 3, 1, 32, 3, excl=False) == splits(512, 512, 3, 1, 32, 3, excl=True) == 2
 
 
 # ------------------------------------------------------------------------------------------------------------------
