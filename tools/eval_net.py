@@ -212,7 +212,7 @@ def run(args, rank=0, world=1, local_rank=0):
         print("rank %d: inference_on_dataset %d images in %.3f s = %.1f images/s (batch %d, %s, images on the %s)"
               % (rank, stats["images"], stats["seconds"], stats["images_per_sec"], b,
                  "synchronous" if args.serial else "streamed, %d sub-batch streams" % cfg.ENGINE.PIPELINE_SPLITS,
-                 args.images_on if records is None else "disk (%s, %d decode %s workers)" % (args.image_dir, args.decode_workers, args.decode_backend)), flush=True)
+                 args.images_on if records is None else "disk (%s, %d decode %s workers)" % (args.image_dir, loader.num_workers, args.decode_backend)), flush=True)
         if rank != 0:
             return None
         preds = res["predictions"]
