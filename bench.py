@@ -699,6 +699,9 @@ def _run_worker(args, make_step, rank, world, distributed, device):
                 nd = [len(o["instances"]) for o in tta(ins)]
                 torch.cuda.synchronize()
                 dt_group = (time.perf_counter() - t0) / n_img
+                for _ in range(PRIME):       # the one-image call's chunks of 3 views are plans of their own
+                    tta([ins[0]])
+                torch.cuda.synchronize()
                 t0 = time.perf_counter()
                 for k in range(min(3, n_img)):
                     tta([ins[k]])

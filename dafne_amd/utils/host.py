@@ -5,7 +5,7 @@ import os
 __all__ = ["usable_cpus"]
 
 
-def usable_cpus():
+def usable_cpus(cgroup_root="/sys/fs/cgroup"):
     """CPUs this process can actually keep busy: the scheduler affinity, capped by the cgroup CPU bandwidth quota
     (cgroup v2 `cpu.max`, v1 `cpu.cfs_quota_us / cpu.cfs_period_us`).  `os.cpu_count()` ignores both: the MI355X boxes of this
     project show 256 CPUs under a quota of 16, and every thread beyond the quota gets the WHOLE process group throttled --
@@ -16,15 +16,15 @@ def usable_cpus():
         n = os.cpu_count() or 1
     quota = None
     try:
-        with open("/sys/fs/cgroup/cpu.max") as f:
+        with open(os.path.join(cgroup_root, "cpu.max")) as f:
             q, p = f.read().split()[:2]
             if q != "max":
                 quota = float(q) / float(p)
     except (OSError, ValueError):
         try:
-            with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as f:
+            with open(os.path.join(cgroup_root, "cpu", "cpu.cfs_quota_us")) as f:
                 q = float(f.read())
-            with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as f:
+            with open(os.path.join(cgroup_root, "cpu", "cpu.cfs_period_us")) as f:
                 p = float(f.read())
             if q > 0 and p > 0:
                 quota = q / p
