@@ -739,7 +739,39 @@ def _run_worker(args, make_step, rank, world, distributed, device):
                                           "entry": "evaluation.inference.inference_on_dataset -> OneStageDetector.forward_streamed "
                                                    "(ENGINE.PIPELINE_SPLITS %d), DafneEvaluator.process per batch" % cfg.ENGINE.PIPELINE_SPLITS}
 
-            for fn in (side_forward, side_r50, side_fp8, side_tta):
+            def side_files():
+                # the same model fed from IMAGE FILES through the reference-shaped loader: build_test_loader(cfg, dir)
+                # (tools/plain_train_net.py:280-313) -> inference_on_dataset.  PNG tiles written to a temporary directory first
+                # (smooth content + noise: 2 MB each); PIL decode on host threads is the bound here, not the GPU -- reported with
+                # the CPU count it ran on, never as `value`.
+                import shutil
+                import tempfile
+                from dafne_amd.data import build_test_loader
+                from dafne_amd.evaluation.inference import DafneEvaluator, inference_on_dataset
+                from dafne_amd.utils.host import usable_cpus
+                sys.path.insert(0, os.path.join(ROOT, "tools"))
+                import eval_net
+                nthreads = torch.get_num_threads()
+                root = tempfile.mkdtemp(prefix="dafne_tiles_")
+                try:
+                    n_files = 12 * args.batch
+                    eval_net.write_synthetic_tiles(root, n_files, args.size, args.size, 0)
+                    mk = lambda: build_test_loader(cfg, root, batch_size=args.batch, device=device, num_workers=64, prefetch_batches=4)
+                    ev = DafneEvaluator("tiles", cfg, distributed=False)
+                    inference_on_dataset(model, list(mk())[:2], ev)               # warm-up (plans exist already; pinned staging)
+                    st = {}
+                    ld = mk()
+                    r = inference_on_dataset(model, ld, ev, st)
+                    assert r["num_images"] == n_files
+                    out["through_files"] = {"images_per_sec": st["images_per_sec"], "files": n_files, "decode_threads": ld.num_workers,
+                                            "cpus_usable": usable_cpus(), "cpus_visible": os.cpu_count(),
+                                            "bound": "host PNG decode (PIL), not the GPU",
+                                            "entry": "data.build_test_loader -> evaluation.inference.inference_on_dataset"}
+                finally:
+                    shutil.rmtree(root, ignore_errors=True)
+                    torch.set_num_threads(nthreads)
+
+            for fn in (side_forward, side_r50, side_fp8, side_tta, side_files):
                 try:
                     fn()
                 except Exception as e:      # noqa: BLE001
