@@ -135,10 +135,11 @@ def _gn_ref(y, gamma, beta, groups, eps=1e-5):
 
 
 @pytest.mark.parametrize("cin,cout,H,W,N,relu", [
-    (256, 256, 64, 64, 13, False),      # 13 x 16 tiles of 8x32, FPN-output-like (the library wants >= 200 tiles)
-    (64, 256, 40, 100, 10, True),       # one slab, ragged in both directions (40 = 5x8, 100 = 3x32 + 4)
-    (128, 512, 33, 47, 10, True),       # two channel tiles, ragged rows (33) and columns (47)
-    (320, 256, 24, 64, 36, False),      # five slabs
+    # (the library sends a layer here when 8 images of its shape make >= 200 tiles of 8x32 -- a nominal batch, whatever N is)
+    (256, 256, 128, 96, 3, False),      # 16 x 3 tiles per image, FPN-output-like
+    (64, 256, 40, 132, 3, True),        # one slab, ragged in both directions (40 = 5x8, 132 = 4x32 + 4)
+    (128, 512, 33, 79, 2, True),        # two channel tiles, ragged rows (33) and columns (79)
+    (320, 256, 40, 160, 2, False),      # five slabs
 ])
 def test_patch_kernel_vs_torch(cin, cout, H, W, N, relu):
     """3x3 patch kernel (conv.hip: conv3x3_patch_kernel): 2-D tiles, patch DMA with halo, tap-offset reads."""
@@ -163,8 +164,8 @@ def test_patch_kernel_gn_stats_and_gn_input_chain():
     d = dev()
     L = _lib.load()
     g = torch.Generator().manual_seed(77)
-    C, N = 256, 16
-    sizes = [(40, 72), (16, 32), (8, 8)]        # 15 + 2 + 1 tiles per image
+    C, N = 256, 4
+    sizes = [(48, 104), (16, 32), (8, 8)]       # 24 + 2 + 1 tiles per image (the patch kernel takes >= 200 per nominal batch of 8)
     xs = [bfr(torch.randn(N, C, h, w, generator=g)) for h, w in sizes]
     w1 = bfr(torch.randn(C, C, 3, 3, generator=g) / (C * 9) ** 0.5)
     w2 = bfr(torch.randn(C, C, 3, 3, generator=g) / (C * 9) ** 0.5)
@@ -432,20 +433,20 @@ def test_big_tile_groupnorm_stats_and_residual():
     """256x256 tile path: GN partial sums (reduced on the host here) and residual+ReLU."""
     from dafne_amd import engine, _lib
     g = torch.Generator().manual_seed(6)
-    N, C, H, W = 2, 256, 256, 256
-    x = bfr(torch.randn(N, 64, H, W, generator=g))
-    w = bfr(torch.randn(C, 64, 1, 1, generator=g) / 8.0)
+    N, C, H, W, CI = 2, 256, 128, 128, 320     # (1x1 layers with <= 256 input channels go to 128-wide tiles: conv_ws)
+    x = bfr(torch.randn(N, CI, H, W, generator=g))
+    w = bfr(torch.randn(C, CI, 1, 1, generator=g) / CI ** 0.5)
     b = torch.randn(C, generator=g) * 0.1
     y = F.conv2d(x, w, b)
     d = dev()
     a = engine.Act.from_nchw(x.to(d))
     wp, bp = engine.pack_conv(w, b, d)
     oa = engine.Act(N, H, W, C, d)
-    probe = engine.ConvCall(wp, bp, 64, C, 1, 1, 0, 0, [(a.t, oa.t, None, H, W, H, W)], N)
+    probe = engine.ConvCall(wp, bp, CI, C, 1, 1, 0, 0, [(a.t, oa.t, None, H, W, H, W)], N)
     assert probe.tile_pixels() == 256
     nt = probe.num_tiles()
     partial = torch.zeros(nt, C // 8, 2, dtype=torch.float32, device=d)
-    engine.ConvCall(wp, bp, 64, C, 1, 1, 0, engine.F_GN, [(a.t, oa.t, None, H, W, H, W)], N, gn_partial=partial)(
+    engine.ConvCall(wp, bp, CI, C, 1, 1, 0, engine.F_GN, [(a.t, oa.t, None, H, W, H, W)], N, gn_partial=partial)(
         _lib.current_stream())
     torch.cuda.synchronize()
     close_bf16(oa.nchw_float().cpu(), bfr(y))
@@ -792,8 +793,9 @@ def _rp_call(wp, bp, cout, flags, segs, N, d, **kw):
 
 @pytest.mark.parametrize("cout,sizes,N,relu", [
     (256, [(64, 64)], 8, True),                                   # res4-like: exact 4 x 32 tiles
-    (256, [(128, 128), (64, 64), (32, 32), (16, 16), (8, 8)], 2, False),      # the five head levels in one launch
-    (512, [(33, 47), (5, 70)], 3, True),                          # two channel tiles; ragged rows and columns, 3 tile columns
+    # (the generic entry point must stay on conv_igemm here: < 200 patch-kernel tiles per nominal batch of 8)
+    (256, [(64, 64), (32, 32), (16, 16), (8, 8), (4, 4)], 2, False),          # five levels in one launch
+    (512, [(25, 47), (5, 70)], 3, True),                          # two channel tiles; ragged rows and columns, 3 tile columns
     (256, [(1, 1), (3, 2)], 1, False),                            # smaller than a tile
 ])
 def test_resident_patch_kernel_equals_generic_conv(cout, sizes, N, relu):

@@ -316,13 +316,17 @@ def test_tta_groups_of_images_match_the_per_image_calls():
         assert torch.equal(ix.pred_classes, iy.pred_classes) and torch.equal(ix.centerness, iy.centerness), k
 
 
-def test_an_image_gets_the_same_detections_in_any_batch():
+@pytest.mark.parametrize("h,w", [(160, 192), (512, 640)])
+def test_an_image_gets_the_same_detections_in_any_batch(h, w):
     """Batch invariance of the whole path: image k's packed detections are the same bits at batch 1, in a batch of 3 and in a
-    batch of 8 (serial layout and sub-batch streams).  Holds because every kernel's per-output arithmetic is a function of the
-    image's own shape (tile mapping, K order, split-K slice count), never of the batch."""
+    batch of 8 (serial layout and sub-batch streams).  Holds because every kernel's per-output arithmetic AND the choice of
+    kernel are functions of the image's own shape -- tile mapping, K order, split-K slice count, and the occupancy heuristics
+    count the tiles of a nominal batch of 8 (conv.hip kNominalBatch, conv_wr.hip): at 512 x 640 a batch of 1-3 used to put the
+    towers' first layers on the generic tile (other GroupNorm partial sums than the resident-patch kernel's) and the stride-2
+    shortcuts on other kernels than a batch of 8."""
     cfg, m, P = build("dota-1.0_r101.yaml", seed=23)
     g = torch.Generator().manual_seed(5)
-    b8 = torch.randint(0, 256, (8, 3, 160, 192), generator=g, dtype=torch.uint8).to(dev())
+    b8 = torch.randint(0, 256, (8, 3, h, w), generator=g, dtype=torch.uint8).to(dev())
     r8, c8 = m.detect_packed(b8)
     torch.cuda.synchronize()
     r8, c8 = r8.clone(), c8.clone()
@@ -336,6 +340,28 @@ def test_an_image_gets_the_same_detections_in_any_batch():
     rp, cp = m.detect_packed(b8, pipelined=True, splits=2)
     torch.cuda.synchronize()
     assert torch.equal(cp, c8) and all(torch.equal(rp[i, :int(c8[i])], r8[i, :int(c8[i])]) for i in range(8))
+    if h >= 512:
+        names = lambda n: [c.kernel_name() for c in m.plan(n, h, w).calls]
+        assert names(1) == names(3) == names(8)              # one launch list per image shape
+
+
+def test_tta_groups_equal_the_per_image_calls_at_view_sizes_that_cross_the_tile_thresholds():
+    """The released TTA sizes on a 1024^2 tile give views of 450 .. 1200 pixels; at 450-700 a chunk of 3 views and a chunk of 9
+    used to differ in kernel choice.  Two sizes of that range on 640^2 images, groups of 3 against one image per call."""
+    from dafne_amd.modeling.tta import OneStageRCNNWithTTA
+    cfg, m, P = build("dota-1.5_r101.yaml", seed=21)
+    cfg.TEST.AUG.MIN_SIZES = [450, 700]
+    cfg.TEST.AUG.MAX_SIZE = 1200
+    g = torch.Generator().manual_seed(14)
+    inputs = [{"image": torch.randint(0, 256, (3, 640, 640), generator=g, dtype=torch.uint8).to(dev()), "height": 640, "width": 640}
+              for _ in range(3)]
+    a = OneStageRCNNWithTTA(cfg, m, images_per_group=1)(inputs)
+    b = OneStageRCNNWithTTA(cfg, m, images_per_group=3)(inputs)
+    for k, (x, y) in enumerate(zip(a, b)):
+        ix, iy = x["instances"], y["instances"]
+        assert len(ix) == len(iy) > 0, k
+        assert torch.equal(ix.pred_corners, iy.pred_corners) and torch.equal(ix.scores, iy.scores), k
+        assert torch.equal(ix.pred_classes, iy.pred_classes), k
 
 
 def test_pipelined_side_stream_equals_serial():
