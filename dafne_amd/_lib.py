@@ -120,6 +120,8 @@ SIGNATURES = {
     "dafne_bottleneck_block_mid_scratch_bytes": (c_size_t, []),
     "dafne_bottleneck_block_mid_hip": (c_int, [c_void_p] * 6 + [c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "dafne_stem_pool_hip": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "dafne_stem_pool_conv1_hip": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p,
+                                          c_void_p]),
     "dafne_maxpool3x3s2_nhwc_bf16_hip": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "dafne_groupnorm_relu_nhwc_bf16_hip": (c_int, [ctypes.POINTER(GnSeg), c_int, c_int, c_int, c_void_p, c_void_p,
                                                    c_void_p, c_void_p, c_float, c_void_p]),

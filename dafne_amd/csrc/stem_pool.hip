@@ -14,6 +14,9 @@
 //     patch row (2 taps x 4 ch), so im2col is just an LDS address;
 //   * 8 waves = 2 channel halves x 4 fragment lanes; a wave keeps its 14 weight fragments in registers for the
 //     whole kernel (weights never touch LDS);
+//   * CONV1 (round 4): res2.0's first convolution (1x1, 64 -> 64, + ReLU) on the pooled tile while it is still in LDS --
+//     the pooled map is written once and not read back by a separate launch (67 MB at batch 8); K order and epilogue
+//     expression of the generic kernel: bit-identical to stem_pool -> dafne_conv2d_nhwc_bf16_hip;
 //   * K is walked in the same order as the generic kernel's stem path (the skipped kh = 7 steps multiply zero
 //     weights), and max of post-ReLU bf16 values is exact: results are bit-identical to conv -> pool.
 #include "common.h"
@@ -35,6 +38,9 @@ constexpr int kPatchBytes = kPatchChunks * 16;   // 25 024
 constexpr int kStgRow = 64 * 2 + 16;             // staged conv pixel: 64 ch bf16 + pad (bank spread, 16-B aligned)
 constexpr int kOffStg = 2 * kPatchBytes;
 constexpr int kSmem = kOffStg + kCPx * kStgRow;  // 134 288 B
+constexpr int kOffPT = kSmem;                    // CONV1: the pooled tile [128 px][128 B], chunk ^ ((px >> 1) & 7)
+constexpr int kSmem1 = kOffPT + kTH * kTW * 128; // 150 672 B
+static_assert(kSmem1 <= 160 * 1024, "LDS budget");
 constexpr int kFetch = (kPatchChunks + 511) / 512;   // chunks per thread: 4
 
 struct StemDev {
@@ -42,6 +48,9 @@ struct StemDev {
     const char* w;       // bf16 [64, 256]: k = (kh 0..7, kw 0..7, c 0..3)
     const float* bias;   // [64]
     char* out;           // bf16 [N, H/4+2, W/4+2, 64]
+    const char* w1;      // CONV1: bf16 [64, 64] (cout, cin)
+    const float* b1;     // CONV1: [64]
+    char* out1;          // CONV1: bf16 [N, H/4+2, W/4+2, 64]
     int N, H, W;         // padded image size (multiples of 4; conv H/2 x W/2, pool H/4 x W/4)
     int tiles_x, tiles_y, tiles;
 };
@@ -60,6 +69,7 @@ __device__ __forceinline__ unsigned max_u16x2(unsigned a, unsigned b) {
     return r;
 }
 
+template <bool CONV1>
 __global__ void __launch_bounds__(512) stem_pool_kernel(StemDev P) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const int tid = threadIdx.x;
@@ -125,6 +135,16 @@ __global__ void __launch_bounds__(512) stem_pool_kernel(StemDev P) {
 
     const float4 bia[4] = {*(const float4*)(P.bias + cf * 32 + 0 + 4 * half), *(const float4*)(P.bias + cf * 32 + 8 + 4 * half),
                            *(const float4*)(P.bias + cf * 32 + 16 + 4 * half), *(const float4*)(P.bias + cf * 32 + 24 + 4 * half)};
+
+    // CONV1: wave = (cout half cf) x (pooled row fl of the tile: pixels fl * 32 + frow); its four k16 weight fragments
+    bf16x8 a1[4];
+    float4 bia1[4];
+    if constexpr (CONV1) {
+#pragma unroll
+        for (int kc = 0; kc < 4; kc++) a1[kc] = *(const bf16x8*)(P.w1 + ((size_t)(cf * 32 + frow) * 64 + 16 * kc + 8 * half) * 2);
+#pragma unroll
+        for (int g = 0; g < 4; g++) bia1[g] = *(const float4*)(P.b1 + cf * 32 + 8 * g + 4 * half);
+    }
 
     for (int it = 0; tile < P.tiles; tile += G, it++) {
         const int buf = it & 1;
@@ -199,9 +219,42 @@ __global__ void __launch_bounds__(512) stem_pool_kernel(StemDev P) {
             const int py = ty * kTH + qy, px = tx * kTW + qx;
             if (py < Hq && px < Wq)
                 *(u32x4*)(P.out + ((((size_t)img * (Hq + 2) + py + 1) * (Wq + 2) + px + 1) * 64 + ch * 8) * 2) = m;
+            if constexpr (CONV1) *(u32x4*)(lds + kOffPT + q * 128 + ((ch ^ ((q >> 1) & 7)) * 16)) = m;
         }
         if (more) stash(buf ^ 1, pre);
-        __syncthreads();     // next patch complete; everyone is done with the staging tile
+        __syncthreads();     // next patch complete; everyone is done with the staging tile (CONV1: the pooled tile is complete)
+        if constexpr (CONV1) {
+            // (the next tile's pool phase rewrites the pooled tile only behind its own first barrier: every wave is past this)
+            f32x16 c1;
+#pragma unroll
+            for (int k = 0; k < 16; k++) c1[k] = 0.f;
+            const int q = fl * 32 + frow;
+#pragma unroll
+            for (int kc = 0; kc < 4; kc++) {
+                const bf16x8 bq = *(const bf16x8*)(lds + kOffPT + q * 128 + (((2 * kc + half) ^ ((q >> 1) & 7)) * 16));
+                c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1[kc], bq, c1, 0, 0, 0);
+            }
+            u32x2 pk[4];
+#pragma unroll
+            for (int g = 0; g < 4; g++) {
+                const float v0 = fmaxf(c1[4 * g] + bia1[g].x, 0.f), v1 = fmaxf(c1[4 * g + 1] + bia1[g].y, 0.f);
+                const float v2 = fmaxf(c1[4 * g + 2] + bia1[g].z, 0.f), v3 = fmaxf(c1[4 * g + 3] + bia1[g].w, 0.f);
+                pk[g].x = pack_bf16(v0, v1);
+                pk[g].y = pack_bf16(v2, v3);
+            }
+            const int py = ty * kTH + fl, px = tx * kTW + frow;
+            const bool ok = py < Hq && px < Wq;
+            char* o1 = P.out1 + ((((size_t)img * (Hq + 2) + py + 1) * (Wq + 2) + px + 1) * 64 + cf * 32 + 8 * half) * 2;
+#pragma unroll
+            for (int gp = 0; gp < 2; gp++) {
+                // lanes 0..31 get (group 2gp: own channels 0..3 | the upper half-wave's 4..7), lanes 32..63 the same of group 2gp+1
+                const u32x2 a = pk[2 * gp], c2 = pk[2 * gp + 1];
+                const auto r0 = __builtin_amdgcn_permlane32_swap(a.x, c2.x, false, false);
+                const auto r1 = __builtin_amdgcn_permlane32_swap(a.y, c2.y, false, false);
+                const u32x4 v = {r0[0], r1[0], r0[1], r1[1]};
+                if (ok) *(u32x4*)(o1 + gp * 32) = v;
+            }
+        }
     }
 }
 
@@ -209,24 +262,37 @@ __global__ void __launch_bounds__(512) stem_pool_kernel(StemDev P) {
 
 extern "C" {
 
-int dafne_stem_pool_hip(const void* d_in, const void* d_weight, const float* d_bias, int n_images, int H, int W,
-                        void* d_out, void* stream) {
+static int stem_launch(const void* d_in, const void* d_weight, const float* d_bias, const void* d_w1, const float* d_b1, int n_images,
+                       int H, int W, void* d_out, void* d_out1, void* stream, bool conv1) {
     if (!d_in || !d_weight || !d_bias || !d_out || n_images < 1) return dafne::fail(DAFNE_E_INVALID, "stem_pool: null argument");
+    if (conv1 && (!d_w1 || !d_b1 || !d_out1)) return dafne::fail(DAFNE_E_INVALID, "stem_pool_conv1: null argument");
     if (H < 4 || W < 4 || (H % 4) || (W % 4)) return dafne::fail(DAFNE_E_INVALID, "stem_pool: image size %dx%d must be a multiple of 4", H, W);
     StemDev D;
     D.in = (const char*)d_in; D.w = (const char*)d_weight; D.bias = d_bias; D.out = (char*)d_out;
+    D.w1 = (const char*)d_w1; D.b1 = d_b1; D.out1 = (char*)d_out1;
     D.N = n_images; D.H = H; D.W = W;
     D.tiles_x = (W / 4 + kTW - 1) / kTW;
     D.tiles_y = (H / 4 + kTH - 1) / kTH;
     const long long tiles = (long long)D.tiles_x * D.tiles_y * n_images;
     if (tiles > (1ll << 30)) return dafne::fail(DAFNE_E_UNSUPPORTED, "stem_pool: too many tiles");
     D.tiles = (int)tiles;
-    DAFNE_MAX_LDS_ONCE(kSmem, (const void*)stem_pool_kernel);
+    DAFNE_MAX_LDS_ONCE(kSmem1, (const void*)stem_pool_kernel<false>, (const void*)stem_pool_kernel<true>);
     int cus = 0;
     if (int rc = dafne::device_cus(&cus)) return rc;
     const int grid = D.tiles < cus ? D.tiles : cus;
-    hipLaunchKernelGGL(stem_pool_kernel, dim3(grid), dim3(512), kSmem, (hipStream_t)stream, D);
-    return dafne::check_launch("stem_pool");
+    if (conv1) hipLaunchKernelGGL(stem_pool_kernel<true>, dim3(grid), dim3(512), kSmem1, (hipStream_t)stream, D);
+    else hipLaunchKernelGGL(stem_pool_kernel<false>, dim3(grid), dim3(512), kSmem, (hipStream_t)stream, D);
+    return dafne::check_launch(conv1 ? "stem_pool_conv1" : "stem_pool");
+}
+
+int dafne_stem_pool_hip(const void* d_in, const void* d_weight, const float* d_bias, int n_images, int H, int W,
+                        void* d_out, void* stream) {
+    return stem_launch(d_in, d_weight, d_bias, nullptr, nullptr, n_images, H, W, d_out, nullptr, stream, false);
+}
+
+int dafne_stem_pool_conv1_hip(const void* d_in, const void* d_weight, const float* d_bias, const void* d_w1, const float* d_b1,
+                              int n_images, int H, int W, void* d_out, void* d_out1, void* stream) {
+    return stem_launch(d_in, d_weight, d_bias, d_w1, d_b1, n_images, H, W, d_out, d_out1, stream, true);
 }
 
 }  // extern "C"

@@ -638,13 +638,28 @@ class DensePlan:
         wgt, bias = P["stem"]
         x = pool.get(n, h // 4, w // 4, 64)
         stem_flops = 2 * n * (h // 2) * (w // 2) * 64 * 7 * 7 * 3
+        stem_y1 = None            # res2.0's conv1 output when the stem kernel computed it
         if os.environ.get("DAFNE_FUSE_STEM", "1") != "0":
             # conv7x7/s2 + ReLU + max-pool in one kernel: the half-resolution map never reaches HBM
-            fc = FnCall(L.dafne_stem_pool_hip, (_lib.ptr(self.stem_in), _lib.ptr(wgt), _lib.ptr(bias), n, h, w, _lib.ptr(x.t)),
-                        (self.stem_in, wgt, bias, x), "stem_pool", flops=stem_flops,
-                        nbytes=n * ((h + 6) * (w + 6) * 8 + (h // 4) * (w // 4) * 128))
-            self.calls.append(fc)
-            self.flops += stem_flops
+            c1 = P.get("res2.0.conv1")
+            if (os.environ.get("DAFNE_FUSE_STEM_CONV1", "1") != "0" and c1 is not None and tuple(c1[0].shape) == (64, 64)
+                    and c1[1] is not None):
+                # ... and res2.0's first convolution (1x1, 64 -> 64, ReLU) on the pooled tile while it is in LDS
+                # (stem_pool.hip CONV1): the pooled map is not read back by a launch of its own (67 MB at batch 8)
+                stem_y1 = pool.get(n, h // 4, w // 4, 64)
+                c1_flops = 2 * n * (h // 4) * (w // 4) * 64 * 64
+                fc = FnCall(L.dafne_stem_pool_conv1_hip, (_lib.ptr(self.stem_in), _lib.ptr(wgt), _lib.ptr(bias), _lib.ptr(c1[0]),
+                                                          _lib.ptr(c1[1]), n, h, w, _lib.ptr(x.t), _lib.ptr(stem_y1.t)),
+                            (self.stem_in, wgt, bias, c1[0], c1[1], x, stem_y1), "stem_pool_conv1", flops=stem_flops + c1_flops,
+                            nbytes=n * ((h + 6) * (w + 6) * 8 + (h // 4) * (w // 4) * 256))
+                self.calls.append(fc)
+                self.flops += stem_flops + c1_flops
+            else:
+                fc = FnCall(L.dafne_stem_pool_hip, (_lib.ptr(self.stem_in), _lib.ptr(wgt), _lib.ptr(bias), n, h, w, _lib.ptr(x.t)),
+                            (self.stem_in, wgt, bias, x), "stem_pool", flops=stem_flops,
+                            nbytes=n * ((h + 6) * (w + 6) * 8 + (h // 4) * (w // 4) * 128))
+                self.calls.append(fc)
+                self.flops += stem_flops
         else:
             stem_out = pool.get(n, h // 2, w // 2, 64)
             c = ConvCall(wgt, bias, 4, 64, 7, 2, 3, F_RELU,
@@ -667,7 +682,7 @@ class DensePlan:
         fuse_blk_mid = fuse_mid and os.environ.get("DAFNE_FUSE_BLK_MID", "1") != "0"
         fuse_blk_narrow = fuse_narrow and os.environ.get("DAFNE_FUSE_BLK_NARROW", "1") != "0"
         for si, nb in enumerate(STAGE_BLOCKS[depth]):
-            y1_next = None
+            y1_next = stem_y1 if si == 0 else None
             for b in range(nb):
                 p = "res%d.%d." % (si + 2, b)
                 stride = 2 if (b == 0 and si > 0) else 1

@@ -480,6 +480,14 @@ int dafne_bottleneck_block_mid_hip(const void* d_in, const void* d_res, const vo
  */
 int dafne_stem_pool_hip(const void* d_in, const void* d_weight, const float* d_bias, int n_images, int H, int W,
                         void* d_out, void* stream);
+/*
+ * The same, plus the first convolution of res2.0 (detectron2 BottleneckBlock.conv1 [recalled]: 1x1, 64 -> 64, FrozenBN folded,
+ * + ReLU) computed on the pooled tile while it is in LDS: d_w1 bf16 [64, 64] (cout, cin: the weight of
+ * dafne_conv2d_nhwc_bf16_hip), d_b1 fp32 [64], d_out1 bf16 [N, H/4+2, W/4+2, 64] (interior written).  d_out as above.
+ * Bit-identical to dafne_stem_pool_hip followed by dafne_conv2d_nhwc_bf16_hip(1x1, RELU) on d_out.
+ */
+int dafne_stem_pool_conv1_hip(const void* d_in, const void* d_weight, const float* d_bias, const void* d_w1, const float* d_b1,
+                              int n_images, int H, int W, void* d_out, void* d_out1, void* stream);
 /* 3x3 stride-2 pad-1 max pool of a post-ReLU map: [N,Hin+2,Win+2,C] -> [N,Hin/2+2,Win/2+2,C] */
 int dafne_maxpool3x3s2_nhwc_bf16_hip(const void* d_in, void* d_out, int n_images, int Hin, int Win,
                                      int C, void* stream);

@@ -459,6 +459,48 @@ def test_big_tile_groupnorm_stats_and_residual():
     close_bf16(got, bfr(F.relu(y + res)))
 
 
+@pytest.mark.parametrize("N,H,W", [(2, 64, 96), (1, 132, 260), (3, 16, 128)])
+def test_stem_pool_conv1_equals_stem_pool_then_conv(N, H, W):
+    """dafne_stem_pool_conv1_hip (stem_pool.hip CONV1: res2.0's 1x1 64 -> 64 convolution on the pooled tile in LDS) against
+    dafne_stem_pool_hip followed by dafne_conv2d_nhwc_bf16_hip: both outputs bit-identical, halos untouched; ragged tiles
+    (33 x 65 pooled pixels) and several tiles per workgroup."""
+    from dafne_amd import engine, _lib
+    L = _lib.load()
+    d = dev()
+    g = torch.Generator().manual_seed(N * 1000 + H + W)
+    img = torch.randint(0, 256, (N, 3, H, W), generator=g, dtype=torch.uint8).to(d)
+    w = bfr(torch.randn(64, 3, 7, 7, generator=g) / 200.0)
+    b = torch.randn(64, generator=g) * 0.1
+    w1 = bfr(torch.randn(64, 64, 1, 1, generator=g) / 8.0)
+    b1 = torch.randn(64, generator=g) * 0.1
+    wp, bp = engine.pack_stem(w, b, d)
+    w1p, b1p = engine.pack_conv(w1, b1, d)
+    assert tuple(w1p.shape) == (64, 64)
+    st = _lib.current_stream()
+    stem_in = torch.zeros(N, H + 6, W + 6, 4, dtype=BF, device=d)
+    m3 = (ctypes.c_float * 3)(103.53, 116.28, 123.675)
+    s3 = (ctypes.c_float * 3)(1.0, 1.0, 1.0)
+    _lib.check(L.dafne_preprocess_image_hip(_lib.ptr(img), 0, N, H, W, None, m3, s3, H, W, _lib.ptr(stem_in), st))
+    Hq, Wq = H // 4, W // 4
+    p_ref, u_ref = engine.Act(N, Hq, Wq, 64, d), engine.Act(N, Hq, Wq, 64, d)
+    _lib.check(L.dafne_stem_pool_hip(_lib.ptr(stem_in), _lib.ptr(wp), _lib.ptr(bp), N, H, W, _lib.ptr(p_ref.t), st))
+    engine.ConvCall(w1p, b1p, 64, 64, 1, 1, 0, engine.F_RELU, [(p_ref.t, u_ref.t, None, Hq, Wq, Hq, Wq)], N)(st)
+    p_f, u_f = engine.Act(N, Hq, Wq, 64, d), engine.Act(N, Hq, Wq, 64, d)
+    for _ in range(2):
+        _lib.check(L.dafne_stem_pool_conv1_hip(_lib.ptr(stem_in), _lib.ptr(wp), _lib.ptr(bp), _lib.ptr(w1p), _lib.ptr(b1p), N, H, W,
+                                               _lib.ptr(p_f.t), _lib.ptr(u_f.t), st))
+    torch.cuda.synchronize()
+    assert torch.equal(p_f.t, p_ref.t)
+    assert torch.equal(u_f.t, u_ref.t), float((u_f.t.float() - u_ref.t.float()).abs().max())
+    assert float(u_f.t[:, 0].abs().max()) == 0 and float(u_f.t[:, :, -1].abs().max()) == 0
+    assert float(u_f.t.float().abs().max()) > 0
+    ref = F.relu(F.conv2d(p_ref.nchw_float().cpu(), w1, b1))
+    close_bf16(u_f.nchw_float().cpu(), bfr(ref))
+    with pytest.raises(_lib.DafneHipError):
+        _lib.check(L.dafne_stem_pool_conv1_hip(_lib.ptr(stem_in), _lib.ptr(wp), _lib.ptr(bp), None, _lib.ptr(b1p), N, H, W,
+                                               _lib.ptr(p_f.t), _lib.ptr(u_f.t), st), "stem_pool_conv1")
+
+
 def test_stem_preprocess_maxpool():
     from dafne_amd import engine, _lib
     L = _lib.load()
