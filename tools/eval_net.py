@@ -122,8 +122,6 @@ def run(args, rank=0, world=1, local_rank=0):
     n = args.num_images
     records = None
     if args.write_synthetic_dir:
-        if args.tta:
-            raise SystemExit("--write-synthetic-dir / --image-dir feed the single-scale loop (the TTA wrapper builds its own views)")
         if rank == 0 and not os.path.isdir(args.write_synthetic_dir):
             write_synthetic_tiles(args.write_synthetic_dir, n, h, w, args.seed)
         if world > 1:
@@ -131,8 +129,8 @@ def run(args, rank=0, world=1, local_rank=0):
             dist.barrier()
         args.image_dir = args.write_synthetic_dir
     if args.image_dir:
-        if args.tta:
-            raise SystemExit("--image-dir feeds the single-scale loop (the TTA wrapper builds its own views)")
+        if args.tta_shard_views:
+            raise SystemExit("--tta-shard-views runs on synthetic tiles (every rank needs every image); --tta alone takes --image-dir")
         from dafne_amd.data import list_image_records
         records = list_image_records(args.image_dir)
         if n > 0:
@@ -172,15 +170,18 @@ def run(args, rank=0, world=1, local_rank=0):
         if rank != 0:
             return None
         out = instances_to_rows([o["instances"] for o in merged], k_cap, dev)
-    elif tta is not None:
+    elif tta is not None and records is None:
         out = inference_on_images(detect_batch, n, k_cap, batch_size=args.batch, rank=rank, world=world, device=dev)
         torch.cuda.synchronize()
         if rank != 0:
             return None
     else:
         # the reference's loop: inference_on_dataset(model, data_loader, evaluator) (plain_train_net.py:316-336), streamed --
-        # batch i runs on the benchmarked layout while batch i - 1's outputs go to the evaluator
+        # batch i runs on the benchmarked layout while batch i - 1's outputs go to the evaluator.  With --tta and image files it is
+        # do_test_with_TTA's (plain_train_net.py:338-356): the same loader, the model wrapped in OneStageRCNNWithTTA (called
+        # synchronously per batch; the wrapper groups and pipelines the views of a batch's images itself)
         from dafne_amd.evaluation.inference import DafneEvaluator, inference_on_dataset
+        runner = tta if tta is not None else model
         if args.images_on == "device":
             for x in mine:
                 x["image"] = x["image"].to(dev)
@@ -198,7 +199,7 @@ def run(args, rank=0, world=1, local_rank=0):
             import itertools
             warm = (loader * args.warmup_batches)[:args.warmup_batches] if isinstance(loader, list) else \
                 list(itertools.islice(itertools.cycle(list(itertools.islice(iter(loader), 2))), args.warmup_batches))
-            inference_on_dataset(model, warm, None)     # (two per plan set: eager, then graph capture)
+            inference_on_dataset(runner, warm, None)     # (two per plan set: eager, then graph capture)
         if args.serial:
             class _Sync:                      # the synchronous form: model(inputs) per batch
                 def __init__(self, m):
@@ -206,11 +207,12 @@ def run(args, rank=0, world=1, local_rank=0):
 
                 def __call__(self, inputs):
                     return self.m(inputs)
-            res = inference_on_dataset(_Sync(model), loader, ev, stats)
+            res = inference_on_dataset(_Sync(runner), loader, ev, stats)
         else:
-            res = inference_on_dataset(model, loader, ev, stats)
+            res = inference_on_dataset(runner, loader, ev, stats)
         print("rank %d: inference_on_dataset %d images in %.3f s = %.1f images/s (batch %d, %s, images on the %s)"
               % (rank, stats["images"], stats["seconds"], stats["images_per_sec"], b,
+                 "TTA, synchronous per batch" if tta is not None else
                  "synchronous" if args.serial else "streamed, %d sub-batch streams" % cfg.ENGINE.PIPELINE_SPLITS,
                  args.images_on if records is None else "disk (%s, %d decode %s workers)" % (args.image_dir, loader.num_workers, args.decode_backend)), flush=True)
         if rank != 0:
