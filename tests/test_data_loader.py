@@ -219,3 +219,36 @@ def test_files_through_the_loader_equal_the_detector_on_the_decoded_arrays(tmp_p
     assert [(p["height"], p["width"]) for p in preds] == sizes
     for p, e in zip(preds, expected):
         assert len(p["scores"]) == len(e["instances"])
+
+
+@pytest.mark.gpu
+def test_tta_wrapper_over_the_loader_equals_tta_on_the_decoded_arrays(tmp_path):
+    """do_test_with_TTA's shape (plain_train_net.py:338-356): the same test loader, the model wrapped in OneStageRCNNWithTTA.
+    The loader hands the wrapper the single-scale-resized image with the file's own height / width; the wrapper's views start from
+    that image (tta.py:71-99, `pre` transform)."""
+    from dafne_amd.data import build_test_loader, inference_resize_shape
+    from dafne_amd.evaluation.inference import inference_on_dataset
+    from dafne_amd.modeling.tta import OneStageRCNNWithTTA
+    from test_inference_loop import _gpu_model, _same
+    cfg, m = _gpu_model("dota-1.5_r101.yaml", splits=1)
+    if hasattr(cfg, "defrost"):
+        cfg.defrost()
+    cfg.INPUT.MIN_SIZE_TEST, cfg.INPUT.MAX_SIZE_TEST = 128, 224
+    cfg.TEST.AUG.MIN_SIZES, cfg.TEST.AUG.MAX_SIZE = [96, 160], 256
+    sizes = [(100, 150), (128, 160), (128, 160)]
+    arrs = _write(str(tmp_path), sizes, seed=8)
+    dev = torch.device("cuda", 0)
+    tta = OneStageRCNNWithTTA(cfg, m)
+    inputs = []
+    for a, (h, w) in zip(arrs, sizes):
+        nh, nw = inference_resize_shape(cfg, h, w)
+        r = np.asarray(Image.fromarray(a[:, :, ::-1]).resize((nw, nh), Image.BILINEAR))
+        inputs.append({"image": torch.from_numpy(np.ascontiguousarray(r.transpose(2, 0, 1))).to(dev), "height": h, "width": w})
+    expected = tta(inputs[:2]) + tta(inputs[2:])
+    torch.cuda.synchronize()
+    got = inference_on_dataset(tta, build_test_loader(cfg, str(tmp_path), batch_size=2, device=dev), None)
+    assert len(got) == 3 and all(len(o["instances"]) > 0 for o in got)
+    for i, (a, e) in enumerate(zip(got, expected)):
+        assert a["instances"].image_size == sizes[i]
+        assert torch.equal(a["instances"].pred_corners, e["instances"].pred_corners), i
+        assert torch.equal(a["instances"].scores, e["instances"].scores), i
