@@ -161,7 +161,7 @@ def _defaults():
                     FP8_CONV3X3_KERNEL="patch",
                     # sub-batches on concurrent streams in the streamed evaluation loop (OneStageDetector.forward_streamed /
                     # evaluation.inference.inference_on_dataset): the layout bench.py times
-                    PIPELINE_SPLITS=2,
+                    PIPELINE_SPLITS=2, MAX_PLANS=48,
                     # replay every sub-batch's dense launches from a HIP graph in the pipelined / streamed step (one host call
                     # per stream and step instead of ~200)
                     HIP_GRAPHS=True),

@@ -174,14 +174,29 @@ class OneStageDetector(nn.Module):
             self._consts[key] = t
         return t
 
+    def _lru_get(self, cache, key, build):
+        """cache[key], built on first use; the caches of launch plans (buffers of a whole network at one batch shape: 0.3-5 GB
+        each) keep the cfg.ENGINE.MAX_PLANS most recently used shapes.  Before one is dropped the device is synchronised: its
+        launches may still be queued, and its buffers go back to the allocator."""
+        if key in cache:
+            cache[key] = cache.pop(key)              # dicts keep insertion order: most recently used last
+            return cache[key]
+        cap = max(2, int(getattr(self.cfg.ENGINE, "MAX_PLANS", 48)))
+        if len(cache) >= cap:
+            torch.cuda.synchronize(self.device)
+            while len(cache) >= cap:
+                cache.pop(next(iter(cache)))
+        cache[key] = build()
+        return cache[key]
+
     def plan(self, n, h, w, slot=0, graph=False):
-        key = (n, h, w, slot)
-        if key not in self._plans:
+        def build():
             nc = self.proposal_generator.dafne_head.num_classes
-            self._plans[key] = engine.DensePlan(self._weights(), n, h, w, self.depth, nc, self.device)
+            return engine.DensePlan(self._weights(), n, h, w, self.depth, nc, self.device)
+        p = self._lru_get(self._plans, (n, h, w, slot), build)
         if graph:
-            self._plans[key].capture()
-        return self._plans[key]
+            p.capture()
+        return p
 
     # ------------------------------------------------------------ fused path
     def detect_packed(self, images_u8, valid_hw=None, out_hw=None, layout_hwc=False, do_postprocess=True,
@@ -257,7 +272,8 @@ class OneStageDetector(nn.Module):
                 self.side_stream = _shared_stream(images_u8.device, "side", 0)
                 self._pipe = {}
             key = (n, hn, wn, splits)
-            if key not in self._pipe:
+
+            def build_pipe():
                 nc = self.proposal_generator.dafne_head.num_classes
                 bounds = [(k * n) // splits for k in range(splits + 1)]
                 # two complete plan sets (A/B) with their own head-output buffers: decode + NMS of
@@ -274,8 +290,9 @@ class OneStageDetector(nn.Module):
                 # of hardware queues, and two sub-batches landing on one queue serialise (dense part alone,
                 # 4 splits: 714 -> 960 img/s); the high-priority pool gives each its own queue.  With the
                 # post-process stream in the mix 3 splits measured best (scratch/split_sweep.sh)
-                self._pipe[key] = {"i": 0, "cs": [_shared_stream(images_u8.device, "compute", k) for k in range(splits)], "ho": hos,
-                                   "plans": plan_sets, "bounds": bounds, "cand": [None, None], "done": [None, None]}
+                return {"i": 0, "cs": [_shared_stream(images_u8.device, "compute", k) for k in range(splits)], "ho": hos,
+                        "plans": plan_sets, "bounds": bounds, "cand": [None, None], "done": [None, None]}
+            self._lru_get(self._pipe, key, build_pipe)
             st = self._pipe[key]
             slot = st["i"] & 1
             st["i"] += 1

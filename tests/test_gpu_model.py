@@ -364,6 +364,32 @@ def test_tta_groups_equal_the_per_image_calls_at_view_sizes_that_cross_the_tile_
         assert torch.equal(ix.pred_classes, iy.pred_classes), k
 
 
+def test_plan_caches_keep_the_most_recent_shapes():
+    """cfg.ENGINE.MAX_PLANS bounds both plan caches (a launch plan holds a whole network's buffers at one batch shape); a shape
+    that was dropped is rebuilt on its next use and gives the same detections."""
+    cfg, m, P = build("dota-1.0_r50.yaml", seed=29)
+    cfg.ENGINE.MAX_PLANS = 3
+    g = torch.Generator().manual_seed(2)
+    shapes = [(96, 128), (128, 128), (128, 160), (160, 160), (96, 160)]
+    imgs = [torch.randint(0, 256, (2, 3, h, w), generator=g, dtype=torch.uint8).to(dev()) for h, w in shapes]
+    first = []
+    for im in imgs:
+        r, c = m.detect_packed(im)
+        rp, cp = m.detect_packed(im, pipelined=True, splits=2)
+        torch.cuda.synchronize()
+        assert torch.equal(c, cp)
+        first.append((r.clone(), c.clone()))
+        assert len(m._plans) <= 3 and len(m._pipe) <= 3
+    assert (2, 96, 128, 0) not in m._plans and (2, 96, 160, 0) in m._plans          # least recently used went first
+    r, c = m.detect_packed(imgs[0])                                                # rebuilt
+    rp, cp = m.detect_packed(imgs[0], pipelined=True, splits=2)
+    torch.cuda.synchronize()
+    for rr, cc in ((r, c), (rp, cp)):
+        assert torch.equal(cc, first[0][1])
+        assert all(torch.equal(rr[i, :int(cc[i])], first[0][0][i, :int(cc[i])]) for i in range(2))
+    assert len(m._plans) <= 3 and len(m._pipe) <= 3
+
+
 def test_pipelined_side_stream_equals_serial():
     cfg, m, P = build("dota-1.0_r50.yaml", seed=13)
     g = torch.Generator().manual_seed(6)
