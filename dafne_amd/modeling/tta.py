@@ -382,7 +382,16 @@ class OneStageRCNNWithTTA(nn.Module):
         return self._invert_and_concat(self._batch_inference_packed(augmented_inputs), tfms)
 
     def _invert_and_concat(self, outputs, tfms):
-        """tta.py:237-262: every view's corners back through the inverse of its transform list, then one Instances."""
+        """tta.py:237-262: every view's corners back through the inverse of its transform list, then one Instances.
+        The lists this mapper builds are [pre-resize,] resize [, one flip]: their inverses -- un-flip, x * ratio, [x * ratio] -- are
+        applied to ALL views' corners at once with per-row parameters (the same float32 operations in the same order as the
+        per-view loop: equal bits, tests/test_gpu_model.py); anything else takes the per-view loop."""
+        fast = self._invert_and_concat_fast(outputs, tfms)
+        if fast is not None:
+            return fast
+        return self._invert_and_concat_loop(outputs, tfms)
+
+    def _invert_and_concat_loop(self, outputs, tfms):
         lst = []
         for output, tfm in zip(outputs, tfms):
             inst = output["instances"]
@@ -396,6 +405,67 @@ class OneStageRCNNWithTTA(nn.Module):
             r.pred_classes = inst.pred_classes
             lst.append(r)
         return Instances.cat(lst)
+
+    _PIN = {}
+
+    @staticmethod
+    def _pinned_table(n):
+        ev = OneStageRCNNWithTTA._PIN.pop("ev", None)
+        if ev is not None:
+            ev.synchronize()
+        t = OneStageRCNNWithTTA._PIN.get("t")
+        if t is None or t.shape[0] < n:
+            t = torch.empty(max(64, n), 9, dtype=torch.float64).pin_memory()
+            OneStageRCNNWithTTA._PIN["t"] = t
+        return t
+
+    @staticmethod
+    def _invert_and_concat_fast(outputs, tfms):
+        insts = [o["instances"] for o in outputs]
+        if not insts or any(i.pred_corners.dtype != torch.float32 for i in insts):
+            return None
+        rows = []                      # per view: (flip x?, width, flip y?, height, ratio x 1, ratio y 1, ratio x 2, ratio y 2)
+        for tfm in tfms:
+            ops = list(tfm.tfms)
+            fx = fy = False
+            wv = hv = 0.0
+            if ops and isinstance(ops[-1], HFlipT):
+                fx, wv = True, float(ops.pop().width)
+            elif ops and isinstance(ops[-1], VFlipT):
+                fy, hv = True, float(ops.pop().height)
+            if not ops or len(ops) > 2 or not all(isinstance(t, ResizeT) for t in ops):
+                return None
+            inv = [t.inverse() for t in reversed(ops)]           # un-resize of the view first, then of the pre-resize
+            rx = [t.new_w * 1.0 / t.w for t in inv] + [1.0]
+            ry = [t.new_h * 1.0 / t.h for t in inv] + [1.0]
+            rows.append((fx, wv, fy, hv, rx[0], ry[0], rx[1], ry[1]))
+        dev = insts[0].pred_corners.device
+        counts = [len(i) for i in insts]
+        total = sum(counts)
+        table = torch.tensor([list(map(float, r)) + [float(n)] for r, n in zip(rows, counts)], dtype=torch.float64)     # [views, 9]
+        if dev.type == "cuda":
+            # ONE small upload from a pinned buffer, asynchronous on the caller's stream (a pageable host-to-device copy makes
+            # the host wait for the device: measured 33 instead of 19 ms per image, the next group's convolutions drained first)
+            pin = OneStageRCNNWithTTA._pinned_table(table.shape[0])
+            pin[: table.shape[0]].copy_(table)
+            table = pin[: table.shape[0]].to(dev, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(dev))
+            OneStageRCNNWithTTA._PIN["ev"] = ev                     # the buffer is rewritten only after this copy has read it
+        expand = torch.repeat_interleave(table[:, :8], table[:, 8].to(torch.int64), dim=0, output_size=total)          # [rows, 8]
+        per_row = lambda col, dt: expand[:, col].to(dt).unsqueeze(1)
+        c = torch.cat([i.pred_corners for i in insts], dim=0)                       # [n, 8] = 4 x (x, y)
+        x, y = c[:, 0::2], c[:, 1::2]
+        x = torch.where(per_row(0, torch.bool), per_row(1, torch.float32) - x, x)
+        y = torch.where(per_row(2, torch.bool), per_row(3, torch.float32) - y, y)
+        x = x * per_row(4, torch.float32) * per_row(6, torch.float32)               # (x * r1) * r2, as two apply_coords calls
+        y = y * per_row(5, torch.float32) * per_row(7, torch.float32)
+        r = Instances(insts[0].image_size)
+        r.scores = torch.cat([i.scores for i in insts], dim=0)
+        r.centerness = torch.cat([i.centerness for i in insts], dim=0)
+        r.pred_corners = torch.stack([x, y], dim=2).reshape(-1, 8)
+        r.pred_classes = torch.cat([i.pred_classes for i in insts], dim=0)
+        return r
 
     def _merge_detections(self, instances):
         return self.model.proposal_generator.dafne_outputs.select_over_all_levels([instances])[0]

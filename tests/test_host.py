@@ -36,3 +36,37 @@ def test_usable_cpus_honours_the_cgroup_v1_quota(tmp_path):
 
 def test_usable_cpus_on_this_host_is_sane():
     assert 1 <= usable_cpus() <= (os.cpu_count() or 1)
+
+
+def test_tta_batched_inverse_transforms_equal_the_per_view_loop():
+    """tta.py:237-262 inverts every view's transform list on its corners; the wrapper does it for all views at once with per-row
+    parameters (un-flip, x * ratio, x * ratio of the pre-resize): the same float32 operations in the same order -> equal bits."""
+    import torch
+    from dafne_amd.modeling.tta import HFlipT, OneStageRCNNWithTTA, ResizeT, TransformList, VFlipT
+    from dafne_amd.structures import Instances
+    g = torch.Generator().manual_seed(0)
+    tfms, outs = [], []
+    for k, (nh, nw) in enumerate([(450, 450), (700, 933), (1200, 1200), (96, 128)]):
+        for flip in (None, "h", "v"):
+            ops = [ResizeT(1000, 1024, 1024, 1024)] if k % 2 else []
+            ops.append(ResizeT(1024, 1024, nh, nw))
+            if flip == "h":
+                ops.append(HFlipT(nw))
+            if flip == "v":
+                ops.append(VFlipT(nh))
+            tfms.append(TransformList(ops))
+            n = int(torch.randint(0, 50, (1,), generator=g))
+            inst = Instances((1000, 1024))
+            inst.pred_corners = torch.rand(n, 8, generator=g) * 1300 - 50
+            inst.scores = torch.rand(n, generator=g)
+            inst.centerness = torch.rand(n, generator=g)
+            inst.pred_classes = torch.randint(0, 16, (n,), generator=g)
+            outs.append({"instances": inst})
+    a = OneStageRCNNWithTTA._invert_and_concat_loop(None, outs, tfms)
+    b = OneStageRCNNWithTTA._invert_and_concat_fast(outs, tfms)
+    assert b is not None and a.image_size == b.image_size and len(a) == len(b)
+    for k in ("pred_corners", "scores", "centerness", "pred_classes"):
+        assert torch.equal(getattr(a, k), getattr(b, k)), k
+    # a list the fast path does not know (two flips) falls back to the loop
+    odd = [TransformList([ResizeT(8, 8, 4, 4), HFlipT(4), VFlipT(4)])]
+    assert OneStageRCNNWithTTA._invert_and_concat_fast(outs[:1], odd) is None
