@@ -386,10 +386,10 @@ class OneStageRCNNWithTTA(nn.Module):
         The lists this mapper builds are [pre-resize,] resize [, one flip]: their inverses -- un-flip, x * ratio, [x * ratio] -- are
         applied to ALL views' corners at once with per-row parameters (the same float32 operations in the same order as the
         per-view loop: equal bits, tests/test_gpu_model.py); anything else takes the per-view loop."""
-        fast = self._invert_and_concat_fast(outputs, tfms)
+        fast = OneStageRCNNWithTTA._invert_and_concat_fast(outputs, tfms)          # (neither form needs `self`)
         if fast is not None:
             return fast
-        return self._invert_and_concat_loop(outputs, tfms)
+        return OneStageRCNNWithTTA._invert_and_concat_loop(self, outputs, tfms)
 
     def _invert_and_concat_loop(self, outputs, tfms):
         lst = []
