@@ -107,18 +107,25 @@ def build_model(depth, device, seed=0, cfgname=None, cls_prior=None, tower_std=N
 PRIME = 4       # steps that build everything built on first use: both plan sets run once eagerly, then their graphs are captured
 
 
-def time_steps(step_fn, steps, warmup, distributed, device="cuda", per_rank=None):
+def time_steps(step_fn, steps, warmup, distributed, device="cuda", per_rank=None, flush_fn=None):
     """W untimed steps, then EXACTLY `steps` steps bracketed by barrier + device synchronize on both sides; the
-    result is the MAX over ranks (the slowest rank's time).  device "cpu" is the gloo test's layout (no GPU)."""
+    result is the MAX over ranks (the slowest rank's time).  device "cpu" is the gloo test's layout (no GPU).
+    flush_fn: a step function that leaves part of its step to the NEXT call (the deferred post-process of the timed layout)
+    completes it here -- after the warm-up (nothing of an untimed step leaks into the timed region) and after the last timed
+    step, INSIDE the timed region (all of the K steps' work is timed)."""
     sync = torch.cuda.synchronize if str(device).startswith("cuda") else (lambda: None)
     for _ in range(warmup):
         step_fn()
+    if flush_fn is not None:
+        flush_fn()
     if distributed:
         dist.barrier()
     sync()
     t0 = time.perf_counter()
     for _ in range(steps):
         step_fn()
+    if flush_fn is not None:
+        flush_fn()
     if distributed:
         dist.barrier()
     sync()
@@ -432,6 +439,9 @@ def parse_args(argv=None):
                     help="pipelined (default, the timed configuration): sub-batches on concurrent streams, post-process of step i "
                          "under the convolutions of step i+1.  serial: the whole batch, every kernel alone on ONE stream -- the "
                          "layout the isolated roofline is quoted on (profiles/r03_kernel_stats_isolated.txt)")
+    ap.add_argument("--no-defer", action="store_true",
+                    help="pipelined mode: every step's decode + NMS enqueued right behind its own convolutions (round 3's form) instead "
+                         "of at the next step's head towers (detect_packed(defer=True)); for A/B runs")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip roofline profile pass, R50 and NMS side metrics")
     return ap.parse_args(argv)
@@ -538,17 +548,28 @@ def _run_worker(args, make_step, rank, world, distributed, device):
             if distributed:
                 gathered["out"] = gather_detections(rows, counts, dst=0)
             return rows, counts
-        rows, counts = model.detect_packed(batch, pipelined=True, splits=args.splits)
-        if distributed:
+        # the loop's form of the pipelined step: this call's convolutions, then the PREVIOUS call's decode + NMS, which start on
+        # the side stream when this call's sub-batches reach their head towers (detect_packed(defer=True)); flush() completes the
+        # last step.  Every step's whole path runs once; time_steps flushes before and INSIDE the end of the timed region.
+        if args.no_defer:
+            return after(model.detect_packed(batch, pipelined=True, splits=args.splits))
+        return after(model.detect_packed(batch, pipelined=True, splits=args.splits, defer=True))
+
+    def after(res):
+        if res is not None and distributed:
             with torch.cuda.stream(model.side_stream):
-                gathered["out"] = gather_detections(rows, counts, dst=0)
-        return rows, counts
+                gathered["out"] = gather_detections(res[0], res[1], dst=0)
+        return res
+
+    def flush():
+        return after(model.flush_deferred()) if (args.mode != "serial" and not args.no_defer) else None
 
     for _ in range(PRIME):                 # untimed, before the W warm-up steps: launch plans, packed weights, HIP graphs
         step()
     per_rank = []
-    dt = time_steps(step, args.steps, args.warmup, distributed, device, per_rank=per_rank)
-    rows, counts = step()
+    dt = time_steps(step, args.steps, args.warmup, distributed, device, per_rank=per_rank, flush_fn=flush)
+    last = step()
+    rows, counts = flush() if (args.mode != "serial" and not args.no_defer) else (last if args.mode != "serial" else step())
     torch.cuda.synchronize()
     out = headline(args, world, dt, float(counts.float().mean().item()))
     out["config"]["mode"] = args.mode
@@ -654,8 +675,9 @@ def _run_worker(args, make_step, rank, world, distributed, device):
             # headline line
             def side_r50():
                 cfg50, m50, _ = build_model(50, device, seed=0)
-                f50 = lambda: m50.detect_packed(batch, pipelined=True, splits=args.splits)
-                dt50 = min(time_steps(f50, max(args.steps // 2, 3), PRIME, False), time_steps(f50, max(args.steps // 2, 3), 1, False))     # side metric: best of two
+                f50 = lambda: m50.detect_packed(batch, pipelined=True, splits=args.splits, defer=True)     # the timed layout's loop form
+                dt50 = min(time_steps(f50, max(args.steps // 2, 3), PRIME, False, flush_fn=m50.flush_deferred),
+                           time_steps(f50, max(args.steps // 2, 3), 1, False, flush_fn=m50.flush_deferred))     # side metric: best of two
                 out["configs1_r50_b8"] = {"images_per_sec": args.batch * max(args.steps // 2, 3) / dt50,
                                           "workload": "DOTA-1.0 1024x1024 R50-FPN bf16, batch 8, 1 GPU"}
                 del m50
@@ -668,13 +690,15 @@ def _run_worker(args, make_step, rank, world, distributed, device):
                 b16 = torch.cat([batch, batch.flip(0)])[:16]
                 n8 = max(args.steps // 4, 3)
                 m8.calibrate_fp8(b16)                  # explicit: the activation scales are part of the model
-                dt8 = time_steps(lambda: m8.detect_packed(b16, pipelined=True, splits=args.splits), n8, PRIME, False)
+                dt8 = time_steps(lambda: m8.detect_packed(b16, pipelined=True, splits=args.splits, defer=True), n8, PRIME, False,
+                                 flush_fn=m8.flush_deferred)
                 r8, c8 = m8.detect_packed(b16, pipelined=True, splits=args.splits)
                 torch.cuda.synchronize()
                 out["configs4_fp8w_r101_b16"] = {"images_per_sec": b16.shape[0] * n8 / dt8, "detections_per_image_mean": float(c8.float().mean().item()), "dtype": "fp8 e4m3 weights; 41 3x3 layers (res4/res5, FPN outputs, head towers) on fp8 MFMA with calibrated e4m3 activations, the rest bf16",
                                                  "workload": "UCAS-AOD head (2 classes) 1024x1024 R101-FPN, batch 16, 1 GPU"}
                 m8b = build_model(101, device, seed=0, cfgname="ucas_aod_r101.yaml", cls_prior=-1.5)[1]
-                dt8b = time_steps(lambda: m8b.detect_packed(b16, pipelined=True, splits=args.splits), n8, PRIME, False)
+                dt8b = time_steps(lambda: m8b.detect_packed(b16, pipelined=True, splits=args.splits, defer=True), n8, PRIME, False,
+                                  flush_fn=m8b.flush_deferred)
                 out["configs4_fp8w_r101_b16"]["bf16_same_workload_images_per_sec"] = b16.shape[0] * n8 / dt8b
                 del m8, m8b
 

@@ -884,6 +884,7 @@ class DensePlan:
         p7 = conv("p7", p6r, 3, 2, 1, 0)
         outs["p6"], outs["p7"] = p6, p7
         self.features = [outs[k] for k in ("p3", "p4", "p5", "p6", "p7")]
+        self.head_start = len(self.calls)          # launches [0, head_start) are backbone + FPN, the rest the head
         self.head = HeadPlan(weights, self.features, num_classes, device, pool, self, head_outputs) if with_head else None
 
     def run(self, stream=None):
@@ -906,6 +907,22 @@ class DensePlan:
             for c in self.calls:
                 c(_lib.current_stream())
         self.graph = g
+
+    def capture_parts(self):
+        """The launch list as TWO HIP graphs -- backbone + FPN, then the head -- so that an event can be recorded on the stream
+        where the head towers begin (OneStageDetector.detect_packed(defer=True) starts the previous step's post-process there)."""
+        if getattr(self, "graph_parts", None) is not None:
+            return
+        self.run(_lib.current_stream())  # warm-up outside capture
+        torch.cuda.synchronize()
+        parts = []
+        for lo, hi in ((0, self.head_start), (self.head_start, len(self.calls))):
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                for c in self.calls[lo:hi]:
+                    c(_lib.current_stream())
+            parts.append(g)
+        self.graph_parts = tuple(parts)
 
 
 class HeadOutputs:

@@ -6,9 +6,10 @@ outputs)`, then `evaluator.evaluate()`; `DafneEvaluator.process` moves every ima
 (dafne/evaluation/dafne_evaluator.py:44-58) and `evaluate()` gathers the per-rank lists on rank 0 (:60-64).
 
 Here the loop is STREAMED: `model.forward_streamed(inputs)` enqueues batch i on the layout bench.py times (sub-batches on
-concurrent streams, post-process on a side stream under the next batch's convolutions) and hands back the outputs of
-batch i - 1, which go to `evaluator.process` while batch i runs; `model.flush()` drains the last one.  The evaluator sees
-exactly the (inputs, outputs) pairs of the synchronous loop, in the same order.  A model without `forward_streamed` (the TTA
+concurrent streams, the previous batch's post-process on a side stream under this batch's head towers) and hands back the
+outputs of the OLDEST batch in flight (batch i - 2 for the detector; None while the pipeline fills), which go to
+`evaluator.process` while the later batches run; `model.flush()` drains the rest, oldest first, one batch per call.  The
+evaluator sees exactly the (inputs, outputs) pairs of the synchronous loop, in the same order.  A model without `forward_streamed` (the TTA
 wrapper) is called synchronously.
 """
 import time
@@ -115,7 +116,7 @@ def inference_on_dataset(model, data_loader, evaluator=None, stats=None):
         torch.cuda.synchronize()
     t0 = time.perf_counter()
     n = 0
-    prev_inputs = None
+    in_flight = []                       # inputs of the batches the streamed model has not handed back yet, oldest first
     was_training = getattr(model, "training", False)
     if hasattr(model, "eval"):
         model.eval()
@@ -123,16 +124,18 @@ def inference_on_dataset(model, data_loader, evaluator=None, stats=None):
         for inputs in data_loader:
             n += len(inputs)
             if streamed:
-                out_prev = model.forward_streamed(inputs)
-                if out_prev is not None:
-                    deliver(prev_inputs, out_prev)
-                prev_inputs = inputs
+                in_flight.append(inputs)
+                out_old = model.forward_streamed(inputs)         # the outputs of the OLDEST batch in flight, or None
+                if out_old is not None:
+                    deliver(in_flight.pop(0), out_old)
             else:
                 deliver(inputs, model(inputs))
         if streamed:
-            last = model.flush()
-            if last is not None:
-                deliver(prev_inputs, last)
+            while in_flight:
+                out_old = model.flush()
+                if out_old is None:
+                    raise RuntimeError("inference_on_dataset: the model dropped %d batch(es) in flight" % len(in_flight))
+                deliver(in_flight.pop(0), out_old)
     if cuda:
         torch.cuda.synchronize()
     dt = time.perf_counter() - t0

@@ -72,6 +72,9 @@ class OneStageDetector(nn.Module):
         self._graphs = {}
         self._act_q8 = None
         self._pending = None
+        self.__dict__.pop("_deferred", None)
+        self.__dict__.pop("_deferred_res", None)
+        self.__dict__.pop("_stream_q", None)
         if hasattr(self, "_pipe"):
             self._pipe = {}
         self.backbone.invalidate()
@@ -200,7 +203,7 @@ class OneStageDetector(nn.Module):
 
     # ------------------------------------------------------------ fused path
     def detect_packed(self, images_u8, valid_hw=None, out_hw=None, layout_hwc=False, do_postprocess=True,
-                      pipelined=False, splits=1, stream_offset=0, graphs=None):
+                      pipelined=False, splits=1, stream_offset=0, graphs=None, defer=False):
         """images_u8: device uint8 [N,3,H,W] (or [N,H,W,3] with layout_hwc) BGR.
         valid_hw: optional per-image (h, w) true sizes; out_hw: optional per-image
         requested output (height, width).  Returns (rows [N,k_cap,18], counts [N])
@@ -216,7 +219,12 @@ class OneStageDetector(nn.Module):
         sub-batches use: consecutive calls with different offsets (the TTA wrapper's chunks) run concurrently.
         graphs: replay the sub-batches' dense launches from HIP graphs (None: cfg.ENGINE.HIP_GRAPHS).  Worth it for a loop over
         one shape (host enqueue 1.9 -> 0.4 ms per step); the TTA wrapper's 27 views of 9 shapes pass False (GPU-bound at 26.7
-        ms per image either way, and every shape's capture costs ~10 ms)."""
+        ms per image either way, and every shape's capture costs ~10 ms).
+        defer=True (pipelined only; a LOOP's form): this call enqueues its convolutions and then the decode / NMS / rescale of
+        the PREVIOUS deferred call, which starts on the side stream when this call's sub-batches reach their head towers --
+        the persistent tower kernel leaves CUs idle (232 of 256 workgroups) that the post-process kernels fill, while beside
+        the backbone's chip-wide launches they cost 3.7 % of the step (scratch/no_post.py, defer_post.py: +1.4 .. +4 %).
+        Returns the PREVIOUS call's (rows, counts) -- None on the first call; flush_deferred() enqueues and returns the last."""
         if not images_u8.is_cuda or images_u8.dtype != torch.uint8:
             raise RuntimeError("detect_packed needs a uint8 CUDA tensor (the MI355X engine has no CPU path)")
         if self.cfg.ENGINE.WEIGHT_DTYPE == "fp8_e4m3" and self._act_q8 is None:
@@ -258,8 +266,14 @@ class OneStageDetector(nn.Module):
                                                     _lib.current_stream()), "dafne_preprocess_image_hip")
             plan.run()
 
+        if defer and not pipelined:
+            raise ValueError("detect_packed(defer=True) is a form of the pipelined step")
         with torch.cuda.device(images_u8.device):
             images_u8 = images_u8.contiguous()
+            if not defer and self.__dict__.get("_deferred") is not None:
+                # a deferred post-process is pending and this call is not part of that loop: run it first (its plan set's
+                # head outputs must be read before anything reuses them); flush_deferred() hands the result out
+                self.__dict__["_deferred_res"] = self._run_deferred(self.__dict__.pop("_deferred"), ())
             if not pipelined:
                 plan = self.plan(n, hn, wn)
                 dense(images_u8, 0, n, plan)
@@ -342,11 +356,19 @@ class OneStageDetector(nn.Module):
                 # left the whole process at 1010-1050 images/s, eager and graph steps alike; eager first: 1300 both ways).
                 eager_first = st.setdefault("runs", [0, 0])
                 if eager_first[slot] == 0:
-                    for j in range(max(len(p.calls) for p in plans)):
-                        for k in range(splits):
-                            if j < len(plans[k].calls):
-                                plans[k].calls[j](sp[k])
+                    tower_evs = self._enqueue_eager(plans, cs, sp, splits, defer)
+                elif defer:
+                    tower_evs = []
+                    for k in range(splits):
+                        with torch.cuda.stream(cs[k]):
+                            plans[k].capture_parts()
+                            plans[k].graph_parts[0].replay()
+                            e = torch.cuda.Event()
+                            e.record(cs[k])                   # this sub-batch is at its head towers
+                            tower_evs.append(e)
+                            plans[k].graph_parts[1].replay()
                 else:
+                    tower_evs = []
                     for k in range(splits):
                         if plans[k].graph is None:
                             with torch.cuda.stream(cs[k]):
@@ -355,11 +377,17 @@ class OneStageDetector(nn.Module):
                             plans[k].graph.replay()
                 eager_first[slot] += 1
             else:
-                ncalls = max(len(p.calls) for p in plans)
-                for j in range(ncalls):
-                    for k in range(splits):
-                        if j < len(plans[k].calls):
-                            plans[k].calls[j](sp[k])
+                tower_evs = self._enqueue_eager(plans, cs, sp, splits, defer)
+            if defer:
+                ends = []
+                for k in range(splits):
+                    ev = torch.cuda.Event()
+                    ev.record(cs[k])
+                    ends.append(ev)
+                prev = self.__dict__.get("_deferred")
+                self.__dict__["_deferred"] = {"st": st, "slot": slot, "ends": ends, "sizes": sizes, "do": do_postprocess, "main": main,
+                                              "strides": strides}
+                return self._run_deferred(prev, tower_evs) if prev is not None else None
             for k in range(splits):
                 mark("end", k, cs[k])
             with torch.cuda.stream(self.side_stream):
@@ -379,6 +407,45 @@ class OneStageDetector(nn.Module):
             for t in res:                     # allocated on the side stream, consumed on the caller's
                 t.record_stream(main)
             return res
+
+    @staticmethod
+    def _enqueue_eager(plans, cs, sp, splits, defer):
+        """Launch j of every sub-batch before launch j + 1; defer: an event per stream where its head begins."""
+        evs = []
+        for j in range(max(len(p.calls) for p in plans)):
+            for k in range(splits):
+                if j < len(plans[k].calls):
+                    if defer and j == plans[k].head_start:
+                        e = torch.cuda.Event()
+                        e.record(cs[k])
+                        evs.append(e)
+                    plans[k].calls[j](sp[k])
+        return evs
+
+    def _run_deferred(self, p, tower_evs):
+        """Decode + rotated NMS + rescale of a deferred step on the side stream: behind that step's convolutions and behind
+        `tower_evs` (the step after it has reached its head towers)."""
+        st, slot = p["st"], p["slot"]
+        outs = self.proposal_generator.dafne_outputs
+        with torch.cuda.stream(self.side_stream):
+            for ev in list(p["ends"]) + list(tower_evs):
+                self.side_stream.wait_event(ev)
+            cand = outs.decode_packed(head_levels(st["ho"][slot], p["strides"]), out=st["cand"][slot])
+            st["cand"][slot] = cand
+            res = outs.select_packed(cand, sizes=p["sizes"], scale_corners=p["do"])
+            done = torch.cuda.Event()
+            done.record(self.side_stream)
+        st["done"][slot] = done
+        for t in res:                     # allocated on the side stream, consumed on the caller's
+            t.record_stream(p["main"])
+        return res
+
+    def flush_deferred(self):
+        """(rows, counts) of the last detect_packed(defer=True) call -- its post-process is enqueued now -- or None."""
+        p = self.__dict__.pop("_deferred", None)
+        if p is not None:
+            return self._run_deferred(p, ())
+        return self.__dict__.pop("_deferred_res", None)
 
     def _pack_inputs(self, batched_inputs, staged=False):
         """list[{"image": uint8 CHW BGR, "height", "width"}] -> (device uint8 batch [n,3,H,W], valid (h, w) per image, requested
@@ -460,21 +527,44 @@ class OneStageDetector(nn.Module):
     def forward_streamed(self, batched_inputs, do_postprocess=True):
         """forward() for an evaluation LOOP (detectron2's inference_on_dataset: `for inputs in loader: outputs = model(inputs);
         evaluator.process(inputs, outputs)`, called from tools/plain_train_net.py:316-336): ENQUEUES this batch on the layout
-        bench.py times -- cfg.ENGINE.PIPELINE_SPLITS sub-batches on concurrent streams, decode / rotated NMS / rescale on the
-        side stream under the next batch's convolutions -- and returns the outputs of the PREVIOUS call (None on the first
-        one); flush() returns the last batch's.  Same per-image results as forward() up to the bf16 noise floor of another batch
-        composition (identical when PIPELINE_SPLITS == 1).  The host never waits for the GPU except for the
-        previous batch's detection counts (a pinned 4-byte-per-image copy behind its NMS).
+        bench.py times -- cfg.ENGINE.PIPELINE_SPLITS sub-batches on concurrent streams; the decode / rotated NMS / rescale of
+        the PREVIOUS batch starts on the side stream when this batch reaches its head towers (detect_packed(defer=True)) -- and
+        returns the outputs of the OLDEST batch in flight once two later ones are enqueued: call i returns batch i - 2's outputs
+        (None on the first two calls), whose post-process was enqueued a whole call ago and has finished without the host
+        waiting.  flush() hands out the batches still in flight, oldest first, one per call, then None.
+        Same per-image results as forward() (an image gets the same bits in any batch: DESIGN section 5).
         evaluation.inference.inference_on_dataset drives this."""
         if self.training:
             raise NotImplementedError("training is outside the scope of the MI355X inference engine")
         splits = max(1, int(self.cfg.ENGINE.PIPELINE_SPLITS))
         batch, valid, out_hw = self._pack_inputs(batched_inputs, staged=True)
-        rows, counts = self.detect_packed(batch, valid_hw=valid, out_hw=out_hw, do_postprocess=do_postprocess,
-                                          pipelined=True, splits=splits)
+        q = self.__dict__.setdefault("_stream_q", [])       # batches in flight, oldest first: [out_hw, packed results or None]
+        res = self.detect_packed(batch, valid_hw=valid, out_hw=out_hw, do_postprocess=do_postprocess,
+                                 pipelined=True, splits=splits, defer=True)
+        if res is not None:                                  # the previous call's batch: its post-process was enqueued just now
+            self._stage_counts(q[-1], res)
+        q.append([out_hw, None])
+        if len(q) > 2:
+            return self._finish_streamed(q.pop(0))
+        return None
+
+    def flush(self):
+        """Outputs of the oldest forward_streamed() batch still in flight (None when there is none): call until None."""
+        q = self.__dict__.get("_stream_q") or []
+        if not q:
+            return None
+        if q[-1][1] is None:                                 # the newest batch's post-process has not been enqueued yet
+            res = self.flush_deferred()
+            if res is not None:
+                self._stage_counts(q[-1], res)
+        return self._finish_streamed(q.pop(0))
+
+    def _stage_counts(self, entry, res):
+        """The detection counts of a batch go to a pinned host buffer behind its NMS (4 bytes per image)."""
+        rows, counts = res
         with torch.cuda.stream(self.side_stream):
             ring = self.__dict__.setdefault("_counts_ring", {"i": 0, "buf": {}})
-            ck = (ring["i"] % 3, tuple(counts.shape))           # three pinned buffers: this call's, the pending one, the one the
+            ck = (ring["i"] % 4, tuple(counts.shape))           # four pinned buffers: up to three batches in flight + the one the
             ring["i"] += 1                                      # caller may still be reading
             if ck not in ring["buf"]:
                 ring["buf"][ck] = torch.empty(counts.shape, dtype=counts.dtype).pin_memory()
@@ -482,19 +572,14 @@ class OneStageDetector(nn.Module):
             counts_h.copy_(counts, non_blocking=True)
             ready = torch.cuda.Event()
             ready.record(self.side_stream)
-        prev, self._pending = getattr(self, "_pending", None), (rows, counts_h, out_hw, ready)
-        return self._finish_streamed(prev)
-
-    def flush(self):
-        """Outputs of the last forward_streamed() call (None if there is none pending)."""
-        prev, self._pending = getattr(self, "_pending", None), None
-        return self._finish_streamed(prev)
+        entry[1] = (rows, counts_h, ready)
 
     @staticmethod
-    def _finish_streamed(p):
-        if p is None:
-            return None
-        rows, counts_h, out_hw, ready = p
+    def _finish_streamed(entry):
+        out_hw, packed = entry
+        if packed is None:
+            raise RuntimeError("forward_streamed: a batch left the queue before its post-process was enqueued")
+        rows, counts_h, ready = packed
         ready.synchronize()                      # that batch's post-process (side stream) is done; later batches keep running
         return [{"instances": r} for r in pp.rows_to_instances(rows, counts_h.clone(), out_hw)]
 

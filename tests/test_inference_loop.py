@@ -26,10 +26,13 @@ def _inst(g, k):
 
 
 class _StubStreamed:
-    """forward_streamed / flush with the engine's contract: call i returns the outputs of call i - 1."""
+    """forward_streamed / flush with the engine's contract: a call enqueues its batch and hands back the outputs of the OLDEST
+    batch in flight once more than `depth` are (the detector: depth 2), else None; flush() hands out the rest, oldest first,
+    one batch per call, then None."""
 
-    def __init__(self):
-        self.pending = None
+    def __init__(self, depth=2):
+        self.depth = depth
+        self.pending = []
         self.calls = []
         self.training = False
 
@@ -45,12 +48,11 @@ class _StubStreamed:
 
     def forward_streamed(self, inputs):
         self.calls.append(("stream", [x["image_id"] for x in inputs]))
-        prev, self.pending = self.pending, self._run(inputs)
-        return prev
+        self.pending.append(self._run(inputs))
+        return self.pending.pop(0) if len(self.pending) > self.depth else None
 
     def flush(self):
-        prev, self.pending = self.pending, None
-        return prev
+        return self.pending.pop(0) if self.pending else None
 
 
 class _Recorder:
@@ -73,14 +75,15 @@ def _loader(n, b, lo=0):
     return [items[i:i + b] for i in range(0, n, b)]
 
 
-@pytest.mark.parametrize("n,b", [(7, 3), (1, 4), (8, 8), (0, 2)])
-def test_streamed_loop_pairs_inputs_with_their_outputs(n, b):
+@pytest.mark.parametrize("depth", [1, 2, 3])
+@pytest.mark.parametrize("n,b", [(7, 3), (1, 4), (8, 8), (0, 2), (9, 2)])
+def test_streamed_loop_pairs_inputs_with_their_outputs(n, b, depth):
     from dafne_amd.evaluation.inference import inference_on_dataset
-    m, ev, stats = _StubStreamed(), _Recorder(), {}
+    m, ev, stats = _StubStreamed(depth), _Recorder(), {}
     res = inference_on_dataset(m, _loader(n, b), ev, stats)
     assert res == {"n": n} and stats["images"] == n
     assert ev.pairs == [(g, g, g % 5 + 1) for g in range(n)]            # every image once, in order, with ITS outputs
-    assert all(c[0] == "stream" for c in m.calls) and m.pending is None   # drained
+    assert all(c[0] == "stream" for c in m.calls) and m.pending == []   # drained
 
     class Sync:                                                            # a model without the streamed form (the TTA wrapper)
         def __call__(self, inputs):
@@ -254,3 +257,45 @@ def test_graph_replay_equals_eager_launches(monkeypatch):
         for i in range(8):
             assert torch.equal(r[i, :int(c0[i])], r0[i, :int(c0[i])])
     assert all(p.graph is not None for ps in st["plans"] for p in ps)          # both plan sets were captured and replayed
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("graphs", [False, True])
+def test_deferred_post_process_gives_the_step_results_one_call_later(graphs):
+    """detect_packed(defer=True): call i enqueues its convolutions, then the decode + NMS of call i - 1 (started where call i's
+    sub-batches reach their head towers), and returns call i - 1's results; flush_deferred() the last.  Same bits as the
+    immediate form on the same batches -- eager launches and the two-part HIP graphs -- also across a change of shape and
+    with an immediate call in between."""
+    cfg, m = _gpu_model(splits=2)
+    g = torch.Generator().manual_seed(31)
+    dev = torch.device("cuda", 0)
+    batches = [torch.randint(0, 256, (4, 3, 128, 160), generator=g, dtype=torch.uint8).to(dev) for _ in range(5)]
+    batches.insert(3, torch.randint(0, 256, (4, 3, 96, 224), generator=g, dtype=torch.uint8).to(dev))       # another plan set
+    want = []
+    for b in batches:
+        r, c = m.detect_packed(b, pipelined=True, splits=2, graphs=graphs)
+        torch.cuda.synchronize()
+        want.append((r.clone(), c.clone()))
+    assert m.flush_deferred() is None
+    for rep in range(2):                                   # second pass: graphs are captured and replayed
+        got = []
+        for b in batches:
+            res = m.detect_packed(b, pipelined=True, splits=2, graphs=graphs, defer=True)
+            if res is not None:
+                got.append(res)
+        assert len(got) == len(batches) - 1
+        got.append(m.flush_deferred())
+        assert m.flush_deferred() is None
+        torch.cuda.synchronize()
+        for i, ((r, c), (rw, cw)) in enumerate(zip(got, want)):
+            assert torch.equal(c, cw), (rep, i)
+            assert all(torch.equal(r[k, :int(cw[k])], rw[k, :int(cw[k])]) for k in range(4)), (rep, i)
+    # an immediate call while a deferred step is pending: the pending one is completed first and stays retrievable
+    assert m.detect_packed(batches[0], pipelined=True, splits=2, graphs=graphs, defer=True) is None
+    r1, c1 = m.detect_packed(batches[1], pipelined=True, splits=2, graphs=graphs)
+    r0, c0 = m.flush_deferred()
+    torch.cuda.synchronize()
+    assert torch.equal(c0, want[0][1]) and torch.equal(c1, want[1][1])
+    assert torch.equal(r0[0, :int(c0[0])], want[0][0][0, :int(c0[0])]) and torch.equal(r1[0, :int(c1[0])], want[1][0][0, :int(c1[0])])
+    with pytest.raises(ValueError):
+        m.detect_packed(batches[0], defer=True)
