@@ -10,6 +10,10 @@ decode/top-k -> rotated NMS -> rescale/gather, and for N>1 the final detection
 gather to rank 0 over RCCL.  Weak scaling: every rank runs the same per-GPU batch
 (images are independent; weights replicated); value = images of all ranks / the
 slowest rank's time.
+The timed layout is a loop's: step i enqueues its convolutions (sub-batches on concurrent streams) and then the decode / NMS /
+gather of step i - 1, which start where step i reaches its head towers; the last step's are completed by a flush INSIDE the
+timed region, the warm-up's before it -- K steps = K whole passes (--no-defer: every step's post-process right behind its own
+convolutions, round 3's form).
 
 Workload (config.workload): BASELINE.json's metric names R101-FPN on 1024x1024
 DOTA tiles at 1/2/4/8 GPUs, i.e. the per-GPU shard of configs[2] (batch 8 per GPU,
