@@ -213,39 +213,44 @@ def conv_kernel_profile(model, batch, splits, reps=3):
     return stats
 
 
-def conv_kernel_profile_isolated(model, batch, reps=3):
+def conv_kernel_profile_isolated(model, batch, reps=5):
     """Same per-launch event timing, but the whole batch as ONE plan on one stream: every
-    launch has the GPU to itself (kernel quality without stream sharing)."""
+    launch has the GPU to itself (kernel quality without stream sharing).  Per launch the MEDIAN over `reps` passes: one
+    disturbed pass (a clock dip: seen once, conv_bneck 125 instead of 77 us in every launch of a run) does not end up in the
+    roofline record."""
     from dafne_amd import engine, _lib
     n, _, h, w = batch.shape
     plan = model.plan(n, h, w)
     model.detect_packed(batch)
     torch.cuda.synchronize()
     stream = _lib.current_stream()
-    stats = {}
+    timed = [c for c in plan.calls if getattr(c, "flops", 0) > 0]        # ConvCall or a matrix FnCall (stem_pool)
+    per_call = [[] for _ in timed]
     for _ in range(reps):
         evs = []
         for c in plan.calls:
-            if getattr(c, "flops", 0) > 0:        # ConvCall or a matrix FnCall (stem_pool)
+            if getattr(c, "flops", 0) > 0:
                 a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 a.record()
                 c(stream)
                 b.record()
-                evs.append((c, a, b))
+                evs.append((a, b))
             else:
                 c(stream)
         torch.cuda.synchronize()
-        for c, a, b in evs:
-            name = c.kernel_name()
-            s = stats.setdefault(name, {"ms": 0.0, "flops": 0.0, "bytes": 0.0, "launches": 0})
-            s["ms"] += a.elapsed_time(b) / reps
-            s["flops"] += c.flops / reps
-            s["bytes"] += c.bytes / reps
-            s["launches"] += 1
+        for i, (a, b) in enumerate(evs):
+            per_call[i].append(a.elapsed_time(b))
+    stats = {}
+    for c, ts in zip(timed, per_call):
+        s = stats.setdefault(c.kernel_name(), {"ms": 0.0, "flops": 0.0, "bytes": 0.0, "launches": 0})
+        s["ms"] += sorted(ts)[len(ts) // 2]
+        s["flops"] += c.flops
+        s["bytes"] += c.bytes
+        s["launches"] += 1
     return {k: {"tflops": v["flops"] / (v["ms"] * 1e-3) / 1e12, "frac": v["flops"] / (v["ms"] * 1e-3) / 1e12 / PEAK_BF16_TFLOPS,
                 "hbm_gbps_algorithmic": v["bytes"] / (v["ms"] * 1e-3) / 1e9,
                 "hbm_frac": v["bytes"] / (v["ms"] * 1e-3) / 1e9 / PEAK_HBM_GBPS,
-                "ms_per_step": v["ms"], "launches": v["launches"] // reps, "flops": v["flops"], "bytes": v["bytes"]}
+                "ms_per_step": v["ms"], "launches": v["launches"], "flops": v["flops"], "bytes": v["bytes"]}
             for k, v in stats.items()}
 
 
