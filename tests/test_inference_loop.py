@@ -260,6 +260,62 @@ def test_graph_replay_equals_eager_launches(monkeypatch):
 
 
 @pytest.mark.gpu
+def test_graph_capture_survives_runtime_calls_of_other_threads():
+    """A multi-process job has threads that call the HIP runtime while the main thread captures its launch plans (RCCL's
+    watchdog polling events, a loader staging the next batch in pinned memory).  The plans are captured with thread-local
+    error checking (engine._CAPTURE_MODE): a capture-unsafe call elsewhere -- here pinned allocations, device allocations
+    and event queries in a loop -- neither breaks the capture nor changes the replayed results."""
+    import threading
+    from dafne_amd import engine
+    assert engine._CAPTURE_MODE == "thread_local"
+    cfg, m = _gpu_model()
+    g = torch.Generator().manual_seed(33)
+    batches = [torch.randint(0, 256, (4, 3, 128, 160), generator=g, dtype=torch.uint8).cuda() for _ in range(6)]
+    ref = []
+    for b in batches:
+        r, c = m.detect_packed(b, pipelined=True, splits=2, graphs=False)
+        torch.cuda.synchronize()
+        ref.append((r.clone(), c.clone()))
+    m.invalidate()                                                             # fresh plan sets: the captures below are new
+    stop, errs = threading.Event(), []
+
+    def noise():
+        try:
+            torch.cuda.set_device(0)
+            side = torch.cuda.Stream()
+            k = 0
+            while not stop.is_set():
+                k += 1
+                h = torch.empty(4096 << (k % 12), dtype=torch.uint8).pin_memory()     # new size classes: hipHostMalloc, capture-unsafe
+                with torch.cuda.stream(side):                                         # under the default ("global") checking
+                    d = h.to("cuda", non_blocking=True)
+                    e = torch.cuda.Event()
+                    e.record(side)
+                while not e.query():
+                    pass
+                e.synchronize()
+                del h, d
+        except Exception as ex:                                                # pragma: no cover
+            errs.append(ex)
+
+    th = threading.Thread(target=noise, daemon=True)
+    th.start()
+    try:
+        for b, (r0, c0) in zip(batches, ref):
+            r, c = m.detect_packed(b, pipelined=True, splits=2, graphs=True)
+            torch.cuda.synchronize()
+            assert torch.equal(c, c0)
+            for i in range(4):
+                assert torch.equal(r[i, :int(c0[i])], r0[i, :int(c0[i])])
+    finally:
+        stop.set()
+        th.join(timeout=30)
+    assert not errs, errs
+    st = m._pipe[(4, 128, 160, 2)]
+    assert all(p.graph is not None for ps in st["plans"] for p in ps)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("graphs", [False, True])
 def test_deferred_post_process_gives_the_step_results_one_call_later(graphs):
     """detect_packed(defer=True): call i enqueues its convolutions, then the decode + NMS of call i - 1 (started where call i's
