@@ -44,12 +44,22 @@ class DAFNeOutputs(nn.Module):
     def predict_packed(self, levels, sizes=None, k_cap=None, scale_corners=True):
         """levels: list[postprocess.LevelInput] (NHWC fp32).  Returns (rows, counts):
         [N,k_cap,18] float32 detections and their per-image counts, on the GPU."""
-        if not self.stride_norm:
-            raise NotImplementedError("ENABLE_FPN_STRIDE_NORM=False is not used by any released config")
         cand = self.decode_packed(levels)
         return self.select_packed(cand, sizes=sizes, k_cap=k_cap, scale_corners=scale_corners)
 
     def decode_packed(self, levels, out=None):
+        if not self.stride_norm:
+            # ENABLE_FPN_STRIDE_NORM false (dafne_outputs.py:771-774): the regression is already in pixels.  The decode kernel
+            # computes (reg * scale) * stride; with scale / stride for a power-of-two stride both products only shift the
+            # exponent, so the result has the bits of reg * scale (no other rounding: tests/test_gpu_decode.py)
+            adj = []
+            for lv in levels:
+                if lv.stride <= 0 or lv.stride & (lv.stride - 1):
+                    raise NotImplementedError("ENABLE_FPN_STRIDE_NORM=False with an FPN stride that is not a power of two (%d)" % lv.stride)
+                adj.append(pp.LevelInput(lv.logits, lv.delta, lv.center, lv.ctrness, lv.stride, lv.scale / lv.stride,
+                                         delta_ps=lv.delta_ps, center_ps=lv.center_ps, ctrness_ps=lv.ctrness_ps,
+                                         logits_ps=lv.logits_ps))
+            levels = adj
         return pp.decode_levels(levels, num_classes=self.num_classes, pre_nms_thresh=self.pre_nms_thresh_test,
                                 pre_nms_topk=self.pre_nms_topk_test, thresh_with_ctr=self.thresh_with_ctr,
                                 sort_corners=self.sort_corners, out=out)

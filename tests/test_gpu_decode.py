@@ -10,6 +10,7 @@ from oracle import postprocess as opp
 
 pytestmark = pytest.mark.gpu
 VARIANTS = ["d10", "d15", "hrsc", "ucas", "d10_topk", "d15_topk"]
+NO_STRIDE_NORM = ["d10_nsn", "d15_nsn"]       # ENABLE_FPN_STRIDE_NORM false (make_golden_stride_norm.py)
 TOL = 1e-3
 
 
@@ -38,13 +39,16 @@ def test_sort_quadrilateral_golden(golden):
     assert np.array_equal(out, g["sorted"])
 
 
-@pytest.mark.parametrize("name", VARIANTS)
+@pytest.mark.parametrize("name", VARIANTS + NO_STRIDE_NORM)
 def test_predict_proposals_golden(golden, name):
     from dafne_amd.modeling.dafne.dafne_outputs import DAFNeOutputs
-    g = golden("predict_proposals")
+    nsn = name in NO_STRIDE_NORM
+    g = golden("predict_no_stride_norm" if nsn else "predict_proposals")
     C, topk, post, twc, sortc = [int(v) for v in g[name + "_cfg"]]
     thr, nms_thr = [float(v) for v in g[name + "_thr"]]
-    outs = DAFNeOutputs(_cfg(C, topk, post, twc, sortc, thr, nms_thr))
+    cfg = _cfg(C, topk, post, twc, sortc, thr, nms_thr)
+    cfg.MODEL.DAFNE.ENABLE_FPN_STRIDE_NORM = not nsn
+    outs = DAFNeOutputs(cfg)
     logits = [torch.from_numpy(g["%s_logits%d" % (name, l)]).to(dev()) for l in range(5)]
     regs = [torch.from_numpy(g["%s_reg%d" % (name, l)]).to(dev()) for l in range(5)]
     ctrs = [torch.from_numpy(g["%s_ctr%d" % (name, l)]).to(dev()) for l in range(5)]

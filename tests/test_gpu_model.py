@@ -29,11 +29,12 @@ def dev():
     return torch.device("cuda", 0)
 
 
-def build(cfgname, seed):
+def build(cfgname, seed, stride_norm=True):
     import dafne_amd.modeling  # noqa: F401
     from dafne_amd.config import load_cfg
     from dafne_amd.registry import build_model
     cfg = load_cfg(os.path.join(ROOT, "configs", cfgname))
+    cfg.MODEL.DAFNE.ENABLE_FPN_STRIDE_NORM = bool(stride_norm)
     m = build_model(cfg)
     P = om.make_params(cfg.MODEL.RESNETS.DEPTH, cfg.MODEL.DAFNE.NUM_CLASSES, seed=seed)
     m.load_state_dict(P)
@@ -69,12 +70,13 @@ def test_backbone_and_head_vs_oracle():
         assert rel(ctrs[l].cpu(), h_e[3][l]) < 2.5e-2, ("ctr", l)
 
 
-@pytest.mark.parametrize("cfgname", ["dota-1.0_r50.yaml", "dota-1.5_r101.yaml"])
-def test_end_to_end_detections_vs_oracle_postprocess(cfgname):
+@pytest.mark.parametrize("cfgname,stride_norm", [("dota-1.0_r50.yaml", True), ("dota-1.5_r101.yaml", True), ("dota-1.0_r50.yaml", False)])
+def test_end_to_end_detections_vs_oracle_postprocess(cfgname, stride_norm):
     """OneStageDetector.forward (fused path) vs: engine head outputs -> numpy oracle
-    decode / NMS / cap / detector_postprocess."""
+    decode / NMS / cap / detector_postprocess.  stride_norm False: MODEL.DAFNE.ENABLE_FPN_STRIDE_NORM off
+    (dafne_outputs.py:771-774; no released config), serial and sub-batch-stream layouts."""
     from dafne_amd.modeling.dafne.dafne import head_levels
-    cfg, m, P = build(cfgname, seed=5)
+    cfg, m, P = build(cfgname, seed=5, stride_norm=stride_norm)
     d = cfg.MODEL.DAFNE
     g = torch.Generator().manual_seed(1)
     ims = [torch.randint(0, 256, (3, 160, 192), generator=g, dtype=torch.uint8),
@@ -96,7 +98,8 @@ def test_end_to_end_detections_vs_oracle_postprocess(cfgname):
             levels.append((np.transpose(lg, (2, 0, 1)), np.transpose(reg, (2, 0, 1)), np.transpose(dc[..., 8:9], (2, 0, 1))))
         det = opp.predict_proposals(levels, strides, thresh=d.INFERENCE_TH_TEST, topk=d.PRE_NMS_TOPK_TEST,
                                     nms_thresh=d.NMS_TH, post_topk=d.POST_NMS_TOPK_TEST,
-                                    thresh_with_ctr=d.THRESH_WITH_CTR, sort_corners=d.SORT_CORNERS, fast=True)
+                                    thresh_with_ctr=d.THRESH_WITH_CTR, sort_corners=d.SORT_CORNERS, fast=True,
+                                    stride_norm=stride_norm)
         hw = tuple(ims[i].shape[1:])
         exp = opp.detector_postprocess(det, hw, (inputs[i]["height"], inputs[i]["width"]), hw)
         assert len(inst) == exp["scores"].shape[0] and len(inst) > 0
@@ -125,6 +128,16 @@ def test_end_to_end_detections_vs_oracle_postprocess(cfgname):
         # positions may differ only where scores are (nearly) tied
         moved = np.nonzero(gk != ek)[0]
         assert all(abs(gs[j] - exp["scores"][j]) < 1e-6 for j in moved)
+    if not stride_norm:
+        # the sub-batch-stream layout decodes through the same switch: same rows as the serial call
+        batch, valid, out_hw = m._pack_inputs(inputs)
+        r0, c0 = m.detect_packed(batch, valid_hw=valid, out_hw=out_hw)
+        torch.cuda.synchronize()
+        r1, c1 = m.detect_packed(batch, valid_hw=valid, out_hw=out_hw, pipelined=True, splits=2)
+        torch.cuda.synchronize()
+        assert torch.equal(c0, c1)
+        for i in range(2):
+            assert torch.equal(r0[i, :int(c0[i])], r1[i, :int(c0[i])])
 
 
 def test_checkpoint_file_to_engine_vs_oracle(tmp_path):

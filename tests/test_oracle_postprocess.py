@@ -6,6 +6,7 @@ import pytest
 from oracle import postprocess as pp
 
 VARIANTS = ["d10", "d15", "hrsc", "ucas", "d10_topk", "d15_topk"]
+NO_STRIDE_NORM = ["d10_nsn", "d15_nsn"]
 
 
 def test_sort_quadrilateral_golden(golden):
@@ -27,9 +28,12 @@ def _key(d):
         + d["locations"][:, 0].astype(np.int64) * 32 + d["pred_classes"]
 
 
-@pytest.mark.parametrize("name", VARIANTS)
+@pytest.mark.parametrize("name", VARIANTS + NO_STRIDE_NORM)
 def test_predict_proposals_golden(golden, name):
-    g = golden("predict_proposals")
+    """The *_nsn variants: MODEL.DAFNE.ENABLE_FPN_STRIDE_NORM false (dafne_outputs.py:771-774), fixture of
+    make_golden_stride_norm.py."""
+    nsn = name in NO_STRIDE_NORM
+    g = golden("predict_no_stride_norm" if nsn else "predict_proposals")
     C, topk, post, twc, sortc = [int(v) for v in g[name + "_cfg"]]
     thr, nms_thr = [float(v) for v in g[name + "_thr"]]
     strides = [8, 16, 32, 64, 128]
@@ -37,7 +41,7 @@ def test_predict_proposals_golden(golden, name):
         levels = [(g["%s_logits%d" % (name, l)][im], g["%s_reg%d" % (name, l)][im],
                    g["%s_ctr%d" % (name, l)][im]) for l in range(5)]
         det = pp.predict_proposals(levels, strides, thresh=thr, topk=topk, nms_thresh=nms_thr,
-                                   post_topk=post, thresh_with_ctr=bool(twc), sort_corners=bool(sortc))
+                                   post_topk=post, thresh_with_ctr=bool(twc), sort_corners=bool(sortc), stride_norm=not nsn)
         ref = {k: g["%s_im%d_%s" % (name, im, k)] for k in
                ("pred_boxes", "pred_corners", "scores", "centerness", "pred_classes", "locations", "fpn_levels")}
         # same detections, same (descending-score) order; keyed compare guards ties
