@@ -12,7 +12,11 @@ outputs of the OLDEST batch in flight (batch i - 2 for the detector; None while 
 evaluator sees exactly the (inputs, outputs) pairs of the synchronous loop, in the same order.  A model without `forward_streamed` (the TTA
 wrapper) is called synchronously.
 """
+import copy
+import logging
+import os
 import time
+from collections import OrderedDict
 
 import torch
 
@@ -39,10 +43,14 @@ class DafneEvaluator(DatasetEvaluator):
     global image order.  distributed: ONE collective pair over fixed-layout device buffers (gather.gather_detections: RCCL
     on the MI355X, gloo in the CPU tests) instead of the reference's pickled lists -- every rank must have processed the same
     number of images (the driver pads shards; `pad_to`).  The dataset-specific scoring (`_eval_predictions`: Task1 files, tile
-    merge, voc_eval) lives in evaluation/dota_evaluation.py."""
+    merge, voc_eval) lives in the subclasses -- DotaEvaluator (dota_evaluation.py), HrscEvaluator (hrsc_evaluation.py),
+    UcasAodEvaluator (ucas_aod_evaluation.py); `get_evaluator` picks one by dataset name as tools/plain_train_net.py:171-214
+    does -- which return the reference's {"task1": {class: ap, ..., "map": ...}} from evaluate()."""
 
-    def __init__(self, dataset_name, cfg, distributed, output_dir=None, k_cap=None, device=None, pad_to=None):
+    def __init__(self, dataset_name, cfg, distributed, output_dir=None, k_cap=None, device=None, pad_to=None, metadata=None):
         self._dataset_name, self._cfg, self._distributed, self._output_dir = dataset_name, cfg, distributed, output_dir
+        self._metadata = metadata        # the reference reads MetadataCatalog.get(dataset_name): .root_dir, .is_test
+        self._logger = logging.getLogger(__name__)
         self._k_cap = k_cap
         self._device = device
         self._pad_to = pad_to            # images every rank contributes to the gather (ceil(n / world): shards may be ragged)
@@ -92,8 +100,19 @@ class DafneEvaluator(DatasetEvaluator):
             predictions = [p for p in preds if p["image_id"] >= 0]
         else:
             predictions = self._predictions
-        self._results = {"predictions": predictions, "num_images": len(predictions)}
-        return self._results
+        if not hasattr(self, "_eval_predictions"):
+            self._results = {"predictions": predictions, "num_images": len(predictions)}
+            return self._results
+        # a dataset evaluator (DotaEvaluator / HrscEvaluator / UcasAodEvaluator): dafne_evaluator.py:69-84
+        if len(predictions) == 0:
+            self._logger.warning("[DafneEvaluator] Did not receive valid predictions.")
+            return {}
+        if self._output_dir:
+            os.makedirs(self._output_dir, exist_ok=True)
+            torch.save(predictions, os.path.join(self._output_dir, "instances_predictions.pth"))
+        self._results = OrderedDict()
+        self._eval_predictions(predictions)
+        return copy.deepcopy(self._results)
 
 
 def inference_on_dataset(model, data_loader, evaluator=None, stats=None):
@@ -144,3 +163,21 @@ def inference_on_dataset(model, data_loader, evaluator=None, stats=None):
     if stats is not None:
         stats.update(images=n, seconds=dt, images_per_sec=n / dt if dt > 0 else float("inf"))
     return evaluator.evaluate() if evaluator is not None else collected
+
+
+def get_evaluator(cfg, dataset_name, output_folder=None, metadata=None, distributed=True, **kw):
+    """tools/plain_train_net.py:171-214: the evaluator of a dataset, by its name ("dota", "hrsc", "ucas"; the reference's
+    fourth, ICDAR15, has no released config and no counterpart here).  metadata: an object with .root_dir (and .is_test for
+    DOTA) -- what the reference takes from MetadataCatalog.get(dataset_name).  kw: k_cap / device / pad_to of DafneEvaluator."""
+    if output_folder is None:
+        output_folder = os.path.join(cfg.OUTPUT_DIR, "inference", dataset_name)
+    name = dataset_name.lower()
+    if "dota" in name:
+        from .dota_evaluation import DotaEvaluator as cls
+    elif "hrsc" in name:
+        from .hrsc_evaluation import HrscEvaluator as cls
+    elif "ucas" in name:
+        from .ucas_aod_evaluation import UcasAodEvaluator as cls
+    else:
+        raise NotImplementedError("no Evaluator for the dataset %r (dota / hrsc / ucas)" % (dataset_name,))
+    return cls(dataset_name=dataset_name, cfg=cfg, distributed=distributed, output_dir=output_folder, metadata=metadata, **kw)

@@ -61,6 +61,12 @@ def parse_args(argv=None):
     ap.add_argument("--output", default="")
     ap.add_argument("--task1-dir", default="", help="DOTA configs: write Task1_<class>.txt files here and merge the tiles "
                                                     "(Task1_merged/) with the device NMS (dota_evaluation.py:110-184)")
+    ap.add_argument("--dataset-name", default="",
+                    help="score the predictions as the reference's evaluator of this dataset does (get_evaluator, tools/plain_train_net.py:"
+                         "171-214: a name containing dota / hrsc / ucas): Task1 files + VOC07 AP per class against the annotations under "
+                         "--dataset-root (labelTxt/ | labelXml/ | Annotations/), written to --eval-dir; use with --image-dir")
+    ap.add_argument("--dataset-root", default="", help="the dataset's root directory (MetadataCatalog's root_dir in the reference)")
+    ap.add_argument("--eval-dir", default="", help="output folder of --dataset-name (default OUTPUT_DIR/inference/<dataset name>)")
     ap.add_argument("opts", nargs=argparse.REMAINDER, help="KEY VALUE config overrides")
     return ap.parse_args(argv)
 
@@ -247,6 +253,17 @@ def run(args, rank=0, world=1, local_rank=0):
         n_in = sum(len(open(os.path.join(t1, f)).readlines()) for f in os.listdir(t1))
         n_out = sum(len(open(os.path.join(merged, f)).readlines()) for f in os.listdir(merged))
         print("Task1: %d tile detections -> %d after the tile merge (%s)" % (n_in, n_out, merged))
+    if args.dataset_name:
+        import types
+        from collections import OrderedDict
+        from dafne_amd.evaluation.inference import get_evaluator
+        ev2 = get_evaluator(cfg, args.dataset_name, output_folder=args.eval_dir or None, distributed=False,
+                            metadata=types.SimpleNamespace(root_dir=args.dataset_root, is_test="test" in args.dataset_name.lower()))
+        os.makedirs(ev2._output_dir, exist_ok=True)
+        ev2._results = OrderedDict()
+        ev2._eval_predictions(preds)
+        for k, v in ev2._results.get("task1", {}).items():
+            print("%-18s: %.4f" % (k, v))
     return preds
 
 
