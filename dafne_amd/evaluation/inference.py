@@ -171,6 +171,10 @@ def get_evaluator(cfg, dataset_name, output_folder=None, metadata=None, distribu
     DOTA) -- what the reference takes from MetadataCatalog.get(dataset_name).  kw: k_cap / device / pad_to of DafneEvaluator."""
     if output_folder is None:
         output_folder = os.path.join(cfg.OUTPUT_DIR, "inference", dataset_name)
+    if metadata is None:
+        from ..data.datasets import MetadataCatalog          # filled by data.datasets.register_dota / _hrsc / _ucas_aod
+        if dataset_name in MetadataCatalog:
+            metadata = MetadataCatalog.get(dataset_name)
     name = dataset_name.lower()
     if "dota" in name:
         from .dota_evaluation import DotaEvaluator as cls

@@ -49,7 +49,8 @@ def hrsc_xml(rng, n):
     body = "".join("<HRSC_Object><Object_ID>%d</Object_ID><Class_ID>100000001</Class_ID><difficult>%d</difficult>"
                    "<mbox_cx>%.4f</mbox_cx><mbox_cy>%.4f</mbox_cy><mbox_w>%.4f</mbox_w><mbox_h>%.4f</mbox_h><mbox_ang>%.6f</mbox_ang>"
                    "</HRSC_Object>" % (k, d, cx, cy, w, h, a) for k, (cx, cy, w, h, a, d) in enumerate(rows))
-    return "<HRSC_Image><Img_ID>1</Img_ID><HRSC_Objects>%s</HRSC_Objects></HRSC_Image>" % body
+    return ("<HRSC_Image><Img_ID>1</Img_ID><Img_SizeWidth>%d</Img_SizeWidth><Img_SizeHeight>%d</Img_SizeHeight>"
+            "<HRSC_Objects>%s</HRSC_Objects></HRSC_Image>" % (int(rng.integers(900, 1300)), int(rng.integers(600, 900)), body))
 
 
 def ucas_txt(rng, n):
@@ -132,6 +133,18 @@ def main():
             assert all(o["name"] == "ship" for o in objs)
             gts[img] = [(0, np.array(o["bbox"])) for o in objs]
         fx["hrsc_images"] = np.array(images)
+        # the records of load_hrsc (hrsc2016.py:54-128) for an ImageSets/test.txt naming the three images
+        os.makedirs(os.path.join(root, "ImageSets"))
+        with open(os.path.join(root, "ImageSets", "test.txt"), "w") as f:
+            f.write("\n".join(images) + "\n")
+        HD = ref_functions("dafne/data/datasets/hrsc2016.py", ["load_hrsc", "xywha2xy4"],
+                           {"np": np, "ET": ET, "os": os, "BoxMode": types.SimpleNamespace(XYWH_ABS=1), "name2label": {"ship": 0}})
+        nodebug = mg.AttrDict({"DEBUG": {"OVERFIT_NUM_IMAGES": -1}})
+        recs = HD["load_hrsc"](root, "test", nodebug)
+        fx["hrsc_rec_file"] = np.array([os.path.relpath(r["file_name"], root) for r in recs])
+        fx["hrsc_rec_id"] = np.array([r["image_id"] for r in recs], np.int64)
+        fx["hrsc_rec_wh"] = np.array([[r["width"], r["height"]] for r in recs], np.int64)
+        fx["hrsc_rec_nobj"] = np.array([len(r["annotations"]) for r in recs], np.int64)
         fx["hrsc_xywha"] = rng.uniform(-3, 300, (6, 5))
         fx["hrsc_xywha_out"] = np.array([H["xywha2xy4"](r) for r in fx["hrsc_xywha"]])
         preds = predictions_for(gts, rng, images, 1000.0)
@@ -180,6 +193,13 @@ def main():
             print("ucas", img, n, "lines ->", len(objs), "objects")
             gts[img] = [(classnames.index(o["name"]), np.array(o["bbox"], np.float64)) for o in objs]
         fx["ucas_images"] = np.array(images)
+        os.makedirs(os.path.join(root, "ImageSets"))
+        with open(os.path.join(root, "ImageSets", "test.txt"), "w") as f:
+            f.write("\n".join(images) + "\n")
+        UD = ref_functions("dafne/data/datasets/ucas_aod.py", ["load_ucas_aod"], dict(D))
+        recs = UD["load_ucas_aod"](root, "test", mg.AttrDict({"DEBUG": {"OVERFIT_NUM_IMAGES": 2}}))          # the first two only
+        fx["ucas_rec_file"] = np.array([os.path.relpath(r["file_name"], root) for r in recs])
+        fx["ucas_rec_id"] = np.array([r["image_id"] for r in recs])
         preds = predictions_for(gts, rng, images, 1000.0)
         out = os.path.join(tmp, "ucas_out")
         os.makedirs(os.path.join(out, "Task1"))

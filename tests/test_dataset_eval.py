@@ -100,6 +100,49 @@ def test_get_evaluator_picks_the_dataset_class():
         get_evaluator(cfg, "icdar15_test")
 
 
+def test_registered_datasets_yield_the_reference_records(tmp_path):
+    """register_hrsc / register_ucas_aod / register_dota (tools/plain_train_net.py:568-570): names, directory layout, record
+    fields as the reference's load_hrsc / load_ucas_aod return them (fixture) and as load_dota_json builds them; the metadata
+    the evaluators read; get_evaluator finds it by name."""
+    import json
+    from dafne_amd.data import DatasetCatalog, MetadataCatalog, register_all
+    from dafne_amd.evaluation.inference import get_evaluator
+    ns = types.SimpleNamespace
+    data = str(tmp_path)
+    hroot, uroot = os.path.join(data, "hrsc"), os.path.join(data, "UCAS-AOD")
+    _write_hrsc(hroot)
+    _write_ucas(uroot)
+    for root, images in ((hroot, G["hrsc_images"]), (uroot, G["ucas_images"])):
+        os.makedirs(os.path.join(root, "ImageSets"))
+        with open(os.path.join(root, "ImageSets", "test.txt"), "w") as f:
+            f.write("\n".join(str(i) for i in images) + "\n")
+    droot = os.path.join(data, "dota_1_5_split", "val1024")
+    os.makedirs(droot)
+    with open(os.path.join(droot, "DOTA1_5_val1024.json"), "w") as f:
+        json.dump({"images": [{"id": 7, "file_name": "P0007__1__0___0.png", "height": 1024, "width": 1024},
+                              {"id": 2, "file_name": "P0002__1__824___0.png", "height": 1024, "width": 1024}],
+                   "annotations": [], "categories": []}, f)
+    register_all(ns(DEBUG=ns(OVERFIT_NUM_IMAGES=-1)), data_dir=data)
+    recs = DatasetCatalog.get("hrsc_test")
+    assert [os.path.relpath(r["file_name"], hroot) for r in recs] == [str(v) for v in G["hrsc_rec_file"]]
+    assert [r["image_id"] for r in recs] == G["hrsc_rec_id"].tolist()
+    assert [[r["width"], r["height"]] for r in recs] == G["hrsc_rec_wh"].tolist()
+    recs = DatasetCatalog.get("dota_1_5_val_1024")
+    assert [r["image_id"] for r in recs] == [2, 7] and recs[0]["file_name"] == os.path.join(droot, "images", "P0002__1__824___0.png")
+    m = MetadataCatalog.get("dota_1_5_val_1024")
+    assert m.root_dir == droot and m.is_test is False and m.evaluator_type == "dota"
+    assert MetadataCatalog.get("hrsc_test").is_test and MetadataCatalog.get("hrsc_test").root_dir == hroot
+    ev = get_evaluator(_cfg(), "hrsc_test", distributed=False)
+    assert ev._metadata is MetadataCatalog.get("hrsc_test")
+    register_all(ns(DEBUG=ns(OVERFIT_NUM_IMAGES=2)), data_dir=data)                  # re-registration replaces; first N images
+    recs = DatasetCatalog.get("ucas_aod_test")
+    assert [os.path.relpath(r["file_name"], uroot) for r in recs] == [str(v) for v in G["ucas_rec_file"]]
+    assert [r["image_id"] for r in recs] == [str(v) for v in G["ucas_rec_id"]]
+    with pytest.raises(KeyError):
+        os.environ.pop("DAFNE_DATA_DIR", None)
+        register_all(None)
+
+
 # ------------------------------------------------------------------------------------------------------------------ GPU
 @pytest.mark.gpu
 @pytest.mark.parametrize("thr", [0.5, 0.75])
@@ -144,3 +187,46 @@ def test_ucas_evaluator_end_to_end_matches_reference(tmp_path):
         assert res["task1"][c] == float(G["ucas_ap_" + c])
     assert res["task1"]["map"] == pytest.approx((float(G["ucas_ap_car"]) + float(G["ucas_ap_airplane"])) / 2, abs=1e-15)
     assert os.path.exists(os.path.join(str(tmp_path / "out"), "instances_predictions.pth"))
+
+
+@pytest.mark.gpu
+def test_reference_shaped_chain_on_a_registered_dataset(tmp_path, monkeypatch):
+    """do_test's chain (tools/plain_train_net.py:316-336,568-570) on a tiny HRSC-layout dataset: register_hrsc ->
+    build_test_loader(cfg, "hrsc_test") -> inference_on_dataset(model, loader, get_evaluator(cfg, "hrsc_test")) ->
+    {"task1": {"ship": ap, "map": ap}}; the Task1 file holds every detection of every image under the image's id."""
+    from PIL import Image
+    import dafne_amd.modeling  # noqa: F401
+    from dafne_amd.config import load_cfg
+    from dafne_amd.data import build_test_loader, register_hrsc
+    from dafne_amd.evaluation.inference import get_evaluator, inference_on_dataset
+    from dafne_amd.registry import build_model
+    from oracle import model as om
+    root = tmp_path / "hrsc"
+    _write_hrsc(str(root))
+    os.makedirs(str(root / "images"))
+    os.makedirs(str(root / "ImageSets"))
+    rng = np.random.default_rng(5)
+    ids = [str(v) for v in G["hrsc_images"]]
+    for img, (w, h) in zip(ids, G["hrsc_rec_wh"].tolist()):
+        Image.fromarray(rng.integers(0, 256, (h, w, 3), dtype=np.uint8)).save(str(root / "images" / ("%d.bmp" % int(img))))
+    with open(str(root / "ImageSets" / "test.txt"), "w") as f:
+        f.write("\n".join(ids) + "\n")
+    cfg = load_cfg(os.path.join(ROOT, "configs", "hrsc_r50.yaml"))
+    cfg.INPUT.MIN_SIZE_TEST, cfg.INPUT.MAX_SIZE_TEST = 256, 512
+    cfg.OUTPUT_DIR = str(tmp_path / "out")
+    monkeypatch.setenv("DAFNE_DATA_DIR", str(tmp_path))
+    register_hrsc(cfg)
+    m = build_model(cfg)
+    m.load_state_dict(om.make_params(cfg.MODEL.RESNETS.DEPTH, cfg.MODEL.DAFNE.NUM_CLASSES, seed=3))
+    m.to(torch.device("cuda", 0))
+    m.invalidate()
+    loader = build_test_loader(cfg, "hrsc_test", batch_size=2, device=torch.device("cuda", 0), num_workers=2)
+    ev = get_evaluator(cfg, "hrsc_test", distributed=False)
+    res = inference_on_dataset(m, loader, ev)
+    assert set(res) == {"task1"} and set(res["task1"]) == {"ship", "map"} and 0.0 <= res["task1"]["ship"] <= 1.0
+    out = os.path.join(cfg.OUTPUT_DIR, "inference", "hrsc_test")
+    lines = open(os.path.join(out, "Task1", "Task1_ship.txt")).read().splitlines()
+    preds = torch.load(os.path.join(out, "instances_predictions.pth"), weights_only=False)
+    assert len(preds) == 3 and len(lines) == sum(len(p["scores"]) for p in preds) > 0
+    assert {l.split(" ")[0] for l in lines} <= {str(int(i)) for i in ids}
+    assert [(p["height"], p["width"]) for p in preds] == [(h, w) for w, h in G["hrsc_rec_wh"].tolist()]      # the files' own sizes

@@ -64,7 +64,8 @@ def parse_args(argv=None):
     ap.add_argument("--dataset-name", default="",
                     help="score the predictions as the reference's evaluator of this dataset does (get_evaluator, tools/plain_train_net.py:"
                          "171-214: a name containing dota / hrsc / ucas): Task1 files + VOC07 AP per class against the annotations under "
-                         "--dataset-root (labelTxt/ | labelXml/ | Annotations/), written to --eval-dir; use with --image-dir")
+                         "--dataset-root (labelTxt/ | labelXml/ | Annotations/), written to --eval-dir.  Images: --image-dir, or -- with "
+                         "$DAFNE_DATA_DIR set -- the registered dataset of that name (dota_1_5_val_1024, hrsc_test, ucas_aod_test, ...)")
     ap.add_argument("--dataset-root", default="", help="the dataset's root directory (MetadataCatalog's root_dir in the reference)")
     ap.add_argument("--eval-dir", default="", help="output folder of --dataset-name (default OUTPUT_DIR/inference/<dataset name>)")
     ap.add_argument("opts", nargs=argparse.REMAINDER, help="KEY VALUE config overrides")
@@ -134,11 +135,19 @@ def run(args, rank=0, world=1, local_rank=0):
             import torch.distributed as dist
             dist.barrier()
         args.image_dir = args.write_synthetic_dir
-    if args.image_dir:
-        if args.tta_shard_views:
-            raise SystemExit("--tta-shard-views runs on synthetic tiles (every rank needs every image); --tta alone takes --image-dir")
+    if args.dataset_name and not args.image_dir and os.environ.get("DAFNE_DATA_DIR"):
+        # the reference's way (plain_train_net.py:568-570, do_test): the dataset by its registered name below $DAFNE_DATA_DIR
+        from dafne_amd.data import DatasetCatalog, MetadataCatalog, register_all
+        register_all(cfg)
+        records = DatasetCatalog.get(args.dataset_name)
+        args.image_dir = MetadataCatalog.get(args.dataset_name).image_root
+        args.dataset_root = args.dataset_root or MetadataCatalog.get(args.dataset_name).root_dir
+    elif args.image_dir:
         from dafne_amd.data import list_image_records
         records = list_image_records(args.image_dir)
+    if records is not None:
+        if args.tta_shard_views:
+            raise SystemExit("--tta-shard-views runs on synthetic tiles (every rank needs every image); --tta alone takes --image-dir")
         if n > 0:
             records = records[:n]
         n = len(records)
