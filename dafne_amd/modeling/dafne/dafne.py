@@ -124,6 +124,11 @@ class DAFNe(nn.Module):
         self.in_features = cfg.MODEL.DAFNE.IN_FEATURES
         self.fpn_strides = cfg.MODEL.DAFNE.FPN_STRIDES
         self.yield_proposal = cfg.MODEL.DAFNE.YIELD_PROPOSAL
+        if list(self.in_features) != ["p3", "p4", "p5", "p6", "p7"] or list(self.fpn_strides) != [8, 16, 32, 64, 128]:
+            # the fused detector plan (engine.DensePlan) always builds P3..P7 of the ResNet-FPN and decodes them with these
+            # strides; a subset would otherwise be decoded with the wrong levels' strides without a word
+            raise NotImplementedError("engine builds the released pyramid: MODEL.DAFNE.IN_FEATURES p3..p7 with FPN_STRIDES 8..128 "
+                                      "(got %s / %s)" % (list(self.in_features), list(self.fpn_strides)))
         self.dafne_head = DAFNeHead(cfg, [input_shape[f] for f in self.in_features])
         self.in_channels_to_top_module = self.dafne_head.in_channels_to_top_module
         self.dafne_outputs = DAFNeOutputs(cfg)
