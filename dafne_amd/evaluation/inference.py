@@ -83,21 +83,27 @@ class DafneEvaluator(DatasetEvaluator):
                 raise RuntimeError("DafneEvaluator(distributed=True) needs k_cap (DAFNeOutputs.packed_k_cap())")
             dev = self._device if self._device is not None else (self._insts[0].scores.device if self._insts else torch.device("cpu"))
             rows, counts = instances_to_rows(self._insts, self._k_cap, dev)
-            ids = torch.tensor([m["image_id"] for m in self._meta], dtype=torch.int64, device=dev)
             n = pad_to if pad_to is not None else len(self._insts)
-            if n > rows.shape[0]:                     # equal shapes on every rank: pad with empty images (id -1)
+            if n > rows.shape[0]:                     # equal shapes on every rank: pad with empty images
                 pad = n - rows.shape[0]
                 rows = torch.cat([rows, rows.new_zeros((pad,) + tuple(rows.shape[1:]))])
                 counts = torch.cat([counts, counts.new_zeros(pad)])
-                ids = torch.cat([ids, ids.new_full((pad,), -1)])
             out = gather_detections(rows, counts, dst=0)
-            idl = [torch.empty_like(ids) for _ in range(dist.get_world_size())] if dist.get_rank() == 0 else None
-            dist.gather(ids, idl, dst=0)
+            # the images' own fields (image_id -- an int for DOTA / HRSC, a string for UCAS-AOD --, file_name, height, width)
+            # travel as the small pickled lists the reference gathers everything in (dafne_evaluator.py:62); a rank's list is in
+            # the order of its rows, its length tells the padding apart
+            metas = [None] * dist.get_world_size()
+            dist.all_gather_object(metas, self._meta)
             if out is None:
                 return {}
-            ids_all = torch.cat(idl).cpu().tolist()
-            preds = to_predictions(out[0], out[1], image_ids=ids_all)
-            predictions = [p for p in preds if p["image_id"] >= 0]
+            rows_all, counts_all = out
+            preds = to_predictions(rows_all, counts_all, image_ids=list(range(rows_all.shape[0])))
+            predictions = []
+            for r, ms in enumerate(metas):
+                for j, m in enumerate(ms):
+                    p = preds[r * n + j]
+                    p.update(m)
+                    predictions.append(p)
         else:
             predictions = self._predictions
         if not hasattr(self, "_eval_predictions"):

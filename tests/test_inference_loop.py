@@ -40,7 +40,7 @@ class _StubStreamed:
         return self
 
     def _run(self, inputs):
-        return [{"instances": _inst(x["image_id"], x["image_id"] % 5 + 1)} for x in inputs]
+        return [{"instances": _inst(x.get("idx", x["image_id"]), x.get("idx", x["image_id"]) % 5 + 1)} for x in inputs]
 
     def __call__(self, inputs):
         self.calls.append(("sync", [x["image_id"] for x in inputs]))
@@ -119,8 +119,22 @@ def _eval_worker(rank, world, port, q):
             preds = sorted(res["predictions"], key=lambda p: p["image_id"])
             ok = ok and [p["image_id"] for p in preds] == list(range(n_total))
             ok = ok and all(p["labels"].tolist() == [g] * (g % 5 + 1) and float(p["corners"][0, 0]) == g for g, p in enumerate(preds))
+            ok = ok and all(p["file_name"] == "f%d" % g and (p["height"], p["width"]) == (64, 64) for g, p in enumerate(preds))
         else:
             ok = ok and res == {}
+    # a dataset evaluator (a subclass with _eval_predictions: DotaEvaluator / HrscEvaluator / UcasAodEvaluator) on string image ids
+    # (UCAS-AOD's): rank 0 scores ALL images with their own file names, the other ranks return {} (dafne_evaluator.py:60-84)
+    class Scoring(DafneEvaluator):
+        def _eval_predictions(self, predictions):
+            self._results["seen"] = [(p["image_id"], p["file_name"], len(p["scores"])) for p in predictions]
+    lo, hi = shard_range(5, rank, world)
+    items = [{"image_id": "P%04d" % i, "idx": i, "file_name": "/d/P%04d.png" % i, "height": 64, "width": 64} for i in range(lo, hi)]
+    ev = Scoring("stub", None, distributed=True, k_cap=16, device=torch.device("cpu"), pad_to=3)
+    res = inference_on_dataset(_StubStreamed(), [items[i:i + 2] for i in range(0, len(items), 2)], ev)
+    if rank == 0:
+        ok = ok and res == {"seen": [("P%04d" % i, "/d/P%04d.png" % i, i % 5 + 1) for i in range(5)]}
+    else:
+        ok = ok and res == {}
     q.put((rank, ok))
     dist.barrier()
     dist.destroy_process_group()
