@@ -110,17 +110,23 @@ def load_weights(model, path_or_state, strict=False):
         raise ValueError("shape mismatch for %s" % bad[:5])
     if strict and (missing or unexpected):
         raise KeyError("missing %s unexpected %s" % (missing[:5], unexpected[:5]))
+    takes_scales = sc is not None and getattr(getattr(model, "cfg", None), "ENGINE", None) is not None \
+        and model.cfg.ENGINE.WEIGHT_DTYPE == "fp8_e4m3" and model.device.type == "cuda"
+    if takes_scales:
+        # everything that can be refused is refused BEFORE the model is touched (a failure used to leave it half-loaded:
+        # new weights, no scales)
+        if missing:
+            # the scales were calibrated for the checkpoint's weights: a partial load serves other weights
+            raise ValueError("fp8 activation scales in the checkpoint, but %d model keys are missing from it: the scales belong to "
+                             "ITS weights (load them explicitly with set_fp8_act_scales if that is intended)" % len(missing))
+        from . import engine
+        engine.check_act_qscales(sc)
     with torch.no_grad():
         for k, v in own.items():
             if k in sd:
                 v.copy_(sd[k].to(v.dtype))
     if hasattr(model, "invalidate"):
         model.invalidate()
-    if sc is not None and getattr(getattr(model, "cfg", None), "ENGINE", None) is not None \
-            and model.cfg.ENGINE.WEIGHT_DTYPE == "fp8_e4m3" and model.device.type == "cuda":
-        if missing or bad:
-            # the scales were calibrated for the checkpoint's weights: a partial load serves other weights
-            raise ValueError("fp8 activation scales in the checkpoint, but %d model keys are missing from it: the scales belong to "
-                             "ITS weights (load them explicitly with set_fp8_act_scales if that is intended)" % len(missing))
-        model.set_fp8_act_scales(sc)
+    if takes_scales:
+        model.set_fp8_act_scales(sc)          # the layer set is checked against the packed weights (needs them loaded)
     return missing, unexpected

@@ -192,10 +192,8 @@ class _Staging:
         self._cur = None
 
     def stage(self, t):
-        if self.i == 0 and torch.get_num_threads() > min(8, usable_cpus()):
-            # the staging copies run on torch's intra-op pool; with one worker per visible core (128-256 on the MI355X hosts,
-            # under a CPU quota of 16) the pool's spin-wait starves the HIP runtime's threads (_pack_inputs: same cap)
-            torch.set_num_threads(min(8, usable_cpus()))
+        # the staging copies run on torch's intra-op pool, which inference_on_dataset caps for the duration of the loop
+        # (utils.host.capped_torch_threads; it used to be shrunk here, process-wide and for good)
         k = self.i % len(self.slots)
         self.i += 1
         n = t.numel()

@@ -118,6 +118,16 @@ def act_qscale_from_amax(amax, margin=2.0):
     return float(2.0 ** math.floor(math.log2(E4M3_MAX / (margin * amax))))
 
 
+def check_act_qscales(scales):
+    """An activation scale is a positive finite power of two (act_qscale_from_amax); raises ValueError otherwise.  Pure
+    host check: checkpoint.load_weights runs it BEFORE it touches the model."""
+    import math
+    for k, v in dict(scales).items():
+        v = float(v)
+        if not (math.isfinite(v) and v > 0 and math.log2(v) == round(math.log2(v))):
+            raise ValueError("fp8 activation scale %r of %s is not a positive power of two" % (v, k))
+
+
 def reduce_amax_over_ranks(calib, group=None, device=None):
     """fp8 calibration in a multi-process job: every rank must end up with the SAME activation scales, whatever images its
     shard holds -- element-wise MAX of the per-layer amax values over the ranks (one all-reduce of a small float64 vector

@@ -21,11 +21,12 @@ def instances_to_rows(instances, k_cap, device=None):
     """list[Instances] (the reference-signature output) -> packed ([n, k_cap, 18] float32, [n] int32): the inverse of
     postprocess.rows_to_instances, used to put TTA results (one merged Instances per image) on the gather path."""
     n = len(instances)
-    dev = device if device is not None else (instances[0].scores.device if n else torch.device("cpu"))
+    real = [i for i in instances if i is not None]           # None = an image without detections output (an empty row)
+    dev = device if device is not None else (real[0].scores.device if real else torch.device("cpu"))
     rows = torch.zeros(n, k_cap, _lib.DET_ROW, dtype=torch.float32, device=dev)
     counts = torch.zeros(n, dtype=torch.int32, device=dev)
     for i, inst in enumerate(instances):
-        k = len(inst)
+        k = 0 if inst is None else len(inst)
         if k > k_cap:
             raise _lib.DafneHipError("image %d has %d detections, more than the gather capacity %d" % (i, k, k_cap))
         counts[i] = k

@@ -20,6 +20,7 @@ from collections import OrderedDict
 
 import torch
 
+from ..utils.host import capped_torch_threads
 from .gather import gather_detections, to_predictions
 from .driver import instances_to_rows
 
@@ -66,24 +67,40 @@ class DafneEvaluator(DatasetEvaluator):
             meta = {"image_id": inp["image_id"], "file_name": inp.get("file_name", ""), "height": inp["height"], "width": inp["width"]}
             self._meta.append(meta)
             pred = dict(meta)
-            if "instances" in out:
-                inst = out["instances"]
-                if self._distributed:
-                    self._insts.append(inst)          # stays on the device: gathered as packed rows in evaluate()
+            inst = out.get("instances")
+            if self._gathers():
+                # stays on the device: gathered as packed rows in evaluate() (no per-image copy / host sync here: the local
+                # predictions would be discarded in favour of the gathered rows).  One entry per image, an output without
+                # "instances" included (None -> an empty image), so that rows and self._meta stay aligned
+                self._insts.append(inst)
+            elif inst is not None:
                 inst = inst.to(torch.device("cpu"))
                 pred["labels"], pred["scores"] = inst.pred_classes, inst.scores
                 pred["corners"], pred["centerness"] = inst.pred_corners, inst.centerness
             self._predictions.append(pred)
 
+    def _gathers(self):
+        import torch.distributed as dist
+        return bool(self._distributed and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1)
+
     def evaluate(self):
         pad_to = self._pad_to
         import torch.distributed as dist
-        if self._distributed and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        if self._gathers():
             if self._k_cap is None:
                 raise RuntimeError("DafneEvaluator(distributed=True) needs k_cap (DAFNeOutputs.packed_k_cap())")
-            dev = self._device if self._device is not None else (self._insts[0].scores.device if self._insts else torch.device("cpu"))
+            real = [i for i in self._insts if i is not None]
+            dev = self._device if self._device is not None else (real[0].scores.device if real else torch.device("cpu"))
             rows, counts = instances_to_rows(self._insts, self._k_cap, dev)
-            n = pad_to if pad_to is not None else len(self._insts)
+            n = pad_to
+            if n is None:
+                # contiguous shards are ragged whenever N % world != 0: every rank contributes the LARGEST local count
+                # (a MAX all-reduce; it used to be the local count, i.e. mismatched shapes in the gather)
+                t = torch.tensor([len(self._insts)], dtype=torch.int64, device=dev)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                n = int(t.item())
+            if n < len(self._insts):
+                raise RuntimeError("DafneEvaluator: pad_to=%d but this rank processed %d images" % (n, len(self._insts)))
             if n > rows.shape[0]:                     # equal shapes on every rank: pad with empty images
                 pad = n - rows.shape[0]
                 rows = torch.cat([rows, rows.new_zeros((pad,) + tuple(rows.shape[1:]))])
@@ -145,7 +162,8 @@ def inference_on_dataset(model, data_loader, evaluator=None, stats=None):
     was_training = getattr(model, "training", False)
     if hasattr(model, "eval"):
         model.eval()
-    with torch.no_grad():
+    # the loop owns the cap on torch's intra-op pool (restored on exit): its host work is latency work
+    with torch.no_grad(), capped_torch_threads(8):
         for inputs in data_loader:
             n += len(inputs)
             if streamed:

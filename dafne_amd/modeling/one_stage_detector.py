@@ -56,6 +56,7 @@ class OneStageDetector(nn.Module):
         self._act_q8 = None         # fp8 model: calibrated activation scales {weight key: in_qscale} (calibrate_fp8)
         self.side_stream = None
         self._consts = {}
+        self._last_head = None
         self.use_graphs = False     # optional: replay each sub-batch's dense plan from a HIP graph (no gain
                                     # measured at batch 8: the GPU, not the host, is the bottleneck)
         self.eval()
@@ -75,6 +76,9 @@ class OneStageDetector(nn.Module):
         self.__dict__.pop("_deferred", None)
         self.__dict__.pop("_deferred_res", None)
         self.__dict__.pop("_stream_q", None)
+        self.__dict__.pop("_staging", None)          # pinned / device staging of forward_streamed's host tiles
+        self.__dict__.pop("_counts_ring", None)
+        self._consts = {}
         if hasattr(self, "_pipe"):
             self._pipe = {}
         self.backbone.invalidate()
@@ -110,13 +114,14 @@ class OneStageDetector(nn.Module):
         # (res4 / res5 conv2, FPN outputs, the two tower layers that read FPN features)
         want = set(k[:-4] for k in P if k.endswith(".fp8") and not k.endswith(".frag")
                    and (k.startswith("res") or k.startswith("fpn_output") or k in ("cls_tower.0.fp8", "center_tower.0.fp8")))
-        if set(scales) != want:
+        # ... plus whatever else a calibration plan of this build probes (corners_tower.0 when the center tower's GroupNorm is
+        # not fused into it: DAFNE_FUSE_GN=0 / a kernel-selection fallback): any layer with e4m3 weights may carry a scale,
+        # the plain-input ones above must
+        allowed = set(k[:-4] for k in P if k.endswith(".fp8") and not k.endswith(".frag"))
+        if not (want <= set(scales) <= allowed):
             raise ValueError("set_fp8_act_scales: scales for %d layers, the model has %d plain-input fp8 layers (missing %s, unknown %s)"
-                             % (len(scales), len(want), sorted(want - set(scales))[:4], sorted(set(scales) - want)[:4]))
-        import math
-        for k, v in scales.items():
-            if not (math.isfinite(v) and v > 0 and math.log2(v) == round(math.log2(v))):
-                raise ValueError("set_fp8_act_scales: scale %r of %s is not a positive power of two" % (v, k))
+                             % (len(scales), len(want), sorted(want - set(scales))[:4], sorted(set(scales) - allowed)[:4]))
+        engine.check_act_qscales(scales)
         self._act_q8 = scales
         self._packed["act_q8"] = dict(self._act_q8)
         self._plans = {}
@@ -276,7 +281,17 @@ class OneStageDetector(nn.Module):
                 self.__dict__["_deferred_res"] = self._run_deferred(self.__dict__.pop("_deferred"), ())
             if not pipelined:
                 plan = self.plan(n, hn, wn)
+                genv = os.environ.get("DAFNE_HIP_GRAPHS")
+                if (self.cfg.ENGINE.HIP_GRAPHS if graphs is None else bool(graphs)) and genv != "0" and plan.graph is None:
+                    # a shape's SECOND call captures its launch list (the first ran eagerly: streams bind to hardware queues
+                    # at their first submission, see the pipelined branch): model([one image]) in a loop -- the reference's
+                    # own evaluation / benchmark loop, tools/benchmark.py:117-145 -- is host-bound when ~200 launches are
+                    # enqueued one by one (bench.py latency_b1)
+                    plan._uses = getattr(plan, "_uses", 0) + 1
+                    if plan._uses >= 2:
+                        plan.capture()
                 dense(images_u8, 0, n, plan)
+                self._last_head = plan.head          # (tests: the head outputs the returned detections were decoded from)
                 return outs.predict_packed(head_levels(plan.head, strides), sizes=sizes,
                                            scale_corners=do_postprocess)
             # ---- pipeline: [preprocess, convs (split over `splits` streams), decode] | [NMS, gather]
@@ -311,6 +326,7 @@ class OneStageDetector(nn.Module):
             slot = st["i"] & 1
             st["i"] += 1
             cs, plans, bounds = st["cs"], st["plans"][slot], st["bounds"]
+            self._last_head = st["ho"][slot]
             if stream_offset:
                 cs = [_shared_stream(images_u8.device, "compute", (int(stream_offset) + k) % 3) for k in range(splits)]
             inputs_ready = torch.cuda.Event()
@@ -469,24 +485,23 @@ class OneStageDetector(nn.Module):
                 for k, im in enumerate(imgs):
                     batch[k, :, : hs[k], : ws[k]] = im
         elif staged:
+            # the staging copies below run on torch's intra-op pool; inference_on_dataset caps that pool for the duration of
+            # the loop (utils.host.capped_torch_threads: with one worker per visible CPU the workers' spin-wait starves the HIP
+            # runtime's completion threads -- 50-200 ms stalls every few batches, 107-170 images/s instead of 1085)
             st = self.__dict__.get("_staging")
             if st is None:
-                st = self.__dict__.setdefault("_staging", {"i": 0, "buf": {}, "free": {}})
-                # the staging copies below run on torch's intra-op pool; with one worker per core (128 on the MI355X hosts)
-                # the workers' spin-wait after every copy starves the HIP runtime's completion threads: the streamed loop
-                # then stalls for 50-200 ms every few batches (measured 107-170 images/s; 1085 with 4 workers).  The loop's
-                # host side is latency work, not throughput work: cap the pool (process-wide, once).
-                cap = min(8, usable_cpus())
-                if torch.get_num_threads() > cap:
-                    torch.set_num_threads(cap)
+                st = self.__dict__.setdefault("_staging", {"i": 0, "pin": [None, None], "free": [None, None], "dev": [None, None, None]})
             slot = st["i"] & 1
             st["i"] += 1
-            key = (slot, n, H, W)
-            if key not in st["buf"]:
-                st["buf"][key] = torch.zeros(n, 3, H, W, dtype=torch.uint8).pin_memory()
-            pinned = st["buf"][key]
-            if st["free"].get(key) is not None:
-                st["free"][key].synchronize()            # the copy that last read this buffer (two calls ago) is done
+            need = n * 3 * H * W
+            # ONE flat pinned buffer per slot and one flat device buffer per ring position, grown to the largest batch seen and
+            # sliced: shortest-edge resizing (HRSC, UCAS-AOD) gives nearly every batch its own (H, W), and a buffer set per
+            # shape would pin host memory and hold HBM without bound (advisor, round 4)
+            if st["free"][slot] is not None:
+                st["free"][slot].synchronize()           # the copy that last read this buffer (two calls ago) is done
+            if st["pin"][slot] is None or st["pin"][slot].numel() < need:
+                st["pin"][slot] = torch.empty(need + need // 4, dtype=torch.uint8).pin_memory()
+            pinned = st["pin"][slot][:need].view(n, 3, H, W)
             if not same:
                 pinned.zero_()
             for k, im in enumerate(imgs):
@@ -496,15 +511,16 @@ class OneStageDetector(nn.Module):
             # would be the fifth one on four hardware queues (two of them then share a queue and serialise).
             # Device batches come from a ring of three persistent buffers (this call's, the batch in flight, the one whose
             # results the previous call handed back: forward_streamed waits for batch i - 1's post-process before it
-            # returns, so the buffer of batch i - 2 is free).
-            dkey = (st["i"] % 3, n, H, W)
-            if dkey not in st.setdefault("dev", {}):
-                st["dev"][dkey] = torch.empty(n, 3, H, W, dtype=torch.uint8, device=dev)
-            batch = st["dev"][dkey]
+            # returns, so the buffer of batch i - 2 is free).  A buffer that is outgrown goes back to the caching allocator,
+            # which keeps it until the streams it was recorded on (detect_packed: record_stream) are past it.
+            d = st["i"] % 3
+            if st["dev"][d] is None or st["dev"][d].numel() < need:
+                st["dev"][d] = torch.empty(need + need // 4, dtype=torch.uint8, device=dev)
+            batch = st["dev"][d][:need].view(n, 3, H, W)
             batch.copy_(pinned, non_blocking=True)
             done = torch.cuda.Event()
             done.record(torch.cuda.current_stream(dev))
-            st["free"][key] = done
+            st["free"][slot] = done
         elif n == 1:
             batch = imgs[0].to(dev, non_blocking=True).unsqueeze(0)
         else:
@@ -519,7 +535,16 @@ class OneStageDetector(nn.Module):
         if self.training:
             raise NotImplementedError("training is outside the scope of the MI355X inference engine")
         batch, valid, out_hw = self._pack_inputs(batched_inputs)
-        rows, counts = self.detect_packed(batch, valid_hw=valid, out_hw=out_hw, do_postprocess=do_postprocess)
+        splits = max(1, int(self.cfg.ENGINE.PIPELINE_SPLITS))
+        if len(batched_inputs) >= 2 and splits >= 2:
+            # the call detectron2's loop makes (tools/plain_train_net.py:316-336: outputs = model(inputs)) runs on the layout
+            # bench.py times: sub-batches on concurrent streams, immediate post-process.  Result-neutral: an image gets the
+            # same bits in any batch composition (test_an_image_gets_the_same_detections_in_any_batch)
+            rows, counts = self.detect_packed(batch, valid_hw=valid, out_hw=out_hw, do_postprocess=do_postprocess,
+                                              pipelined=True, splits=splits)
+            torch.cuda.current_stream(self.device).wait_stream(self.side_stream)      # the rows are produced on the side stream
+        else:
+            rows, counts = self.detect_packed(batch, valid_hw=valid, out_hw=out_hw, do_postprocess=do_postprocess)
         insts = pp.rows_to_instances(rows, counts, out_hw)
         return [{"instances": r} for r in insts]
 
@@ -563,12 +588,12 @@ class OneStageDetector(nn.Module):
         """The detection counts of a batch go to a pinned host buffer behind its NMS (4 bytes per image)."""
         rows, counts = res
         with torch.cuda.stream(self.side_stream):
-            ring = self.__dict__.setdefault("_counts_ring", {"i": 0, "buf": {}})
-            ck = (ring["i"] % 4, tuple(counts.shape))           # four pinned buffers: up to three batches in flight + the one the
-            ring["i"] += 1                                      # caller may still be reading
-            if ck not in ring["buf"]:
-                ring["buf"][ck] = torch.empty(counts.shape, dtype=counts.dtype).pin_memory()
-            counts_h = ring["buf"][ck]
+            ring = self.__dict__.setdefault("_counts_ring", {"i": 0, "buf": [None] * 4})
+            ck = ring["i"] % 4                                  # four pinned buffers: up to three batches in flight + the one the
+            ring["i"] += 1                                      # caller may still be reading; grown to the largest batch, sliced
+            if ring["buf"][ck] is None or ring["buf"][ck].numel() < counts.numel() or ring["buf"][ck].dtype != counts.dtype:
+                ring["buf"][ck] = torch.empty(max(counts.numel(), 16), dtype=counts.dtype).pin_memory()
+            counts_h = ring["buf"][ck][:counts.numel()].view(counts.shape)
             counts_h.copy_(counts, non_blocking=True)
             ready = torch.cuda.Event()
             ready.record(self.side_stream)

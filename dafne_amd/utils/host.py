@@ -2,7 +2,9 @@
 import math
 import os
 
-__all__ = ["usable_cpus"]
+import contextlib
+
+__all__ = ["usable_cpus", "capped_torch_threads"]
 
 
 def usable_cpus(cgroup_root="/sys/fs/cgroup"):
@@ -33,3 +35,22 @@ def usable_cpus(cgroup_root="/sys/fs/cgroup"):
     if quota is not None:
         n = min(n, max(1, int(math.floor(quota))))
     return max(1, n)
+
+
+@contextlib.contextmanager
+def capped_torch_threads(cap=8):
+    """torch's intra-op pool limited to min(cap, usable_cpus()) threads for the duration of the block, restored afterwards.
+    The streamed evaluation loop's host side is latency work (pinned staging copies, a few small tensor ops per batch): with
+    one pool worker per visible CPU the workers' spin-wait after every copy starves the HIP runtime's completion threads
+    (50-200 ms stalls in the launch calls every few batches; profiles/NOTES_r04.md).  The cap used to be set process-wide and
+    never restored from inside the detector (advisor, round 4); the LOOP owns it now (evaluation.inference.inference_on_dataset)."""
+    import torch
+    before = torch.get_num_threads()
+    want = max(1, min(int(cap), usable_cpus()))
+    if before > want:
+        torch.set_num_threads(want)
+    try:
+        yield
+    finally:
+        if torch.get_num_threads() != before:
+            torch.set_num_threads(before)

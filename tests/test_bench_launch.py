@@ -66,7 +66,7 @@ def _run(argv, env_extra=None, launcher=None):
 
 
 def test_plain_command_self_launches_two_ranks():
-    lines = _run(["--gpus", "2", "--steps", "3", "--warmup", "1", "--batch", "4"])
+    lines = _run(["--gpus", "2", "--steps", "3", "--warmup", "1", "--batch", "4", "--regions", "1"])
     assert len(lines) == 1, lines                          # rank 0 only
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["steps"] == 3 and out["warmup"] == 1 and out["scaling"] == "weak"
@@ -87,8 +87,25 @@ def test_plain_command_self_launches_two_ranks():
     assert abs(out["value"] - 8 * 3 / (out["ms_per_step"] * 3e-3)) < 1e-6 * out["value"]
 
 
+def test_value_is_the_median_of_several_timed_regions():
+    """--regions R (default 5): R back-to-back regions of exactly K steps, each bracketed by barrier + synchronize and reduced
+    with MAX over the ranks; `value` / `ms_per_step` are the MEDIAN region's (ms_per_step x steps is one measured region),
+    value_min / value_max and every region's figure sit beside it; the warm-up runs once."""
+    lines = _run(["--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "4", "--regions", "3"])
+    out = json.loads(lines[0])
+    assert out["stub"]["calls_rank0"] == 1 + 3 * 2 + 1     # W + R x K + the recorded step
+    r = out["regions"]
+    assert r["count"] == 3 and r["steps_each"] == 2 and len(r["images_per_sec"]) == 3
+    assert out["value_min"] == min(r["images_per_sec"]) and out["value_max"] == max(r["images_per_sec"])
+    assert out["value"] == sorted(r["images_per_sec"])[1] and out["value_min"] <= out["value"] <= out["value_max"]
+    assert abs(out["value"] - 8 * 2 / (out["ms_per_step"] * 2e-3)) < 1e-6 * out["value"]
+    assert out["ms_per_step"] >= 39.0                      # the slow rank's 40 ms per step in every region
+    pr = out["distributed"]["per_rank_ms_per_step"]
+    assert abs(pr["max"] - out["ms_per_step"]) < 1e-6      # the ranks' own times are the median region's
+
+
 def test_single_gpu_runs_in_process():
-    lines = _run(["--gpus", "1", "--steps", "2", "--warmup", "0"])
+    lines = _run(["--gpus", "1", "--steps", "2", "--warmup", "0", "--regions", "1"])
     out = json.loads(lines[0])
     assert out["n_gpus"] == 1 and out["stub"]["calls_rank0"] == 3 and not out["stub"]["dist_initialized"]     # W + K + the recorded step
     assert out["distributed"]["process_group_size"] == 1 and out["distributed"]["backend"] is None and "gathered_images" not in out["distributed"]
@@ -102,7 +119,7 @@ def test_under_torch_distributed_run():
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
-    lines = _run(["--gpus", "2", "--steps", "2", "--warmup", "1"],
+    lines = _run(["--gpus", "2", "--steps", "2", "--warmup", "1", "--regions", "1"],
                  launcher=["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
                            "--master-port", str(port)])
     assert len(lines) == 1

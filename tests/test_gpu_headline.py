@@ -244,6 +244,93 @@ def test_headline_workload_vs_oracle(headline, mode):
         assert e["abs_corner_delta_px"]["max"] <= min(2.0 * emu_max, 128.0), (i, e, emu_max)
 
 
+def test_headline_timed_layout_vs_oracle():
+    """The code path bench.py TIMES, at the headline size, next to the oracle ("missing 2"): R101-FPN,
+    8 x 1024x1024, bench.build_model's weights; `detect_packed(pipelined=True, splits=2, defer=True)` + `flush_deferred()` --
+    step i's convolutions replayed from TWO-PART HIP graphs (backbone + FPN | head) of two alternating plan sets, step
+    i - 1's decode / rotated NMS / rescale started on the side stream where step i reaches its head towers -- over SIX
+    DIFFERENT batches (a stale head-output buffer, or a race between the side stream's deferred decode and the
+    next-but-one step's tower writes into the same plan set, would hand back another batch's rows), twice (first pass:
+    the plan sets' eager step and the graph capture; second pass: replay only).  Asserted:
+      (a) every step's rows are bit-equal to the immediate call `detect_packed(pipelined=True, splits=2)` on that batch;
+      (b) the last TWO steps (both plan sets' head outputs are still in place after the flush), all 8 images each: decode /
+          top-k / rotated NMS / cap / detector_postprocess of oracle/postprocess.py on the engine's own head outputs --
+          keys bit-exact, scores 1e-6, corners / boxes 1e-3 (BASELINE.json north_star);
+      (c) the same batches through the reference-shaped loop `inference_on_dataset` -> `forward_streamed` (device tiles and
+          host tiles through the pinned staging) and through `model(batched_inputs)`: per image equal to (a).
+    Reference path: dafne/modeling/one_stage_detector.py:45-55, dafne/modeling/dafne/dafne_outputs.py:733-925."""
+    sys.path.insert(0, ROOT)
+    import bench
+    from dafne_amd import postprocess as pp
+    from dafne_amd.evaluation.inference import inference_on_dataset
+    dev = torch.device("cuda", 0)
+    cfg, model, sd = bench.build_model(101, dev, seed=0)
+    assert cfg.ENGINE.PIPELINE_SPLITS == SPLITS and cfg.ENGINE.HIP_GRAPHS
+    d = cfg.MODEL.DAFNE
+    nb = 6
+    batches = []
+    for j in range(nb):
+        g = torch.Generator().manual_seed(100 + j if j else 0)          # batch 0 = rank 0's batch of bench.py
+        batches.append(torch.randint(0, 256, (BATCH, 3, SIZE, SIZE), generator=g, dtype=torch.uint8).to(dev))
+    # (a) expected: the immediate form, one call per batch (the layout test_headline_workload_vs_oracle pins to the oracle)
+    want = []
+    for b in batches:
+        r, c = model.detect_packed(b, pipelined=True, splits=SPLITS)
+        torch.cuda.synchronize()
+        want.append((r.clone(), c.clone()))
+    assert all(int(c.min()) > 0 for _, c in want)
+    assert all(not torch.equal(want[j][0][:, :8], want[j + 1][0][:, :8]) for j in range(nb - 1))         # the batches DO differ
+    assert model.flush_deferred() is None
+    st = model._pipe[(BATCH, SIZE, SIZE, SPLITS)]
+
+    def same_rows(got, exp, tag):
+        (r, c), (rw, cw) = got, exp
+        assert torch.equal(c, cw), (tag, c.tolist(), cw.tolist())
+        for i in range(BATCH):
+            assert torch.equal(r[i, :int(cw[i])], rw[i, :int(cw[i])]), (tag, i)
+
+    for rep in range(2):
+        got = []
+        for b in batches:                                   # no host sync inside the loop: the host runs ahead, as in bench.py
+            res = model.detect_packed(b, pipelined=True, splits=SPLITS, defer=True)
+            if res is not None:
+                got.append(res)
+        got.append(model.flush_deferred())
+        torch.cuda.synchronize()
+        assert len(got) == nb and model.flush_deferred() is None
+        for j in range(nb):
+            same_rows(got[j], want[j], ("deferred", rep, j))
+    # the second pass replayed two-part graphs on both plan sets
+    assert all(getattr(p, "graph_parts", None) is not None for ps in st["plans"] for p in ps)
+    # (b) the last two steps against the oracle on the engine's own head outputs (plan set of step j: the slot it ran on)
+    last_slot = (st["i"] - 1) & 1
+    for j, slot in ((nb - 1, last_slot), (nb - 2, last_slot ^ 1)):
+        hp = st["ho"][slot]
+        rows, counts = got[j]
+        for i in range(BATCH):
+            _check_postprocess_exact(_rows_to_dict(rows, counts, i), _oracle_detections(_levels_numpy(hp, i), d), ("timed", j, i))
+    # (c) the reference-shaped entry points on the same batches
+    exp_inst = [pp.rows_to_instances(r, c, [(SIZE, SIZE)] * BATCH) for r, c in want]
+
+    def same_inst(a, e, tag):
+        assert len(a) == len(e) and a.image_size == e.image_size, tag
+        for f in ("pred_corners", "scores", "centerness", "pred_classes", "fpn_levels", "locations"):
+            assert torch.equal(a.get(f).cpu(), e.get(f).cpu()), (tag, f)
+        assert torch.equal(a.pred_boxes.tensor.cpu(), e.pred_boxes.tensor.cpu()), tag
+    for where in ("device", "host"):
+        loader = [[{"image": (b[k] if where == "device" else b[k].cpu()), "height": SIZE, "width": SIZE, "image_id": j * BATCH + k}
+                   for k in range(BATCH)] for j, b in enumerate(batches)]
+        outs = inference_on_dataset(model, loader)
+        assert len(outs) == nb * BATCH
+        for j in range(nb):
+            for k in range(BATCH):
+                same_inst(outs[j * BATCH + k]["instances"], exp_inst[j][k], (where, j, k))
+    for j in (0, nb - 1):
+        outs = model([{"image": batches[j][k], "height": SIZE, "width": SIZE} for k in range(BATCH)])
+        for k in range(BATCH):
+            same_inst(outs[k]["instances"], exp_inst[j][k], ("forward", j, k))
+
+
 # ------------------------------------------------------------------------------------------------------------------
 # The other BASELINE.json configs at THEIR sizes (the small-image tests never reach these kernel / tile choices either).
 def _features_vs_oracle(feats_img0, fe, f32, tag, floor_factor=1.5):
