@@ -416,30 +416,48 @@ def headline(args, world, dt, det_mean, region_times=None):
     return out
 
 
+_TELEMETRY_DIR = {}
+
+
+def _telemetry_dir(index):
+    """sysfs directory (/sys/class/drm/cardN/device) of HIP device `index`, matched by PCI address: a box shows every GPU of
+    the node in sysfs (cards 0, 8, .., 56) while the process sees one of them as device 0."""
+    import glob
+    if index not in _TELEMETRY_DIR:
+        found = None
+        try:
+            pr = torch.cuda.get_device_properties(index)
+            addr = "%04x:%02x:%02x.0" % (pr.pci_domain_id, pr.pci_bus_id, pr.pci_device_id)
+            for c in sorted(glob.glob("/sys/class/drm/card[0-9]*/device")):
+                if os.path.basename(os.path.realpath(c)) == addr and glob.glob(os.path.join(c, "hwmon", "hwmon*")):
+                    found = c
+        except Exception:      # noqa: BLE001
+            found = None
+        _TELEMETRY_DIR[index] = found
+    return _TELEMETRY_DIR[index]
+
+
 def device_telemetry(index=0):
-    """Shader clock (MHz), socket power (W), temperature of GPU `index` as the driver reports them right now (amdgpu sysfs /
-    hwmon: no subprocess, microseconds): recorded around the timed regions and beside the library GEMM so that a 0.416 box can
-    be told from a 0.445 box.  Fields that cannot be read are absent."""
+    """Shader clock (MHz), socket power (W), temperature of HIP device `index` as the driver reports them right now (amdgpu
+    hwmon: no subprocess, microseconds per read; the same figures `rocm-smi --showpower --showclocks` prints): sampled WHILE
+    the timed loop and the library GEMM run, so that a 0.416 box can be told from a 0.445 box.  Fields that
+    cannot be read are absent."""
     import glob
     out = {}
     try:
-        cards = sorted(glob.glob("/sys/class/drm/card[0-9]*/device/pp_dpm_sclk"))
-        cards = [c for c in cards if os.path.exists(os.path.join(os.path.dirname(c), "hwmon"))] or cards
-        base = os.path.dirname(cards[min(index, len(cards) - 1)])
-        for line in open(os.path.join(base, "pp_dpm_sclk")):
-            if "*" in line:
-                out["sclk_mhz"] = float(line.split(":")[1].strip().rstrip("*").strip().lower().replace("mhz", ""))
+        base = _telemetry_dir(index)
+        if base is None:
+            return {"error": "no sysfs card matches the device's PCI address"}
         hw = sorted(glob.glob(os.path.join(base, "hwmon", "hwmon*")))
-        if hw:
-            for name, key, scale in (("power1_average", "socket_power_w", 1e-6), ("power1_input", "socket_power_w", 1e-6),
-                                     ("power1_cap", "power_cap_w", 1e-6), ("temp1_input", "temp_c", 1e-3),
-                                     ("freq1_input", "sclk_hwmon_mhz", 1e-6)):
-                f = os.path.join(hw[0], name)
-                if key not in out and os.path.exists(f):
-                    try:
-                        out[key] = float(open(f).read().strip()) * scale
-                    except (OSError, ValueError):
-                        pass
+        for name, key, scale in (("power1_input", "socket_power_w", 1e-6), ("power1_average", "socket_power_w", 1e-6),
+                                 ("power1_cap", "power_cap_w", 1e-6), ("freq1_input", "sclk_mhz", 1e-6),
+                                 ("temp2_input", "temp_c", 1e-3), ("temp1_input", "temp_c", 1e-3)):
+            f = os.path.join(hw[0], name)
+            if key not in out and os.path.exists(f):
+                try:
+                    out[key] = float(open(f).read().strip()) * scale
+                except (OSError, ValueError):
+                    pass
     except Exception as e:      # noqa: BLE001  (telemetry must never cost the line)
         out["error"] = repr(e)[:120]
     return out
@@ -473,7 +491,7 @@ class TelemetrySampler:
         k = int(skip_s / self.period)
         smp = self.samples[k:] if len(self.samples) >= 3 * k else self.samples
         out = {"samples": len(smp), "period_s": self.period}
-        for key in ("sclk_mhz", "sclk_hwmon_mhz", "socket_power_w", "temp_c"):
+        for key in ("sclk_mhz", "socket_power_w", "temp_c"):
             v = [s[key] for s in smp if key in s]
             if v:
                 out[key] = {"mean": sum(v) / len(v), "min": min(v), "max": max(v)}

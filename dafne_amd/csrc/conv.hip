@@ -1880,7 +1880,11 @@ __global__ void __launch_bounds__(512) conv3x3_patch_kernel(ConvDev P) {
 //   * GN_INPUT: a wave normalises the pieces IT loaded (GroupNorm + ReLU in place, out-of-image pixels stay zero) ~13
 //     steps after issuing them -- next tile's slabs 0..2 in steps 53.. / 89.. / 125.., its slab 3 in steps 13.. of the
 //     next tile itself (first read at step 108); the two waves of a SIMD four steps apart -- under the other waves' MFMAs; statistics of the next tile's image by
-//     one 256-B DMA piece (double-buffered);
+//     one 256-B DMA piece at step 20 (double-buffered).  Round 5: the normalisation is the scale / shift form y = max(a x + b, 0)
+//     with a = rstd gamma, b = beta - mean a tabulated per tile (256 threads, step 30, published by the barrier of step 36):
+//     45 instead of 77 vector instructions and 80 instead of 88 LDS bytes per piece and lane; against the four-operation
+//     expression of the separate pass (gn_apply_kernel) a normalised bf16 operand differs by one ulp in ~1e-3 of the elements
+//     (one fused rounding instead of three), 191 instead of 196 us per tower layer at batch 8;
 //   * the epilogue is short and asynchronous: at the end of a tile bias / ReLU / GroupNorm sums are applied in the
 //     accumulator layout (a wave holds all 128 pixels of its 32 channels: no cross-wave reduction), the bf16 values are
 //     paired across the two half-waves with v_permlane32_swap (16 contiguous bytes per lane) and stored straight from
@@ -1903,19 +1907,21 @@ constexpr int kROffGB = kROffStat + 512;                // per group: gamma [256
 constexpr int kROffBias = kROffGB + 2 * 2048;           // per group: bias fp32 [Cout <= 1024]
 constexpr int kROffRed = kROffBias + 2 * kRMaxCout * 4; // [32 groups][2] fp32, finalize flag at +256
 constexpr int kROffFin = kROffRed + 512;                // GN_FINALIZE reduction scratch: 32 x 32 x 2 fp32
-constexpr int kRSmem = kROffFin + 32 * 32 * 2 * 4;
+constexpr int kROffAB = kROffFin + 32 * 32 * 2 * 4;     // GN_INPUT: per tile parity, a[256] | b[256] fp32 of the tile's (layer, image)
+constexpr int kRSmem = kROffAB + 2 * 2048;
 static_assert(kRSmem <= 160 * 1024, "LDS budget");
 constexpr int kRDumpBytes = 64 * 1024;
 
 // Vector-memory program order of a wave inside a tile (steady state; A(s + 8) of steps >= 136 are the next tile's first):
 //   step s: [wait A(s)] MFMAs | A(s + 8) | rp_post(s) more operations:
-//     37 (GN_INPUT): the statistics piece of the next tile's image; 40..43 / 76..79 / 112..115: one patch piece of the next
+//     20 (GN_INPUT): the statistics piece of the next tile's image; 40..43 / 76..79 / 112..115: one patch piece of the next
 //     tile's slab 0 / 1 / 2; 143: the four pieces of slab 3 and the tile's 8 row stores.
 // rp_wait(j) = operations issued after A(j) and before the wait for it (vmcnt retires in order).  Steps 0..7 look back
 // into the previous tile; the FIRST tile of a workgroup has the prologue there instead (16 patch pieces, then A(0..7)).
+constexpr int kRStatStep = 20;            // GN_INPUT: the next tile's statistics piece, early enough for the a / b table of step 30
 constexpr int rp_post(int s, bool gnin) {
     int n = 0;
-    if (gnin && s == 37) n += 1;
+    if (gnin && s == kRStatStep) n += 1;
     if ((s >= 40 && s < 44) || (s >= 76 && s < 80) || (s >= 112 && s < 116)) n += 1;
     if (s == kRSteps - 1) n += 4 + 8;
     return n;
@@ -1932,8 +1938,8 @@ constexpr int rp_wait(int j, bool gnin, bool first) {
     return n;
 }
 static_assert(rp_wait(0, false, true) == 7 && rp_wait(0, false, false) == 19 && rp_wait(7, false, false) == 19 && rp_wait(8, false, false) == 7 &&
-              rp_wait(48, false, false) == 11 && rp_wait(48, true, false) == 11 && rp_wait(45, true, false) == 12 && rp_wait(52, false, false) == 7 &&
-              rp_wait(143, true, false) == 7, "vmcnt bookkeeping");
+              rp_wait(48, false, false) == 11 && rp_wait(48, true, false) == 11 && rp_wait(45, true, false) == 11 &&
+              rp_wait(52, false, false) == 7 && rp_wait(143, true, false) == 7 && rp_wait(kRStatStep + 8, true, false) == 8, "vmcnt bookkeeping");
 
 template <int J>
 __device__ __forceinline__ void rp_load(bf16x8 (&ar)[kRRing], const char* wf_cur, const char* wf_nxt, unsigned voff) {
@@ -2069,52 +2075,67 @@ __global__ void __launch_bounds__(512, 2) conv3x3_rp_kernel(ConvDev PA, ConvDev 
     };
     // GroupNorm + ReLU of one landed patch piece of tile c, in place (inline-asm LDS ops: a plain LDS access would make the
     // compiler drain vmcnt).  A lane handles LOGICAL chunk lane&7 (8 channels = one group) of pixel lane>>3 of the piece.
+    // scale / shift form (round 5): y = max(a x + b, 0) with a = rstd gamma, b = beta - mean a of the tile's (layer, image),
+    // tabulated once per tile (ab_table).  The piece's patch coordinates come from the wave-uniform part of its pixel index
+    // (scalar division by the row pitch) plus the lane's 0..7; the LDS address is lane * 16 XOR the column swizzle; packed fp32
+    // math, ReLU as a packed 16-bit integer max on the rounded pairs (max(round(y), 0) = round(max(y, 0)): rounding is monotonic
+    // and keeps the sign bit), out-of-image pixels masked to zero.
     auto gn_piece = [&](const RpTile& c, int sl, int ii, int statbuf) {
         if (ii == 3 && wave + 3 * NW >= kRPieces) return;                 // duplicate of this wave's piece ii = 2
         int lane = lane_;
-        asm volatile("" : "+v"(lane));       // recompute the per-lane addresses at every call: hoisted out of the tile loop they spill
-        const int pc = ppc[ii];
-        const int pp = pc * 8 + (lane >> 3);
-        const int p = pp / kRCols, q = pp - p * kRCols;
-        const int gy = c.Y0 + p, gx = c.X0 + q;                           // haloed coordinates
-        const bool inside = gy >= 1 && gy <= c.H && gx >= 1 && gx <= c.W && pp < kRRows * kRCols;
-        const int phys = (lane & 7) ^ ((q >> 1) & 7);
-        const unsigned ad = lds_base + (unsigned)(sl * kRSlab + pc * 1024 + (lane >> 3) * 128 + phys * 16);
-        const int ch = sl * kBK + (lane & 7) * 8;
-        const unsigned ts = lds_base + (unsigned)(kROffStat + statbuf * 256 + (ch >> 3) * 8);
-        const unsigned tg = lds_base + (unsigned)(kROffGB + c.grp * (2 * kRCin * 4) + ch * 4);
-        const unsigned tb = tg + (unsigned)kRCin * 4u;
-        // two halves of 4 channels (register budget: the constants of 8 channels at once spill inside the tile loop)
-        u32x4 v;
-        u32x2 ms;
-        f32x4 gq, bq;
-        asm volatile("ds_read_b128 %0, %4\n\tds_read_b64 %1, %5\n\tds_read_b128 %2, %6\n\tds_read_b128 %3, %7\n\ts_waitcnt lgkmcnt(0)"
-                     : "=&v"(v), "=&v"(ms), "=&v"(gq), "=&v"(bq)
-                     : "v"(ad), "v"(ts), "v"(tg), "v"(tb)
+        asm volatile("" : "+v"(lane));       // recompute the per-lane parts at every call: hoisted out of the tile loop they spill
+        const int pc = ppc[ii];                                           // wave-uniform
+        const int S = pc * 8, pS = S / kRCols, qS = S - pS * kRCols;      // scalar
+        int q = qS + (lane >> 3);
+        const int wrap = q >= kRCols ? 1 : 0;
+        q -= wrap * kRCols;
+        const int p = pS + wrap;
+        const bool inside = (unsigned)(c.Y0 + p - 1) < (unsigned)c.H && (unsigned)(c.X0 + q - 1) < (unsigned)c.W && p < kRRows;
+        const unsigned msk = inside ? 0xffffffffu : 0u;
+        const unsigned ad = (((unsigned)lane << 4) ^ (((unsigned)q << 3) & 0x70u)) + (lds_base + (unsigned)(sl * kRSlab + pc * 1024));
+        const unsigned ta = (((unsigned)lane << 5) & 0xe0u) + (lds_base + (unsigned)(kROffAB + statbuf * 2048 + sl * kBK * 4));
+        typedef __attribute__((ext_vector_type(2))) short s16x2;
+        auto cvt = [&](unsigned w, f32x2 a, f32x2 b) -> unsigned {       // two channels: bf16 pair -> a x + b -> ReLU -> bf16 pair
+            const f32x2 x = {__uint_as_float(w << 16), __uint_as_float(w & 0xffff0000u)};
+            const f32x2 y = __builtin_elementwise_fma(a, x, b);
+            const s16x2 r = __builtin_elementwise_max(__builtin_bit_cast(s16x2, pack_bf16(y[0], y[1])), (s16x2){0, 0});
+            return __builtin_bit_cast(unsigned, r) & msk;
+        };
+        u32x4 v, o;
+        f32x4 aq, bq;
+        asm volatile("ds_read_b128 %0, %3\n\tds_read_b128 %1, %4\n\tds_read_b128 %2, %4 offset:1024\n\ts_waitcnt lgkmcnt(0)"
+                     : "=&v"(v), "=&v"(aq), "=&v"(bq)
+                     : "v"(ad), "v"(ta)
                      : "memory");
-        const float gmean = __uint_as_float(ms.x), grstd = __uint_as_float(ms.y);
-        u32x4 o;
-        {
-            const float x0 = bf2f((unsigned short)(v.x & 0xffff)), x1 = bf2f((unsigned short)(v.x >> 16));
-            const float x2 = bf2f((unsigned short)(v.y & 0xffff)), x3 = bf2f((unsigned short)(v.y >> 16));
-            const float y0 = fmaxf((x0 - gmean) * grstd * gq[0] + bq[0], 0.f), y1 = fmaxf((x1 - gmean) * grstd * gq[1] + bq[1], 0.f);      // expression of gn_apply_kernel
-            const float y2 = fmaxf((x2 - gmean) * grstd * gq[2] + bq[2], 0.f), y3 = fmaxf((x3 - gmean) * grstd * gq[3] + bq[3], 0.f);
-            o.x = inside ? pack_bf16(y0, y1) : 0u;
-            o.y = inside ? pack_bf16(y2, y3) : 0u;
-        }
-        asm volatile("ds_read_b128 %0, %2 offset:16\n\tds_read_b128 %1, %3 offset:16\n\ts_waitcnt lgkmcnt(0)"
-                     : "=&v"(gq), "=&v"(bq)
-                     : "v"(tg), "v"(tb)
+        o.x = cvt(v.x, (f32x2){aq[0], aq[1]}, (f32x2){bq[0], bq[1]});
+        o.y = cvt(v.y, (f32x2){aq[2], aq[3]}, (f32x2){bq[2], bq[3]});
+        asm volatile("ds_read_b128 %0, %2 offset:16\n\tds_read_b128 %1, %2 offset:1040\n\ts_waitcnt lgkmcnt(0)"
+                     : "=&v"(aq), "=&v"(bq)
+                     : "v"(ta)
                      : "memory");
-        {
-            const float x0 = bf2f((unsigned short)(v.z & 0xffff)), x1 = bf2f((unsigned short)(v.z >> 16));
-            const float x2 = bf2f((unsigned short)(v.w & 0xffff)), x3 = bf2f((unsigned short)(v.w >> 16));
-            const float y0 = fmaxf((x0 - gmean) * grstd * gq[0] + bq[0], 0.f), y1 = fmaxf((x1 - gmean) * grstd * gq[1] + bq[1], 0.f);
-            const float y2 = fmaxf((x2 - gmean) * grstd * gq[2] + bq[2], 0.f), y3 = fmaxf((x3 - gmean) * grstd * gq[3] + bq[3], 0.f);
-            o.z = inside ? pack_bf16(y0, y1) : 0u;
-            o.w = inside ? pack_bf16(y2, y3) : 0u;
-        }
+        o.z = cvt(v.z, (f32x2){aq[0], aq[1]}, (f32x2){bq[0], bq[1]});
+        o.w = cvt(v.w, (f32x2){aq[2], aq[3]}, (f32x2){bq[2], bq[3]});
         asm volatile("ds_write_b128 %0, %1" ::"v"(ad), "v"(o) : "memory");
+    };
+    // the a / b table of tile c's (layer, image) -> AB buffer b, by the first 256 threads (one channel each) from the landed
+    // statistics piece and the layer's gamma / beta; inline-asm LDS operations (a plain access would make the compiler drain vmcnt)
+    auto ab_table = [&](const RpTile& c, int b) {
+        if (tid < kRCin) {
+            int td = tid;
+            asm volatile("" : "+v"(td));
+            const unsigned tsd = lds_base + (unsigned)(kROffStat + b * 256) + (unsigned)(td >> 3) * 8u;
+            const unsigned tgd = lds_base + (unsigned)(kROffGB + c.grp * (2 * kRCin * 4)) + (unsigned)td * 4u;
+            u32x2 ms;
+            float gm, bt;
+            asm volatile("ds_read_b64 %0, %3\n\tds_read_b32 %1, %4\n\tds_read_b32 %2, %4 offset:1024\n\ts_waitcnt lgkmcnt(0)"
+                         : "=&v"(ms), "=&v"(gm), "=&v"(bt)
+                         : "v"(tsd), "v"(tgd)
+                         : "memory");
+            const float av = __uint_as_float(ms.y) * gm;
+            const float bv = __builtin_fmaf(-__uint_as_float(ms.x), av, bt);
+            const unsigned tad = lds_base + (unsigned)(kROffAB + b * 2048) + (unsigned)td * 4u;
+            asm volatile("ds_write_b32 %0, %1\n\tds_write_b32 %0, %2 offset:1024" ::"v"(tad), "v"(av), "v"(bv) : "memory");
+        }
     };
     // statistics (mean, rstd of the 32 groups) of tile c's image -> stat buffer b: one 256-byte DMA piece, issued by every wave
     auto stat_piece = [&](const RpTile& c, int b) {
@@ -2163,6 +2184,10 @@ __global__ void __launch_bounds__(512, 2) conv3x3_rp_kernel(ConvDev PA, ConvDev 
         if (GNIN && tid < 64)
             ((float*)(lds + kROffStat))[tid] = (PG(cur.grp).in_stats + ((size_t)cur.si * P.N + cur.img) * (kRCin / 8) * 2)[tid];
         __syncthreads();
+        if (GNIN) {
+            ab_table(cur, 0);
+            __syncthreads();
+        }
     }
     patch_map(cur);
 #pragma unroll
@@ -2314,6 +2339,9 @@ __global__ void __launch_bounds__(512, 2) conv3x3_rp_kernel(ConvDev PA, ConvDev 
                 if constexpr (j >= 125 && j < 133) { if (((j - 125) >> 2) == gnlate) gn_piece(nxt, 2, (j - 125) & 3, sb_nxt); }
             }
             if constexpr (j == 37) patch_map(nxt);
+            // the next tile's a / b table: its statistics piece (step 20) is covered by this wave's wait of step 29; published by
+            // the barrier of step 36, first read at step 53
+            if constexpr (GNIN && j == 30) ab_table(nxt, sb_nxt);
             // ---- the previous tile's GroupNorm sums
             if constexpr (j >= 1 && j < 9) {
                 if (gn) {
@@ -2342,7 +2370,7 @@ __global__ void __launch_bounds__(512, 2) conv3x3_rp_kernel(ConvDev PA, ConvDev 
             __builtin_amdgcn_sched_barrier(0);
             rp_load<j + kRRing>(ar, wf_cur, wf_nxt, voff);
             // ---- counted vector-memory operations behind the weight load (rp_post)
-            if constexpr (GNIN && j == 37) stat_piece(nxt, sb_nxt);
+            if constexpr (GNIN && j == kRStatStep) stat_piece(nxt, sb_nxt);
             if constexpr (j >= 40 && j < 44) patch_piece(0, j - 40);
             if constexpr (j >= 76 && j < 80) patch_piece(1, j - 76);
             if constexpr (j >= 112 && j < 116) patch_piece(2, j - 112);

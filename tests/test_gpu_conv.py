@@ -902,8 +902,9 @@ def test_resident_patch_kernel_gn_chain(fused_finalize):
     """Two tower layers over three ragged levels on the resident-patch kernel: layer 1 emits its raw output + per-tile
     GroupNorm partial sums (finalised by a separate launch, or by the last tile of every image: GN_FINALIZE), layer 2
     applies GroupNorm + ReLU to its patch in LDS (GN_INPUT).  Layer 1's output is bit-identical to the patch kernel's;
-    the statistics agree with it to fp32 summation order and with torch; given THE SAME statistics layer 2 is bit-identical
-    to the patch kernel's GN_INPUT form; and the whole chain matches torch within bf16 noise."""
+    the statistics agree with it to fp32 summation order and with torch; given THE SAME statistics layer 2 agrees with
+    the same kernel on a separately normalised map and with the patch kernel's GN_INPUT form up to one bf16 ulp in < 4e-3 of the
+    outputs (round 5: scale / shift normalisation, one rounding instead of three); and the whole chain matches torch within bf16 noise."""
     from dafne_amd import engine, _lib
     d = dev()
     L = _lib.load()
@@ -954,7 +955,8 @@ def test_resident_patch_kernel_gn_chain(fused_finalize):
         assert torch.allclose(stats_r[k, :, :, 0].cpu(), y.mean(-1), atol=2e-3)
         assert torch.allclose(stats_r[k, :, :, 1].cpu(), torch.rsqrt(y.var(-1, unbiased=False) + 1e-5), rtol=5e-3)
     # layer 2 with GN_INPUT (normalisation applied to the patch in LDS) against the SAME kernel on a map normalised by the
-    # separate pass (dafne_groupnorm_relu_nhwc_bf16_hip from the same partial sums): same arithmetic, same rounding points.
+    # separate pass (dafne_groupnorm_relu_nhwc_bf16_hip from the same partial sums): the same statistics; the on-load form
+    # rounds once (scale / shift), the pass three times: operands one bf16 ulp apart in ~1e-3 of the elements.
     # (Against the patch kernel's GN_INPUT form the outputs differ in ~2e-4 of the elements by one bf16 ulp: that kernel
     # walks K as (slab, kw, K half, kh), this one as (slab, kh, kw, k16) like conv_igemm_kernel.)
     out_r = [engine.Act(N, h, w, C, d) for h, w in sizes]
@@ -976,10 +978,14 @@ def test_resident_patch_kernel_gn_chain(fused_finalize):
     torch.cuda.synchronize()
     assert torch.equal(stats_u, stats_r)              # the fused finalisation reduces in the separate kernel's order
     for a, b_, c_ in zip(out_r, out_u, out_p):
-        assert torch.equal(a.t, b_.t)
+        # round 5: the on-load form is y = max(a x + b, 0) with a = rstd gamma, b = beta - mean a (one fused rounding) against
+        # ((x - mean) rstd) gamma + beta of the separate pass: a normalised bf16 OPERAND differs by one ulp now and then, which
+        # moves ~1e-3 of the outputs by one bf16 ulp (measured 4e-5 .. 1e-3; scratch/rp_gnab_check.py)
+        du = (a.t.float() - b_.t.float()).abs()
+        assert float((du > 0).float().mean()) < 4e-3 and float(du.max()) <= 2.0 ** -7 * float(b_.t.float().abs().max())
         assert float(a.t[:, 0].abs().max()) == 0 and float(a.t[:, :, -1].abs().max()) == 0
         dlt = (a.t.float() - c_.t.float()).abs()
-        assert float((dlt > 0).float().mean()) < 2e-3 and float(dlt.max()) <= 2.0 ** -7 * float(c_.t.float().abs().max())
+        assert float((dlt > 0).float().mean()) < 4e-3 and float(dlt.max()) <= 2.0 ** -7 * float(c_.t.float().abs().max())
     for x, a in zip(xs, out_r):
         y1n = bfr(_gn_ref(F.conv2d(x, w1, b1, padding=1), gamma.cpu(), beta.cpu(), C // 8))
         ref = bfr(F.conv2d(y1n, w2, b2, padding=1))
