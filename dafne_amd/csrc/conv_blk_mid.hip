@@ -92,19 +92,16 @@ __device__ __forceinline__ void static_for(F&& f) {
 //   A0  conv3 fragments of half 0        8 L   (registers a3; free since GEMM1(half 1) of tile k-1)
 //   A1  conv2 fragments                 72 L   ring of 8: W(j) is awaited with vmcnt(min(7, 71 - j)) -- only later W are younger
 //   P   patch of tile k+1                7 L   behind the barrier that retires the patch
-//   -- half 0:  GEMM1 (a3 is older than every W: landed)
-//   A3  conv3 fragments of half 1        8 L
-//   R0  conv1' fragments 0..7            8 L
-//   X1  shortcut rows, half 1            8 L   (registers rr: half 0's rows were parked in the Y buffer before GEMM1)
-//   S0  Y rows of half 0                 8 S
-//       GEMM2 step j: a1(j) awaited with vmcnt(23) for j < 8 (younger: 7 - j of R0, X1, S0, j refills) and with
-//       vmcnt(min(15 - j, 7)) for j >= 8 (only later refills); the refill a1(j + 8) follows the MFMAs of step j < 8.
-//       Step 15 waits with vmcnt(0): A3, X1 (and S0) are complete behind it.
-//   -- half 1:  rr -> Y buffer, GEMM1
-//   R1  conv1' fragments 16..23          8 L
-//   X2  shortcut rows of tile k+1, half 0  8 L
-//   S1  Y rows of half 1                 8 S
-//       GEMM2 as above (vmcnt(0) at its last step: P and X2 are complete for tile k+1 -- its top needs a barrier only)
+//   -- half 0 (round 5: ONE operation per wave behind every GEMM step instead of bursts -- a wave needs ~250 cycles to issue a
+//      load once the CU's address path is backed up, and nothing else of that wave runs meanwhile):
+//       GEMM1 (a3 is older than every W: landed), step g = 0..15:  g < 7: P(g) (patch piece of tile k+1) | g < 8: R0(g) (conv1'
+//       fragment, ring slot g) | g >= 8: X1(g - 8) (shortcut rows of half 1 -> rr; half 0's were parked before GEMM1)
+//       A3 (conv3 fragments of half 1): two behind every channel group of GEMM1's last epilogue
+//       GEMM2 step j: [wait a1(j)] MFMAs | j < 8: refill a1(j + 8) | j even: S0 row pass j / 2.
+//       a1(j) awaited with vmcnt(23 + ceil(j / 2) + max(0, 6 - j)) for j < 8 and vmcnt(19 - j) for j >= 8.  P, X1 and A3 are
+//       OLDER than every refill: complete behind the waits of j >= 8.
+//   -- half 1:  rr -> Y buffer;  GEMM1 with R1 / X2 (rows of tile k+1, half 0);  GEMM2 with S1: vmcnt(15 + ceil(j / 2)) for j < 8,
+//       vmcnt(19 - j) for j >= 8; X2 is older than the refills, i.e. complete for tile k+1 -- its top needs a barrier only
 //   S2  Z rows                           4 S   (HEAD)
 template <bool HEAD>
 __global__ void __launch_bounds__(512, 2) conv_blk_mid_kernel(MidBlkDev P) {
@@ -147,9 +144,8 @@ __global__ void __launch_bounds__(512, 2) conv_blk_mid_kernel(MidBlkDev P) {
 
     // ---- patch DMA: 52 pieces (2 slabs x 26) of 8 patch pixels x 128 B; wave w moves pieces w, w + 8, .. (7 per wave, the
     // surplus ones repeat the last piece: every wave issues the same number of DMAs)
-    auto issue_patch = [&](const TileXY& T) {
-#pragma unroll
-        for (int ii = 0; ii < 7; ii++) {
+    auto issue_patch1 = [&](const TileXY& T, int ii) {
+        {
             int pi = wave + kNW * ii;
             pi = pi < 2 * kPPieces ? pi : 2 * kPPieces - 1;
             const int sl = pi >= kPPieces ? 1 : 0;
@@ -165,18 +161,24 @@ __global__ void __launch_bounds__(512, 2) conv_blk_mid_kernel(MidBlkDev P) {
                                              (lvoid*)(lds + kOffPatch + sl * kPSlab + pc * 1024), 16, 0, 0);
         }
     };
+    auto issue_patch = [&](const TileXY& T) {
+#pragma unroll
+        for (int ii = 0; ii < 7; ii++) issue_patch1(T, ii);
+    };
     // shortcut rows of half h: pass i of 8, 32 threads read one pixel's 512 B
     u32x4 rr[8];
 #pragma unroll
     for (int i = 0; i < 8; i++) rr[i] = u32x4{0u, 0u, 0u, 0u};
+    auto issue_x1 = [&](const TileXY& T, int h, auto I) {
+        constexpr int i = decltype(I)::value;
+        u32x4(&rq)[8] = rr;                  // (a non-dependent use: a generic lambda captures rr only through one)
+        int idx = tid + kNT * i;
+        asm volatile("" : "+v"(idx));
+        const char* src = P.res + (size_t)pix_index(T, idx >> 5) * (kCB * 2) + h * 512 + (idx & 31) * 16;
+        asm volatile("global_load_dwordx4 %0, %1, off nt" : "+v"(rq[i]) : "v"(src) : "memory");
+    };
     auto issue_x = [&](const TileXY& T, int h) {
-#pragma unroll
-        for (int i = 0; i < 8; i++) {
-            int idx = tid + kNT * i;
-            asm volatile("" : "+v"(idx));
-            const char* src = P.res + (size_t)pix_index(T, idx >> 5) * (kCB * 2) + h * 512 + (idx & 31) * 16;
-            asm volatile("global_load_dwordx4 %0, %1, off nt" : "+v"(rr[i]) : "v"(src) : "memory");
-        }
+        static_for<0, 8>([&](auto I) { issue_x1(T, h, I); });
     };
     auto park_x = [&]() {                                      // rr -> Y buffer ([slab][px][64 ch], chunk ^ ((px >> 1) & 7))
 #pragma unroll
@@ -241,11 +243,23 @@ __global__ void __launch_bounds__(512, 2) conv_blk_mid_kernel(MidBlkDev P) {
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
+#ifdef DAFNE_MID_TIMING
+    unsigned long long mstamp[24];
+    int nms = 0;
+#define MID_STAMP() do { if (nms < 24) mstamp[nms++] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define MID_STAMP()
+#endif
     for (int kk = 0; kk < my_tiles; kk++) {
+#ifdef DAFNE_MID_TIMING
+        nms = 0;
+#endif
+        MID_STAMP();                                                   // 0: tile start
         const int t = (int)blockIdx.x + kk * G;
         const TileXY T = tile_xy(t);
         const TileXY Tn = tile_xy(kk + 1 < my_tiles ? t + G : t);      // the last tile re-requests itself: fixed instruction count
         barrier();       // patch k (every wave's pieces: each drained its queue at the end of the previous tile) visible; LDS of tile k-1 retired
+        MID_STAMP();                                                   // 1: behind the top barrier
         // ================================================================ phase A: T = relu(conv2(U) + bias2)
         {
             int ln = lane;
@@ -290,6 +304,7 @@ __global__ void __launch_bounds__(512, 2) conv_blk_mid_kernel(MidBlkDev P) {
                 __builtin_amdgcn_sched_barrier(0);
                 if constexpr (j + kRing < kStepsA) load_frag(wr[j % kRing], vo2 + (unsigned)((j + kRing) * 1024));
             });
+            MID_STAMP();                                               // 2: phase A MFMA loop done (this wave)
             // (acc + bias2) -> ReLU -> bf16 -> T tile: channels cg * 32 .. = half (cg & 1) of slab (cg >> 1)
 #pragma unroll
             for (int r = 0; r < 2; r++) {
@@ -308,10 +323,10 @@ __global__ void __launch_bounds__(512, 2) conv_blk_mid_kernel(MidBlkDev P) {
                 }
             }
         }
-        barrier();       // T complete; every wave is done with the patch
-        issue_patch(Tn);                                               // P
+        barrier();       // T complete; every wave is done with the patch (its next tile's pieces: P, inside GEMM1 of half 0)
         park_x();                                                      // shortcut rows of half 0 (loaded during the previous tile)
         barrier();
+        MID_STAMP();                                                   // 3: T complete, half 0 rows parked
 
         // ================================================================ phase B: two 256-channel halves
         f32x16 acc2[2];
@@ -325,6 +340,10 @@ __global__ void __launch_bounds__(512, 2) conv_blk_mid_kernel(MidBlkDev P) {
                 park_x();                                              // rows of half 1 (X1: complete behind GEMM2's vmcnt(0))
                 barrier();
             }
+            // ---- round 5: ONE vector-memory operation per wave behind every GEMM1 step -- the next tile's patch pieces (P, half 0), the
+            // conv1' fragments (R: the ring is free since phase A / the previous GEMM2) and the next shortcut rows (X: rr is free
+            // since park_x) -- instead of bursts of 16-24 per wave with the matrix pipe idle: a wave needs ~250 cycles to ISSUE
+            // a load once the CU's address path is backed up (phase stamps, NOTES_r05)
             // ---- GEMM1: Y half (32 channels of this wave x 128 px, two 64-pixel halves) = W3 . T, then in place in the Y buffer
             // (acc + bias3) + X -> ReLU -> bf16
 #pragma unroll
@@ -334,13 +353,23 @@ __global__ void __launch_bounds__(512, 2) conv_blk_mid_kernel(MidBlkDev P) {
                 for (int b = 0; b < 2; b++)
 #pragma unroll
                     for (int k = 0; k < 16; k++) acc1[b][k] = 0.f;
-#pragma unroll
-                for (int s = 0; s < 8; s++) {
+                static_for<0, 8>([&](auto SS) {
+                    constexpr int s = decltype(SS)::value;
                     bf16x8 b0, b1;
                     bread2(b0, b1, tbase[s & 3], (s >> 2) * kSlab + (2 * ph2) * 4096);
                     acc1[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3[s], b0, acc1[0], 0, 0, 0);
                     acc1[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3[s], b1, acc1[1], 0, 0, 0);
-                }
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (ph2 == 0) {
+                        if constexpr (h == 0 && s < 7) issue_patch1(Tn, s);                                     // P
+                        load_frag(wr[s], vo1 + (unsigned)((h * 16 + s) * 1024));                                // R0 / R1
+                    } else {
+                        if constexpr (h == 0) issue_x1(T, 1, SS);                                               // X1
+                        else issue_x1(Tn, 0, SS);                                                               // X2
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                });
+                MID_STAMP();                                           // GEMM1 quarter done (wave 0)
                 const unsigned ebase = lds_base + (unsigned)(kOffY + (wave >> 1) * kSlab + (2 * ph2) * 4096 + frow * 128 + 8 * half);
 #pragma unroll
                 for (int g = 0; g < 4; g++) {
@@ -361,19 +390,25 @@ __global__ void __launch_bounds__(512, 2) conv_blk_mid_kernel(MidBlkDev P) {
                         rc[b].y = pack_bf16(fmaxf(vhi[0], 0.f), fmaxf(vhi[1], 0.f));
                     }
                     asm volatile("ds_write_b64 %2, %0\n\tds_write_b64 %2, %1 offset:4096" ::"v"(rc[0]), "v"(rc[1]), "v"(ead) : "memory");
+                    // A3: the conv3 fragments of half 1, two behind every group of the LAST epilogue of half 0 (a3 was GEMM1's operand
+                    // until the step loop above ended)
+                    if (h == 0 && ph2 == 1) {
+                        switch (g) {
+#define A3_CASE(G) case G: load_frag(a3[2 * G], vo3 + (unsigned)((64 + 2 * G) * 1024)); load_frag(a3[2 * G + 1], vo3 + (unsigned)((64 + 2 * G + 1) * 1024)); break;
+                            A3_CASE(0) A3_CASE(1) A3_CASE(2) A3_CASE(3)
+#undef A3_CASE
+                        }
+                    }
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
-            if constexpr (h == 0) load_a3(1);                          // A3
-            static_for<0, kRing>([&](auto J) {                        // R0 / R1
-                load_frag(wr[decltype(J)::value], vo1 + (unsigned)((h * 16 + decltype(J)::value) * 1024));
-            });
-            if constexpr (h == 0) issue_x(T, 1);                       // X1
-            else issue_x(Tn, 0);                                       // X2
+            MID_STAMP();                                               // both epilogues done (wave 0)
+            MID_STAMP();                                               // loads issued (wave 0)
             barrier();       // the Y half is complete
+            MID_STAMP();                                               // 4 / 7: GEMM1 + epilogue of the half done (all waves)
             // ---- Y half rows -> HBM: pass i of 8, 32 threads write one pixel's 512 B (exactly 8 stores per lane)          S0 / S1
-#pragma unroll
-            for (int i = 0; i < 8; i++) {
+            // round 5: one pass behind every second GEMM2 step instead of eight in a row in front of it
+            auto store_rows = [&](int i) {
                 int idx = tid + kNT * i;
                 asm volatile("" : "+v"(idx));
                 const int px = idx >> 5, j = idx & 31;
@@ -384,12 +419,14 @@ __global__ void __launch_bounds__(512, 2) conv_blk_mid_kernel(MidBlkDev P) {
                 char* d = P.dump + (size_t)px * (kCB * 2);
                 a = pix_valid(T, px) ? a : d;
                 __builtin_nontemporal_store(v, (u32x4*)(a + h * 512 + j * 16));
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            // ---- GEMM2 over this half's K range: Z (32 channels cg x 64 px rp) += W1[:, half h] . Y half
+            };
+            MID_STAMP();                                               // 5 / 8: (rows are issued inside GEMM2 now)
+            // ---- GEMM2 over this half's K range: Z (32 channels cg x 64 px rp) += W1[:, half h] . Y half.  Step s: [wait a1(s)] MFMAs |
+            // refill a1(s + 8) (s < 8) | row pass s / 2 (s even).  Younger than a1(s), s < 8: the patch pieces behind it (half 0: 6 - s),
+            // the rest of R (7 - s), X (8), A3 (8, half 0), s refills, ceil(s / 2) row passes; s >= 8: 15 - s refills and 4 row passes
             static_for<0, 16>([&](auto SS) {
                 constexpr int s = decltype(SS)::value;
-                constexpr int wn = s < 8 ? 23 : ((15 - s) < 7 ? (15 - s) : 7);
+                constexpr int wn = s < 8 ? (h == 0 ? 23 + (s < 6 ? 6 - s : 0) : 15) + (s + 1) / 2 : 19 - s;
                 asm volatile("s_waitcnt vmcnt(%1)" : "+v"(wr[s % kRing]) : "n"(wn) : "memory");
                 bf16x8 b0, b1;
                 bread2(b0, b1, ybase[s & 3], (s >> 2) * kSlab);
@@ -399,8 +436,11 @@ __global__ void __launch_bounds__(512, 2) conv_blk_mid_kernel(MidBlkDev P) {
                 }
                 __builtin_amdgcn_sched_barrier(0);
                 if constexpr (s < 8) load_frag(wr[s % kRing], vo1 + (unsigned)((h * 16 + s + 8) * 1024));
+                if constexpr ((s & 1) == 0) store_rows(s >> 1);
+                __builtin_amdgcn_sched_barrier(0);
             });
             barrier();       // every wave is done with the Y half (row stores and GEMM2 have read it)
+            MID_STAMP();                                               // 6 / 9: GEMM2 of the half done (all waves)
         });
         // ================================================================ Z = relu(acc2 + bias1) -> staging (the T tile's LDS) -> rows
         if constexpr (HEAD) {
@@ -436,6 +476,13 @@ __global__ void __launch_bounds__(512, 2) conv_blk_mid_kernel(MidBlkDev P) {
             }
         }
         __builtin_amdgcn_sched_barrier(0);
+        MID_STAMP();                                                   // 10: Z rows issued
+#ifdef DAFNE_MID_TIMING
+        if (tid == 0 && kk == 1 && blockIdx.x < 64) {                  // the second tile of a workgroup: steady state
+            unsigned long long* o = (unsigned long long*)P.dump + blockIdx.x * 24;
+            for (int q = 0; q < 23; q++) o[q] = mstamp[q] - mstamp[0];
+        }
+#endif
     }
     // nothing may still be on its way into this workgroup's LDS (the last tile re-requested its own patch) or registers
     asm volatile("s_waitcnt vmcnt(0)"
