@@ -100,8 +100,9 @@ __device__ __forceinline__ unsigned pack_bf16(float a, float b) {
 //     phase A: one patch piece of slabs 1..3 at steps 0..11; slabs 0..2 of the first residual chunk (their Y-buffer space
 //              does not overlap the patch) one piece at steps 60, 64, .., 80 -- HBM is idle while every CU is in phase A --,
 //              its slab 3 (2 pieces, into the side buffer) after step 143, behind the barrier that retires the patch;
-//     phase B: 2 pieces of slab q = 0..2 of the next residual chunk after the last step of slab group q of GEMM2 (into the
-//              Y buffer, as conv_b2b.hip); its slab 3 goes to a 16-KB SIDE buffer right after GEMM1 + epilogue of the
+//     phase B: the pieces of slabs 0 + 1 of the next residual chunk after the last step of slab group 1 of GEMM2, those of slab 2
+//              after group 2 (into the Y buffer; round 4: slab q behind group q, a barrier behind every group); its slab 3 goes to
+//              a 16-KB SIDE buffer right after GEMM1 + epilogue of the
 //              current chunk, i.e. a whole GEMM2 + GEMM1 ahead of its use (in conv_b2b it is issued last and has one GEMM1,
 //              2.6 us, to arrive from HBM: chunks 1..2 took 18-25k cycles against 15k for chunk 0).
 // bn_wait(j) = number of those instructions issued after A(j) and before the wait for it: vmcnt retires in order, so
@@ -117,7 +118,7 @@ constexpr int bn_post(int s) {
                (s == kStepsA - 1 ? 2 : 0);
     const int j = s - kStepsA, i = j & 31;
     if ((j >> 5) >= kChunks - 1) return 0;
-    return ((i >= 16 && (i & 3) == 3 && i != 31) || i == 15) ? 2 : 0;
+    return i == 23 ? 4 : ((i == 27 || i == 15) ? 2 : 0);      // slabs 0 + 1 behind slab group 1, slab 2 behind group 2, slab 3 (side) behind GEMM1
 }
 constexpr int bn_wait(int j) {
     int n = 0;
@@ -133,8 +134,9 @@ constexpr int bn_wait(int j) {
 // spot checks (hand-counted): steady state 7; the trickle adds one per step; phase B around the side-buffer and slab pieces
 static_assert(bn_wait(0) == 7 && bn_wait(1) == 8 && bn_wait(7) == 14 && bn_wait(8) == 15 && bn_wait(12) == 15 && bn_wait(13) == 14 &&
               bn_wait(20) == 7 && bn_wait(61) == 8 && bn_wait(68) == 9 && bn_wait(100) == 7 && bn_wait(kStepsA + 7) == 9 &&
-              bn_wait(kStepsA + 8) == 7 && bn_wait(kStepsA + 16) == 9 && bn_wait(kStepsA + 23) == 15 && bn_wait(kStepsA + 24) == 13 &&
-              bn_wait(kStepsA + 31) == 15 && bn_wait(kStepsA + 39) == 7 && bn_wait(kStepsA + 127) == 4, "vmcnt bookkeeping");
+              bn_wait(kStepsA + 8) == 7 && bn_wait(kStepsA + 16) == 9 && bn_wait(kStepsA + 23) == 13 && bn_wait(kStepsA + 24) == 13 &&
+              bn_wait(kStepsA + 28) == 15 && bn_wait(kStepsA + 31) == 17 && bn_wait(kStepsA + 39) == 7 && bn_wait(kStepsA + 127) == 4,
+              "vmcnt bookkeeping");
 
 template <int I, int N, class F>
 __device__ __forceinline__ void static_for(F&& f) {
@@ -296,6 +298,30 @@ __global__ void __launch_bounds__(512, 2) conv_bneck_kernel(BneckDev P) {
         char* d = P.dump + (size_t)px * (kCB * 2);
         a = pix_valid(px) ? a : d;
         *(u32x4*)(a + col0b + sl * 128 + q * 16) = v;
+    };
+    // round 5: the Y row stores with everything per-lane precomputed -- a lane stores the same two tile pixels (px0 = tid >> 3 and
+    // px0 + 64: same swizzle, LDS address + 8192) in every pass, so the two row addresses are computed ONCE (4 VGPRs); slab and
+    // chunk are immediates of the LDS read / the store.  The generic form above costs ~30 vector instructions per pass (clamps,
+    // 64-bit multiplies, the dump select): 8 passes per chunk made GEMM2 take 425 cycles per step against 285 in GEMM1.
+    char* yrow[2];
+    {
+        const int px0 = tid >> 3, q = tid & 7;
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            const int px = px0 + 64 * h;
+            char* a = P.out + (size_t)pix_index(px) * (kCB * 2);
+            char* d = P.dump + (size_t)px * (kCB * 2);
+            yrow[h] = (pix_valid(px) ? a : d) + q * 16;
+        }
+    }
+    const unsigned ylds = lds_base + (unsigned)(kOffY + (tid >> 3) * 128 + (((tid & 7) ^ (((tid >> 3) >> 1) & 7)) * 16));
+    auto store_y = [&](auto SL, auto H, auto C) {
+        constexpr int sl = decltype(SL)::value, h = decltype(H)::value, c = decltype(C)::value;
+        const unsigned la = ylds;                // (non-dependent uses: a generic lambda captures the two only through them)
+        char* const* yr = yrow;
+        u32x4 v;
+        asm volatile("ds_read_b128 %0, %1 offset:%2\n\ts_waitcnt lgkmcnt(0)" : "=&v"(v) : "v"(la), "n"(sl * kSlab + h * 8192) : "memory");
+        asm volatile("global_store_dwordx4 %0, %1, off offset:%2" :: "v"(yr[h]), "v"(v), "n"(c * 512 + sl * 128) : "memory");
     };
     // acc + bias (+ residual already in the buffer) -> ReLU -> bf16, in place in the buffer at byte offset buf
     // (conv_b2b.hip's epilogue; the expressions are those of the separate kernels)
@@ -465,19 +491,31 @@ __global__ void __launch_bounds__(512, 2) conv_bneck_kernel(BneckDev P) {
                     for (int b = 0; b < kPF; b++) acc2[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ar[j % kRing], bfr[j & 1][b], acc2[b], 0, 0, 0);
                 }
                 if constexpr (i == 0) {
-                    store_slab(q, 0, P.out, kCB * 2, (unsigned)c * 512u);
-                    store_slab(q, 1, P.out, kCB * 2, (unsigned)c * 512u);
+                    store_y(Q, std::integral_constant<int, 0>{}, C);
+                    store_y(Q, std::integral_constant<int, 1>{}, C);
                 }
                 __builtin_amdgcn_sched_barrier(0);
                 load_step(std::integral_constant<int, j + kRing>{});
             });
-            barrier();
-            if constexpr (c + 1 < kChunks && q < 3) dma_slab((unsigned)(c + 1) * 512u, q);
+            // round 5: a barrier only where a residual slab lands behind it -- behind slab group 1 (slabs 0 and 1 of the next chunk,
+            // 4 pieces) and behind group 2 (slab 2); none behind groups 0 and 3 and none in the last chunk (16 -> 6 barriers per
+            // block in GEMM2).  The next epilogue's in-place writes are ordered behind every wave's GEMM2 reads by the barrier
+            // that follows GEMM1 of the next chunk / precedes the Z epilogue.
+            if constexpr (c + 1 < kChunks && q == 1) {
+                barrier();
+                dma_slab((unsigned)(c + 1) * 512u, 0);
+                dma_slab((unsigned)(c + 1) * 512u, 1);
+            }
+            if constexpr (c + 1 < kChunks && q == 2) {
+                barrier();
+                dma_slab((unsigned)(c + 1) * 512u, 2);
+            }
             __builtin_amdgcn_sched_barrier(0);
         });
         BN_STAMP();
     });
     if constexpr (HEAD) {
+        barrier();                                   // every wave is done reading the last Y chunk (no barrier behind slab group 3 any more)
         epilogue(acc2, 256 + kCB, false, kOffY);
         barrier();
         BN_STAMP();
