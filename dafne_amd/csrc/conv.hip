@@ -1876,7 +1876,8 @@ __global__ void __launch_bounds__(512) conv3x3_patch_kernel(ConvDev P) {
 // across tiles (workgroup p of G runs tiles p, p + G, ...):
 //   * the NEXT tile's patch lands while the current tile computes: slab s of the patch is dead after step 36 (s + 1) - 1, a
 //     barrier at steps 36 / 72 / 108 retires it and the next tile's slab s is DMA'd into its place in steps 40.. / 76.. /
-//     112.. (one piece per wave and step), slab 3 right behind the tile's last step;
+//     112.. (one piece per wave and step); slab 3 of a tile is requested in that tile's own steps 0..3, behind its step-0
+//     barrier (round 5: it was a burst of four behind the last step, in front of the epilogue, with an extra barrier);
 //   * GN_INPUT: a wave normalises the pieces IT loaded (GroupNorm + ReLU in place, out-of-image pixels stay zero) ~13
 //     steps after issuing them -- next tile's slabs 0..2 in steps 53.. / 89.. / 125.., its slab 3 in steps 13.. of the
 //     next tile itself (first read at step 108); the two waves of a SIMD four steps apart -- under the other waves' MFMAs; statistics of the next tile's image by
@@ -1914,16 +1915,18 @@ constexpr int kRDumpBytes = 64 * 1024;
 
 // Vector-memory program order of a wave inside a tile (steady state; A(s + 8) of steps >= 136 are the next tile's first):
 //   step s: [wait A(s)] MFMAs | A(s + 8) | rp_post(s) more operations:
-//     20 (GN_INPUT): the statistics piece of the next tile's image; 40..43 / 76..79 / 112..115: one patch piece of the next
-//     tile's slab 0 / 1 / 2; 143: the four pieces of slab 3 and the tile's 8 row stores.
+//     0..3: one patch piece of THIS tile's slab 3 (first read at step 108; round 5 -- it was a burst of four behind step 143, in
+//     the epilogue); 20 (GN_INPUT): the statistics piece of the next tile's image; 40..43 / 76..79 / 112..115: one patch piece of
+//     the next tile's slab 0 / 1 / 2; 143: the tile's 8 row stores.
 // rp_wait(j) = operations issued after A(j) and before the wait for it (vmcnt retires in order).  Steps 0..7 look back
-// into the previous tile; the FIRST tile of a workgroup has the prologue there instead (16 patch pieces, then A(0..7)).
+// into the previous tile; the FIRST tile of a workgroup has the prologue there instead (12 patch pieces, then A(0..7)).
 constexpr int kRStatStep = 20;            // GN_INPUT: the next tile's statistics piece, early enough for the a / b table of step 30
 constexpr int rp_post(int s, bool gnin) {
     int n = 0;
     if (gnin && s == kRStatStep) n += 1;
+    if (s < 4) n += 1;                                   // slab 3 of THIS tile's patch (round 5; it was a burst of 4 behind step 143)
     if ((s >= 40 && s < 44) || (s >= 76 && s < 80) || (s >= 112 && s < 116)) n += 1;
-    if (s == kRSteps - 1) n += 4 + 8;
+    if (s == kRSteps - 1) n += 8;
     return n;
 }
 constexpr int rp_wait(int j, bool gnin, bool first) {
@@ -1937,7 +1940,8 @@ constexpr int rp_wait(int j, bool gnin, bool first) {
     for (int s = j - kRRing + 1; s < j; s++) n += 1 + rp_post((s + kRSteps) % kRSteps, gnin);
     return n;
 }
-static_assert(rp_wait(0, false, true) == 7 && rp_wait(0, false, false) == 19 && rp_wait(7, false, false) == 19 && rp_wait(8, false, false) == 7 &&
+static_assert(rp_wait(0, false, true) == 7 && rp_wait(3, false, true) == 10 && rp_wait(7, false, true) == 11 && rp_wait(0, false, false) == 15 &&
+              rp_wait(4, false, false) == 19 && rp_wait(7, false, false) == 19 && rp_wait(8, false, false) == 11 && rp_wait(12, false, false) == 7 &&
               rp_wait(48, false, false) == 11 && rp_wait(48, true, false) == 11 && rp_wait(45, true, false) == 11 &&
               rp_wait(52, false, false) == 7 && rp_wait(143, true, false) == 7 && rp_wait(kRStatStep + 8, true, false) == 8, "vmcnt bookkeeping");
 
@@ -2191,7 +2195,7 @@ __global__ void __launch_bounds__(512, 2) conv3x3_rp_kernel(ConvDev PA, ConvDev 
     }
     patch_map(cur);
 #pragma unroll
-    for (int sl = 0; sl < 4; sl++)
+    for (int sl = 0; sl < 3; sl++)            // slab 3 follows in steps 0..3 of the tile, like every tile's
 #pragma unroll
         for (int ii = 0; ii < 4; ii++) patch_piece(sl, ii);
     {
@@ -2199,9 +2203,9 @@ __global__ void __launch_bounds__(512, 2) conv3x3_rp_kernel(ConvDev PA, ConvDev 
         rp_static_for<0, kRRing>([&](auto J) { rp_load<decltype(J)::value>(ar, wf0, wf0, voff); });
     }
     if (GNIN) {
-        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");      // this wave's 16 patch pieces have landed (the 8 A loads are younger)
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");      // this wave's 12 patch pieces have landed (the 8 A loads are younger)
 #pragma unroll
-        for (int sl = 0; sl < 4; sl++)
+        for (int sl = 0; sl < 3; sl++)
 #pragma unroll
             for (int ii = 0; ii < 4; ii++) gn_piece(cur, sl, ii, 0);
     }
@@ -2333,7 +2337,7 @@ __global__ void __launch_bounds__(512, 2) conv3x3_rp_kernel(ConvDev PA, ConvDev 
             // (waves w and w + 4 share a SIMD: the second half of the workgroup converts four steps later, so that one of the
             // two always has MFMAs for the matrix pipe)
             if constexpr (GNIN) {
-                if constexpr (j >= 13 && j < 21) { if (!first && ((j - 13) >> 2) == gnlate) gn_piece(cur, 3, (j - 13) & 3, sb_cur); }
+                if constexpr (j >= 13 && j < 21) { if (((j - 13) >> 2) == gnlate) gn_piece(cur, 3, (j - 13) & 3, sb_cur); }
                 if constexpr (j >= 53 && j < 61) { if (((j - 53) >> 2) == gnlate) gn_piece(nxt, 0, (j - 53) & 3, sb_nxt); }
                 if constexpr (j >= 89 && j < 97) { if (((j - 89) >> 2) == gnlate) gn_piece(nxt, 1, (j - 89) & 3, sb_nxt); }
                 if constexpr (j >= 125 && j < 133) { if (((j - 125) >> 2) == gnlate) gn_piece(nxt, 2, (j - 125) & 3, sb_nxt); }
@@ -2371,17 +2375,17 @@ __global__ void __launch_bounds__(512, 2) conv3x3_rp_kernel(ConvDev PA, ConvDev 
             rp_load<j + kRRing>(ar, wf_cur, wf_nxt, voff);
             // ---- counted vector-memory operations behind the weight load (rp_post)
             if constexpr (GNIN && j == kRStatStep) stat_piece(nxt, sb_nxt);
+            if constexpr (j < 4) patch_piece(3, j);              // this tile's slab 3 (pofs / pin are this tile's until step 37)
             if constexpr (j >= 40 && j < 44) patch_piece(0, j - 40);
             if constexpr (j >= 76 && j < 80) patch_piece(1, j - 76);
             if constexpr (j >= 112 && j < 116) patch_piece(2, j - 112);
             __builtin_amdgcn_sched_barrier(0);
         });
         RP_STAMP(5);
-        // ---- end of tile: slab 3 of the next tile, then this tile's epilogue
-        barrier();                                             // every wave is done with slab 3
+        // ---- end of tile: this tile's epilogue.  (Round 5: no barrier and no patch pieces here -- slab 3 of the next tile's patch is
+        // requested in that tile's steps 0..3, behind its step-0 barrier, which also retires this tile's slab 3; a wave that is done
+        // with its 144 steps goes straight into its epilogue while its SIMD mate still has the matrix pipe.)
         RP_STAMP(6);
-#pragma unroll
-        for (int ii = 0; ii < 4; ii++) patch_piece(3, ii);
         {
             f32x4 bia4[4];
             const unsigned bad = lds_base + (unsigned)(kROffBias + (cur.grp * kRMaxCout + cur.nt * 256 + wave * 32 + 4 * half) * 4);
