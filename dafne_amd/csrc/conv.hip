@@ -467,6 +467,7 @@ __global__ void __launch_bounds__(WC * WP * 64) conv_igemm_kernel(ConvDev P) {
     // 16-lane groups cover 256 contiguous bytes; residual reads are coalesced the same
     // way, and 8 channels == one GroupNorm group.
     const bool relu = P.flags & DAFNE_CONV_RELU;
+    const float relu_lo = relu ? 0.f : -__builtin_inff();
     const bool has_res = P.flags & DAFNE_CONV_RESIDUAL;
     const bool has_up = P.flags & DAFNE_CONV_UPSAMPLE_ADD;
     const bool out_f32 = P.flags & DAFNE_CONV_OUT_F32;
@@ -502,13 +503,11 @@ __global__ void __launch_bounds__(WC * WP * 64) conv_igemm_kernel(ConvDev P) {
             for (int a = 0; a < TC; a++)
 #pragma unroll
                 for (int g = 0; g < 4; g++) {
-                    float v0 = acc[a][b][4 * g] + bia4[a][g].x, v1 = acc[a][b][4 * g + 1] + bia4[a][g].y;
-                    float v2 = acc[a][b][4 * g + 2] + bia4[a][g].z, v3 = acc[a][b][4 * g + 3] + bia4[a][g].w;
-                    if (relu) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f); }
-                    if (gn && valid) {
-                        gsum[a][g] += (v0 + v1) + (v2 + v3);
-                        gsq[a][g] += (v0 * v0 + v1 * v1) + (v2 * v2 + v3 * v3);
-                    }
+                    // (branch-free: ReLU as a max with 0 / -inf, the GroupNorm sums added under a select -- x + 0 is exact; round 5)
+                    const float v0 = fmaxf(acc[a][b][4 * g] + bia4[a][g].x, relu_lo), v1 = fmaxf(acc[a][b][4 * g + 1] + bia4[a][g].y, relu_lo);
+                    const float v2 = fmaxf(acc[a][b][4 * g + 2] + bia4[a][g].z, relu_lo), v3 = fmaxf(acc[a][b][4 * g + 3] + bia4[a][g].w, relu_lo);
+                    gsum[a][g] += valid ? (v0 + v1) + (v2 + v3) : 0.f;
+                    gsq[a][g] += valid ? (v0 * v0 + v1 * v1) + (v2 * v2 + v3 * v3) : 0.f;
                     uint2 pk;
                     pk.x = pack_bf16(v0, v1);
                     pk.y = pack_bf16(v2, v3);
@@ -1756,6 +1755,7 @@ __global__ void __launch_bounds__(512) conv3x3_patch_kernel(ConvDev P) {
 
     // ------------------------------------------------------------ epilogue (bias, ReLU, GN sums, bf16)
     const bool relu = P.flags & DAFNE_CONV_RELU;
+    const float relu_lo = relu ? 0.f : -__builtin_inff();
     const bool gn = P.flags & DAFNE_CONV_GN_STATS;
     const bool fin = gn && (P.flags & DAFNE_CONV_GN_FINALIZE);     // wave-uniform
     float fin_sq[2] = {0.f, 0.f};
@@ -1784,13 +1784,11 @@ __global__ void __launch_bounds__(512) conv3x3_patch_kernel(ConvDev P) {
         for (int a = 0; a < TC; a++)
 #pragma unroll
             for (int g = 0; g < 4; g++) {
-                float v0 = acc[a][b][4 * g] + bia4[a][g].x, v1 = acc[a][b][4 * g + 1] + bia4[a][g].y;
-                float v2 = acc[a][b][4 * g + 2] + bia4[a][g].z, v3 = acc[a][b][4 * g + 3] + bia4[a][g].w;
-                if (relu) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f); }
-                if (gn && valid) {
-                    gsum[a][g] += (v0 + v1) + (v2 + v3);
-                    gsq[a][g] += (v0 * v0 + v1 * v1) + (v2 * v2 + v3 * v3);
-                }
+                // (branch-free: ReLU as a max with 0 / -inf, the GroupNorm sums added under a select -- x + 0 is exact; round 5)
+                const float v0 = fmaxf(acc[a][b][4 * g] + bia4[a][g].x, relu_lo), v1 = fmaxf(acc[a][b][4 * g + 1] + bia4[a][g].y, relu_lo);
+                const float v2 = fmaxf(acc[a][b][4 * g + 2] + bia4[a][g].z, relu_lo), v3 = fmaxf(acc[a][b][4 * g + 3] + bia4[a][g].w, relu_lo);
+                gsum[a][g] += valid ? (v0 + v1) + (v2 + v3) : 0.f;
+                gsq[a][g] += valid ? (v0 * v0 + v1 * v1) + (v2 * v2 + v3 * v3) : 0.f;
                 uint2 pk;
                 pk.x = pack_bf16(v0, v1);
                 pk.y = pack_bf16(v2, v3);
@@ -1919,7 +1917,7 @@ constexpr int kRDumpBytes = 64 * 1024;
 //     the epilogue); 20 (GN_INPUT): the statistics piece of the next tile's image; 40..43 / 76..79 / 112..115: one patch piece of
 //     the next tile's slab 0 / 1 / 2; 143: the tile's 8 row stores.
 // rp_wait(j) = operations issued after A(j) and before the wait for it (vmcnt retires in order).  Steps 0..7 look back
-// into the previous tile; the FIRST tile of a workgroup has the prologue there instead (12 patch pieces, then A(0..7)).
+// into the previous tile; the FIRST tile of a workgroup has the prologue there instead (12 patch pieces, A(0..7), 8 dummy stores).
 constexpr int kRStatStep = 20;            // GN_INPUT: the next tile's statistics piece, early enough for the a / b table of step 30
 constexpr int rp_post(int s, bool gnin) {
     int n = 0;
@@ -1929,37 +1927,33 @@ constexpr int rp_post(int s, bool gnin) {
     if (s == kRSteps - 1) n += 8;
     return n;
 }
-constexpr int rp_wait(int j, bool gnin, bool first) {
-    int n = 0;
-    if (first && j < kRRing) {
-        n += kRRing - 1 - j;
-        for (int s = 0; s < j; s++) n += 1 + rp_post(s, gnin);
-        return n;
-    }
-    n += rp_post((j - kRRing + kRSteps) % kRSteps, gnin);
+// (Round 5: ONE sequence for every tile.  The first tile of a workgroup used to have its own counts for steps 0..7 -- the prologue
+// has no row stores behind A(0..7) -- and `if (first) wait(kF) else wait(kN)` on the ring register made the compiler put a COPY of
+// the register in front of the steady-state wait: the MFMAs of steps 0..7 of every later tile could read a fragment that had not
+// landed.  The prologue now issues 8 dummy dword stores to the dump area behind A(0..7): same queue, same counts, no branch.)
+constexpr int rp_wait(int j, bool gnin) {
+    int n = rp_post((j - kRRing + kRSteps) % kRSteps, gnin);
     for (int s = j - kRRing + 1; s < j; s++) n += 1 + rp_post((s + kRSteps) % kRSteps, gnin);
     return n;
 }
-static_assert(rp_wait(0, false, true) == 7 && rp_wait(3, false, true) == 10 && rp_wait(7, false, true) == 11 && rp_wait(0, false, false) == 15 &&
-              rp_wait(4, false, false) == 19 && rp_wait(7, false, false) == 19 && rp_wait(8, false, false) == 11 && rp_wait(12, false, false) == 7 &&
-              rp_wait(48, false, false) == 11 && rp_wait(48, true, false) == 11 && rp_wait(45, true, false) == 11 &&
-              rp_wait(52, false, false) == 7 && rp_wait(143, true, false) == 7 && rp_wait(kRStatStep + 8, true, false) == 8, "vmcnt bookkeeping");
+static_assert(rp_wait(0, false) == 15 && rp_wait(4, false) == 19 && rp_wait(7, false) == 19 && rp_wait(8, false) == 11 && rp_wait(12, false) == 7 &&
+              rp_wait(48, false) == 11 && rp_wait(48, true) == 11 && rp_wait(45, true) == 11 &&
+              rp_wait(52, false) == 7 && rp_wait(143, true) == 7 && rp_wait(kRStatStep + 8, true) == 8, "vmcnt bookkeeping");
 
 template <int J>
 __device__ __forceinline__ void rp_load(bf16x8 (&ar)[kRRing], const char* wf_cur, const char* wf_nxt, unsigned voff) {
     const char* sb = (J < kRSteps ? wf_cur : wf_nxt) + (size_t)(J % kRSteps) * 1024;
-    asm volatile("global_load_dwordx4 %0, %1, %2" : "=&v"(ar[J % kRRing]) : "v"(voff), "s"(sb) : "memory");
+    // "+v": the destination is loop-carried and stays ONE register from the zero-initialisation on.  With an output-only
+    // operand every load defines a new value, which the compiler may move between registers (at the loop's back edge, inside
+    // the plain-C++ epilogue) while the load is still in flight: the copy takes the OLD bits.  Round 5 found it as run-to-run
+    // different detections in the deferred layout (tests/test_gpu_headline.py::test_headline_timed_layout_vs_oracle) once the
+    // barrier at the end of a tile -- which had been giving the eight loads time to land -- was gone.
+    asm volatile("global_load_dwordx4 %0, %1, %2" : "+v"(ar[J % kRRing]) : "v"(voff), "s"(sb) : "memory");
 }
 template <int J, bool GNIN>
-__device__ __forceinline__ void rp_wait_for(bf16x8 (&ar)[kRRing], bool first) {
-    constexpr int kN = rp_wait(J, GNIN, false);
-    if constexpr (J < kRRing) {
-        constexpr int kF = rp_wait(J, GNIN, true);
-        if (first) asm volatile("s_waitcnt vmcnt(%1)" : "+v"(ar[J % kRRing]) : "n"(kF) : "memory");
-        else asm volatile("s_waitcnt vmcnt(%1)" : "+v"(ar[J % kRRing]) : "n"(kN) : "memory");
-    } else {
-        asm volatile("s_waitcnt vmcnt(%1)" : "+v"(ar[J % kRRing]) : "n"(kN) : "memory");
-    }
+__device__ __forceinline__ void rp_wait_for(bf16x8 (&ar)[kRRing]) {
+    constexpr int kN = rp_wait(J, GNIN);
+    asm volatile("s_waitcnt vmcnt(%1)" : "+v"(ar[J % kRRing]) : "n"(kN) : "memory");
 }
 template <int I, int N, class F>
 __device__ __forceinline__ void rp_static_for(F&& f) {
@@ -2160,6 +2154,8 @@ __global__ void __launch_bounds__(512, 2) conv3x3_rp_kernel(ConvDev PA, ConvDev 
 
     const unsigned voff = (unsigned)(wave * kRSteps * 1024 + lane * 16);
     bf16x8 ar[kRRing];
+#pragma unroll
+    for (int k = 0; k < kRRing; k++) ar[k] = bf16x8{};
     auto barrier = [&]() {
         __builtin_amdgcn_sched_barrier(0);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -2202,8 +2198,15 @@ __global__ void __launch_bounds__(512, 2) conv3x3_rp_kernel(ConvDev PA, ConvDev 
         const char* wf0 = PG(cur.grp).w + (size_t)cur.nt * (NW * kRSteps * 1024);
         rp_static_for<0, kRRing>([&](auto J) { rp_load<decltype(J)::value>(ar, wf0, wf0, voff); });
     }
+    // 8 dummy dword stores (the wave's 256 B of the dump area each): the queue behind A(0..7) now looks like a steady-state tile's
+    // -- A(136..143), then the previous tile's 8 row stores -- so steps 0..7 of the first tile wait with the same counts
+    {
+        char* dd = dump + (size_t)tid * 128;
+#pragma unroll
+        for (int k = 0; k < 8; k++) asm volatile("global_store_dword %0, %1, off offset:%2" :: "v"(dd), "v"(0), "n"(k * 4) : "memory");
+    }
     if (GNIN) {
-        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");      // this wave's 12 patch pieces have landed (the 8 A loads are younger)
+        asm volatile("s_waitcnt vmcnt(16)" ::: "memory");     // this wave's 12 patch pieces have landed (8 A loads + 8 stores are younger)
 #pragma unroll
         for (int sl = 0; sl < 3; sl++)
 #pragma unroll
@@ -2325,7 +2328,7 @@ __global__ void __launch_bounds__(512, 2) conv3x3_rp_kernel(ConvDev PA, ConvDev 
         rp_static_for<0, kRSteps>([&](auto J) {
             constexpr int j = decltype(J)::value;
             constexpr int sl = j / 36, t = j % 36, kh = t / 12, kw = (t >> 2) % 3, kc = t & 3;
-            rp_wait_for<j, GNIN>(ar, first);
+            rp_wait_for<j, GNIN>(ar);
             if constexpr (j == 0 || j == 36 || j == 72 || j == 108) {
                 barrier();
                 if constexpr (j == 0) RP_STAMP(1);
@@ -2403,19 +2406,21 @@ __global__ void __launch_bounds__(512, 2) conv3x3_rp_kernel(ConvDev PA, ConvDev 
                           + (cur.nt * 256 + wave * 32 + 8 * half) * 2;
             char* dbase = dump + (size_t)tid * 128;
             const bool colok = cur.valid && (cur.X0 + frow) < cur.W;
+            // round 5: branch-free (the runtime flags were exec-mask branches around every group: 414 vector + 215 scalar
+            // instructions per tile): ReLU as a max with 0 or -inf, the GroupNorm sums always formed and ADDED under a select
+            // (x + 0 is exact: the sums of a plain / out-of-image row are unchanged bit for bit)
+            const float lo = relu ? 0.f : -__builtin_inff();
 #pragma unroll
             for (int b = 0; b < 4; b++) {
                 const bool valid = colok && (cur.Y0 + b) < cur.H;
                 u32x2 pk[4];
 #pragma unroll
                 for (int g = 0; g < 4; g++) {
-                    float v0 = acc[b][4 * g] + bia4[g][0], v1 = acc[b][4 * g + 1] + bia4[g][1];
-                    float v2 = acc[b][4 * g + 2] + bia4[g][2], v3 = acc[b][4 * g + 3] + bia4[g][3];
-                    if (relu) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f); }
-                    if (gn && valid) {
-                        gsum[g] += (v0 + v1) + (v2 + v3);
-                        gsq[g] += (v0 * v0 + v1 * v1) + (v2 * v2 + v3 * v3);
-                    }
+                    const float v0 = fmaxf(acc[b][4 * g] + bia4[g][0], lo), v1 = fmaxf(acc[b][4 * g + 1] + bia4[g][1], lo);
+                    const float v2 = fmaxf(acc[b][4 * g + 2] + bia4[g][2], lo), v3 = fmaxf(acc[b][4 * g + 3] + bia4[g][3], lo);
+                    const float s4 = (v0 + v1) + (v2 + v3), q4 = (v0 * v0 + v1 * v1) + (v2 * v2 + v3 * v3);
+                    gsum[g] += valid ? s4 : 0.f;
+                    gsq[g] += valid ? q4 : 0.f;
                     pk[g].x = pack_bf16(v0, v1);
                     pk[g].y = pack_bf16(v2, v3);
                 }
@@ -2772,6 +2777,7 @@ __global__ void __launch_bounds__(512) conv3x3_patch_fp8_kernel(ConvDev P) {
 
     // ------------------------------------------------------------ epilogue (scale, bias, ReLU, GN sums, bf16)
     const bool relu = P.flags & DAFNE_CONV_RELU;
+    const float relu_lo = relu ? 0.f : -__builtin_inff();
     const bool gn = P.flags & DAFNE_CONV_GN_STATS;
     const bool fin = gn && (P.flags & DAFNE_CONV_GN_FINALIZE);     // wave-uniform
     float fin_sq[2] = {0.f, 0.f};
@@ -2796,13 +2802,11 @@ __global__ void __launch_bounds__(512) conv3x3_patch_fp8_kernel(ConvDev P) {
             for (int b = 0; b < TP; b++) {
                 const int px = (wp * TP + b) * 32 + frow;
                 const bool valid = (Y0 + wp * TP + b) < H && (X0 + frow) < W;
-                float v0 = acc[a][b][4 * g] * osc.x + bia.x, v1 = acc[a][b][4 * g + 1] * osc.y + bia.y;
-                float v2 = acc[a][b][4 * g + 2] * osc.z + bia.z, v3 = acc[a][b][4 * g + 3] * osc.w + bia.w;
-                if (relu) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f); }
-                if (gn && valid) {
-                    gsum[a][g] += (v0 + v1) + (v2 + v3);
-                    gsq[a][g] += (v0 * v0 + v1 * v1) + (v2 * v2 + v3 * v3);
-                }
+                // (branch-free: ReLU as a max with 0 / -inf, the GroupNorm sums added under a select -- x + 0 is exact; round 5)
+                const float v0 = fmaxf(acc[a][b][4 * g] * osc.x + bia.x, relu_lo), v1 = fmaxf(acc[a][b][4 * g + 1] * osc.y + bia.y, relu_lo);
+                const float v2 = fmaxf(acc[a][b][4 * g + 2] * osc.z + bia.z, relu_lo), v3 = fmaxf(acc[a][b][4 * g + 3] * osc.w + bia.w, relu_lo);
+                gsum[a][g] += valid ? (v0 + v1) + (v2 + v3) : 0.f;
+                gsq[a][g] += valid ? (v0 * v0 + v1 * v1) + (v2 * v2 + v3 * v3) : 0.f;
                 uint2 pk;
                 pk.x = pack_bf16(v0, v1);
                 pk.y = pack_bf16(v2, v3);
@@ -2924,18 +2928,18 @@ template <int J>
 __device__ __forceinline__ void r8_load(i32x4 (&alo)[kR8Ring], i32x4 (&ahi)[kR8Ring], const char* wf, unsigned voff) {
     const char* sb = wf + (size_t)(J % kR8Steps) * 2048;
     asm volatile("global_load_dwordx4 %0, %2, %3\n\tglobal_load_dwordx4 %1, %2, %3 offset:1024"
-                 : "=&v"(alo[J % kR8Ring]), "=&v"(ahi[J % kR8Ring]) : "v"(voff), "s"(sb) : "memory");
+                 : "+v"(alo[J % kR8Ring]), "+v"(ahi[J % kR8Ring]) : "v"(voff), "s"(sb) : "memory");      // "+v": see rp_load
 }
 template <int J>
-__device__ __forceinline__ void r8_wait_for(i32x4 (&alo)[kR8Ring], i32x4 (&ahi)[kR8Ring], bool first) {
+__device__ __forceinline__ void r8_wait_for(i32x4 (&alo)[kR8Ring], i32x4 (&ahi)[kR8Ring], bool /*first*/) {
+    // ONE wait per step for every tile (round 5): `if (first) wait(kF) else wait(kN)` on the ring registers made the compiler put
+    // a copy of them in front of one of the two waits (conv3x3_rp_kernel: rp_wait).  In the ring's first steps the first tile
+    // and the steady state differ in what sits behind the fragment in the queue; the SMALLER count is right for both (it only
+    // asks for more of the queue to have retired).
     constexpr int kN = r8_wait(J, false);
-    if constexpr (J < kR8Ring) {
-        constexpr int kF = r8_wait(J, true);
-        if (first) asm volatile("s_waitcnt vmcnt(%2)" : "+v"(alo[J % kR8Ring]), "+v"(ahi[J % kR8Ring]) : "n"(kF) : "memory");
-        else asm volatile("s_waitcnt vmcnt(%2)" : "+v"(alo[J % kR8Ring]), "+v"(ahi[J % kR8Ring]) : "n"(kN) : "memory");
-    } else {
-        asm volatile("s_waitcnt vmcnt(%2)" : "+v"(alo[J % kR8Ring]), "+v"(ahi[J % kR8Ring]) : "n"(kN) : "memory");
-    }
+    constexpr int kF = J < kR8Ring ? r8_wait(J, true) : kN;
+    constexpr int kW = kF < kN ? kF : kN;
+    asm volatile("s_waitcnt vmcnt(%2)" : "+v"(alo[J % kR8Ring]), "+v"(ahi[J % kR8Ring]) : "n"(kW) : "memory");
 }
 
 template <bool GNIN>
@@ -3003,8 +3007,10 @@ __global__ void __launch_bounds__(512, 2) conv3x3_rp8_kernel(ConvDev P, char* du
         }
     };
     u32x4 raw[2][4];                                       // slab parity, piece
+#pragma unroll
+    for (int k = 0; k < 8; k++) raw[k >> 2][k & 3] = u32x4{0u, 0u, 0u, 0u};
     auto raw_load = [&](int sl, int ii) {
-        asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(raw[sl & 1][ii]) : "v"(praw[ii] + sl * 128) : "memory");
+        asm volatile("global_load_dwordx4 %0, %1, off" : "+v"(raw[sl & 1][ii]) : "v"(praw[ii] + sl * 128) : "memory");      // "+v": see rp_load
     };
     const float qs = P.in_qscale;
     // one landed piece (registers) -> optional GroupNorm + ReLU -> e4m3 -> the patch of slab sl (8 bytes per lane)
@@ -3083,6 +3089,8 @@ __global__ void __launch_bounds__(512, 2) conv3x3_rp8_kernel(ConvDev P, char* du
 
     const unsigned voff = (unsigned)(wave * kR8Steps * 2048 + lane * 16);
     i32x4 alo[kR8Ring], ahi[kR8Ring];
+#pragma unroll
+    for (int k = 0; k < kR8Ring; k++) alo[k] = ahi[k] = i32x4{0, 0, 0, 0};
     auto barrier = [&]() {
         __builtin_amdgcn_sched_barrier(0);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -3091,6 +3099,7 @@ __global__ void __launch_bounds__(512, 2) conv3x3_rp8_kernel(ConvDev P, char* du
     };
 
     const bool relu = P.flags & DAFNE_CONV_RELU;
+    const float relu_lo = relu ? 0.f : -__builtin_inff();
     const bool gn = P.flags & DAFNE_CONV_GN_STATS;
     const bool fin = gn && (P.flags & DAFNE_CONV_GN_FINALIZE);
     const int G8 = P.Cout / 8;
@@ -3280,13 +3289,11 @@ __global__ void __launch_bounds__(512, 2) conv3x3_rp8_kernel(ConvDev P, char* du
                 u32x2 pk[4];
 #pragma unroll
                 for (int g = 0; g < 4; g++) {
-                    float v0 = acc[b][4 * g] * osc4[g][0] + bia4[g][0], v1 = acc[b][4 * g + 1] * osc4[g][1] + bia4[g][1];
-                    float v2 = acc[b][4 * g + 2] * osc4[g][2] + bia4[g][2], v3 = acc[b][4 * g + 3] * osc4[g][3] + bia4[g][3];
-                    if (relu) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f); }
-                    if (gn && valid) {
-                        gsum[g] += (v0 + v1) + (v2 + v3);
-                        gsq[g] += (v0 * v0 + v1 * v1) + (v2 * v2 + v3 * v3);
-                    }
+                    // (branch-free: ReLU as a max with 0 / -inf, the GroupNorm sums added under a select -- x + 0 is exact; round 5)
+                    const float v0 = fmaxf(acc[b][4 * g] * osc4[g][0] + bia4[g][0], relu_lo), v1 = fmaxf(acc[b][4 * g + 1] * osc4[g][1] + bia4[g][1], relu_lo);
+                    const float v2 = fmaxf(acc[b][4 * g + 2] * osc4[g][2] + bia4[g][2], relu_lo), v3 = fmaxf(acc[b][4 * g + 3] * osc4[g][3] + bia4[g][3], relu_lo);
+                    gsum[g] += valid ? (v0 + v1) + (v2 + v3) : 0.f;
+                    gsq[g] += valid ? (v0 * v0 + v1 * v1) + (v2 * v2 + v3 * v3) : 0.f;
                     pk[g].x = pack_bf16(v0, v1);
                     pk[g].y = pack_bf16(v2, v3);
                 }

@@ -176,11 +176,13 @@ __global__ void __launch_bounds__(512, 2) conv_b2b_kernel(B2bDev P) {
     // are, so 7 steps (~1 us of matrix work for the two waves of a SIMD) cover the L2 latency.  Readiness is tracked by
     // hand (b2b_wait); stores of a ragged tile are clamped, not predicated, to keep the instruction count exact.
     const unsigned voff = (unsigned)(wave * 16 * 1024 + lane * 16);
-    bf16x8 ar[kRing];
+    bf16x8 ar[kRing];             // ("+v" in the loads: one register per ring slot from this zero-initialisation on; conv.hip rp_load)
+#pragma unroll
+    for (int k = 0; k < kRing; k++) ar[k] = bf16x8{};
 #define B2B_LOAD_STEP(j)                                                                                        \
     {                                                                                                           \
         const char* sb = P.wf + (size_t)((j) >> 4) * kPhaseBytes + ((j) & 15) * 1024;                           \
-        asm volatile("global_load_dwordx4 %0, %1, %2" : "=&v"(ar[(j) % kRing]) : "v"(voff), "s"(sb) : "memory");    \
+        asm volatile("global_load_dwordx4 %0, %1, %2" : "+v"(ar[(j) % kRing]) : "v"(voff), "s"(sb) : "memory");     \
     }
 #define B2B_WAIT_STEP(j)                                                                                        \
     {                                                                                                           \

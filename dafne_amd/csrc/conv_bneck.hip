@@ -152,11 +152,13 @@ template <int J>
 __device__ __forceinline__ void bn_load(bf16x8 (&ar)[kRing], const char* wf, unsigned voffA, unsigned voffB) {
     if constexpr (J < kStepsA) {
         const char* sb = wf + (size_t)J * 1024;
-        asm volatile("global_load_dwordx4 %0, %1, %2" : "=&v"(ar[J % kRing]) : "v"(voffA), "s"(sb) : "memory");
+        // "+v": ONE register per ring slot from the zero-initialisation on (an output-only operand lets the compiler move the
+        // value between registers -- e.g. inside the plain-C++ epilogues -- while the load is in flight: conv.hip rp_load)
+        asm volatile("global_load_dwordx4 %0, %1, %2" : "+v"(ar[J % kRing]) : "v"(voffA), "s"(sb) : "memory");
     } else if constexpr (J < kSteps) {
         constexpr int jb = J - kStepsA;
         const char* sb = wf + (size_t)kWABytes + (size_t)(jb >> 4) * kPhaseBytes + (jb & 15) * 1024;
-        asm volatile("global_load_dwordx4 %0, %1, %2" : "=&v"(ar[J % kRing]) : "v"(voffB), "s"(sb) : "memory");
+        asm volatile("global_load_dwordx4 %0, %1, %2" : "+v"(ar[J % kRing]) : "v"(voffB), "s"(sb) : "memory");
     }
 }
 // the four B fragments of phase-A step J (patch rows kh .. kh + 3 at tap column kw, chunk kc of slab sl): inline asm,
@@ -274,6 +276,8 @@ __global__ void __launch_bounds__(512, 2) conv_bneck_kernel(BneckDev P) {
     const unsigned voffA = (unsigned)(wave * kStepsA * 1024 + lane * 16);
     const unsigned voffB = (unsigned)(wave * 16 * 1024 + lane * 16);
     bf16x8 ar[kRing];
+#pragma unroll
+    for (int k = 0; k < kRing; k++) ar[k] = bf16x8{};
     auto load_step = [&](auto J) { bn_load<decltype(J)::value>(ar, P.wf, voffA, voffB); };
     auto wait_step = [&](auto J) { bn_wait_for<decltype(J)::value>(ar); };
 

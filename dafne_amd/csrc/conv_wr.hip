@@ -284,6 +284,7 @@ __global__ void __launch_bounds__(512, 2) conv_wr_kernel(WrDev P) {
 
     // ---- epilogue: (acc + bias) + residual -> ReLU -> bf16, in place in the [4 slabs][128 px][128 B] buffer
     const bool relu = P.flags & DAFNE_CONV_RELU;
+    const float relu_lo = relu ? 0.f : -__builtin_inff();
     const bool has_res = P.flags & DAFNE_CONV_RESIDUAL, has_up = P.flags & DAFNE_CONV_UPSAMPLE_ADD;
     if (has_res || has_up) {
         // residual rows by DMA: a slab is 16 pieces of 8 px x 128 B; wave w moves pieces w and w + 8 of every slab
@@ -316,11 +317,10 @@ __global__ void __launch_bounds__(512, 2) conv_wr_kernel(WrDev P) {
                 u32x2 r = *(const u32x2*)(ea + b * 4096);
                 r.x &= rmask;
                 r.y &= rmask;
-                float v0 = (acc[b][4 * g] + bia[g][0]) + __uint_as_float(r.x << 16);
-                float v1 = (acc[b][4 * g + 1] + bia[g][1]) + __uint_as_float(r.x & 0xffff0000u);
-                float v2 = (acc[b][4 * g + 2] + bia[g][2]) + __uint_as_float(r.y << 16);
-                float v3 = (acc[b][4 * g + 3] + bia[g][3]) + __uint_as_float(r.y & 0xffff0000u);
-                if (relu) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f); }
+                const float v0 = fmaxf((acc[b][4 * g] + bia[g][0]) + __uint_as_float(r.x << 16), relu_lo);       // (a max with 0 / -inf: no branch)
+                const float v1 = fmaxf((acc[b][4 * g + 1] + bia[g][1]) + __uint_as_float(r.x & 0xffff0000u), relu_lo);
+                const float v2 = fmaxf((acc[b][4 * g + 2] + bia[g][2]) + __uint_as_float(r.y << 16), relu_lo);
+                const float v3 = fmaxf((acc[b][4 * g + 3] + bia[g][3]) + __uint_as_float(r.y & 0xffff0000u), relu_lo);
                 u32x2 o;
                 o.x = pack_bf16(v0, v1);
                 o.y = pack_bf16(v2, v3);

@@ -289,8 +289,8 @@ def test_headline_timed_layout_vs_oracle():
         for i in range(BATCH):
             assert torch.equal(r[i, :int(cw[i])], rw[i, :int(cw[i])]), (tag, i)
 
-    for rep in range(2):
-        got = []
+    for rep in range(4):                                    # (round 5: 4 passes -- a copy of an in-flight register in the tower kernel showed
+        got = []                                            # as 1..16 of 36 differing steps, never in single-launch tests; NOTES_r05)
         for b in batches:                                   # no host sync inside the loop: the host runs ahead, as in bench.py
             res = model.detect_packed(b, pipelined=True, splits=SPLITS, defer=True)
             if res is not None:
