@@ -19,35 +19,81 @@ __device__ __forceinline__ float bf2f(unsigned short h) { return __uint_as_float
 
 // (x - mean) / std, zero pad to the batch size, 3 -> 4 channels, 3-pixel border
 // for the 7x7/s2 stem.  out: [N, Hn+6, Wn+6, 4] bf16 (border and 4th channel 0).
+// Round 5: one workgroup per OUTPUT ROW (no 64-bit divisions per pixel), the three 256-entry tables bf16((v - mean) / std) built
+// per workgroup in LDS with the expression the per-pixel form evaluated (same bits), a lane owns four consecutive output pixels
+// (2 x 16-byte stores) and -- planar images whose rows are dword-aligned -- reads them as two dwords per plane (input x =
+// 4g - 3 .. 4g: the last three bytes of dword g - 1 and the first of dword g).  38.8 -> us at batch 8 (100 MB of traffic).
 __global__ void __launch_bounds__(256) preprocess_kernel(const unsigned char* __restrict__ img, int hwc,
                                                          int H, int W, const int* __restrict__ valid_hw,
                                                          float m0, float m1, float m2, float s0, float s1,
                                                          float s2, int Hn, int Wn, uint2* __restrict__ out,
-                                                         int N) {
-    const long long total = (long long)N * (Hn + 6) * (Wn + 6);
-    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
-        const int xp = (int)(i % (Wn + 6));
-        const long long t = i / (Wn + 6);
-        const int yp = (int)(t % (Hn + 6));
-        const int n = (int)(t / (Hn + 6));
-        const int y = yp - 3, x = xp - 3;
+                                                         int N, int dword_rows) {
+    __shared__ unsigned short lut[3][256];
+    {
+        const float v = (float)threadIdx.x;
+        lut[0][threadIdx.x] = f2bf((v - m0) / s0);
+        lut[1][threadIdx.x] = f2bf((v - m1) / s1);
+        lut[2][threadIdx.x] = f2bf((v - m2) / s2);
+    }
+    __syncthreads();
+    const int WP = Wn + 6, HP = Hn + 6;
+    const int rows = N * HP;
+    const int nG = (WP + 3) >> 2;
+    const size_t pl = (size_t)H * W;
+    for (int row = blockIdx.x; row < rows; row += gridDim.x) {
+        const int n = row / HP;
+        const int y = row - n * HP - 3;
         const int vh = valid_hw ? valid_hw[2 * n] : H, vw = valid_hw ? valid_hw[2 * n + 1] : W;
-        uint2 o = make_uint2(0u, 0u);
-        if (y >= 0 && y < vh && x >= 0 && x < vw) {
-            float c0, c1, c2;
-            if (hwc) {
-                const unsigned char* p = img + (((size_t)n * H + y) * W + x) * 3;
-                c0 = p[0]; c1 = p[1]; c2 = p[2];
-            } else {
-                const size_t pl = (size_t)H * W;
-                const unsigned char* p = img + (size_t)n * 3 * pl + (size_t)y * W + x;
-                c0 = p[0]; c1 = p[pl]; c2 = p[2 * pl];
+        const bool live = y >= 0 && y < vh;
+        uint2* orow = out + (size_t)row * WP;
+        const bool al16 = ((((size_t)row * WP) & 1) == 0);
+        for (int g = threadIdx.x; g < nG; g += 256) {
+            uint2 o[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) o[j] = make_uint2(0u, 0u);
+            if (live) {
+                unsigned c[3][4];
+                if (dword_rows) {
+                    const unsigned char* r = img + ((size_t)n * 3 * H + y) * W;
+#pragma unroll
+                    for (int ch = 0; ch < 3; ch++) {
+                        const unsigned a = (g >= 1 && 4 * g - 4 < W) ? *(const unsigned*)(r + ch * pl + 4 * g - 4) : 0u;
+                        const unsigned b = (4 * g < W) ? *(const unsigned*)(r + ch * pl + 4 * g) : 0u;
+                        c[ch][0] = (a >> 8) & 0xffu; c[ch][1] = (a >> 16) & 0xffu; c[ch][2] = a >> 24; c[ch][3] = b & 0xffu;
+                    }
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; j++) {
+                        int x = 4 * g - 3 + j;
+                        x = x < 0 ? 0 : (x < W ? x : W - 1);          // clamped: masked below
+                        if (hwc) {
+                            const unsigned char* p = img + (((size_t)n * H + y) * W + x) * 3;
+                            c[0][j] = p[0]; c[1][j] = p[1]; c[2][j] = p[2];
+                        } else {
+                            const unsigned char* p = img + (size_t)n * 3 * pl + (size_t)y * W + x;
+                            c[0][j] = p[0]; c[1][j] = p[pl]; c[2][j] = p[2 * pl];
+                        }
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    const int x = 4 * g - 3 + j;
+                    if (x >= 0 && x < vw) {
+                        o[j].x = (unsigned)lut[0][c[0][j]] | ((unsigned)lut[1][c[1][j]] << 16);
+                        o[j].y = (unsigned)lut[2][c[2][j]];
+                    }
+                }
             }
-            c0 = (c0 - m0) / s0; c1 = (c1 - m1) / s1; c2 = (c2 - m2) / s2;
-            o.x = (unsigned)f2bf(c0) | ((unsigned)f2bf(c1) << 16);
-            o.y = (unsigned)f2bf(c2);
+            if (4 * g + 3 < WP && al16) {
+                uint4* d = (uint4*)(orow + 4 * g);
+                d[0] = make_uint4(o[0].x, o[0].y, o[1].x, o[1].y);
+                d[1] = make_uint4(o[2].x, o[2].y, o[3].x, o[3].y);
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; j++)
+                    if (4 * g + j < WP) orow[4 * g + j] = o[j];
+            }
         }
-        out[i] = o;
     }
 }
 
@@ -230,10 +276,13 @@ int dafne_preprocess_image_hip(const uint8_t* d_img, int layout_hwc, int n_image
                                int Wn, void* d_out, void* stream) {
     if (!d_img || !d_out || !mean3 || !std3 || n_images < 1 || H < 1 || W < 1 || Hn < H || Wn < W)
         return dafne::fail(DAFNE_E_INVALID, "preprocess: bad args");
-    const long long total = (long long)n_images * (Hn + 6) * (Wn + 6);
-    hipLaunchKernelGGL(preprocess_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, d_img,
+    const long long rows = (long long)n_images * (Hn + 6);
+    if (rows > (1ll << 30)) return dafne::fail(DAFNE_E_UNSUPPORTED, "preprocess: too many rows");
+    // dword reads of planar rows: every row of every plane starts on a 4-byte boundary
+    const int dword_rows = !layout_hwc && (W % 4) == 0 && (((size_t)d_img) & 3) == 0;
+    hipLaunchKernelGGL(preprocess_kernel, dim3((unsigned)(rows < 8192 ? rows : 8192)), dim3(256), 0, (hipStream_t)stream, d_img,
                        layout_hwc, H, W, d_valid_hw, mean3[0], mean3[1], mean3[2], std3[0], std3[1], std3[2], Hn,
-                       Wn, (uint2*)d_out, n_images);
+                       Wn, (uint2*)d_out, n_images, dword_rows);
     return dafne::check_launch("preprocess");
 }
 

@@ -544,6 +544,39 @@ def test_stem_preprocess_maxpool():
     assert torch.equal(stem2, stem_in)
 
 
+@pytest.mark.parametrize("N,H,W,Hn,Wn,hwc", [(2, 64, 96, 64, 96, 0), (3, 50, 70, 64, 96, 0), (2, 33, 45, 64, 64, 0), (2, 33, 45, 64, 64, 1),
+                                              (1, 61, 67, 61, 67, 0), (4, 1024, 1024, 1024, 1024, 0), (2, 800, 1216, 800, 1216, 1)])
+def test_preprocess_rows_lut_form(N, H, W, Hn, Wn, hwc):
+    """dafne_preprocess_image_hip (round 5: a workgroup per output row, bf16((v - mean) / std) tabulated, dword reads of aligned planar
+    rows) against (x - mean) / std in fp32 -> bf16 (one_stage_detector.py:100-107): per-image valid sizes inside a zero-padded
+    batch, padded (Hn, Wn) beyond the batch size, widths that are not a multiple of 4 (byte path, odd row pitch: 8-byte
+    stores), both input layouts, the headline size; border, padding and the 4th channel stay zero."""
+    from dafne_amd import _lib
+    L = _lib.load()
+    d = dev()
+    g = torch.Generator().manual_seed(N * 1000 + H + W)
+    img = torch.randint(0, 256, (N, 3, H, W), generator=g, dtype=torch.uint8)
+    valid = torch.tensor([[max(1, H - 7 * k), max(1, W - 5 * k)] for k in range(N)], dtype=torch.int32)
+    mean, std = [103.53, 116.28, 123.675], [57.375, 57.12, 58.395]
+    ref = torch.zeros(N, Hn + 6, Wn + 6, 4)
+    xn = bfr((img.float() - torch.tensor(mean).view(1, 3, 1, 1)) / torch.tensor(std).view(1, 3, 1, 1)).permute(0, 2, 3, 1)
+    for k in range(N):
+        vh, vw = int(valid[k, 0]), int(valid[k, 1])
+        ref[k, 3:3 + vh, 3:3 + vw, :3] = xn[k, :vh, :vw]
+    src = (img.permute(0, 2, 3, 1).contiguous() if hwc else img).to(d)
+    m3 = (ctypes.c_float * 3)(*mean)
+    s3 = (ctypes.c_float * 3)(*std)
+    for vt in (valid.to(d), None):
+        out = torch.full((N, Hn + 6, Wn + 6, 4), 7.0, dtype=BF, device=d)
+        _lib.check(L.dafne_preprocess_image_hip(_lib.ptr(src), hwc, N, H, W, _lib.ptr(vt) if vt is not None else None, m3, s3, Hn, Wn,
+                                                _lib.ptr(out), _lib.current_stream()))
+        torch.cuda.synchronize()
+        if vt is None:
+            ref = torch.zeros(N, Hn + 6, Wn + 6, 4)
+            ref[:, 3:3 + H, 3:3 + W, :3] = xn
+        assert torch.equal(out.float().cpu(), ref)
+
+
 @pytest.mark.parametrize("N,H,W", [(1, 32, 32), (3, 160, 224), (2, 1024, 1024), (1, 480, 1216)])
 def test_stem_pool_fused_equals_conv_then_pool(N, H, W):
     """dafne_stem_pool_hip against the stem through the generic kernel + max-pool launch: ragged tiles
