@@ -597,6 +597,19 @@ class DensePlan:
         # conv3x3_c64.hip: 65 -> 49 us per launch when it has the GPU to itself, but nothing in the timed 3-stream layout (its
         # persistent workgroups hold every CU's LDS, so the other sub-batches' kernels cannot share the chip with it): opt-in
         use_c64 = os.environ.get("DAFNE_CONV_C64", "0") == "1"
+        # whole-block kernels write Y = relu(conv3(T) + X) OVER X when X is dead after the block (an identity block's input, or
+        # block 0's projection output): a tile reads its own X rows and nobody else's (the halo is on the 3x3's input only), so
+        # the stores go to DRAM pages the same workgroup has just read (open rows, lines still in L2)
+        inplace_res = os.environ.get("DAFNE_INPLACE_RES", "1") != "0"
+
+        def res_dead(sc_, x_, b_):
+            # the shortcut operand is not needed after the block: block 0's projection output always; an identity block's input
+            # unless it is a retained feature
+            if not inplace_res or sc_ is None:
+                return False
+            if b_ == 0:
+                return sc_ is not x_
+            return not any(sc_ is f for f in feats.values())
 
         def conv(key, tin, k, stride, pad, flags, res=None, out=None, cout=None):
             wgt, bias = P[key]
@@ -727,7 +740,8 @@ class DensePlan:
                         P[key] = pack_bneck(w2, w3, w1)
                     if bneck_scratch is None:
                         bneck_scratch = torch.empty(L.dafne_bottleneck_body_scratch_bytes(), dtype=torch.uint8, device=device)
-                    y3 = pool.get(n, y1.h, y1.w, 1024)
+                    inpl = res_dead(sc, x, b)
+                    y3 = sc if inpl else pool.get(n, y1.h, y1.w, 1024)
                     y1_next = pool.get(n, y1.h, y1.w, 256) if bn_head else None
                     fl = 2 * n * y1.h * y1.w * (256 * 2304 + 256 * 1024 + (1024 * 256 if bn_head else 0))
                     nb_ = n * y1.h * y1.w * (256 + 1024 + 1024 + (256 if bn_head else 0)) * 2 + (256 * 2304 + 2 * 1024 * 256) * 2
@@ -739,9 +753,9 @@ class DensePlan:
                                              "conv_bneck" if bn_head else "conv_bneck_last", flops=fl, nbytes=nb_))
                     self.flops += fl
                     pool.put(y1)
-                    if b == 0 and sc is not None:
+                    if b == 0 and sc is not None and sc is not y3:
                         pool.put(sc)
-                    if not any(x is f for k, f in feats.items() if k != "res2"):
+                    if x is not y3 and not any(x is f for k, f in feats.items() if k != "res2"):
                         pool.put(x)
                     x = y3
                     continue
@@ -760,7 +774,8 @@ class DensePlan:
                     if blk_scratch is None:
                         blk_scratch = torch.empty(L.dafne_bottleneck_block_narrow_scratch_bytes(), dtype=torch.uint8, device=device)
                     src = x if proj else sc               # projection: the block input; identity: the previous block's output
-                    y3 = pool.get(n, y1.h, y1.w, 256)
+                    inpl = (not proj) and res_dead(sc, x, b)
+                    y3 = sc if inpl else pool.get(n, y1.h, y1.w, 256)
                     y1_next = pool.get(n, y1.h, y1.w, 64) if head else None
                     px = n * y1.h * y1.w
                     fl = 2 * px * (64 * 576 + 64 * 256 + (256 * 64 if head else 0) + (64 * 256 if proj else 0))
@@ -773,7 +788,7 @@ class DensePlan:
                                              "conv_blk_narrow" + ("_proj" if proj else "") + ("" if head else "_last"), flops=fl, nbytes=nb_))
                     self.flops += fl
                     pool.put(y1)
-                    if not any(x is f for k, f in feats.items() if k != "res2"):
+                    if x is not y3 and not any(x is f for k, f in feats.items() if k != "res2"):
                         pool.put(x)
                     x = y3
                     continue
@@ -788,7 +803,8 @@ class DensePlan:
                         P[key] = pack_blk_mid(w2, w3, w1)
                     if blk_mid_scratch is None:
                         blk_mid_scratch = torch.empty(L.dafne_bottleneck_block_mid_scratch_bytes(), dtype=torch.uint8, device=device)
-                    y3 = pool.get(n, y1.h, y1.w, 512)
+                    inpl = res_dead(sc, x, b)
+                    y3 = sc if inpl else pool.get(n, y1.h, y1.w, 512)
                     y1_next = pool.get(n, y1.h, y1.w, 128) if head else None
                     px = n * y1.h * y1.w
                     fl = 2 * px * (128 * 1152 + 128 * 512 + (512 * 128 if head else 0))
@@ -801,9 +817,9 @@ class DensePlan:
                                              "conv_blk_mid" + ("" if head else "_last"), flops=fl, nbytes=nb_))
                     self.flops += fl
                     pool.put(y1)
-                    if b == 0 and sc is not None:
+                    if b == 0 and sc is not None and sc is not y3:
                         pool.put(sc)
-                    if not any(x is f for k, f in feats.items() if k != "res2"):
+                    if x is not y3 and not any(x is f for k, f in feats.items() if k != "res2"):
                         pool.put(x)
                     x = y3
                     continue

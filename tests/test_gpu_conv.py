@@ -850,6 +850,14 @@ def test_bottleneck_body_fused_equals_three_convs(N, H, W):
     assert torch.equal(y_t, y_u.t) and bool((z_t == 5.0).all())
     for lo, hi in ((0, guard), (guard + ny, 2 * guard + ny), (2 * guard + ny + nz, 3 * guard + ny + nz)):
         assert bool((slab[lo:hi] == 7.0).all())
+    # in place (the engine's form for a block whose shortcut operand is dead afterwards): d_out == d_res -- a tile reads its own X
+    # rows chunk by chunk before it stores the chunk's Y rows over them; same bits, zero halo kept
+    x_ip = xa.t.clone()
+    z_t.zero_()
+    _lib.check(L.dafne_bottleneck_body_hip(_lib.ptr(ua.t), _lib.ptr(x_ip), _lib.ptr(wf), _lib.ptr(b2p), _lib.ptr(b3p), _lib.ptr(b1p),
+                                           N, H, W, _lib.ptr(x_ip), _lib.ptr(z_t), _lib.ptr(scr), nscr, st), "bneck (in place)")
+    torch.cuda.synchronize()
+    assert torch.equal(x_ip, y_u.t) and torch.equal(z_t, z_u.t)
     t_ref = bfr(F.relu(F.conv2d(u, w2, b2, padding=1)))
     close_bf16(t_u.nchw_float().cpu(), t_ref)
     y_ref = bfr(F.relu(F.conv2d(t_u.nchw_float().cpu(), w3, b3) + x))
@@ -1255,6 +1263,18 @@ def test_bottleneck_block_narrow_equals_the_separate_launches(N, H, W, head, pro
     else:
         assert float(z_f.t.float().abs().max()) == 0           # untouched
     assert float(y_f.t[:, 0].abs().max()) == 0 and float(y_f.t[:, :, -1].abs().max()) == 0 and float(y_f.t[:, -1].abs().max()) == 0
+    if not proj:
+        # in place (identity block whose input is dead afterwards): d_out == d_res, same bits
+        x_ip = xa.t.clone()
+        z_f.t.zero_()
+        _lib.check(L.dafne_bottleneck_block_narrow_hip(_lib.ptr(ua.t), _lib.ptr(x_ip), _lib.ptr(wf), _lib.ptr(b2p), _lib.ptr(b3p), None,
+                                                       _lib.ptr(b1p) if head else None, N, H, W, _lib.ptr(x_ip),
+                                                       _lib.ptr(z_f.t) if head else None, _lib.ptr(scratch), scratch.numel(), st),
+                   "blk_narrow (in place)")
+        torch.cuda.synchronize()
+        assert torch.equal(x_ip, y_u.t)
+        if head:
+            assert torch.equal(z_f.t, z_u.t)
     if N * H * W <= 3 * 64 * 64:
         t_ref = bfr(F.relu(F.conv2d(u, w2, b2, padding=1)))
         sc = bfr(F.conv2d(x, ws, bs_)) if proj else x
@@ -1309,6 +1329,16 @@ def test_bottleneck_block_mid_equals_the_separate_launches(N, H, W, head):
     else:
         assert float(z_f.t.float().abs().max()) == 0           # untouched
     assert float(y_f.t[:, 0].abs().max()) == 0 and float(y_f.t[:, :, -1].abs().max()) == 0 and float(y_f.t[:, -1].abs().max()) == 0
+    # in place (the shortcut operand is dead afterwards): d_out == d_res, same bits
+    x_ip = xa.t.clone()
+    z_f.t.zero_()
+    _lib.check(L.dafne_bottleneck_block_mid_hip(_lib.ptr(ua.t), _lib.ptr(x_ip), _lib.ptr(wf), _lib.ptr(b2p), _lib.ptr(b3p),
+                                                _lib.ptr(b1p) if head else None, N, H, W, _lib.ptr(x_ip),
+                                                _lib.ptr(z_f.t) if head else None, _lib.ptr(scratch), scratch.numel(), st), "blk_mid (in place)")
+    torch.cuda.synchronize()
+    assert torch.equal(x_ip, y_u.t)
+    if head:
+        assert torch.equal(z_f.t, z_u.t)
     if N * H * W <= 3 * 64 * 64:
         t_ref = bfr(F.relu(F.conv2d(u, w2, b2, padding=1)))
         y_ref = bfr(F.relu(F.conv2d(t_ref, w3, b3) + x))
