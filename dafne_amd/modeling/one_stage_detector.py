@@ -308,7 +308,11 @@ class OneStageDetector(nn.Module):
                 # two complete plan sets (A/B) with their own head-output buffers: decode + NMS of
                 # call i run on the side stream while call i+1's convolutions already write set B
                 hos, plan_sets = [], []
-                for _ in range(2):
+                # plan sets (each with its own head-output buffers): two for a batch that is split over the compute streams; FOUR
+                # for a batch too small to split (one image per call), whose consecutive calls run on alternating streams -- a
+                # set is reusable only when its post-process has finished, which starts at the NEXT call's head towers
+                nsets = 2 if splits > 1 else max(2, int(os.environ.get("DAFNE_B1_SETS", "4")))
+                for _ in range(nsets):
                     ho = engine.HeadOutputs(n, hn, wn, nc, self._weights()["scales"], self.device)
                     hos.append(ho)
                     plan_sets.append([engine.DensePlan(self._weights(), bounds[k + 1] - bounds[k], hn, wn, self.depth,
@@ -320,10 +324,10 @@ class OneStageDetector(nn.Module):
                 # 4 splits: 714 -> 960 img/s); the high-priority pool gives each its own queue.  With the
                 # post-process stream in the mix 3 splits measured best (scratch/split_sweep.sh)
                 return {"i": 0, "cs": [_shared_stream(images_u8.device, "compute", k) for k in range(splits)], "ho": hos,
-                        "plans": plan_sets, "bounds": bounds, "cand": [None, None], "done": [None, None]}
+                        "plans": plan_sets, "bounds": bounds, "cand": [None] * nsets, "done": [None] * nsets, "runs": [0] * nsets}
             self._lru_get(self._pipe, key, build_pipe)
             st = self._pipe[key]
-            slot = st["i"] & 1
+            slot = st["i"] % len(st["plans"])
             st["i"] += 1
             cs, plans, bounds = st["cs"], st["plans"][slot], st["bounds"]
             self._last_head = st["ho"][slot]
@@ -370,7 +374,7 @@ class OneStageDetector(nn.Module):
                 # stream to a hardware queue at its first submission, and torch's capture stream, created first, took one of
                 # the few queues the three sub-batch streams need for themselves (measured: capture in the very first step
                 # left the whole process at 1010-1050 images/s, eager and graph steps alike; eager first: 1300 both ways).
-                eager_first = st.setdefault("runs", [0, 0])
+                eager_first = st["runs"]
                 if eager_first[slot] == 0:
                     tower_evs = self._enqueue_eager(plans, cs, sp, splits, defer)
                 elif defer:
@@ -564,8 +568,15 @@ class OneStageDetector(nn.Module):
         splits = max(1, int(self.cfg.ENGINE.PIPELINE_SPLITS))
         batch, valid, out_hw = self._pack_inputs(batched_inputs, staged=True)
         q = self.__dict__.setdefault("_stream_q", [])       # batches in flight, oldest first: [out_hw, packed results or None]
+        # a batch too small to split (the reference's own loop: ONE image per call, tools/plain_train_net.py:316-336) alternates
+        # between two compute streams, call by call: the convolutions of image i + 1 run beside those of image i on the other
+        # plan set -- at batch 1 a res4 block is 32 tiles for 256 CUs
+        rot = 0
+        if min(splits, len(batched_inputs)) == 1 and os.environ.get("DAFNE_B1_ROTATE", "1") != "0":
+            rot = self.__dict__.get("_stream_rot", 0)
+            self.__dict__["_stream_rot"] = (rot + 1) % max(1, int(os.environ.get("DAFNE_B1_STREAMS", "3")))
         res = self.detect_packed(batch, valid_hw=valid, out_hw=out_hw, do_postprocess=do_postprocess,
-                                 pipelined=True, splits=splits, defer=True)
+                                 pipelined=True, splits=splits, defer=True, stream_offset=rot)
         if res is not None:                                  # the previous call's batch: its post-process was enqueued just now
             self._stage_counts(q[-1], res)
         q.append([out_hw, None])

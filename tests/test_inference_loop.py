@@ -259,6 +259,30 @@ def test_streamed_loop_equals_forward_per_image(where):
 
 
 @pytest.mark.gpu
+def test_single_image_batches_rotate_streams_and_plan_sets():
+    """The reference's own loop shape -- ONE image per call (tools/plain_train_net.py:316-336, tools/benchmark.py:117-145) -- through
+    inference_on_dataset: consecutive calls run on alternating compute streams and four plan sets (forward_streamed, round 5), so
+    the convolutions of up to three images are in flight at once.  13 different images of one shape, large enough for the calls
+    to overlap: every image's result EQUALS model([input]); repeated with the rotation off (same results again)."""
+    from dafne_amd.evaluation.inference import inference_on_dataset
+    cfg, m = _gpu_model()
+    g = torch.Generator().manual_seed(21)
+    items = [{"image": torch.randint(0, 256, (3, 512, 640), generator=g, dtype=torch.uint8).cuda(), "height": 512, "width": 640, "image_id": i}
+             for i in range(13)]
+    expected = [m([it])[0] for it in items]
+    torch.cuda.synchronize()
+    assert not torch.equal(expected[0]["instances"].scores, expected[1]["instances"].scores)          # the images really differ
+    for rep in range(2):
+        got = inference_on_dataset(m, [[it] for it in items])
+        assert len(got) == len(items)
+        for i, (a, e) in enumerate(zip(got, expected)):
+            assert _same(a, e), (rep, i, len(a["instances"]), len(e["instances"]))
+        assert m.flush() is None
+    pipe = [st for key, st in m._pipe.items() if key[0] == 1]
+    assert pipe and len(pipe[0]["plans"]) == 4                       # four plan sets for the unsplittable batch
+
+
+@pytest.mark.gpu
 def test_streamed_loop_on_the_benchmarked_layout():
     """The default layout (ENGINE.PIPELINE_SPLITS 2: bench.py's): batches of 8 through forward_streamed give exactly what
     detect_packed(pipelined=True, splits=2) gives for the same batch (the call bench.py times), in order, and EXACTLY what
