@@ -535,6 +535,33 @@ def library_gemm_reference(device, batch):
     return out
 
 
+def library_hbm_reference(device, mb=1024):
+    """What plain streaming kernels (torch's elementwise launches) sustain on THIS box over a buffer far beyond L2 + MALL, measured
+    live: a pure write (fill), a copy (read one buffer, write another) and an in-place update (read and write the same lines).
+    The convolution blocks' traffic is a read + write mix, so `copy_total` / `inplace_total` -- not the 8 TB/s nominal peak -- is the
+    practical ceiling `roofline_hbm.frac` and the res2 / res3 rows of `kernels_isolated` are to be read against."""
+    n = mb * 1024 * 1024 // 2
+    x = torch.empty(n, dtype=torch.bfloat16, device=device).normal_()
+    y = torch.empty_like(x)
+    def rate(fn, nbytes, reps=10):
+        for _ in range(2):
+            fn()
+        torch.cuda.synchronize()
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        for _ in range(reps):
+            fn()
+        e.record()
+        torch.cuda.synchronize()
+        return nbytes * reps / (s.elapsed_time(e) * 1e-3) / 1e9
+    nb = 2 * n
+    out = {"buffer_mb": mb, "unit": "GB/s", "fill_write_only": rate(lambda: y.fill_(1.5), nb), "copy_total": rate(lambda: y.copy_(x), 2 * nb),
+           "inplace_total": rate(lambda: torch.relu_(y), 2 * nb),
+           "note": "torch elementwise kernels, read + write bytes counted; measured in this run"}
+    del x, y
+    return out
+
+
 def distributed_record(args, world, distributed, per_rank_s, gathered):
     """What the collective DELIVERED, so that an N > 1 line proves itself: `n_gpus` in the headline is the launcher's
     WORLD_SIZE; this records the process group's own size and backend, the number of images the last step's detection
@@ -804,6 +831,12 @@ def _run_worker(args, make_step, rank, world, distributed, device):
                                             "traffic": trw, "traffic_unit": "HBM bytes per launch (2 x FETCH_SIZE + WRITE_SIZE), " + srcw})
             else:
                 out["roofline_hbm"].update({"achieved": None, "frac": None, "traffic": None})
+            try:
+                out["roofline_hbm"]["library_rates"] = library_hbm_reference(device)
+                if out["roofline_hbm"].get("achieved"):
+                    out["roofline_hbm"]["frac_of_library_copy"] = out["roofline_hbm"]["achieved"] / out["roofline_hbm"]["library_rates"]["copy_total"]
+            except Exception as e:       # a side measurement must never cost the headline line
+                out["roofline_hbm"]["library_rates"] = {"error": repr(e)}
             if wsk:
                 out["roofline_hbm"]["timed_layout"] = {"algorithmic_gbps_cache_inclusive": wsk["bytes"] / (wsk["ms"] * 1e-3) / 1e9,
                                                         "launches_per_step": wsk["launches"], "avg_launch_us": wsk["avg_launch_us"]}
