@@ -587,7 +587,7 @@ def parse_args(argv=None):
     ap.add_argument("--batch", type=int, default=8, help="images per GPU per step")
     ap.add_argument("--depth", type=int, default=101, choices=[50, 101])
     ap.add_argument("--size", type=int, default=1024)
-    ap.add_argument("--splits", type=int, default=2,
+    ap.add_argument("--splits", type=int, default=3,
                     help="dense part runs as this many sub-batches on concurrent HIP streams")
     ap.add_argument("--mode", choices=["pipelined", "serial"], default="pipelined",
                     help="pipelined (default, the timed configuration): sub-batches on concurrent streams, post-process of step i "

@@ -160,8 +160,9 @@ def _defaults():
                     # model: every plan (whole batch, pipelined sub-batches, TTA chunks) of one model uses the same kernel
                     FP8_CONV3X3_KERNEL="patch",
                     # sub-batches on concurrent streams in the streamed evaluation loop (OneStageDetector.forward_streamed /
-                    # evaluation.inference.inference_on_dataset): the layout bench.py times
-                    PIPELINE_SPLITS=2, MAX_PLANS=48,
+                    # evaluation.inference.inference_on_dataset): the layout bench.py times.  Round 5: three sub-batches of UNEQUAL
+                    # size (one_stage_detector.subbatch_bounds: 8 images = 3 + 2 + 3), so that the streams drift out of phase
+                    PIPELINE_SPLITS=int(os.environ.get("DAFNE_PIPELINE_SPLITS", "3")), MAX_PLANS=48,
                     # replay every sub-batch's dense launches from a HIP graph in the pipelined / streamed step (one host call
                     # per stream and step instead of ~200)
                     HIP_GRAPHS=True),

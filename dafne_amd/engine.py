@@ -505,8 +505,9 @@ def wr_takes(k, stride, cin, cout, npx):
 
 class WrWorkspace:
     """Split-K workspace of a plan's dafne_conv2d_wr_hip calls (arrival tickets + fp32 partial slabs).  One per plan: its calls
-    run on ONE stream, back to back, and each leaves the tickets zero.  Grown while the plan is built, allocated (zeroed) at
-    the first launch."""
+    run on ONE stream, back to back, and each leaves the tickets zero.  Grown while the plan is built, allocated (zeroed) when
+    the plan is complete (DensePlan.__init__) -- never at a launch: the fill would run on torch's current stream, not the
+    launch's."""
 
     def __init__(self, device):
         self.device, self.bytes, self.t = device, 0, None
@@ -912,6 +913,13 @@ class DensePlan:
         self.features = [outs[k] for k in ("p3", "p4", "p5", "p6", "p7")]
         self.head_start = len(self.calls)          # launches [0, head_start) are backbone + FPN, the rest the head
         self.head = HeadPlan(weights, self.features, num_classes, device, pool, self, head_outputs) if with_head else None
+        # the split-K workspace is allocated and ZEROED here, on the stream the plan is built on, like every other buffer of the
+        # plan.  (Round 4 zeroed it at the first launch: torch.zeros then ran on torch's current stream while the launch went
+        # to the sub-batch's own stream -- with small images, where the GPU keeps up with the eager enqueue, the fill landed
+        # on the arrival tickets / partial slabs of a running conv_wr: one call of garbage features in ~1 of 8 processes,
+        # found in round 5 as test_batch_invariance_and_determinism / test_tta_packed_chunks... failing now and then.)
+        if any(isinstance(c, WrCall) for c in self.calls):
+            self.wr_ws.tensor()
 
     def run(self, stream=None):
         if self.graph is not None and stream is None:

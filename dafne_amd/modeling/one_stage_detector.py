@@ -26,6 +26,33 @@ from .dafne.dafne import head_levels
 _STREAMS = {}
 
 
+SUBBATCH_WEIGHTS = {2: (5, 3), 3: (3, 2, 3)}
+
+
+def subbatch_bounds(n, splits):
+    """Image ranges of the `splits` sub-batches of a batch of n: deliberately UNEQUAL sizes (weights 3 : 2 : 3, or 5 : 3 for two;
+    largest-remainder apportionment, every sub-batch >= 1 image).  Equal sub-batches run the same launch list at the same pace,
+    so the streams stay in phase and every kernel shares the chip with its own twin (tower beside tower: both at the power limit;
+    res4 beside res4: both write-bound in the same phase).  Sub-batches of different lengths drift against each other and the
+    kernel kinds mix: at batch 8, R101, 1024^2: 4+4 1333, 5+3 1361, 3+2+3 1365-1374 images/s (R50: 1636 / 1670 / 1667; batch 16:
+    8+8 1388, 6+4+6 1396; scratch/r05_uneq_ab.sh, profiles/NOTES_r05.md).  An image's result does not depend on its sub-batch
+    (test_an_image_gets_the_same_detections_in_any_batch).  DAFNE_SPLIT_SIZES="a,b,.." overrides (A/B runs)."""
+    env = os.environ.get("DAFNE_SPLIT_SIZES")
+    if env:
+        sz = [int(v) for v in env.split(",")]
+        if sum(sz) == n and len(sz) == splits and min(sz) >= 1:
+            return [sum(sz[:k]) for k in range(splits + 1)]
+    w = SUBBATCH_WEIGHTS.get(splits)
+    if w is None or n < 2 * splits:
+        return [(k * n) // splits for k in range(splits + 1)]
+    tot = float(sum(w))
+    sz = [int(n * wk / tot) for wk in w]
+    rem = sorted(range(splits), key=lambda k: (-(n * w[k] / tot - sz[k]), k))
+    for k in rem[: n - sum(sz)]:
+        sz[k] += 1
+    return [sum(sz[:k]) for k in range(splits + 1)]
+
+
 def _shared_stream(device, kind, k):
     """Process-wide HIP streams of the pipelined path.  They are shared by every detector instance (TTA
     wrapper, a second model in the same process): each new stream may land on a hardware queue that
@@ -304,7 +331,7 @@ class OneStageDetector(nn.Module):
 
             def build_pipe():
                 nc = self.proposal_generator.dafne_head.num_classes
-                bounds = [(k * n) // splits for k in range(splits + 1)]
+                bounds = subbatch_bounds(n, splits)
                 # two complete plan sets (A/B) with their own head-output buffers: decode + NMS of
                 # call i run on the side stream while call i+1's convolutions already write set B
                 hos, plan_sets = [], []
@@ -325,7 +352,14 @@ class OneStageDetector(nn.Module):
                 # post-process stream in the mix 3 splits measured best (scratch/split_sweep.sh)
                 return {"i": 0, "cs": [_shared_stream(images_u8.device, "compute", k) for k in range(splits)], "ho": hos,
                         "plans": plan_sets, "bounds": bounds, "cand": [None] * nsets, "done": [None] * nsets, "runs": [0] * nsets}
-            self._lru_get(self._pipe, key, build_pipe)
+            if key not in self._pipe:
+                self._lru_get(self._pipe, key, build_pipe)
+                # plan building enqueued buffer fills, weight packing and uploads on the caller's stream: finished before any
+                # sub-batch stream touches the plans (once per shape; the steps themselves never wait for the host).  The
+                # streams are ordered behind it by `inputs_ready` as well; this makes a new shape's first step independent of it
+                torch.cuda.synchronize(images_u8.device)
+            else:
+                self._lru_get(self._pipe, key, build_pipe)
             st = self._pipe[key]
             slot = st["i"] % len(st["plans"])
             st["i"] += 1

@@ -37,7 +37,7 @@ from oracle import postprocess as opp
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LEVELS = ("p3", "p4", "p5", "p6", "p7")
-SIZE, BATCH, SPLITS = 1024, 8, 2
+SIZE, BATCH, SPLITS = 1024, 8, 3          # bench.py's default layout: three unequal sub-batches (3 + 2 + 3)
 
 
 def rel(a, b):
@@ -106,10 +106,10 @@ def _deviation(got, ref):
 
 REGIMES = {
     # the weights bench.py times: He-normal everywhere (activations O(1): the bench does not time an all-zero network)
-    "bench_weights": {"images": (0, 2, 5), "modes": ("serial", "pipelined2"), "kw": {}},
+    "bench_weights": {"images": (0, 2, 5), "modes": ("serial", "pipelined3"), "kw": {}},
     # the reference's own initialisation of the head (dafne.py:269-285: tower / prediction convolutions N(0, 0.01), GroupNorm
     # affine 1 / 0) -- the statistics a trained head starts from -- with the class prior raised so that candidates exist
-    "reference_init": {"images": (0, 5), "modes": ("pipelined2",), "kw": {"tower_std": 0.01, "cls_prior": -1.5}},
+    "reference_init": {"images": (0, 5), "modes": ("pipelined3",), "kw": {"tower_std": 0.01, "cls_prior": -1.5}},
 }
 
 
@@ -154,7 +154,7 @@ def _run(model, batch, mode):
     st = model._pipe[(BATCH, SIZE, SIZE, SPLITS)]
     slot = (st["i"] - 1) & 1
     bounds = st["bounds"]
-    assert bounds == [0, 4, 8]                              # the 4 / 4 sub-batch split of the timed region
+    assert bounds == [0, 3, 5, 8]                           # the 3 + 2 + 3 sub-batch split of the timed region
 
     def feats(i):
         k = max(j for j in range(SPLITS) if bounds[j] <= i)
@@ -162,7 +162,7 @@ def _run(model, batch, mode):
     return rows, counts, st["ho"][slot], feats
 
 
-@pytest.mark.parametrize("mode", ["serial", "pipelined2"])
+@pytest.mark.parametrize("mode", ["serial", "pipelined3"])
 def test_headline_workload_vs_oracle(headline, mode):
     H = headline
     if mode not in REGIMES[H["regime"]]["modes"]:
@@ -171,7 +171,7 @@ def test_headline_workload_vs_oracle(headline, mode):
     d = cfg.MODEL.DAFNE
     rows, counts, hp, feats = _run(model, H["batch"], mode)
     rep = {"regime": H["regime"], "mode": mode, "images": {}}
-    if mode == "pipelined2":
+    if mode == "pipelined3":
         st = model._pipe[(BATCH, SIZE, SIZE, SPLITS)]
         rep["kernels_per_sub_batch"] = [sorted(set(c.kernel_name() for c in p.calls if hasattr(c, "kernel_name"))) for p in st["plans"][0]]
 
@@ -246,13 +246,13 @@ def test_headline_workload_vs_oracle(headline, mode):
 
 def test_headline_timed_layout_vs_oracle():
     """The code path bench.py TIMES, at the headline size, next to the oracle ("missing 2"): R101-FPN,
-    8 x 1024x1024, bench.build_model's weights; `detect_packed(pipelined=True, splits=2, defer=True)` + `flush_deferred()` --
+    8 x 1024x1024, bench.build_model's weights; `detect_packed(pipelined=True, splits=3, defer=True)` + `flush_deferred()` --
     step i's convolutions replayed from TWO-PART HIP graphs (backbone + FPN | head) of two alternating plan sets, step
     i - 1's decode / rotated NMS / rescale started on the side stream where step i reaches its head towers -- over SIX
     DIFFERENT batches (a stale head-output buffer, or a race between the side stream's deferred decode and the
     next-but-one step's tower writes into the same plan set, would hand back another batch's rows), twice (first pass:
     the plan sets' eager step and the graph capture; second pass: replay only).  Asserted:
-      (a) every step's rows are bit-equal to the immediate call `detect_packed(pipelined=True, splits=2)` on that batch;
+      (a) every step's rows are bit-equal to the immediate call `detect_packed(pipelined=True, splits=3)` on that batch;
       (b) the last TWO steps (both plan sets' head outputs are still in place after the flush), all 8 images each: decode /
           top-k / rotated NMS / cap / detector_postprocess of oracle/postprocess.py on the engine's own head outputs --
           keys bit-exact, scores 1e-6, corners / boxes 1e-3 (BASELINE.json north_star);
@@ -358,7 +358,7 @@ def test_config1_r50_batch8_full_size_vs_oracle():
         x, _ = om.preprocess([batch[0]], cfg.MODEL.PIXEL_MEAN, cfg.MODEL.PIXEL_STD)
         f32 = om.backbone_forward(P, x, 50)
         fe = om.backbone_forward(P, x, 50, emulate_bf16=True)
-    rows, counts, hp, feats = _run(model, batch.to(dev), "pipelined2")
+    rows, counts, hp, feats = _run(model, batch.to(dev), "pipelined3")
     _features_vs_oracle(feats(0), fe, f32, "r50")
     for i in range(BATCH):
         _check_postprocess_exact(_rows_to_dict(rows, counts, i), _oracle_detections(_levels_numpy(hp, i), cfg.MODEL.DAFNE), ("r50", i))

@@ -213,6 +213,24 @@ def test_batch_invariance_and_determinism():
         assert torch.equal(x["instances"].pred_corners, z["instances"].pred_corners)       # batch-size independent
 
 
+def test_split_k_workspace_is_zeroed_when_the_plan_is_built():
+    """engine.WrWorkspace (round 5): the split-K workspace of a plan's conv_wr launches exists -- zeroed, on the build stream -- as
+    soon as the plan does.  Round 4 zeroed it at the first launch, on torch's current stream instead of the launch's: with small
+    images the fill raced the first conv_wr kernels of a sub-batch plan (one call of garbage features in ~1 of 8 processes)."""
+    from dafne_amd import engine
+    cfg, m, P = build("dota-1.0_r50.yaml", seed=7)
+    plan = m.plan(1, 128, 128)
+    assert any(isinstance(c, engine.WrCall) for c in plan.calls)
+    assert plan.wr_ws.t is not None and not bool(plan.wr_ws.t.any())
+    img = torch.randint(0, 256, (3, 3, 128, 128), dtype=torch.uint8, device=dev())
+    m.detect_packed(img, pipelined=True, splits=3)
+    torch.cuda.synchronize()
+    for sets in next(iter(m._pipe.values()))["plans"]:
+        for p in sets:
+            assert p.wr_ws.t is not None
+            assert not bool(p.wr_ws.t[:64 * 1024].any())          # the arrival tickets are zero again after every launch
+
+
 def test_tta_merge_vs_oracle():
     """OneStageRCNNWithTTA: per-view detections come from the engine; the inverse
     transforms + merged NMS + cap are checked against the numpy/C oracle."""

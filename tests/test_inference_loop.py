@@ -284,14 +284,14 @@ def test_single_image_batches_rotate_streams_and_plan_sets():
 
 @pytest.mark.gpu
 def test_streamed_loop_on_the_benchmarked_layout():
-    """The default layout (ENGINE.PIPELINE_SPLITS 2: bench.py's): batches of 8 through forward_streamed give exactly what
-    detect_packed(pipelined=True, splits=2) gives for the same batch (the call bench.py times), in order, and EXACTLY what
+    """The default layout (ENGINE.PIPELINE_SPLITS 3, unequal sub-batches: bench.py's): batches of 8 through forward_streamed give exactly what
+    detect_packed(pipelined=True, splits=3) gives for the same batch (the call bench.py times), in order, and EXACTLY what
     model(batch) gives (round 5: forward() of >= 2 images runs on the same sub-batch layout; an image gets the same bits in
     any batch composition anyway)."""
     from dafne_amd import postprocess as pp
     from dafne_amd.evaluation.inference import inference_on_dataset
     cfg, m = _gpu_model()
-    assert cfg.ENGINE.PIPELINE_SPLITS == 2
+    assert cfg.ENGINE.PIPELINE_SPLITS == 3
     g = torch.Generator().manual_seed(9)
     items = [{"image": torch.randint(0, 256, (3, 128, 160), generator=g, dtype=torch.uint8), "height": 128, "width": 160, "image_id": i}
              for i in range(24)]
@@ -300,7 +300,7 @@ def test_streamed_loop_on_the_benchmarked_layout():
     assert len(got) == 24
     for k, batch in enumerate(loader):
         bd = torch.stack([x["image"] for x in batch]).cuda()
-        rows, counts = m.detect_packed(bd, pipelined=True, splits=2)
+        rows, counts = m.detect_packed(bd, pipelined=True, splits=3)
         torch.cuda.synchronize()
         direct = pp.rows_to_instances(rows, counts, [(128, 160)] * 8)
         for i in range(8):

@@ -221,3 +221,16 @@ def test_c2_trunk_covers_every_bottom_up_key(tmp_path, depth):
                                  sd[k0 + ".norm.running_mean"], sd[k0 + ".norm.running_var"])
     assert torch.allclose(w, sd[k0 + ".weight"] * sd[k0 + ".norm.weight"][:, None, None, None], rtol=1e-6, atol=0)
     assert torch.equal(b, sd[k0 + ".norm.bias"])
+
+
+def test_subbatch_bounds_are_unequal_and_cover_the_batch():
+    """one_stage_detector.subbatch_bounds (round 5): sub-batches of deliberately unequal size (weights 3:2:3 / 5:3), contiguous,
+    covering the batch, every one >= 1 image; tiny batches fall back to the even split."""
+    from dafne_amd.modeling.one_stage_detector import subbatch_bounds
+    assert subbatch_bounds(8, 3) == [0, 3, 5, 8] and subbatch_bounds(8, 2) == [0, 5, 8]
+    assert subbatch_bounds(16, 3) == [0, 6, 10, 16] and subbatch_bounds(12, 3) == [0, 5, 8, 12]
+    for n in range(1, 40):
+        for s in (1, 2, 3, 4):
+            k = min(s, n)
+            b = subbatch_bounds(n, k)
+            assert b[0] == 0 and b[-1] == n and len(b) == k + 1 and all(b[i + 1] > b[i] for i in range(k)), (n, s, b)
