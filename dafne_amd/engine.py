@@ -574,8 +574,8 @@ class DensePlan:
         MFMA kernel (dafne_conv2d_nhwc_fp8w_hip with in_qscale = the layer's scale)."""
         assert h % 32 == 0 and w % 32 == 0
         # shared_gpu: the plan runs next to other plans on concurrent streams (the sub-batches of the pipelined step): launches
-        # stay small so that the streams interleave at a fine grain (no pairing of tower layers: measured -1..-4 % there,
-        # +1.1 % when every launch has the GPU to itself)
+        # carry no F_EXCL hint.  (Until round 5 the tower layers were not paired there either: -1..-4 % in the in-phase layouts;
+        # with unequal sub-batches the pairs gain +0.7 %, HeadPlan)
         self.shared_gpu = bool(shared_gpu)
         self._build(weights, n, h, w, depth, num_classes, device, with_head, head_outputs, calib)
 
@@ -1021,8 +1021,10 @@ class HeadPlan:
         def seg_list(ins, outs, f32=False):
             return [(i.t, (o if f32 else o.t), None, i.h, i.w, i.h, i.w) for i, o in zip(ins, outs)]
 
+        # (round 5: pairs in the sub-batch plans of the pipelined step as well -- with three sub-batches of unequal size 1371-1373
+        # against 1356-1365 img/s, two alternating runs; in round 3's in-phase layout the pairs cost 1-4 % there)
         pair_towers = os.environ.get("DAFNE_RP_PAIR", "1") != "0" and (not getattr(plan, "shared_gpu", False)
-                                                                       or os.environ.get("DAFNE_RP_PAIR_SHARED", "0") == "1")
+                                                                       or os.environ.get("DAFNE_RP_PAIR_SHARED", "1") == "1")
         deferred = []              # intermediate maps of cls_tower / center_tower: released when BOTH towers are built (see below)
 
         def tower(name, ins, in_gn, consumers):
