@@ -235,7 +235,7 @@ class OneStageDetector(nn.Module):
 
     # ------------------------------------------------------------ fused path
     def detect_packed(self, images_u8, valid_hw=None, out_hw=None, layout_hwc=False, do_postprocess=True,
-                      pipelined=False, splits=1, stream_offset=0, graphs=None, defer=False):
+                      pipelined=False, splits=1, stream_offset=0, graphs=None, defer=False, even=False):
         """images_u8: device uint8 [N,3,H,W] (or [N,H,W,3] with layout_hwc) BGR.
         valid_hw: optional per-image (h, w) true sizes; out_hw: optional per-image
         requested output (height, width).  Returns (rows [N,k_cap,18], counts [N])
@@ -256,7 +256,9 @@ class OneStageDetector(nn.Module):
         the PREVIOUS deferred call, which starts on the side stream when this call's sub-batches reach their head towers --
         the persistent tower kernel leaves CUs idle (232 of 256 workgroups) that the post-process kernels fill, while beside
         the backbone's chip-wide launches they cost 3.7 % of the step (scratch/no_post.py, defer_post.py: +1.4 .. +4 %).
-        Returns the PREVIOUS call's (rows, counts) -- None on the first call; flush_deferred() enqueues and returns the last."""
+        Returns the PREVIOUS call's (rows, counts) -- None on the first call; flush_deferred() enqueues and returns the last.
+        even=True: sub-batches of EQUAL size (a lone step with a host wait behind it -- forward() -- ends when its longest
+        stream does; the unequal sizes of subbatch_bounds pay only in a loop whose steps overlap)."""
         if not images_u8.is_cuda or images_u8.dtype != torch.uint8:
             raise RuntimeError("detect_packed needs a uint8 CUDA tensor (the MI355X engine has no CPU path)")
         if self.cfg.ENGINE.WEIGHT_DTYPE == "fp8_e4m3" and self._act_q8 is None:
@@ -327,11 +329,11 @@ class OneStageDetector(nn.Module):
             if self.side_stream is None:
                 self.side_stream = _shared_stream(images_u8.device, "side", 0)
                 self._pipe = {}
-            key = (n, hn, wn, splits)
+            key = (n, hn, wn, splits, "even") if (even and splits > 1) else (n, hn, wn, splits)
 
             def build_pipe():
                 nc = self.proposal_generator.dafne_head.num_classes
-                bounds = subbatch_bounds(n, splits)
+                bounds = [(k * n) // splits for k in range(splits + 1)] if even else subbatch_bounds(n, splits)
                 # two complete plan sets (A/B) with their own head-output buffers: decode + NMS of
                 # call i run on the side stream while call i+1's convolutions already write set B
                 hos, plan_sets = [], []
@@ -573,13 +575,16 @@ class OneStageDetector(nn.Module):
         if self.training:
             raise NotImplementedError("training is outside the scope of the MI355X inference engine")
         batch, valid, out_hw = self._pack_inputs(batched_inputs)
-        splits = max(1, int(self.cfg.ENGINE.PIPELINE_SPLITS))
+        splits = min(2, max(1, int(self.cfg.ENGINE.PIPELINE_SPLITS)))
         if len(batched_inputs) >= 2 and splits >= 2:
-            # the call detectron2's loop makes (tools/plain_train_net.py:316-336: outputs = model(inputs)) runs on the layout
-            # bench.py times: sub-batches on concurrent streams, immediate post-process.  Result-neutral: an image gets the
-            # same bits in any batch composition (test_an_image_gets_the_same_detections_in_any_batch)
+            # the call detectron2's loop makes (tools/plain_train_net.py:316-336: outputs = model(inputs)) runs on sub-batch
+            # streams as well, immediate post-process.  TWO sub-batches of EQUAL size: the host waits behind every call, so a
+            # call ends when its longest stream does (batch 8, R101, 1024^2: 4+4 6.80 ms per call, 5+3 6.87, 3+2+3 7.80;
+            # scratch/fwd_sync_probe.py) -- the unequal three-way split of the streamed loop pays only where steps overlap.
+            # Result-neutral: an image gets the same bits in any batch composition (DESIGN section 5,
+            # test_an_image_gets_the_same_detections_in_any_batch)
             rows, counts = self.detect_packed(batch, valid_hw=valid, out_hw=out_hw, do_postprocess=do_postprocess,
-                                              pipelined=True, splits=splits)
+                                              pipelined=True, splits=splits, even=True)
             torch.cuda.current_stream(self.device).wait_stream(self.side_stream)      # the rows are produced on the side stream
         else:
             rows, counts = self.detect_packed(batch, valid_hw=valid, out_hw=out_hw, do_postprocess=do_postprocess)

@@ -305,9 +305,11 @@ def test_streamed_loop_on_the_benchmarked_layout():
         direct = pp.rows_to_instances(rows, counts, [(128, 160)] * 8)
         for i in range(8):
             assert _same(got[8 * k + i], {"instances": direct[i]}), (k, i)
-        sync = m(batch)                          # round 5: forward() itself runs >= 2 images on the sub-batch layout
+        sync = m(batch)                          # round 5: forward() itself runs >= 2 images on sub-batch streams
         for i in range(8):
             assert _same(got[8 * k + i], sync[i]), (k, i)
+    # the streamed loop: three sub-batches of unequal size; the synchronous call: two equal ones (a lone step ends with its longest stream)
+    assert m._pipe[(8, 128, 160, 3)]["bounds"] == [0, 3, 5, 8] and m._pipe[(8, 128, 160, 2, "even")]["bounds"] == [0, 4, 8]
 
 
 @pytest.mark.gpu
