@@ -59,7 +59,22 @@ def _shared_stream(device, kind, k):
     is already in use, and two sub-batches on one queue serialise."""
     key = (str(device), kind, k)
     if key not in _STREAMS:
-        _STREAMS[key] = torch.cuda.Stream(device=device, priority=-1 if kind == "compute" else 0)
+        # ALL of them are created and bound to their hardware queues together, at the first request (a throw-away submission each
+        # and a host wait).  ROCm binds a stream to a hardware queue at its first submission, and graph capture brings streams of
+        # its own: a compute stream that was first used AFTER another layout's graphs had been captured (model(batch) three
+        # times, then the streamed loop) landed on a queue it shared, and two of the three sub-batches serialised -- 1200
+        # instead of 1395 img/s for the rest of the process (round 5, scratch/order_probe.py)
+        made = []
+        for kd, kk in [("compute", 0), ("compute", 1), ("compute", 2), ("side", 0)] + [(kind, k)]:
+            kkey = (str(device), kd, kk)
+            if kkey not in _STREAMS:
+                _STREAMS[kkey] = torch.cuda.Stream(device=device, priority=-1 if kd == "compute" else 0)
+                made.append(_STREAMS[kkey])
+        for st in made:
+            with torch.cuda.stream(st):
+                torch.zeros(1, device=device)
+        for st in made:
+            st.synchronize()
     return _STREAMS[key]
 
 
@@ -585,7 +600,10 @@ class OneStageDetector(nn.Module):
             # test_an_image_gets_the_same_detections_in_any_batch)
             rows, counts = self.detect_packed(batch, valid_hw=valid, out_hw=out_hw, do_postprocess=do_postprocess,
                                               pipelined=True, splits=splits, even=True)
-            torch.cuda.current_stream(self.device).wait_stream(self.side_stream)      # the rows are produced on the side stream
+            # the rows are produced on the side stream and the host needs them now: a HOST wait on that stream.  (A device-side
+            # wait_stream of the caller's stream, followed by the read-back's own wait, cost 0.85 ms per call once all the
+            # shared streams are bound: 7.70 against 6.84 ms per call of 8, scratch/fwd_phase_probe.py)
+            self.side_stream.synchronize()
         else:
             rows, counts = self.detect_packed(batch, valid_hw=valid, out_hw=out_hw, do_postprocess=do_postprocess)
         insts = pp.rows_to_instances(rows, counts, out_hw)
