@@ -17,10 +17,17 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 ARCH = "gfx950"
 
 COMMON = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
+# -fno-slp-vectorize on every translation unit WITHOUT matrix instructions: the SLP vectoriser turns scalar fp32 code into packed
+# v_pk_{add,mul,fma}_f32 / v_pk_mov_b32 with op_sel / neg modifiers, and on gfx950 such a kernel returned wrong results when
+# matrix (MFMA) kernels of OTHER streams ran on the same CUs -- sort_quad_kernel, a pure elementwise function of its input: 7783 of
+# 30000 launches wrong beside plain torch.matmul on three streams, 0 of 30000 without the packed instructions, 0 idle (round 5:
+# scratch/race_probe11.py, profiles/NOTES_r05.md; tests/test_gpu_reproducible.py).  The convolution units keep their explicit
+# two-wide arithmetic: their outputs are compared bit for bit across thousands of concurrent runs (same test).
 PER_FILE = {
-    "poly_nms.hip": ["-ffp-contract=off"],
-    "decode.hip": ["-ffp-contract=off"],
-    "resize.hip": ["-ffp-contract=off"],
+    "poly_nms.hip": ["-ffp-contract=off", "-fno-slp-vectorize"],
+    "decode.hip": ["-ffp-contract=off", "-fno-slp-vectorize"],
+    "resize.hip": ["-ffp-contract=off", "-fno-slp-vectorize"],
+    "dense_ops.hip": ["-fno-slp-vectorize"],
 }
 
 

@@ -105,6 +105,11 @@ class _Instances:
         return self._fields
 
     def to(self, *a, **k):
+        # a host twin (postprocess.rows_to_instances(host_rows=...): the streamed loop copies a batch's packed rows to pinned host
+        # memory behind its NMS, once): `.to("cpu")` -- what every evaluator does per image -- is then no device copy at all
+        twin = self.__dict__.get("_cpu_twin")
+        if twin is not None and not k and len(a) == 1 and isinstance(a[0], (str, torch.device)) and torch.device(a[0]).type == "cpu":
+            return twin()
         r = _Instances(self._image_size)
         for n, v in self._fields.items():
             r.set(n, v.to(*a, **k) if hasattr(v, "to") else v)

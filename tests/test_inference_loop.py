@@ -259,6 +259,29 @@ def test_streamed_loop_equals_forward_per_image(where):
 
 
 @pytest.mark.gpu
+def test_streamed_outputs_carry_a_host_twin():
+    """forward_streamed copies a batch's packed rows to pinned host memory behind its NMS; the Instances it hands out live on the
+    device (as forward()'s do) and `.to("cpu")` -- the reference's evaluators call it per image, dafne_evaluator.py:48-55 -- returns
+    Instances built from that copy: equal, field by field, to the device-to-host copy of the same Instances."""
+    from dafne_amd.evaluation.inference import inference_on_dataset
+    cfg, m = _gpu_model()
+    g = torch.Generator().manual_seed(33)
+    items = [{"image": torch.randint(0, 256, (3, 128, 160), generator=g, dtype=torch.uint8).cuda(), "height": 135, "width": 163, "image_id": i}
+             for i in range(10)]
+    got = inference_on_dataset(m, [items[i:i + 4] for i in range(0, 10, 4)])
+    assert len(got) == 10
+    for o in got:
+        inst = o["instances"]
+        assert inst.scores.is_cuda and inst.__dict__.get("_cpu_twin") is not None
+        twin = inst.to(torch.device("cpu"))
+        assert len(twin) == len(inst) > 0 and twin.image_size == inst.image_size
+        for name, v in inst.get_fields().items():
+            w = twin.get(name)
+            a, b = (v.tensor, w.tensor) if hasattr(v, "tensor") else (v, w)
+            assert not b.is_cuda and b.dtype == a.dtype and torch.equal(a.cpu(), b), name
+
+
+@pytest.mark.gpu
 def test_single_image_batches_rotate_streams_and_plan_sets():
     """The reference's own loop shape -- ONE image per call (tools/plain_train_net.py:316-336, tools/benchmark.py:117-145) -- through
     inference_on_dataset: consecutive calls run on alternating compute streams and four plan sets (forward_streamed, round 5), so
@@ -275,8 +298,13 @@ def test_single_image_batches_rotate_streams_and_plan_sets():
     for rep in range(2):
         got = inference_on_dataset(m, [[it] for it in items])
         assert len(got) == len(items)
-        for i, (a, e) in enumerate(zip(got, expected)):
-            assert _same(a, e), (rep, i, len(a["instances"]), len(e["instances"]))
+        bad = [i for i, (a, e) in enumerate(zip(got, expected)) if not _same(a, e)]
+        if bad:          # which side moved?  (a failure message that tells a wrong first call from a wrong streamed call)
+            again = [m([it])[0] for it in items]
+            torch.cuda.synchronize()
+            raise AssertionError("rep %d: streamed != model([input]) for images %s; model([input]) repeated equals its first run: %s; "
+                                 "streamed equals the repeated run: %s" % (rep, bad, [_same(a, e) for a, e in zip(again, expected)],
+                                                                            [_same(a, e) for a, e in zip(got, again)]))
         assert m.flush() is None
     pipe = [st for key, st in m._pipe.items() if key[0] == 1]
     assert pipe and len(pipe[0]["plans"]) == 4                       # four plan sets for the unsplittable batch
