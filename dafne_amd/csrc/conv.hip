@@ -3690,7 +3690,11 @@ __global__ void __launch_bounds__(512) conv3x3_pred16_kernel(ConvDev P) {
             // the expression of gn_apply_kernel, two channels per instruction (v_pk_add / v_pk_mul / v_pk_fma_f32 round like
             // their scalar forms); ReLU on the rounded pair as 16-bit integers (a negative bf16 is a negative int16; the
             // rounding keeps the sign, so max before or after it is the same number)
-            const f32x2 m2 = {ms[0], ms[0]}, r2 = {ms[1], ms[1]};
+            f32x2 m2 = {ms[0], ms[0]}, r2 = {ms[1], ms[1]};
+            // both halves MATERIALISED: left to itself the compiler multiplies by the (mean, rstd) pair with `op_sel:[1,0]` (the low
+            // lane reading the pair's HIGH half) -- the one packed-fp32 operand form that returns wrong lanes beside matrix kernels of
+            // other waves on gfx950 (scratch/pk_probe.py: 1194 of 1500 launches; every other form 0; profiles/NOTES_r05.md)
+            asm volatile("" : "+v"(m2), "+v"(r2));
             const unsigned msk = (inside >> i) & 1u ? 0xffffffffu : 0u;
             unsigned w[4] = {o.x, o.y, o.z, o.w};
 #pragma unroll
