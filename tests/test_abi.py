@@ -61,3 +61,119 @@ def test_cpu_tensor_is_rejected():
     from dafne_amd.modeling.nms import batched_nms_poly
     with pytest.raises(_lib.DafneHipError):
         batched_nms_poly(torch.zeros(3, 8), torch.zeros(3), torch.zeros(3, dtype=torch.int64), 0.1)
+
+
+# ---- every ctypes binding a maintainer could copy (INTEGRATION.md snippets, shims/, dafne_amd/_lib.py) has the arity and the
+# ---- argument classes of the C declaration in include/dafne_amd.h
+
+def _header_prototypes():
+    """name -> list of argument classes ('ptr', 'int', 'i64', 'size', 'double', 'float', 'struct') from the header text."""
+    text = open(os.path.join(ROOT, "include", "dafne_amd.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    text = re.sub(r"//[^\n]*", "", text)
+    protos = {}
+    for m in re.finditer(r"\b(dafne_[a-z0-9_]+)\s*\(([^;{}]*?)\)\s*;", text, flags=re.S):
+        name, args = m.group(1), " ".join(m.group(2).split())
+        kinds = []
+        if args and args != "void":
+            for a in args.split(","):
+                a = a.strip()
+                if "*" in a or "[" in a:
+                    kinds.append("ptr")
+                elif re.match(r"(const\s+)?(unsigned\s+)?int\b|(const\s+)?int32_t\b|(const\s+)?uint32_t\b", a):
+                    kinds.append("int")
+                elif re.match(r"(const\s+)?int64_t\b|(const\s+)?long long\b", a):
+                    kinds.append("i64")
+                elif re.match(r"(const\s+)?size_t\b", a):
+                    kinds.append("size")
+                elif re.match(r"(const\s+)?double\b", a):
+                    kinds.append("double")
+                elif re.match(r"(const\s+)?float\b", a):
+                    kinds.append("float")
+                else:
+                    kinds.append("struct")
+        protos[name] = kinds
+    return protos
+
+
+_CLASS = {"c_void_p": "ptr", "c_char_p": "ptr", "c_int": "int", "c_int32": "int", "c_uint32": "int", "c_uint": "int",
+          "c_int64": "i64", "c_longlong": "i64", "c_size_t": "size", "c_double": "double", "c_float": "float",
+          "vp": "ptr", "ci": "int", "cd": "double", "cs": "size"}
+
+
+def _snippet_bindings(text):
+    """(name, [classes]) of every `X.<name>.argtypes = [...]` in a source / markdown text."""
+    out = []
+    for m in re.finditer(r"\.(dafne_[a-z0-9_]+)\.argtypes\s*=\s*\[(.*?)\]", text, flags=re.S):
+        toks = [t.strip().split(".")[-1] for t in m.group(2).replace("\n", " ").split(",") if t.strip()]
+        out.append((m.group(1), [_CLASS.get(t, "?" + t) for t in toks]))
+    return out
+
+
+def test_documented_bindings_match_the_header():
+    protos = _header_prototypes()
+    assert len(protos) > 30 and protos["dafne_poly_nms_hip"] == ["ptr", "int", "double", "ptr", "ptr", "ptr", "size", "int", "ptr"]
+    seen = 0
+    for rel in ("INTEGRATION.md", "README.md", os.path.join("shims", "_dafne_amd_lib.py")):
+        path = os.path.join(ROOT, rel)
+        if not os.path.exists(path):
+            continue
+        for name, classes in _snippet_bindings(open(path).read()):
+            assert name in protos, "%s binds %s, which include/dafne_amd.h does not declare" % (rel, name)
+            assert classes == protos[name], "%s: argtypes of %s = %s, header says %s" % (rel, name, classes, protos[name])
+            seen += 1
+    assert seen >= 6, "no binding snippets found"
+
+
+def test_documented_calls_pass_as_many_arguments_as_they_bind():
+    """The snippets' CALLS: `_L.<name>(...)` passes exactly len(argtypes) arguments (round 5's document passed 11 to a
+    12-parameter function: the stream landed in `flags`)."""
+    protos = _header_prototypes()
+    text = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    calls = 0
+    for m in re.finditer(r"=\s*_L\.(dafne_[a-z0-9_]+)\(", text):
+        name = m.group(1)
+        depth, i, args, cur = 1, m.end(), [], ""
+        while depth:
+            ch = text[i]
+            if ch in "([":
+                depth += 1
+            elif ch in ")]":
+                depth -= 1
+                if depth == 0:
+                    break
+            if ch == "," and depth == 1:
+                args.append(cur)
+                cur = ""
+            else:
+                cur += ch
+            i += 1
+        if cur.strip():
+            args.append(cur)
+        args = [re.sub(r"#[^\n]*", "", a).strip() for a in args]
+        args = [a for a in args if a]
+        assert len(args) == len(protos[name]), "INTEGRATION.md calls %s with %d arguments, the header declares %d" % (
+            name, len(args), len(protos[name]))
+        calls += 1
+    assert calls >= 3
+
+
+def test_ctypes_table_matches_the_header():
+    import ctypes
+    from dafne_amd import _lib
+    protos = _header_prototypes()
+
+    by_type = {ctypes.c_void_p: "ptr", ctypes.c_char_p: "ptr", ctypes.c_int: "int", ctypes.c_int32: "int", ctypes.c_uint32: "int",
+               ctypes.c_int64: "i64", ctypes.c_size_t: "size", ctypes.c_double: "double", ctypes.c_float: "float"}
+
+    def cls(t):
+        if isinstance(t, type) and issubclass(t, ctypes._Pointer):
+            return "ptr"
+        return by_type.get(t, "struct")
+    for name, (_, argtypes) in _lib.SIGNATURES.items():
+        got = [cls(t) for t in argtypes]
+        want = ["ptr" if k == "struct" else k for k in protos[name]]      # structs are passed by pointer or by value: see below
+        if "struct" in protos[name]:
+            assert len(got) == len(want), name
+            continue
+        assert got == want, "%s: ctypes %s, header %s" % (name, got, want)
