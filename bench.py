@@ -272,6 +272,110 @@ def conv_kernel_profile_isolated(model, batch, reps=5):
             for k, v in stats.items()}
 
 
+def energy_ledger(model, batch, device, seconds=2.0):
+    """Joules, not only cycles: the package runs at its power cap in the timed loop, so a kernel's TIME there
+    is roughly its ENERGY / cap.  Every instantiation of `kernels_isolated` is looped alone (all its launches of the serial plan,
+    in plan order, back to back) for >= `seconds` while amdgpu's hwmon power / clock are sampled; the same for the practical
+    ceilings: the 8192^3 library GEMM and a plain copy.  Per entry: socket_w, sclk_mhz, ms_per_step (looped: the chip is warm and
+    at the clock its power allows -- slower than the single-shot `kernels_isolated` figure), joules_per_step = socket_w x
+    ms_per_step, pj_per_flop, and the same minus the idle draw (`*_above_idle`).  The hwmon figure is a ~1-s average: the first
+    second of every loop is dropped.  Inputs of an entry are whatever the serial plan left in its buffers (random-weight
+    activations); in-place launches (res4's Y over X) feed on their own output inside a loop -- values grow, bit patterns stay
+    dense."""
+    import collections
+    from dafne_amd import _lib
+    idx = device.index if getattr(device, "index", None) is not None else 0
+    n, _, h, w = batch.shape
+    plan = model.plan(n, h, w)
+    model.detect_packed(batch)
+    torch.cuda.synchronize()
+    stream = _lib.current_stream()
+    groups = collections.OrderedDict()
+    for c in plan.calls:
+        if getattr(c, "flops", 0) > 0:
+            groups.setdefault(c.kernel_name(), []).append(c)
+
+    def looped(fn, seconds):
+        for _ in range(3):
+            fn()
+        torch.cuda.synchronize()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(5):
+            fn()
+        b.record()
+        torch.cuda.synchronize()
+        per = max(a.elapsed_time(b) / 5, 1e-3)                       # ms per pass
+        chunk = max(1, int(200.0 / per))                             # host syncs every ~0.2 s: a bounded launch queue
+        npass = 0
+        with TelemetrySampler(idx) as ts:
+            t0 = time.perf_counter()
+            a.record()
+            while time.perf_counter() - t0 < seconds + 1.0:
+                for _ in range(chunk):
+                    fn()
+                npass += chunk
+                torch.cuda.synchronize()
+            b.record()
+            torch.cuda.synchronize()
+        tel = ts.summary(skip_s=1.0)
+        return a.elapsed_time(b) / npass, tel
+
+    torch.cuda.synchronize()
+    time.sleep(1.5)
+    with TelemetrySampler(idx) as ts:
+        time.sleep(1.2)
+    idle = ts.summary(skip_s=0.0)
+    idle_w = idle.get("socket_power_w", {}).get("mean")
+    out = {"idle": idle, "seconds_per_entry": seconds, "kernels": {}, "unit": "joules per step of %d images" % n,
+           "method": "each entry looped alone for >= %.1f s, hwmon socket power (first second dropped) x looped time" % seconds}
+
+    def entry(ms, tel, flops, nbytes, launches=None):
+        wv = tel.get("socket_power_w", {}).get("mean")
+        e = {"ms_per_step_looped": ms, "socket_w": wv, "sclk_mhz": tel.get("sclk_mhz", {}).get("mean"), "samples": tel.get("samples")}
+        if launches is not None:
+            e["launches"] = launches
+        if wv is not None:
+            e["joules_per_step"] = wv * ms * 1e-3
+            if flops:
+                e["pj_per_flop"] = wv * ms * 1e-3 / flops * 1e12
+            if nbytes:
+                e["pj_per_algorithmic_byte"] = wv * ms * 1e-3 / nbytes * 1e12
+            if idle_w is not None:
+                e["joules_per_step_above_idle"] = (wv - idle_w) * ms * 1e-3
+                if flops:
+                    e["pj_per_flop_above_idle"] = (wv - idle_w) * ms * 1e-3 / flops * 1e12
+        return e
+
+    for name, calls in groups.items():
+        def fn(calls=calls):
+            for c in calls:
+                c(stream)
+        ms, tel = looped(fn, seconds)
+        out["kernels"][name] = entry(ms, tel, sum(c.flops for c in calls), sum(c.bytes for c in calls), len(calls))
+    model.detect_packed(batch)                                       # the plan's buffers back to a forward pass's values
+    torch.cuda.synchronize()
+    a = torch.randn(8192, 8192, device=device).to(torch.bfloat16)
+    b = torch.randn(8192, 8192, device=device).to(torch.bfloat16)
+    ms, tel = looped(lambda: a @ b, seconds)
+    out["library_gemm_8192"] = entry(ms, tel, 2.0 * 8192 ** 3, 0)
+    out["library_gemm_8192"]["tflops_looped"] = 2.0 * 8192 ** 3 / (ms * 1e-3) / 1e12
+    del a, b
+    nb = 1 << 30
+    x = torch.empty(nb // 2, dtype=torch.bfloat16, device=device).normal_()
+    y = torch.empty_like(x)
+    ms, tel = looped(lambda: y.copy_(x), seconds)
+    out["library_copy_1gib"] = entry(ms, tel, 0, 2.0 * nb)
+    out["library_copy_1gib"]["gbps_looped"] = 2.0 * nb / (ms * 1e-3) / 1e9
+    del x, y
+    tot = sum(v.get("joules_per_step", 0.0) for v in out["kernels"].values())
+    out["joules_per_step_sum_of_kernels"] = tot
+    for v in out["kernels"].values():
+        if tot and "joules_per_step" in v:
+            v["share_of_joules"] = v["joules_per_step"] / tot
+    return out
+
+
 def nms_ms_per_image(device, m=10000, n_images=8, reps=5, kind="uniform", stats=None):
     """Rotated-NMS ms/img (A10+A11 only) on the synthetic candidate sets of SURVEY
     8(d) (tests/conftest.py nms_candidate_set: uniform / dense / skewed), seed 1234.  stats (dict): filled with the
@@ -600,6 +704,8 @@ def parse_args(argv=None):
                     help="timed regions of --steps steps each, back to back; value = the median region, value_min / value_max beside it")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip roofline profile pass, R50 and NMS side metrics")
+    ap.add_argument("--no-energy", action="store_true", help="skip the per-kernel energy ledger (about 45 s of looped kernels)")
+    ap.add_argument("--energy-seconds", type=float, default=2.0, help="telemetry window per ledger entry (after a 1-s lead-in)")
     return ap.parse_args(argv)
 
 
@@ -841,6 +947,20 @@ def _run_worker(args, make_step, rank, world, distributed, device):
                 out["roofline_hbm"]["timed_layout"] = {"algorithmic_gbps_cache_inclusive": wsk["bytes"] / (wsk["ms"] * 1e-3) / 1e9,
                                                         "launches_per_step": wsk["launches"], "avg_launch_us": wsk["avg_launch_us"]}
         out["kernels_isolated"] = {k: {kk: vv for kk, vv in v.items() if kk not in ("flops", "bytes")} for k, v in iso.items()}
+        if not args.no_energy:
+            try:
+                led = energy_ledger(model, batch, device, seconds=args.energy_seconds)
+                for k, v in led["kernels"].items():
+                    if k in out["kernels_isolated"]:
+                        out["kernels_isolated"][k].update({kk: v.get(kk) for kk in ("socket_w", "sclk_mhz", "joules_per_step", "pj_per_flop",
+                                                                                     "ms_per_step_looped", "share_of_joules")})
+                out["energy_ledger"] = led
+                wl = out["device_telemetry"].get("during_timed_loop", {}).get("socket_power_w", {}).get("mean")
+                if wl:
+                    out["energy_ledger"]["timed_loop"] = {"socket_w": wl, "joules_per_step": wl * dt / args.steps,
+                                                           "pj_per_flop": wl * dt / args.steps / sum(v["flops"] for v in prof.values()) * 1e12}
+            except Exception as ex:                  # a side measurement must never cost the headline line
+                out["energy_ledger"] = {"error": repr(ex)[:300]}
         tot_flops = sum(v["flops"] for v in prof.values())
         out["model_tflops_end_to_end"] = tot_flops / (dt / args.steps) / 1e12
         out["mfma_frac_end_to_end"] = out["model_tflops_end_to_end"] / PEAK_BF16_TFLOPS

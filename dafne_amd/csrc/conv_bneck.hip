@@ -5,25 +5,42 @@
 //     Y = relu(conv3_b(T) + bias3 + X)            1x1, 256 -> 1024, X = the block's shortcut (identity or projection)
 //     Z = relu(conv1_{b+1}(Y) + bias1)            1x1, 1024 -> 256
 //
-// conv_b2b.hip already keeps Y on chip between conv3 and the next conv1; here T never leaves the CU either: the 3x3's
-// output tile (128 px x 256 ch bf16 = 64 KB) IS the LDS operand of conv3's GEMM.  Per block that removes a 16.8-MB write
-// and read (batch 8), one launch boundary, the 3x3 kernel's epilogue and conv_b2b's exposed prologue (its T tile and first
-// residual chunk were requested by all CUs at once with nothing to compute meanwhile).
+// T never leaves the CU: the 3x3's output tile (128 px x 256 ch bf16 = 64 KB) IS the LDS operand of conv3's GEMM, and a
+// 256-channel chunk of Y is the LDS operand of conv1' before (and while) its rows go to HBM.
 //
 // Structure (8 waves, one workgroup per CU, a workgroup owns a 4 x 32 pixel tile and ALL channels):
 //   phase A (3x3): the (4+2) x (32+2) input patch is DMA'd into LDS for all 256 channels (four 64-channel slabs of
 //     26 KB, [pixel][128 B] with the 16-byte chunk XOR (patch column >> 1) & 7: conflict-free ds_read_b128 at any tap offset) and
 //     STAYS there -- the nine taps read their B fragments from it at tap-dependent pixel offsets (LDS-staged im2col), so
 //     the 144 k16 steps of the layer run without a single barrier between them except one after the first slab.  The
-//     weights stream L2 -> REGISTERS exactly as in conv_b2b: a wave owns 32 output channels and all 128 pixels, so every
-//     1-KiB weight fragment feeds 4 MFMAs and is fetched by exactly one wave (fragment-major packing, ring of 8 steps,
-//     hand-counted vmcnt).  K order = (64-channel slab, kh, kw, k16 step): the order of conv_igemm_kernel, so T is
-//     bit-identical to the separate launch.  Slab 0 is awaited, slabs 1..3 trickle in one piece per wave and step behind
-//     the weight loads (in-order vmcnt: a burst would stall every younger weight wait).
-//   phase B: conv_b2b.hip's four chunks (GEMM1 on the resident T, in-place bias + residual + ReLU in LDS, Y chunk stored
-//     and reused as the K chunk of GEMM2, next residual chunk landing slab by slab), on the same weight stream.
-// Ragged tiles (H % 4 or W % 32 != 0): loads are clamped into the buffer, the rows of out-of-image pixels are STORED to a
-// caller-provided dump area -- never predicated, the vmcnt bookkeeping needs an exact instruction count.
+//     weights stream L2 -> REGISTERS: a wave owns 32 output channels and all 128 pixels, so every 1-KiB weight fragment feeds
+//     4 MFMAs and is fetched by exactly one wave (fragment-major packing, ring of 8 steps, hand-counted vmcnt).  K order =
+//     (64-channel slab, kh, kw, k16 step): the order of conv_igemm_kernel, so T is bit-identical to the separate launch.
+//   phase B (round 6: a TWO-HALF PING-PONG; rounds 3-5 ran conv_b2b.hip's lock-step schedule here -- all eight waves in GEMM1,
+//     then all in the epilogue with the matrix pipe idle, then all in GEMM2 behind the residual DMA and the Y row stores: 68 k
+//     cycles of phase B held 33 k cycles of matrix work).  Per 256-channel chunk c of Y a wave runs four segments, each closed
+//     by a workgroup barrier:
+//         G1(c)   16 k16 steps   acc1 = W3[c] . T
+//         E(c)    the epilogue   y = relu((acc1 + bias3) + x), x and y IN REGISTERS: bf16 -> this wave's 32 channels of the Y
+//                                chunk in LDS (the K operand of conv1') and straight to HBM (8 x 16-byte stores per lane); behind
+//                                pixel fragment b's stores the same registers are re-loaded with chunk c + 1's shortcut values
+//         G2a(c)  8 k16 steps    acc2 += W1[:, c, slabs 0..1] . Y
+//         G2b(c)  8 k16 steps    acc2 += W1[:, c, slabs 2..3] . Y
+//     and waves 4..7 (the SIMD mates of waves 0..3) run the same program ONE SEGMENT LATER (one extra barrier at entry):
+//         segment       4c          4c+1        4c+2        4c+3        4c+4
+//         waves 0..3    G1(c)       E(c)        G2a(c)      G2b(c)      G1(c+1)
+//         waves 4..7    G2b(c-1)    G1(c)       E(c)        G2a(c)      G2b(c)
+//     so an epilogue always runs beside the mate's matrix segment.  Waves 0..3 own slabs 0..1 of every 256-channel output,
+//     waves 4..7 slabs 2..3: G2a(c) reads what waves 0..3 wrote in E(c) (segment 4c+1 <  4c+2, 4c+3), G2b(c) what waves 4..7
+//     wrote (4c+2 < 4c+3, 4c+4); the next writes of the two buffer halves come in segments 4c+5 / 4c+6, behind every read.
+//     The shortcut X does not pass through LDS (rounds 3-5: DMA into the Y buffer, slab by slab behind GEMM2's reads, with
+//     barriers; every wait for a weight fragment also waited for those HBM-latency pieces): a lane loads exactly the values
+//     of its own accumulator elements, a whole chunk ahead.  For that the output rows of every matrix are PERMUTED inside a
+//     wave's 32 (engine.pack_bneck): MFMA row 8g + 4h + i holds channel 16 (g >> 1) + 8h + 4 (g & 1) + i, so the 16 accumulator
+//     registers of a lane and pixel fragment are two runs of 8 consecutive channels = two 16-byte pieces of a pixel's row.
+//     Every output element is the same sum in the same order as before: bit-identical to the separate launches.
+// Ragged tiles (H % 4 or W % 32 != 0): loads are clamped into the buffer; the stores of out-of-image pixels are issued with
+// those lanes' EXEC bits off (the instruction count -- and with it the vmcnt bookkeeping -- is the same for every tile).
 #include <type_traits>
 
 #include "common.h"
@@ -32,6 +49,8 @@ namespace {
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
 typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
 typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
 typedef __attribute__((address_space(1))) void gvoid;
@@ -43,15 +62,13 @@ constexpr int kPPieces = (kPR * kPC + 7) / 8;          // 26 DMA pieces of 8 px 
 constexpr int kPSlab = kPPieces * 1024;                // 26 624 B
 constexpr int kSlab = kPx * 128;                       // one 64-channel slab of a 128-px tile: 16 KB
 constexpr int kBuf = 4 * kSlab;                        // 256 channels: 64 KB
-// LDS map.  The patch is dead when T and the last residual slab are written; the first three residual slabs could be
-// prefetched under phase A (Y slabs 0..2 do not overlap the patch).
-constexpr int kOffY = 0;                               // Y chunk / residual chunk / Z staging
+// LDS map.  The patch is dead when T is written.
+constexpr int kOffY = 0;                               // phase B: the Y chunk (K operand of conv1')
 constexpr int kOffT = kBuf;                            // T tile
 constexpr int kOffPatch = 3 * kSlab;                   // phase A only: [4 slabs][208 px][128 B]
-constexpr int kOffSide = kOffT + kBuf;                 // phase B: slab 3 of the NEXT residual chunk (16 KB; inside the dead patch)
 constexpr int kOffBias = kOffPatch + 4 * kPSlab;       // fp32 [256 conv2 | 1024 conv3 | 256 conv1 | 2 x 256 spare]
 constexpr int kSmemTotal = kOffBias + 8 * 1024;
-static_assert(kOffPatch + 4 * kPSlab >= kOffSide + kSlab && kOffPatch <= kOffSide && kSmemTotal <= 160 * 1024, "LDS budget");
+static_assert(kOffPatch + 4 * kPSlab >= kOffT + kBuf && kSmemTotal <= 160 * 1024, "LDS budget");
 constexpr int kCM = 256, kCB = 1024, kChunks = kCB / 256;
 constexpr int kNW = 8, kNT = 512;
 constexpr int kPF = kPx / 32;                          // pixel fragments per wave
@@ -60,15 +77,15 @@ constexpr int kStepsB = 2 * kChunks * 16;              // 128 k16 steps of conv3
 constexpr int kSteps = kStepsA + kStepsB;
 constexpr int kRing = 8;                               // k16 steps of A fragments in flight per wave
 constexpr int kWABytes = kNW * kStepsA * 1024;         // phase A weights: [8 waves][144 steps][64 lanes][8]
-constexpr int kPhaseBytes = kNW * 16 * 1024;           // one phase of conv_b2b's weights: [8 waves][16 steps][64 lanes][8]
+constexpr int kPhaseBytes = kNW * 16 * 1024;           // one GEMM of phase B: [8 waves][16 steps][64 lanes][8]
 constexpr int kTrickle = 12;                           // patch slabs 1..3: 12 pieces per wave, one per step 0..11
-constexpr int kRes0 = 60, kResStride = 4;              // slabs 0..2 of the first residual chunk: 6 pieces per wave at steps 60, 64, .., 80
-constexpr int kDumpBytes = kPx * kCB * 2;              // 256 KB: one Y row per tile pixel
+constexpr int kRes0 = 60, kResStride = 4;              // the first shortcut chunk: 8 register loads per lane at steps 60, 64, .., 88
+constexpr int kDumpBytes = kPx * kCB * 2;              // scratch the ABI asks for (rounds 3-5: rows of out-of-image pixels; now timing stamps only)
 
 struct BneckDev {
     const char* in;      // bf16 [N, H+2, W+2, 256]   U
     const char* res;     // bf16 [N, H+2, W+2, 1024]  X
-    const char* wf;      // bf16 phase A [8][144][64][8] | phase B [8 phases][8 waves][16 steps][64][8]
+    const char* wf;      // bf16 phase A [8][144][64][8] | phase B [8 GEMMs][8 waves][16 steps][64][8]; rows permuted (see above)
     const float* b2;     // [256]
     const float* b3;     // [1024]
     const float* b1;     // [256]
@@ -87,7 +104,6 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
 }
 
 __device__ __forceinline__ unsigned pack_bf16(float a, float b) {
-    typedef __attribute__((ext_vector_type(2))) float f32x2;
     typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
     f32x2 v = {a, b};
     bf16x2 r = __builtin_convertvector(v, bf16x2);
@@ -95,47 +111,37 @@ __device__ __forceinline__ unsigned pack_bf16(float a, float b) {
 }
 
 // Vector-memory program order of a wave: bias piece (1 DMA) | patch slab 0 (4 DMA) | A(0) .. A(7) | then for every k16
-// step s = 0 .. 271 (0..143 phase A; 144 + j = step j of conv_b2b's schedule):
-//   [wait A(s)] MFMAs | bn_st(s) row stores | A(s + 8) if it exists | bn_post(s) DMA pieces:
-//     phase A: one patch piece of slabs 1..3 at steps 0..11; slabs 0..2 of the first residual chunk (their Y-buffer space
-//              does not overlap the patch) one piece at steps 60, 64, .., 80 -- HBM is idle while every CU is in phase A --,
-//              its slab 3 (2 pieces, into the side buffer) after step 143, behind the barrier that retires the patch;
-//     phase B: the pieces of slabs 0 + 1 of the next residual chunk after the last step of slab group 1 of GEMM2, those of slab 2
-//              after group 2 (into the Y buffer; round 4: slab q behind group q, a barrier behind every group); its slab 3 goes to
-//              a 16-KB SIDE buffer right after GEMM1 + epilogue of the
-//              current chunk, i.e. a whole GEMM2 + GEMM1 ahead of its use (in conv_b2b it is issued last and has one GEMM1,
-//              2.6 us, to arrive from HBM: chunks 1..2 took 18-25k cycles against 15k for chunk 0).
+// step s = 0 .. 271 (0..143 phase A; 144 + 32 c + i = step i of chunk c: i < 16 G1, 16..23 G2a, 24..31 G2b):
+//   [wait A(s)] MFMAs | A(s + 8) if it exists | bn_post(s) more operations:
+//     phase A: one patch piece of slabs 1..3 at steps 0..11; one 16-byte register load of the first shortcut chunk at steps
+//              60, 64, .., 88 (HBM is idle while every CU is in phase A);
+//     phase B: behind the last step of G1(c), in E(c): 8 row stores of Y and (c < 3) the 8 register loads of chunk c + 1's
+//              shortcut values.
 // bn_wait(j) = number of those instructions issued after A(j) and before the wait for it: vmcnt retires in order, so
-// `s_waitcnt vmcnt(bn_wait(j))` is exactly "A(j) and everything older has landed".
-constexpr int bn_st(int s) {
-    if (s < kStepsA) return 0;
-    const int i = (s - kStepsA) & 31;
-    return (i >= 16 && (i & 3) == 0) ? 2 : 0;
-}
+// `s_waitcnt vmcnt(bn_wait(j))` is exactly "A(j) and everything older has landed".  The shortcut loads of chunk c sit in front
+// of A(144 + 32 c - 8): the first step of G2b(c - 1) already waits for them, a whole G1 ahead of their use in E(c).
 constexpr int bn_post(int s) {
     if (s < kStepsA)
-        return (s < kTrickle ? 1 : 0) + ((s >= kRes0 && s < kRes0 + 6 * kResStride && (s - kRes0) % kResStride == 0) ? 1 : 0) +
-               (s == kStepsA - 1 ? 2 : 0);
-    const int j = s - kStepsA, i = j & 31;
-    if ((j >> 5) >= kChunks - 1) return 0;
-    return i == 23 ? 4 : ((i == 27 || i == 15) ? 2 : 0);      // slabs 0 + 1 behind slab group 1, slab 2 behind group 2, slab 3 (side) behind GEMM1
+        return (s < kTrickle ? 1 : 0) + ((s >= kRes0 && s < kRes0 + 8 * kResStride && (s - kRes0) % kResStride == 0) ? 1 : 0);
+    const int j = s - kStepsA, i = j & 31, c = j >> 5;
+    return i == 15 ? 8 + (c + 1 < kChunks ? 8 : 0) : 0;
 }
 constexpr int bn_wait(int j) {
     int n = 0;
     if (j < kRing) {
         n += kRing - 1 - j;                                    // A(j+1 .. 7)
-        for (int s = 0; s < j; s++) n += bn_st(s) + 1 + bn_post(s);
+        for (int s = 0; s < j; s++) n += 1 + bn_post(s);
     } else {
-        n += bn_post(j - kRing);                               // the DMA pieces right behind A(j) at the end of step j - 8
-        for (int s = j - kRing + 1; s < j; s++) n += bn_st(s) + (s + kRing < kSteps ? 1 : 0) + bn_post(s);
+        n += bn_post(j - kRing);                               // the operations right behind A(j) at the end of step j - 8
+        for (int s = j - kRing + 1; s < j; s++) n += (s + kRing < kSteps ? 1 : 0) + bn_post(s);
     }
     return n;
 }
-// spot checks (hand-counted): steady state 7; the trickle adds one per step; phase B around the side-buffer and slab pieces
+// spot checks (hand-counted): steady state 7; the trickle adds one per step; the 16 operations of an epilogue
 static_assert(bn_wait(0) == 7 && bn_wait(1) == 8 && bn_wait(7) == 14 && bn_wait(8) == 15 && bn_wait(12) == 15 && bn_wait(13) == 14 &&
-              bn_wait(20) == 7 && bn_wait(61) == 8 && bn_wait(68) == 9 && bn_wait(100) == 7 && bn_wait(kStepsA + 7) == 9 &&
-              bn_wait(kStepsA + 8) == 7 && bn_wait(kStepsA + 16) == 9 && bn_wait(kStepsA + 23) == 13 && bn_wait(kStepsA + 24) == 13 &&
-              bn_wait(kStepsA + 28) == 15 && bn_wait(kStepsA + 31) == 17 && bn_wait(kStepsA + 39) == 7 && bn_wait(kStepsA + 127) == 4,
+              bn_wait(20) == 7 && bn_wait(61) == 8 && bn_wait(68) == 9 && bn_wait(100) == 7 && bn_wait(kStepsA + 7) == 7 &&
+              bn_wait(kStepsA + 15) == 7 && bn_wait(kStepsA + 16) == 23 && bn_wait(kStepsA + 23) == 23 && bn_wait(kStepsA + 24) == 7 &&
+              bn_wait(kStepsA + 96 + 16) == 15 && bn_wait(kStepsA + 96 + 24) == 7 && bn_wait(kStepsA + 127) == 0,
               "vmcnt bookkeeping");
 
 template <int I, int N, class F>
@@ -191,7 +197,7 @@ __device__ __forceinline__ void bn_wait_for(bf16x8 (&ar)[kRing]) {
     asm volatile("s_waitcnt vmcnt(%1)" : "+v"(ar[J % kRing]) : "n"(kWaitN) : "memory");
 }
 
-// HEAD = false (the stage's last block: no next conv1): GEMM2, its epilogue and the Z rows are skipped; the weight stream still
+// HEAD = false (the stage's last block: no next conv1): GEMM2 and the Z rows are skipped; the weight stream still
 // walks the (zero) conv1' fragments -- the vmcnt bookkeeping is one schedule for both forms.
 template <bool HEAD>
 __global__ void __launch_bounds__(512, 2) conv_bneck_kernel(BneckDev P) {
@@ -208,15 +214,6 @@ __global__ void __launch_bounds__(512, 2) conv_bneck_kernel(BneckDev P) {
     const int ty = tt / P.tiles_x, tx = tt - ty * P.tiles_x;
     const int row0 = ty * kTH, col0 = tx * kTW;
     const int Wp = P.W + 2;
-
-    // tile pixel px = r * 32 + c  <->  image pixel (row0 + r, col0 + c)
-    auto pix_index = [&](int px) {           // haloed pixel index, clamped into the image (loads)
-        int r = row0 + (px >> 5), c = col0 + (px & 31);
-        r = r < P.H ? r : P.H - 1;
-        c = c < P.W ? c : P.W - 1;
-        return (unsigned)((img * (P.H + 2) + r + 1) * Wp + c + 1);
-    };
-    auto pix_valid = [&](int px) { return row0 + (px >> 5) < P.H && col0 + (px & 31) < P.W; };
 
     // ---- patch DMA map: piece pc = 8 consecutive patch pixels (patch pixel pp = p * 34 + q <-> input pixel
     // (row0 - 1 + p, col0 - 1 + q)); wave w moves pieces w, w + 8, w + 16 and min(w + 24, 25) of every slab (the six waves
@@ -238,21 +235,49 @@ __global__ void __launch_bounds__(512, 2) conv_bneck_kernel(BneckDev P) {
         __builtin_amdgcn_global_load_lds((gvoid*)(P.in + pofs[ii] + sl * 128), (lvoid*)(lds + pdst[ii] + sl * kPSlab), 16, 0, 0);
     };
 
-    // ---- residual DMA map (conv_b2b.hip): a slab is 16 pieces of 8 px x 128 B; wave w moves pieces w and w + 8
-    unsigned dpix[2], dq[2];
+    // ---- HBM <-> LDS in QUAD layout: instruction k (0..7) of a wave moves the wave's 64 bytes (its 32 channels) of the 16 tile
+    // pixels 16 k + (lane >> 2): lane & 3 = the 16-byte piece -- 4 consecutive lanes = 64 consecutive bytes of a pixel's row (a
+    // lane-per-pixel access straight from the accumulator layout is 64 separate 16-byte requests per instruction: the CU's
+    // address path then takes 64 cycles per instruction and an epilogue 6-8 k cycles; measured, round 6).  Pixel 16 k + (lane >> 2)
+    // = tile row k >> 1, column 16 (k & 1) + (lane >> 2): the row part of an address is wave-uniform (a scalar base per tile
+    // row), the column part one register per k & 1.  Loads are clamped into the image; stores of out-of-image pixels are issued
+    // with those lanes' EXEC bits off (the instruction count -- vmcnt bookkeeping -- is the same for every tile).
+    const unsigned lq = (unsigned)(wave * 64 + (lane & 3) * 16);
+    unsigned qcz[2], qcx[2];                               // column part: Z rows (512 B per pixel), X / Y rows (2048 B per pixel)
+    unsigned long long colm[2];
 #pragma unroll
-    for (int ii = 0; ii < 2; ii++) {
-        const int px = (wave + kNW * ii) * 8 + (lane >> 3);
-        dpix[ii] = pix_index(px);
-        dq[ii] = (unsigned)(((lane & 7) ^ ((px >> 1) & 7)) * 16);
+    for (int kk = 0; kk < 2; kk++) {
+        int c = col0 + 16 * kk + (lane >> 2);
+        colm[kk] = __builtin_amdgcn_ballot_w64(c < P.W);
+        c = c < P.W ? c : P.W - 1;
+        qcz[kk] = (unsigned)(c + 1) * (unsigned)(kCM * 2) + lq;
+        qcx[kk] = (unsigned)(c + 1) * (unsigned)(kCB * 2) + lq;
     }
-    auto dma_piece = [&](unsigned col0b, int sl, int ii) {       // slabs 0..2 land in the Y buffer, slab 3 in the side buffer
-        __builtin_amdgcn_global_load_lds((gvoid*)(P.res + (size_t)dpix[ii] * (kCB * 2) + col0b + sl * 128 + dq[ii]),
-                                         (lvoid*)(lds + (sl == 3 ? kOffSide : kOffY + sl * kSlab) + (wave + kNW * ii) * 1024), 16, 0, 2);      // aux 2 = nt: X is read once per block (the Y rows, not-nt, are the next block's X)
+    auto row_pix = [&](int kr) {                           // first haloed pixel of tile row kr (clamped), wave-uniform
+        int r = row0 + kr;
+        r = r < P.H ? r : P.H - 1;
+        return (size_t)((img * (P.H + 2) + r + 1) * Wp);
     };
-    auto dma_slab = [&](unsigned col0b, int sl) {                // 2 pieces per wave into slab sl of the Y buffer
-        dma_piece(col0b, sl, 0);
-        dma_piece(col0b, sl, 1);
+    auto row_mask = [&](int k) -> unsigned long long { return row0 + (k >> 1) < P.H ? colm[k & 1] : 0ull; };
+    // shortcut values of the chunk ahead in quad layout: rs[k], loaded by inline asm ("+v": one register set for the whole kernel),
+    // valid behind the weight waits that cover them (see bn_post)
+    u32x4 rs[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) rs[k] = u32x4{};
+    auto res_load = [&](auto C, auto K) {
+        constexpr int c = decltype(C)::value, k = decltype(K)::value;
+        u32x4(&rr)[8] = rs;                     // (a non-dependent use: a generic lambda captures the array only through one)
+        const unsigned vo = qcx[k & 1];
+        const char* xb = P.res + row_pix(k >> 1) * (size_t)(kCB * 2);
+        // nt: X is read once per block (the Y rows, not-nt, are the next block's X)
+        asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3 nt" : "+v"(rr[k]) : "v"(vo), "s"(xb), "n"(c * 512) : "memory");
+    };
+    // a 16-byte row store with the lanes of out-of-image pixels switched off (all 64 lanes are active around it: the kernel has no
+    // divergent control flow); the instruction is issued -- and counted by vmcnt -- whatever the mask
+    auto row_store = [&](char* base, unsigned vo, unsigned long long m, const u32x4& v, auto OFF) {
+        constexpr int off = decltype(OFF)::value;
+        asm volatile("s_mov_b64 exec, %3\n\tglobal_store_dwordx4 %0, %1, %2 offset:%4\n\ts_mov_b64 exec, -1"
+                     :: "v"(vo), "v"(v), "s"(base), "s"(m), "n"(off) : "memory");
     };
 
     // ---- B fragment offsets
@@ -272,7 +297,7 @@ __global__ void __launch_bounds__(512, 2) conv_bneck_kernel(BneckDev P) {
         pb[kw] = (unsigned)(kOffPatch + q * 128 + ((half ^ (sw & 1)) << 4) + ((sw >> 1) << 5));
     }
 
-    // ---- A operand: L2 -> registers through inline asm, ring of 8 k16 steps (conv_b2b.hip)
+    // ---- A operand: L2 -> registers through inline asm, ring of 8 k16 steps
     const unsigned voffA = (unsigned)(wave * kStepsA * 1024 + lane * 16);
     const unsigned voffB = (unsigned)(wave * 16 * 1024 + lane * 16);
     bf16x8 ar[kRing];
@@ -289,103 +314,65 @@ __global__ void __launch_bounds__(512, 2) conv_bneck_kernel(BneckDev P) {
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
     };
-    // the Y buffer (256 channels of 128 px) -> global rows, one slab (64 channels) of 64 pixels per pass: 8 consecutive
-    // threads write one pixel's 128 B.  EXACTLY 8 stores per lane and chunk (vmcnt bookkeeping): out-of-image pixels of a
-    // ragged tile go to the dump area.
-    auto store_slab = [&](int sl, int h, char* dst, unsigned pix_bytes, unsigned col0b) {
-        int idx = tid;
-        asm volatile("" : "+v"(idx));                // recompute the row address at every pass: holding 8 of them spills
-        const int px = h * 64 + (idx >> 3);
-        const int q = idx & 7;
-        const u32x4 v = *(const u32x4*)(lds + kOffY + sl * kSlab + px * 128 + ((q ^ ((px >> 1) & 7)) * 16));
-        char* a = dst + (size_t)pix_index(px) * pix_bytes;
-        char* d = P.dump + (size_t)px * (kCB * 2);
-        a = pix_valid(px) ? a : d;
-        *(u32x4*)(a + col0b + sl * 128 + q * 16) = v;
-    };
-    // round 5: the Y row stores with everything per-lane precomputed -- a lane stores the same two tile pixels (px0 = tid >> 3 and
-    // px0 + 64: same swizzle, LDS address + 8192) in every pass, so the two row addresses are computed ONCE (4 VGPRs); slab and
-    // chunk are immediates of the LDS read / the store.  The generic form above costs ~30 vector instructions per pass (clamps,
-    // 64-bit multiplies, the dump select): 8 passes per chunk made GEMM2 take 425 cycles per step against 285 in GEMM1.
-    char* yrow[2];
-    {
-        const int px0 = tid >> 3, q = tid & 7;
-#pragma unroll
-        for (int h = 0; h < 2; h++) {
-            const int px = px0 + 64 * h;
-            char* a = P.out + (size_t)pix_index(px) * (kCB * 2);
-            char* d = P.dump + (size_t)px * (kCB * 2);
-            yrow[h] = (pix_valid(px) ? a : d) + q * 16;
-        }
-    }
-    const unsigned ylds = lds_base + (unsigned)(kOffY + (tid >> 3) * 128 + (((tid & 7) ^ (((tid >> 3) >> 1) & 7)) * 16));
-    auto store_y = [&](auto SL, auto H, auto C) {
-        constexpr int sl = decltype(SL)::value, h = decltype(H)::value, c = decltype(C)::value;
-        const unsigned la = ylds;                // (non-dependent uses: a generic lambda captures the two only through them)
-        char* const* yr = yrow;
-        u32x4 v;
-        asm volatile("ds_read_b128 %0, %1 offset:%2\n\ts_waitcnt lgkmcnt(0)" : "=&v"(v) : "v"(la), "n"(sl * kSlab + h * 8192) : "memory");
-        asm volatile("global_store_dwordx4 %0, %1, off offset:%2" :: "v"(yr[h]), "v"(v), "n"(c * 512 + sl * 128) : "memory");
-    };
-    // acc + bias (+ residual already in the buffer) -> ReLU -> bf16, in place in the buffer at byte offset buf
-    // (conv_b2b.hip's epilogue; the expressions are those of the separate kernels)
+    // ---- epilogues, in the accumulator layout.  A lane holds, of pixel fragment b, channels 8 half + 16 run + 0..7 of its
+    // wave's 32 (run = 0, 1) in acc[b][8 run .. 8 run + 7] -- one 16-byte piece of the pixel's row per run.  The expressions
+    // are those of the separate kernels: (acc + bias) + residual, max with 0, round to bf16.
     const unsigned lbias_off = lds_base + (unsigned)kOffBias;      // fp32 [256 conv2 | 1024 conv3 | 256 conv1]
-    auto epilogue = [&](f32x16* acc, int bias0, bool with_res, int buf) {
-        typedef __attribute__((ext_vector_type(4))) float f32x4;
-        typedef __attribute__((ext_vector_type(2))) float f32x2;
-        const unsigned rmask = with_res ? 0xffffffffu : 0u;
-        const unsigned ebase = lds_base + (unsigned)(buf + (wave >> 1) * kSlab + frow * 128 + 8 * half);
-        // the residual of slab 3 (waves 6, 7) waits in the side buffer
-        const unsigned rbase = (with_res && (wave >> 1) == 3) ? lds_base + (unsigned)(kOffSide + frow * 128 + 8 * half) : ebase;
+    // LDS address of this lane's piece (pixel fragment 0, run 0) in a [4 slabs][128 px][128 B] buffer: slab wave >> 1, 16-byte
+    // chunk (4 (wave & 1) + 2 run + half) ^ ((frow >> 1) & 7); run 1 = the address XOR 32, fragment b at + 4096 b
+    const unsigned eoff = (unsigned)((wave >> 1) * kSlab + frow * 128 + (((4 * (wave & 1) + half) ^ ((frow >> 1) & 7)) * 16));
+    const unsigned ey[2] = {lds_base + (unsigned)kOffY + eoff, lds_base + (unsigned)kOffY + (eoff ^ 32u)};
+    // the same 8 KB (this wave's 64 bytes of every pixel row of its slab) in quad layout: pixel lane >> 2 of instruction 0, piece
+    // lane & 3 -> chunk (4 (wave & 1) + (lane & 3)) ^ (((lane >> 2) >> 1) & 7); instruction k at + 2048 k (16 pixels on: same swizzle)
+    const unsigned ql = lds_base + (unsigned)(kOffY + (wave >> 1) * kSlab + (lane >> 2) * 128 +
+                                               (((4 * (wave & 1) + (lane & 3)) ^ ((lane >> 3) & 7)) * 16));
+    auto bias16 = [&](int bias0, f32x4 (&bv)[4]) {                 // the lane's 16 biases: bv[2 run], bv[2 run + 1]
+        const unsigned bad = lbias_off + (unsigned)((bias0 + wave * 32 + 8 * half) * 4);
+        asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:16\n\tds_read_b128 %2, %4 offset:64\n\tds_read_b128 %3, %4 offset:80\n\t"
+                     "s_waitcnt lgkmcnt(0)"
+                     : "=&v"(bv[0]), "=&v"(bv[1]), "=&v"(bv[2]), "=&v"(bv[3])
+                     : "v"(bad)
+                     : "memory");
+    };
+    auto piece = [&](const f32x16& a, auto RUN, const f32x4& blo, const f32x4& bhi, const u32x4& r) -> u32x4 {
+        constexpr int run = decltype(RUN)::value;
+        u32x4 o;
 #pragma unroll
-        for (int gp = 0; gp < 2; gp++) {                 // two 8-channel groups at a time (register budget)
-            f32x4 bv[2];
-            u32x2 rc[2][kPF];
-            unsigned ead[2], rad[2];
-            // LDS reads first, one wait.  Inline asm: a plain LDS read here makes the compiler drain
-            // vmcnt (it cannot tell the read from the residual DMA's destination).  Pixel fragments sit 4096 B apart.
-#pragma unroll
-            for (int gg = 0; gg < 2; gg++) {
-                const int g = 2 * gp + gg;
-                ead[gg] = ebase + (unsigned)(((((wave & 1) * 4 + g) ^ ((frow >> 1) & 7))) * 16);
-                rad[gg] = rbase + (unsigned)(((((wave & 1) * 4 + g) ^ ((frow >> 1) & 7))) * 16);
-                const unsigned bad = lbias_off + (unsigned)((bias0 + wave * 32 + 8 * g + 4 * half) * 4);
-                asm volatile("ds_read_b128 %4, %6\n\tds_read_b64 %0, %5\n\tds_read_b64 %1, %5 offset:4096\n\t"
-                             "ds_read_b64 %2, %5 offset:8192\n\tds_read_b64 %3, %5 offset:12288"
-                             : "=&v"(rc[gg][0]), "=&v"(rc[gg][1]), "=&v"(rc[gg][2]), "=&v"(rc[gg][3]), "=&v"(bv[gg])
-                             : "v"(rad[gg]), "v"(bad)
-                             : "memory");
-            }
-            asm volatile("s_waitcnt lgkmcnt(0)"
-                         : "+v"(rc[0][0]), "+v"(rc[0][1]), "+v"(rc[0][2]), "+v"(rc[0][3]), "+v"(rc[1][0]), "+v"(rc[1][1]),
-                           "+v"(rc[1][2]), "+v"(rc[1][3]), "+v"(bv[0]), "+v"(bv[1])
-                         :
-                         : "memory");
-#pragma unroll
-            for (int gg = 0; gg < 2; gg++) {
-                const int g = 2 * gp + gg;
-                const f32x2 blo = {bv[gg][0], bv[gg][1]}, bhi = {bv[gg][2], bv[gg][3]};
-#pragma unroll
-                for (int b = 0; b < kPF; b++) {
-                    u32x2 r = rc[gg][b];
-                    r.x &= rmask;
-                    r.y &= rmask;
-                    const f32x2 rlo = {__uint_as_float(r.x << 16), __uint_as_float(r.x & 0xffff0000u)};
-                    const f32x2 rhi = {__uint_as_float(r.y << 16), __uint_as_float(r.y & 0xffff0000u)};
-                    const f32x2 alo = {acc[b][4 * g], acc[b][4 * g + 1]}, ahi = {acc[b][4 * g + 2], acc[b][4 * g + 3]};
-                    const f32x2 vlo = alo + blo + rlo, vhi = ahi + bhi + rhi;          // (acc + bias) + residual
-                    rc[gg][b].x = pack_bf16(fmaxf(vlo[0], 0.f), fmaxf(vlo[1], 0.f));
-                    rc[gg][b].y = pack_bf16(fmaxf(vhi[0], 0.f), fmaxf(vhi[1], 0.f));
-                }
-                asm volatile("ds_write_b64 %4, %0\n\tds_write_b64 %4, %1 offset:4096\n\t"
-                             "ds_write_b64 %4, %2 offset:8192\n\tds_write_b64 %4, %3 offset:12288"
-                             ::"v"(rc[gg][0]), "v"(rc[gg][1]), "v"(rc[gg][2]), "v"(rc[gg][3]), "v"(ead[gg]) : "memory");
-            }
+        for (int k = 0; k < 4; k++) {
+            const unsigned rw = r[k];
+            const f32x2 rr = {__uint_as_float(rw << 16), __uint_as_float(rw & 0xffff0000u)};
+            const f32x2 aa = {a[8 * run + 2 * k], a[8 * run + 2 * k + 1]};
+            const f32x2 bb = {k < 2 ? blo[2 * k] : bhi[2 * k - 4], k < 2 ? blo[2 * k + 1] : bhi[2 * k - 3]};
+            const f32x2 v = aa + bb + rr;                           // (acc + bias) + residual  (residual 0 where there is none)
+            o[k] = pack_bf16(fmaxf(v[0], 0.f), fmaxf(v[1], 0.f));
         }
+        return o;
+    };
+    auto lds_piece = [&](unsigned ad, const u32x4& v, auto B) {
+        constexpr int b = decltype(B)::value;
+        asm volatile("ds_write_b128 %0, %1 offset:%2" :: "v"(ad), "v"(v), "n"(b * 4096) : "memory");
+    };
+    // the wave's 8 KB of the buffer -> HBM rows in quad layout (LDS operations of one wave execute in order: the pieces this wave
+    // wrote a moment ago are read back without a barrier), four instructions per LDS round trip
+    auto rows_out = [&](char* base, size_t pix_bytes, const unsigned (&qc)[2], auto OFF) {
+        static_for<0, 2>([&](auto G) {
+            constexpr int g = decltype(G)::value;
+            const unsigned qa = ql;
+            u32x4 v[4];
+            asm volatile("ds_read_b128 %0, %4 offset:%5\n\tds_read_b128 %1, %4 offset:%6\n\tds_read_b128 %2, %4 offset:%7\n\tds_read_b128 %3, %4 offset:%8\n\t"
+                         "s_waitcnt lgkmcnt(0)"
+                         : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3])
+                         : "v"(qa), "n"((4 * g) * 2048), "n"((4 * g + 1) * 2048), "n"((4 * g + 2) * 2048), "n"((4 * g + 3) * 2048)
+                         : "memory");
+            static_for<0, 4>([&](auto KK) {
+                constexpr int k = 4 * g + decltype(KK)::value;
+                row_store(base + row_pix(k >> 1) * pix_bytes, qc[k & 1], row_mask(k), v[k & 3], OFF);
+            });
+        });
     };
 
 #ifdef DAFNE_BNECK_TIMING
-    unsigned long long stamp[12];
+    unsigned long long stamp[24];
     int nstamp = 0;
 #define BN_STAMP() stamp[nstamp++] = __builtin_amdgcn_s_memtime()
 #else
@@ -428,25 +415,50 @@ __global__ void __launch_bounds__(512, 2) conv_bneck_kernel(BneckDev P) {
         __builtin_amdgcn_sched_barrier(0);
         load_step(std::integral_constant<int, j + kRing>{});
         if constexpr (j < kTrickle) patch_piece(1 + j / 4, j & 3);
-        if constexpr (j >= kRes0 && j < kRes0 + 6 * kResStride && (j - kRes0) % kResStride == 0)
-            dma_piece(0u, ((j - kRes0) / kResStride) >> 1, ((j - kRes0) / kResStride) & 1);      // R(0), slabs 0..2
+        if constexpr (j >= kRes0 && j < kRes0 + 8 * kResStride && (j - kRes0) % kResStride == 0) {
+            res_load(std::integral_constant<int, 0>{}, std::integral_constant<int, (j - kRes0) / kResStride>{});
+        }
     });
     BN_STAMP();
-    barrier();                                       // every wave is done with the patch: T and the residual may land on it
-    dma_slab(0u, 3);                                 // R(0), slab 3: awaited through the weight waits of GEMM1(0)
-    epilogue(acc1, 0, false, kOffT);
+    barrier();                                       // every wave is done with the patch: T may land on it
+    {
+        f32x4 bv[4];
+        bias16(0, bv);
+        const unsigned et[2] = {ey[0] + (unsigned)(kOffT - kOffY), ey[1] + (unsigned)(kOffT - kOffY)};
+        static_for<0, kPF>([&](auto B) {
+            constexpr int b = decltype(B)::value;
+            static_for<0, 2>([&](auto RUN) {
+                constexpr int run = decltype(RUN)::value;
+                lds_piece(et[run], piece(acc1[b], RUN, bv[2 * run], bv[2 * run + 1], u32x4{}), B);
+            });
+        });
+    }
     barrier();
     BN_STAMP();
 
-    // ================================================================ phase B: conv_b2b.hip's schedule
+    // ================================================================ phase B: the two-half ping-pong (see the top of the file)
 #pragma unroll
     for (int b = 0; b < kPF; b++)
 #pragma unroll
         for (int k = 0; k < 16; k++) acc2[b][k] = 0.f;
+    const bool late = wave >= kNW / 2;               // wave-uniform: waves 4..7 run one segment behind their SIMD mates
+    if (late) barrier();
     static_for<0, kChunks>([&](auto C) {
         constexpr int c = decltype(C)::value;
         constexpr int j0 = kStepsA + 32 * c;
-        // GEMM1: Y chunk c = W3[c] . T  (K = 256 over the four slabs of the T tile)
+        // ---- chunk c's shortcut values: registers (quad layout) -> this wave's own 8 KB of the Y buffer, where E(c) finds them in
+        // the accumulator layout.  The 8 KB are free: its readers were G2a(c - 1) / G2b(c - 1) of both halves, at least one barrier
+        // ago (see the top of the file).  The values have landed: they are older than A(j0 - 8), which the first step of G2b(c - 1)
+        // waited for (chunk 0's: requested in phase A, older than A(96)).  The pin makes the LDS writes depend on an instruction
+        // behind those waits.
+        asm volatile("" : "+v"(rs[0]), "+v"(rs[1]), "+v"(rs[2]), "+v"(rs[3]), "+v"(rs[4]), "+v"(rs[5]), "+v"(rs[6]), "+v"(rs[7]) :: "memory");
+        static_for<0, 8>([&](auto K) {
+            constexpr int k = decltype(K)::value;
+            const unsigned qa = ql;                 // (non-dependent uses: a generic lambda captures the two only through them)
+            const u32x4(&rr)[8] = rs;
+            asm volatile("ds_write_b128 %0, %1 offset:%2" :: "v"(qa), "v"(rr[k]), "n"(k * 2048) : "memory");
+        });
+        // ---- G1(c): acc1 = W3[c] . T  (K = 256 over the four slabs of the T tile)
 #pragma unroll
         for (int b = 0; b < kPF; b++)
 #pragma unroll
@@ -468,70 +480,88 @@ __global__ void __launch_bounds__(512, 2) conv_bneck_kernel(BneckDev P) {
             __builtin_amdgcn_sched_barrier(0);
             load_step(std::integral_constant<int, j + kRing>{});
         });
-        barrier();                                   // every wave's residual pieces are in the Y buffer (older than A(j0+15))
-        if constexpr (c == 0) BN_STAMP();
-        epilogue(acc1, 256 + c * 256, true, kOffY);
         barrier();
-        if constexpr (c + 1 < kChunks) dma_slab((unsigned)(c + 1) * 512u, 3);       // side buffer: free since the epilogue read it
         if constexpr (c == 0) BN_STAMP();
-        // GEMM2: Z += W1[:, chunk c] . Y chunk, slab by slab; then (every wave done with the slab, its row stores have
-        // read it) the same slab of the NEXT residual chunk starts to land in its place
-        static_for<0, 4>([&](auto Q) {
-            constexpr int q = decltype(Q)::value;
-            static_for<0, 4>([&](auto I) {
+        // ---- E(c): chunk c + 1's shortcut values requested (8 quad loads; the registers were emptied at the top of G1(c)); this
+        // wave's 32 channels of Y chunk c: residual pieces from its 8 KB of the Y buffer, y = relu((acc1 + bias3) + x) written over
+        // them (the K operand of conv1'), then the 8 KB read back in quad layout and stored
+        {
+            if constexpr (c + 1 < kChunks) static_for<0, 8>([&](auto K) { res_load(std::integral_constant<int, c + 1>{}, K); });
+            f32x4 bv[4];
+            bias16(256 + c * 256, bv);
+            static_for<0, 2>([&](auto BP) {
+                constexpr int b0 = 2 * decltype(BP)::value;
+                const unsigned e0 = ey[0], e1 = ey[1];
+                u32x4 r[4];
+                asm volatile("ds_read_b128 %0, %4 offset:%6\n\tds_read_b128 %1, %5 offset:%6\n\tds_read_b128 %2, %4 offset:%7\n\tds_read_b128 %3, %5 offset:%7\n\t"
+                             "s_waitcnt lgkmcnt(0)"
+                             : "=&v"(r[0]), "=&v"(r[1]), "=&v"(r[2]), "=&v"(r[3])
+                             : "v"(e0), "v"(e1), "n"(b0 * 4096), "n"((b0 + 1) * 4096)
+                             : "memory");
+                static_for<0, 2>([&](auto BB) {
+                    constexpr int b = b0 + decltype(BB)::value;
+                    static_for<0, 2>([&](auto RUN) {
+                        constexpr int run = decltype(RUN)::value;
+                        lds_piece(ey[run], piece(acc1[b], RUN, bv[2 * run], bv[2 * run + 1], r[2 * (b - b0) + run]), std::integral_constant<int, b>{});
+                    });
+                });
+            });
+            rows_out(P.out, (size_t)(kCB * 2), qcx, std::integral_constant<int, c * 512>{});
+        }
+        barrier();
+        if constexpr (c == 0) BN_STAMP();
+        // ---- G2a(c), G2b(c): acc2 += W1[:, chunk c] . Y chunk, slabs 0..1 (written by waves 0..3) then slabs 2..3 (waves 4..7)
+        static_for<0, 2>([&](auto HH) {
+            constexpr int hh = decltype(HH)::value;
+            static_for<0, 8>([&](auto I) {
                 constexpr int i = decltype(I)::value;
-                constexpr int j = j0 + 16 + 4 * q + i;
+                constexpr int j = j0 + 16 + 8 * hh + i;
+                constexpr int q = 2 * hh + (i >> 2), st = i & 3;
                 wait_step(std::integral_constant<int, j>{});
-                if constexpr (i == 0) bn_bread_b<kOffY, q, 0>(bfr[j & 1], bs, lds_base);
-                if constexpr (i + 1 < 4) {
-                    bn_bread_b<kOffY, q, i + 1>(bfr[(j + 1) & 1], bs, lds_base);
-                    asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(bfr[j & 1][0]), "+v"(bfr[j & 1][1]), "+v"(bfr[j & 1][2]), "+v"(bfr[j & 1][3]) :: "memory");
-                } else {
-                    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(bfr[j & 1][0]), "+v"(bfr[j & 1][1]), "+v"(bfr[j & 1][2]), "+v"(bfr[j & 1][3]) :: "memory");
-                }
-                __builtin_amdgcn_sched_barrier(0);
                 if constexpr (HEAD) {
+                    if constexpr (i == 0) bn_bread_b<kOffY, q, st>(bfr[j & 1], bs, lds_base);
+                    if constexpr (i + 1 < 8) {
+                        bn_bread_b<kOffY, 2 * hh + ((i + 1) >> 2), ((i + 1) & 3)>(bfr[(j + 1) & 1], bs, lds_base);
+                        asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(bfr[j & 1][0]), "+v"(bfr[j & 1][1]), "+v"(bfr[j & 1][2]), "+v"(bfr[j & 1][3]) :: "memory");
+                    } else {
+                        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(bfr[j & 1][0]), "+v"(bfr[j & 1][1]), "+v"(bfr[j & 1][2]), "+v"(bfr[j & 1][3]) :: "memory");
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                     for (int b = 0; b < kPF; b++) acc2[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ar[j % kRing], bfr[j & 1][b], acc2[b], 0, 0, 0);
-                }
-                if constexpr (i == 0) {
-                    store_y(Q, std::integral_constant<int, 0>{}, C);
-                    store_y(Q, std::integral_constant<int, 1>{}, C);
                 }
                 __builtin_amdgcn_sched_barrier(0);
                 load_step(std::integral_constant<int, j + kRing>{});
             });
-            // round 5: a barrier only where a residual slab lands behind it -- behind slab group 1 (slabs 0 and 1 of the next chunk,
-            // 4 pieces) and behind group 2 (slab 2); none behind groups 0 and 3 and none in the last chunk (16 -> 6 barriers per
-            // block in GEMM2).  The next epilogue's in-place writes are ordered behind every wave's GEMM2 reads by the barrier
-            // that follows GEMM1 of the next chunk / precedes the Z epilogue.
-            if constexpr (c + 1 < kChunks && q == 1) {
-                barrier();
-                dma_slab((unsigned)(c + 1) * 512u, 0);
-                dma_slab((unsigned)(c + 1) * 512u, 1);
-            }
-            if constexpr (c + 1 < kChunks && q == 2) {
-                barrier();
-                dma_slab((unsigned)(c + 1) * 512u, 2);
-            }
-            __builtin_amdgcn_sched_barrier(0);
+            // (the last barrier of waves 4..7 would have no partner: waves 0..3 are through)
+            if constexpr (c + 1 < kChunks || hh == 0) barrier();
+            else if (!late) barrier();
+            if constexpr (c == 0) BN_STAMP();
         });
-        BN_STAMP();
     });
+    BN_STAMP();
+    // ---- Z = relu(acc2 + bias1): through the wave's 8 KB of the Y buffer (free: its last readers were G2a(3) / G2b(3)) into quad
+    // layout and out (waves 0..3 beside G2b(3) of waves 4..7)
     if constexpr (HEAD) {
-        barrier();                                   // every wave is done reading the last Y chunk (no barrier behind slab group 3 any more)
-        epilogue(acc2, 256 + kCB, false, kOffY);
-        barrier();
-        BN_STAMP();
-#pragma unroll
-        for (int i = 0; i < 8; i++) store_slab(i >> 1, i & 1, P.next, kCM * 2, 0);
+        f32x4 bv[4];
+        bias16(256 + kCB, bv);
+        static_for<0, kPF>([&](auto B) {
+            constexpr int b = decltype(B)::value;
+            static_for<0, 2>([&](auto RUN) {
+                constexpr int run = decltype(RUN)::value;
+                lds_piece(ey[run], piece(acc2[b], RUN, bv[2 * run], bv[2 * run + 1], u32x4{}), B);
+            });
+        });
+        rows_out(P.next, (size_t)(kCM * 2), qcz, std::integral_constant<int, 0>{});
     }
 #ifdef DAFNE_BNECK_TIMING
+    BN_STAMP();
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     BN_STAMP();
-    if (tid == 0 && blockIdx.x < 64) {       // into the dump area
-        unsigned long long* o = (unsigned long long*)P.dump + blockIdx.x * 12;
+    if ((tid & 255) == 0 && blockIdx.x < 32) {       // waves 0 and 4 of the first workgroups, into the scratch area
+        unsigned long long* o = (unsigned long long*)P.dump + (blockIdx.x * 2 + (tid >> 8)) * 24;
         for (int k = 0; k < nstamp; k++) o[k] = stamp[k] - stamp[0];
+        for (int k = nstamp; k < 24; k++) o[k] = 0;
     }
 #endif
 }

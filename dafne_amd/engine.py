@@ -198,13 +198,31 @@ def pack_b2b(w3, w1):
     return torch.stack([a1, a2], dim=1).contiguous().reshape(8, 8, 16, 64, 8)
 
 
+def _bneck_row_perm(device):
+    """conv_bneck.hip's row order inside a wave's 32 output channels: MFMA row 8g + 4h + i (g = 0..3, h = 0..1, i = 0..3) holds
+    channel 16 (g >> 1) + 8h + 4 (g & 1) + i, so that the 16 accumulator registers of a lane (fixed h) are two runs of 8
+    consecutive channels -- two 16-byte pieces of a pixel's row, loaded / stored straight from registers."""
+    r = torch.arange(32, device=device)
+    g, h, i = r >> 3, (r >> 2) & 1, r & 3
+    return 16 * (g >> 1) + 8 * h + 4 * (g & 1) + i
+
+
 def pack_bneck(w2, w3, w1):
     """Fragment-major weights of dafne_bottleneck_body_hip: the 3x3 conv2 ([256, 2304] bf16 in pack_conv's K order = 64-channel
-    slab, kh, kw, channel) as [8 waves][144 k16 steps][64 lanes][8] (rows wave*32 + (lane & 31), K columns 16*step +
-    8*(lane >> 5) .. +8), followed by pack_b2b(conv3, next conv1)."""
+    slab, kh, kw, channel) as [8 waves][144 k16 steps][64 lanes][8] (rows wave*32 + perm[lane & 31], K columns 16*step +
+    8*(lane >> 5) .. +8), followed by conv3 ([1024, 256]) and the next block's conv1 ([256, 1024]) as [8 GEMMs][8 waves][16 k16
+    steps][64 lanes][8]: GEMM 2c = conv3 rows c*256 + wave*32 + perm[lane & 31] over K = 256, GEMM 2c+1 = conv1 rows wave*32 +
+    perm[lane & 31] over K-chunk c (pack_b2b's layout with the rows of every 32-block in _bneck_row_perm's order)."""
     assert tuple(w2.shape) == (256, 2304) and w2.dtype == BF16
-    a0 = w2.reshape(8, 32, 144, 2, 8).permute(0, 2, 3, 1, 4)                # w, j, h, r, e
-    return torch.cat([a0.contiguous().reshape(-1), pack_b2b(w3, w1).reshape(-1)]).contiguous()
+    assert tuple(w3.shape) == (1024, 256) and tuple(w1.shape) == (256, 1024) and w3.dtype == BF16 and w1.dtype == BF16
+    perm = _bneck_row_perm(w2.device)
+    if os.environ.get("DAFNE_BNECK_OLDPACK") == "1":        # A/B against a round-5 library (scratch/ab_bench.sh); removed with it
+        perm = torch.arange(32, device=w2.device)
+    a0 = w2.reshape(8, 32, 144, 2, 8)[:, perm].permute(0, 2, 3, 1, 4)                       # w, j, h, r, e
+    a1 = w3.reshape(4, 8, 32, 16, 2, 8)[:, :, perm].permute(0, 1, 3, 4, 2, 5)               # c, w, t, h, r, e
+    a2 = w1.reshape(8, 32, 4, 16, 2, 8)[:, perm].permute(2, 0, 3, 4, 1, 5)                  # c, w, t, h, r, e
+    pb = torch.stack([a1, a2], dim=1).contiguous().reshape(-1)
+    return torch.cat([a0.contiguous().reshape(-1), pb]).contiguous()
 
 
 def pack_conv3x3_frag(w):

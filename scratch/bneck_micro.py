@@ -57,8 +57,9 @@ for K in (1, 4):
     del sets
 if os.environ.get("DAFNE_BNECK_STAMPS"):
     torch.cuda.synchronize()
-    s = scr.view(torch.int64)[:64 * 12].reshape(64, 12).cpu()
-    print("phase stamps (cycles since kernel entry; rows = first workgroups):")
-    names = ["start", "phaseA end", "T ready", "GEMM1(0) end", "epi(0) end", "chunk0 end", "chunk1 end", "chunk2 end", "chunk3 end", "Z epi", "stores done"]
-    med = s.median(dim=0).values.tolist()
-    print("   median:", ", ".join("%s %d" % (n, v) for n, v in zip(names, med)))
+    s = scr.view(torch.int64)[:64 * 24].reshape(32, 2, 24).cpu()
+    print("phase stamps (cycles since kernel entry; median over the first 32 workgroups):")
+    names = ["start", "phaseA end", "T ready", "G1(0)", "E(0)", "G2a(0)", "G2b(0)", "chunks done", "Z issued", "drained"]
+    for wv, lab in ((0, "wave 0"), (1, "wave 4")):
+        med = s[:, wv].median(dim=0).values.tolist()
+        print("   %s:" % lab, ", ".join("%s %d" % (n, v) for n, v in zip(names, med)))
