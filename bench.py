@@ -427,7 +427,7 @@ def _nms_one(args):
     return len(opp.batched_nms_poly(b, s_, c, 0.1, fast=True))
 
 
-def cpu_baseline(cfg, sd, depth, budget_s=4.0):
+def cpu_baseline(cfg, sd, depth, budget_s=4.0, keep=None):
     """Oracle (port) on the host cores, bounded (~30 s of CPU work in total): the full path for single 1024^2 images
     (batch 1, ~budget_s) and for ONE batch of 8 ("batch 1 and batch 8"); the rotated NMS alone on the
     M = 10 000 set, one thread and all cores (8 images over a process pool: the C oracle is single-threaded)."""
@@ -443,17 +443,19 @@ def cpu_baseline(cfg, sd, depth, budget_s=4.0):
     cores = min(threads_before, usable_cpus())
     torch.set_num_threads(cores)
 
-    def full_path(imgs):
+    def full_path(imgs, emulate_bf16=False, sink=None):
         with torch.no_grad():
             x, sizes = om.preprocess(imgs, cfg.MODEL.PIXEL_MEAN, cfg.MODEL.PIXEL_STD)
-            f = om.backbone_forward(P, x, depth)
-            lg, rg, ce, ct = om.head_forward(P, [f[k] for k in ("p3", "p4", "p5", "p6", "p7")])
+            f = om.backbone_forward(P, x, depth, emulate_bf16=emulate_bf16)
+            lg, rg, ce, ct = om.head_forward(P, [f[k] for k in ("p3", "p4", "p5", "p6", "p7")], emulate_bf16=emulate_bf16)
         for i in range(len(imgs)):
             levels = [(lg[l][i].numpy(), rg[l][i].numpy(), ct[l][i].numpy()) for l in range(5)]
             det = opp.predict_proposals(levels, d.FPN_STRIDES, thresh=d.INFERENCE_TH_TEST, topk=d.PRE_NMS_TOPK_TEST,
                                         nms_thresh=d.NMS_TH, post_topk=d.POST_NMS_TOPK_TEST,
                                         thresh_with_ctr=d.THRESH_WITH_CTR, sort_corners=d.SORT_CORNERS, fast=True)
-            opp.detector_postprocess(det, (1024, 1024), (1024, 1024), (1024, 1024))
+            det = opp.detector_postprocess(det, (1024, 1024), (1024, 1024), (1024, 1024))
+            if sink is not None:
+                sink.append({k: np.asarray(det[k]) for k in ("pred_corners", "scores", "pred_classes")})
 
     n_done, t_total = 0, 0.0
     while n_done < 1 or (t_total < budget_s and n_done < 8):
@@ -464,8 +466,12 @@ def cpu_baseline(cfg, sd, depth, budget_s=4.0):
         n_done += 1
     imgs8 = [torch.randint(0, 256, (3, 1024, 1024), generator=g, dtype=torch.uint8) for _ in range(8)]
     t0 = time.perf_counter()
-    full_path(imgs8)
+    full_path(imgs8, sink=keep["fp32"] if keep is not None else None)
     t_b8 = time.perf_counter() - t0
+    if keep is not None:         # the checker side of `equivalence_ap` (not timed): the same 8 images through the oracle's bf16 emulation
+        keep["images"] = imgs8
+        for k in range(0, 8, 2):
+            full_path(imgs8[k:k + 2], emulate_bf16=True, sink=keep["bf16_emulation"])
     # rotated NMS alone on the CPU (SURVEY 8(d) "CPU baseline beside it"): the C oracle (hull pre-filter on) on the
     # M = 10 000 uniform candidate set of nms_ms_per_image -- one thread, then all cores
     sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -495,6 +501,29 @@ def cpu_baseline(cfg, sd, depth, budget_s=4.0):
                      "C/numpy post-process" % (n_done, t_total, t_b8, depth)}
     out.update(nms_all)
     return out
+
+
+def equivalence_side_metric(model, keep, device):
+    """"Detections equivalent to the reference" as a number (BASELINE.json north_star): VOC07 AP (the evaluator's own scoring,
+    dafne/evaluation/voc_eval.py:41-224, polygon IoU on the device) of the ENGINE's detections for the cpu_baseline leg's batch of
+    8 images against the FP32 ORACLE's detections of the same images as ground truth, at IoU 0.5 and 0.75, per class and mean --
+    next to the same AP for the oracle's own bf16 emulation (what bf16 arithmetic costs whoever implements it).  The oracle is the
+    checker here, outside every timed region."""
+    from dafne_amd.evaluation.equivalence import equivalence_ap
+    imgs = keep["images"]
+    outs = model([{"image": im.to(device), "height": 1024, "width": 1024} for im in imgs])
+    eng = []
+    for o in outs:
+        inst = o["instances"]
+        eng.append({"pred_corners": inst.pred_corners.float().cpu().numpy(), "scores": inst.scores.float().cpu().numpy(),
+                    "pred_classes": inst.pred_classes.cpu().numpy()})
+    res = {"engine_vs_fp32_oracle": equivalence_ap(eng, keep["fp32"]),
+           "bf16_emulation_vs_fp32_oracle": equivalence_ap(keep["bf16_emulation"], keep["fp32"]),
+           "ground_truth": "the fp32 oracle's own detections (oracle/model.py + oracle/postprocess.py) of 8 seeded 1024x1024 images, "
+                           "random-init weights (bench.build_model)", "entry": "model(batched_inputs)"}
+    for thr in ("iou_0.50", "iou_0.75"):
+        res["engine_minus_emulation_" + thr] = res["engine_vs_fp32_oracle"][thr]["mean"] - res["bf16_emulation_vs_fp32_oracle"][thr]["mean"]
+    return res
 
 
 def headline(args, world, dt, det_mean, region_times=None):
@@ -1179,9 +1208,16 @@ def _run_worker(args, make_step, rank, world, distributed, device):
         out.setdefault("side_metric_errors", {})["extras"] = "%s: %s" % (type(e).__name__, e)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         try:
-            out["cpu_baseline"] = cpu_baseline(cfg, sd, args.depth)
+            keep = {"fp32": [], "bf16_emulation": []} if not args.no_extras else None
+            out["cpu_baseline"] = cpu_baseline(cfg, sd, args.depth, keep=keep)
         except Exception as e:      # noqa: BLE001
             out["cpu_baseline"] = {"error": "%s: %s" % (type(e).__name__, e)}
+            keep = None
+        if keep is not None and len(keep["fp32"]) == 8:
+            try:
+                out["equivalence_ap"] = equivalence_side_metric(model, keep, device)
+            except Exception as e:      # noqa: BLE001
+                out["equivalence_ap"] = {"error": "%s: %s" % (type(e).__name__, e)}
     return out
 
 

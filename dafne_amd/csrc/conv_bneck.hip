@@ -372,9 +372,9 @@ __global__ void __launch_bounds__(512, 2) conv_bneck_kernel(BneckDev P) {
     };
 
 #ifdef DAFNE_BNECK_TIMING
-    unsigned long long stamp[24];
+    unsigned long long stamp[24], rstamp[24];
     int nstamp = 0;
-#define BN_STAMP() stamp[nstamp++] = __builtin_amdgcn_s_memtime()
+#define BN_STAMP() (rstamp[nstamp] = __builtin_amdgcn_s_memrealtime(), stamp[nstamp++] = __builtin_amdgcn_s_memtime())
 #else
 #define BN_STAMP()
 #endif
@@ -559,9 +559,9 @@ __global__ void __launch_bounds__(512, 2) conv_bneck_kernel(BneckDev P) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     BN_STAMP();
     if ((tid & 255) == 0 && blockIdx.x < 32) {       // waves 0 and 4 of the first workgroups, into the scratch area
-        unsigned long long* o = (unsigned long long*)P.dump + (blockIdx.x * 2 + (tid >> 8)) * 24;
-        for (int k = 0; k < nstamp; k++) o[k] = stamp[k] - stamp[0];
-        for (int k = nstamp; k < 24; k++) o[k] = 0;
+        unsigned long long* o = (unsigned long long*)P.dump + (blockIdx.x * 2 + (tid >> 8)) * 48;
+        for (int k = 0; k < 24; k++) o[k] = k < nstamp ? stamp[k] - stamp[0] : 0;
+        for (int k = 0; k < 24; k++) o[24 + k] = k < nstamp ? rstamp[k] - rstamp[0] : 0;      // 100 MHz ticks
     }
 #endif
 }

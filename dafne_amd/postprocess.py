@@ -141,7 +141,8 @@ def rows_to_instances(rows, counts, image_sizes, host_rows=None):
         inst = _instances_of_rows(rows[i, :k], image_sizes[i])
         if host_rows is not None:
             hr, size = host_rows[i, :k].clone(), image_sizes[i]
-            object.__setattr__(inst, "_cpu_twin", (lambda hr=hr, size=size: _instances_of_rows(hr, size)))
+            if hasattr(inst, "attach_cpu_twin"):          # (detectron2's own Instances, when importable, copies field by field)
+                inst.attach_cpu_twin(lambda hr=hr, size=size: _instances_of_rows(hr, size))
         res.append(inst)
     return res
 

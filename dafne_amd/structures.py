@@ -91,12 +91,29 @@ class _Instances:
         if len(self._fields):
             assert len(self) == n, "Adding a field of length %d to Instances of length %d" % (n, len(self))
         self._fields[name] = value
+        self.__dict__.pop("_cpu_twin", None)          # the host twin describes the fields it was made beside: gone with any edit
 
     def has(self, name):
         return name in self._fields
 
     def remove(self, name):
         del self._fields[name]
+        self.__dict__.pop("_cpu_twin", None)
+
+    @staticmethod
+    def _field_state(fields):
+        """Identity and in-place version of every field tensor (torch bumps `_version` on every in-place write, views included:
+        pred_boxes.scale() / .clip(), `scores *= ...`): what the host twin is valid for."""
+        st = []
+        for n, v in fields.items():
+            t = v.tensor if hasattr(v, "tensor") else v
+            st.append((n, id(v), id(t), getattr(t, "_version", None)))
+        return tuple(st)
+
+    def attach_cpu_twin(self, make):
+        """`make()` builds this object's host copy from rows that are already on the host (postprocess.rows_to_instances).  It is
+        handed out by `.to("cpu")` only while no field has been set, removed, replaced or written in place since."""
+        object.__setattr__(self, "_cpu_twin", (make, self._field_state(self._fields)))
 
     def get(self, name):
         return self._fields[name]
@@ -109,7 +126,9 @@ class _Instances:
         # memory behind its NMS, once): `.to("cpu")` -- what every evaluator does per image -- is then no device copy at all
         twin = self.__dict__.get("_cpu_twin")
         if twin is not None and not k and len(a) == 1 and isinstance(a[0], (str, torch.device)) and torch.device(a[0]).type == "cpu":
-            return twin()
+            if twin[1] == self._field_state(self._fields):
+                return twin[0]()
+            self.__dict__.pop("_cpu_twin", None)      # a detectron2-style hook edited the device fields: copy what is there now
         r = _Instances(self._image_size)
         for n, v in self._fields.items():
             r.set(n, v.to(*a, **k) if hasattr(v, "to") else v)

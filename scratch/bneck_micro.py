@@ -57,9 +57,10 @@ for K in (1, 4):
     del sets
 if os.environ.get("DAFNE_BNECK_STAMPS"):
     torch.cuda.synchronize()
-    s = scr.view(torch.int64)[:64 * 24].reshape(32, 2, 24).cpu()
+    s = scr.view(torch.int64)[:64 * 48].reshape(32, 2, 48).cpu()
     print("phase stamps (cycles since kernel entry; median over the first 32 workgroups):")
     names = ["start", "phaseA end", "T ready", "G1(0)", "E(0)", "G2a(0)", "G2b(0)", "chunks done", "Z issued", "drained"]
     for wv, lab in ((0, "wave 0"), (1, "wave 4")):
         med = s[:, wv].median(dim=0).values.tolist()
         print("   %s:" % lab, ", ".join("%s %d" % (n, v) for n, v in zip(names, med)))
+        print("   %s (us):" % lab, ", ".join("%s %.2f" % (n, v / 100.0) for n, v in zip(names, med[24:])))

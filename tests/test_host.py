@@ -70,3 +70,33 @@ def test_tta_batched_inverse_transforms_equal_the_per_view_loop():
     # a list the fast path does not know (two flips) falls back to the loop
     odd = [TransformList([ResizeT(8, 8, 4, 4), HFlipT(4), VFlipT(4)])]
     assert OneStageRCNNWithTTA._invert_and_concat_fast(outs[:1], odd) is None
+
+
+def test_instances_host_twin_is_dropped_by_any_edit():
+    """`Instances.to("cpu")` hands out the host twin made beside the packed rows only while the device-side fields are the ones it
+    was made for: set / remove / attribute assignment and IN-PLACE writes (pred_boxes.scale / clip, `scores *= ..`: what a
+    detectron2-style post-processing hook does before evaluator.process, dafne/evaluation/dafne_evaluator.py:44-58) all drop it."""
+    import torch
+    from dafne_amd.structures import _Boxes, _Instances
+
+    def make():
+        inst = _Instances((10, 10), scores=torch.tensor([0.5, 0.25]), pred_boxes=_Boxes(torch.tensor([[0., 0., 4., 4.], [1., 1., 3., 3.]])))
+        snap = _Instances((10, 10), scores=torch.tensor([0.5, 0.25]), pred_boxes=_Boxes(torch.tensor([[0., 0., 4., 4.], [1., 1., 3., 3.]])),
+                          marker=torch.tensor([1, 1]))
+        inst.attach_cpu_twin(lambda: snap)
+        return inst
+    assert make().to("cpu").has("marker")                                   # untouched: the twin
+    assert make().to(torch.device("cpu")).has("marker")
+    a = make(); a.scores *= 2.0                                             # in-place write on a field tensor
+    r = a.to("cpu"); assert not r.has("marker") and r.scores.tolist() == [1.0, 0.5]
+    a = make(); a.pred_boxes.scale(2.0, 2.0)                                # in-place through a view inside Boxes
+    r = a.to("cpu"); assert not r.has("marker") and r.pred_boxes.tensor[0].tolist() == [0.0, 0.0, 8.0, 8.0]
+    a = make(); a.pred_boxes.clip((2, 2))
+    assert not a.to("cpu").has("marker")
+    a = make(); a.scores = torch.tensor([0.125, 0.75])                       # attribute assignment
+    r = a.to("cpu"); assert not r.has("marker") and r.scores.tolist() == [0.125, 0.75]
+    a = make(); a.set("extra", torch.zeros(2))
+    assert a.to("cpu").has("extra")
+    a = make(); a.remove("scores")
+    assert not a.to("cpu").has("scores")
+    a = make(); assert not a.to("cpu", non_blocking=True).has("marker")     # any other .to() form copies
