@@ -121,6 +121,7 @@ def load_weights(model, path_or_state, strict=False):
                              "ITS weights (load them explicitly with set_fp8_act_scales if that is intended)" % len(missing))
         from . import engine
         engine.check_act_qscales(sc)
+        model.check_fp8_act_scale_keys(sc)     # the layer set too (it follows from the architecture, not from the values)
     with torch.no_grad():
         for k, v in own.items():
             if k in sd:
@@ -128,5 +129,5 @@ def load_weights(model, path_or_state, strict=False):
     if hasattr(model, "invalidate"):
         model.invalidate()
     if takes_scales:
-        model.set_fp8_act_scales(sc)          # the layer set is checked against the packed weights (needs them loaded)
+        model.set_fp8_act_scales(sc)
     return missing, unexpected

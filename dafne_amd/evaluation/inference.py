@@ -90,7 +90,11 @@ class DafneEvaluator(DatasetEvaluator):
             if self._k_cap is None:
                 raise RuntimeError("DafneEvaluator(distributed=True) needs k_cap (DAFNeOutputs.packed_k_cap())")
             real = [i for i in self._insts if i is not None]
-            dev = self._device if self._device is not None else (real[0].scores.device if real else torch.device("cpu"))
+            dev = self._device if self._device is not None else (real[0].scores.device if real else None)
+            if dev is None:
+                # an empty shard (or outputs without "instances"): the collectives below must still run on the backend's device --
+                # under RCCL a CPU tensor here errors or hangs against the other ranks' CUDA tensors
+                dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
             rows, counts = instances_to_rows(self._insts, self._k_cap, dev)
             n = pad_to
             if n is None:

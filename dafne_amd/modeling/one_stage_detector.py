@@ -150,6 +150,19 @@ class OneStageDetector(nn.Module):
         checkpoint.load_weights finds under "fp8_act_scales") instead of calibrating: the scales are part of the fp8 model."""
         if self.cfg.ENGINE.WEIGHT_DTYPE != "fp8_e4m3":
             raise RuntimeError("set_fp8_act_scales: ENGINE.WEIGHT_DTYPE is %r" % (self.cfg.ENGINE.WEIGHT_DTYPE,))
+        scales = self.check_fp8_act_scale_keys(scales)
+        engine.check_act_qscales(scales)
+        self._act_q8 = scales
+        self._packed["act_q8"] = dict(self._act_q8)
+        self._plans = {}
+        self._graphs = {}
+        if hasattr(self, "_pipe"):
+            self._pipe = {}
+
+    def check_fp8_act_scale_keys(self, scales):
+        """Does `scales` ({weight key: in_qscale}) name exactly the layers this model quantises on load?  Raises ValueError
+        otherwise, touches nothing (checkpoint.load_weights calls it BEFORE copying a tensor: the layer set depends on the
+        architecture -- the packed-weight keys -- not on the values).  Returns the scales as {str: float}."""
         P = self._weights()
         scales = {str(k): float(v) for k, v in dict(scales).items()}
         # the layers calibrate_fp8 would scale: every 3x3 layer with e4m3 weights whose input is NOT a GroupNorm output
@@ -161,15 +174,9 @@ class OneStageDetector(nn.Module):
         # the plain-input ones above must
         allowed = set(k[:-4] for k in P if k.endswith(".fp8") and not k.endswith(".frag"))
         if not (want <= set(scales) <= allowed):
-            raise ValueError("set_fp8_act_scales: scales for %d layers, the model has %d plain-input fp8 layers (missing %s, unknown %s)"
+            raise ValueError("fp8 activation scales for %d layers, the model has %d plain-input fp8 layers (missing %s, unknown %s)"
                              % (len(scales), len(want), sorted(want - set(scales))[:4], sorted(set(scales) - allowed)[:4]))
-        engine.check_act_qscales(scales)
-        self._act_q8 = scales
-        self._packed["act_q8"] = dict(self._act_q8)
-        self._plans = {}
-        self._graphs = {}
-        if hasattr(self, "_pipe"):
-            self._pipe = {}
+        return scales
 
     def calibrate_fp8(self, images_u8, valid_hw=None, layout_hwc=False, group=None):
         """Static activation calibration of the fp8 model on one batch (uint8 CUDA images as detect_packed takes them): a

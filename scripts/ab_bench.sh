@@ -1,6 +1,6 @@
 #!/bin/bash
 # same-box A/B of library / engine variants: each line "NAME ENV..." runs bench.py --no-extras twice, alternating
-# usage: scratch/ab_bench.sh "A|" "B|DAFNE_FUSE_GNFIN=0" ...
+# usage: scripts/ab_bench.sh "A|" "B|DAFNE_FUSE_GNFIN=0" ...
 cd ${GRAFT_REPO_ROOT:-/root/repo}
 for rep in 1 2; do
   for spec in "$@"; do

@@ -1,5 +1,5 @@
 #!/bin/bash
-# usage: scratch/build_variant.sh NAME "-DFOO -DBAR"   -> scratch/variants/libNAME.so (conv.hip rebuilt with the defines)
+# usage: scripts/build_variant.sh NAME "-DFOO -DBAR"   -> scratch/variants/libNAME.so (conv.hip rebuilt with the defines)
 set -e
 cd "$(dirname "$0")/.."
 name=$1; defs=$2

@@ -1,5 +1,5 @@
 // Which packed fp32 instruction form returns wrong lanes beside matrix kernels on gfx950?  One kernel per form: every thread runs a
-// dependent chain of ITER instructions on its own four inputs (pure function of the input).  scratch/pk_probe.py runs them beside
+// dependent chain of ITER instructions on its own four inputs (pure function of the input).  scripts/pk_probe.py runs them beside
 // torch.matmul on three streams and compares with the idle result.
 #include <hip/hip_runtime.h>
 typedef __attribute__((ext_vector_type(2))) float f32x2;

@@ -117,3 +117,34 @@ def test_tower_convolution_beside_matrix_kernels():
         return out.t.clone()
     bad, n = _stress(run, torch.equal, 300, 4, dev)
     assert bad == 0, "%d of %d launches of conv3x3_rp differ from the idle result" % (bad, n)
+
+
+def test_whole_dense_path_beside_matrix_kernels():
+    """EVERY convolution kernel of the R101 plan (round 6, VERDICT r5 item 5: conv_bneck, conv_blk_mid, conv_blk_narrow, conv_wr,
+    conv3x3_pred16, the stem, ... -- all of them carry hand-written two-wide fp32 epilogues next to their matrix instructions): the
+    dense part of one plan on a fixed batch, its five FPN maps and every head output compared bit for bit with the idle-GPU pass
+    while vendor GEMMs run on three other streams."""
+    import bench
+    dev = torch.device("cuda", 0)
+    cfg, model, sd = bench.build_model(101, dev, seed=3)
+    g = torch.Generator().manual_seed(8)
+    batch = torch.randint(0, 256, (2, 3, 256, 320), generator=g, dtype=torch.uint8).to(dev)
+    model.detect_packed(batch)
+    torch.cuda.synchronize()
+    plan = model.plan(2, 256, 320)
+    names = set(c.kernel_name() for c in plan.calls if hasattr(c, "kernel_name"))
+    for k in ("conv_bneck", "conv_blk_mid", "conv_wr", "conv3x3_pred16", "conv3x3_rp", "stem_pool_conv1"):
+        assert k in names, (k, sorted(names))
+    hp = plan.head
+
+    def run():
+        model.detect_packed(batch)
+        outs = [a.t.clone() for a in plan.features]
+        for l in range(5):
+            outs += [hp.logits[l].clone(), hp.delta_ctr[l].clone(), hp.center[l].clone()]
+        return outs
+
+    def same(a, b):
+        return all(torch.equal(x, y) for x, y in zip(a, b))
+    bad, n = _stress(run, same, 120, 1, dev)
+    assert n == 120 and bad == 0, "%d of %d passes of the dense path differ from the idle result" % (bad, n)
