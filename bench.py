@@ -522,7 +522,8 @@ def equivalence_side_metric(model, keep, device):
            "ground_truth": "the fp32 oracle's own detections (oracle/model.py + oracle/postprocess.py) of 8 seeded 1024x1024 images, "
                            "random-init weights (bench.build_model)", "entry": "model(batched_inputs)"}
     for thr in ("iou_0.50", "iou_0.75"):
-        res["engine_minus_emulation_" + thr] = res["engine_vs_fp32_oracle"][thr]["mean"] - res["bf16_emulation_vs_fp32_oracle"][thr]["mean"]
+        res["engine_minus_emulation_" + thr] = (res["engine_vs_fp32_oracle"][thr]["weighted_mean"]
+                                                - res["bf16_emulation_vs_fp32_oracle"][thr]["weighted_mean"])
     return res
 
 

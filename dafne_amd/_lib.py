@@ -96,8 +96,6 @@ SIGNATURES = {
     "dafne_conv3x3_c256_tiles_per_image": (c_int, [ctypes.POINTER(ConvParams), ctypes.POINTER(ConvSeg), c_void_p]),
     "dafne_conv3x3_c256_pair_hip": (c_int, [ctypes.POINTER(ConvParams), ctypes.POINTER(ConvSeg), c_void_p,
                                             ctypes.POINTER(ConvParams), ctypes.POINTER(ConvSeg), c_void_p, c_void_p, c_size_t, c_void_p]),
-    "dafne_conv3x3_c256_fp8w_hip": (c_int, [ctypes.POINTER(ConvParams), ctypes.POINTER(ConvSeg), c_void_p, c_void_p, c_float, c_void_p, c_size_t,
-                                            c_void_p]),
     "dafne_conv3x3_c256_scratch_bytes": (c_size_t, []),
     "dafne_conv3x3_c256_hip": (c_int, [ctypes.POINTER(ConvParams), ctypes.POINTER(ConvSeg), c_void_p, c_void_p, c_size_t, c_void_p]),
     "dafne_conv2d_wr_ok": (c_int, [ctypes.POINTER(ConvParams), ctypes.POINTER(ConvSeg)]),

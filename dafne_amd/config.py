@@ -155,9 +155,9 @@ def _defaults():
                     # never depend on image order, batch size or world size; "off" = only the GroupNorm-fed tower layers take e4m3
                     # activations; "first_batch" = opt-in convenience: calibrate on the first batch detect_packed sees
                     FP8_ACT_CALIBRATION="explicit",
-                    # fp8 model: the kernel of its 3x3 layers with 256 input channels -- "patch" (conv3x3_patch_fp8_kernel) or "rp8"
-                    # (conv3x3_rp8_kernel).  The two round the same sums differently (2 bf16 ulps), so the choice is part of the
-                    # model: every plan (whole batch, pipelined sub-batches, TTA chunks) of one model uses the same kernel
+                    # fp8 model: the kernel of its 3x3 layers -- "patch" (conv3x3_patch_fp8_kernel), the only one since round 6
+                    # (rounds 3-5 also had "rp8", a resident-patch form that won alone and lost in the timed layout: removed).  A second
+                    # kernel would round the same sums differently, so the choice is part of the model: the key stays
                     FP8_CONV3X3_KERNEL="patch",
                     # sub-batches on concurrent streams in the streamed evaluation loop (OneStageDetector.forward_streamed /
                     # evaluation.inference.inference_on_dataset): the layout bench.py times.  Round 5: three sub-batches of UNEQUAL

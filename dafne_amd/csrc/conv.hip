@@ -2872,466 +2872,6 @@ __global__ void __launch_bounds__(512) conv3x3_patch_fp8_kernel(ConvDev P) {
 }
 
 // ---------------------------------------------------------------------------------------
-// fp8 (OCP e4m3) twin of conv3x3_rp_kernel: BASELINE config 5 on the resident-patch structure (round 3).
-//
-// Same tiles (4 x 32 pixels x 256 output channels), same persistent loop, same epilogue; what changes:
-//   * the matrix instruction is v_mfma_f32_32x32x64_f8f6f4 (both operands e4m3, no block scales): one instruction covers a
-//     whole 64-channel tap, 36 steps per tile instead of 144, twice the flops per cycle of the matrix pipe;
-//   * weights: e4m3 bytes, fragment-major [Cout/256][8 waves][36 steps][2][64 lanes][16 B] (lane = row & 31 | K half << 5; the
-//     two 16-byte halves of a lane's 32 K values), two coalesced 1-KiB loads per wave and step -- HALF the bytes of the bf16
-//     kernel per tile (590 KB), which is what that kernel's L2 -> CU ingest was bound by;
-//   * the patch is e4m3 in LDS (64 B per pixel and slab, lines of 36 pixels, 16-byte chunk XOR (column >> 2) & 3: the layout of
-//     conv3x3_patch_fp8_kernel; 54 KB for all 256 channels) and is quantised ON THE WAY IN: the bf16 pixels of the next tile are
-//     loaded straight into REGISTERS (16 B per lane = one GroupNorm group of one pixel; 4 loads per wave and slab, two register
-//     sets), and converted -- optional GroupNorm + ReLU, x in_qscale, clamp +-448, v_cvt_pk_fp8_f32 -- into the slab's place
-//     behind the barrier that retires it (steps 9 / 18 / 27, slab 3 behind the next tile's first barrier).  No LDS staging, no
-//     LDS-DMA: the compiler sees no asynchronous LDS write, so the B-fragment reads are plain loads, requested a step ahead;
-//   * epilogue acc * oscale[cout] + bias (oscale = weight scale / in_qscale), then conv3x3_rp_kernel's.
-// Definition and tolerances of the fp8 model: DESIGN.md section 5 (identical to conv3x3_patch_fp8_kernel's).
-constexpr int kR8Steps = 9 * kRCin / 64;                // 36
-constexpr int kR8Ring = 4;                              // steps of A fragments in flight per wave (2 loads each)
-constexpr int kR8Line = 36 * 64;
-constexpr int kR8Slab = kRRows * kR8Line;               // 13 824 B
-constexpr int kR8OffStat = 4 * kR8Slab;                 // GN_INPUT statistics: 2 x [32][2] fp32
-constexpr int kR8OffGB = kR8OffStat + 512;              // gamma [256], beta [256]
-constexpr int kR8OffBias = kR8OffGB + 2048;             // bias [Cout <= 1024]
-constexpr int kR8OffOsc = kR8OffBias + kRMaxCout * 4;   // oscale [Cout <= 1024]
-constexpr int kR8OffRed = kR8OffOsc + kRMaxCout * 4;
-constexpr int kR8OffFin = kR8OffRed + 512;
-constexpr int kR8Smem = kR8OffFin + 32 * 32 * 2 * 4;
-static_assert(kR8Smem <= 80 * 1024, "LDS budget");
-
-// vector-memory program order of a wave inside a tile: step s: [wait A(s)] MFMAs | A(s + 4): 2 loads | r8_post(s): one raw
-// pixel load of the next tile's slab s / 9 at steps 9 sl + 2 .. 9 sl + 5; the tile's 8 row stores after step 35
-constexpr int r8_post(int s) {
-    const int u = s % 9;
-    return ((u >= 2 && u < 6) ? 1 : 0) + (s == kR8Steps - 1 ? 8 : 0);
-}
-constexpr int r8_wait(int j, bool first) {
-    int n = 0;
-    if (first && j < kR8Ring) {
-        n += 2 * (kR8Ring - 1 - j);
-        for (int s = 0; s < j; s++) n += 2 + r8_post(s);
-        return n;
-    }
-    n += r8_post((j - kR8Ring + kR8Steps) % kR8Steps);
-    for (int s = j - kR8Ring + 1; s < j; s++) n += 2 + r8_post((s + kR8Steps) % kR8Steps);
-    return n;
-}
-static_assert(r8_wait(0, true) == 6 && r8_wait(3, true) == 7 && r8_wait(0, false) == 15 && r8_wait(1, false) == 14 && r8_wait(3, false) == 15 &&
-              r8_wait(4, false) == 8 && r8_wait(6, false) == 10 && r8_wait(9, false) == 7 && r8_wait(10, false) == 6 && r8_wait(35, false) == 8,
-              "vmcnt bookkeeping");
-
-typedef __attribute__((ext_vector_type(4))) int i32x4;
-
-template <int J>
-__device__ __forceinline__ void r8_load(i32x4 (&alo)[kR8Ring], i32x4 (&ahi)[kR8Ring], const char* wf, unsigned voff) {
-    const char* sb = wf + (size_t)(J % kR8Steps) * 2048;
-    asm volatile("global_load_dwordx4 %0, %2, %3\n\tglobal_load_dwordx4 %1, %2, %3 offset:1024"
-                 : "+v"(alo[J % kR8Ring]), "+v"(ahi[J % kR8Ring]) : "v"(voff), "s"(sb) : "memory");      // "+v": see rp_load
-}
-template <int J>
-__device__ __forceinline__ void r8_wait_for(i32x4 (&alo)[kR8Ring], i32x4 (&ahi)[kR8Ring], bool /*first*/) {
-    // ONE wait per step for every tile (round 5): `if (first) wait(kF) else wait(kN)` on the ring registers made the compiler put
-    // a copy of them in front of one of the two waits (conv3x3_rp_kernel: rp_wait).  In the ring's first steps the first tile
-    // and the steady state differ in what sits behind the fragment in the queue; the SMALLER count is right for both (it only
-    // asks for more of the queue to have retired).
-    constexpr int kN = r8_wait(J, false);
-    constexpr int kF = J < kR8Ring ? r8_wait(J, true) : kN;
-    constexpr int kW = kF < kN ? kF : kN;
-    asm volatile("s_waitcnt vmcnt(%2)" : "+v"(alo[J % kR8Ring]), "+v"(ahi[J % kR8Ring]) : "n"(kW) : "memory");
-}
-
-template <bool GNIN>
-__global__ void __launch_bounds__(512, 2) conv3x3_rp8_kernel(ConvDev P, char* dump) {
-    constexpr int NT = 512, NW = 8;
-    extern __shared__ __attribute__((aligned(16))) char lds[];
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int frow = lane & 31, half = lane >> 5;
-    const int lane_ = lane;
-    const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) char*)lds;
-
-    const int T = P.mtiles * P.ntiles;
-    const int G = (int)gridDim.x;
-    const int pos = xcd_remap(blockIdx.x, G);
-    const int nmine = (T - pos + G - 1) / G;
-
-    auto decode = [&](int t) {
-        RpTile c;
-        c.valid = t < T;
-        t = t < T ? t : T - 1;
-        c.grp = 0;
-        c.nt = t % P.ntiles;
-        c.mt = t / P.ntiles;
-        int si = 0;
-#pragma unroll
-        for (int k = 1; k < kMaxSegs; k++)
-            if (k < P.n_segs && c.mt >= P.seg[k].tile0) si = k;
-        c.si = si;
-        const SegDev& S = P.seg[si];
-        const int tloc = c.mt - S.tile0;
-        c.img = tloc / S.tiles_per_img;
-        const int tt = tloc - c.img * S.tiles_per_img;
-        const int ty = tt / S.tiles_x;
-        c.Y0 = ty * kRH;
-        c.X0 = (tt - ty * S.tiles_x) * kRW;
-        c.H = S.Hout;
-        c.W = S.Wout;
-        return c;
-    };
-
-    // ---- raw pixel loads: piece pc = 8 consecutive patch pixels, lane = (pixel lane >> 3, 8-channel group lane & 7); wave w takes
-    // pieces w, w + 8, w + 16, w + 24 of every slab (waves 2..7 re-load their third piece instead of a fourth and do not convert it)
-    int ppc[4];
-#pragma unroll
-    for (int ii = 0; ii < 4; ii++) {
-        int pc = wave + NW * ii;
-        if (pc >= kRPieces) pc -= NW;
-        ppc[ii] = pc;
-    }
-    const char* praw[4];                                   // per-lane source of the tile whose patch is being fetched (slab 0)
-    auto patch_map = [&](const RpTile& c) {
-        int lane = lane_;
-        asm volatile("" : "+v"(lane));
-        const int Hp = c.H + 2, Wp = c.W + 2;
-        const unsigned max_pix = (unsigned)(P.N * Hp * Wp - 1);
-#pragma unroll
-        for (int ii = 0; ii < 4; ii++) {
-            const int pp = ppc[ii] * 8 + (lane >> 3);
-            const int p = pp / kRCols, q = pp - p * kRCols;
-            unsigned g = (unsigned)((c.img * Hp + c.Y0 + p) * Wp + c.X0 + q);
-            g = g < max_pix ? g : max_pix;
-            praw[ii] = P.seg[c.si].in + (size_t)g * (kRCin * 2) + (lane & 7) * 16;
-        }
-    };
-    u32x4 raw[2][4];                                       // slab parity, piece
-#pragma unroll
-    for (int k = 0; k < 8; k++) raw[k >> 2][k & 3] = u32x4{0u, 0u, 0u, 0u};
-    auto raw_load = [&](int sl, int ii) {
-        asm volatile("global_load_dwordx4 %0, %1, off" : "+v"(raw[sl & 1][ii]) : "v"(praw[ii] + sl * 128) : "memory");      // "+v": see rp_load
-    };
-    const float qs = P.in_qscale;
-    // one landed piece (registers) -> optional GroupNorm + ReLU -> e4m3 -> the patch of slab sl (8 bytes per lane)
-    auto convert = [&](const RpTile& c, int sl, int ii, int statbuf) {
-        if (ii == 3 && wave + 3 * NW >= kRPieces) return;                 // the duplicate load
-        int lane = lane_;
-        asm volatile("" : "+v"(lane), "+v"(raw[sl & 1][ii]));             // the covering vmcnt wait is behind us: the data is here
-        const int pp = ppc[ii] * 8 + (lane >> 3);
-        const int p = pp / kRCols, q = pp - p * kRCols;
-        const int gy = c.Y0 + p, gx = c.X0 + q;
-        const bool inside = gy >= 1 && gy <= c.H && gx >= 1 && gx <= c.W && pp < kRRows * kRCols;
-        const int lc = lane & 7;
-        const u32x4 v = raw[sl & 1][ii];
-        float x[8];
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-            x[2 * k] = bf2f((unsigned short)(v[k] & 0xffff));
-            x[2 * k + 1] = bf2f((unsigned short)(v[k] >> 16));
-        }
-        if (GNIN) {
-            const int ch = sl * kBK + lc * 8;
-            const unsigned ts = lds_base + (unsigned)(kR8OffStat + statbuf * 256 + (ch >> 3) * 8);
-            const unsigned tg = lds_base + (unsigned)(kR8OffGB + ch * 4);
-            const unsigned tb = tg + (unsigned)kRCin * 4u;
-            u32x2 ms;
-            f32x4 g0, g1, b0, b1;
-            asm volatile("ds_read_b64 %0, %5\n\tds_read_b128 %1, %6\n\tds_read_b128 %2, %6 offset:16\n\t"
-                         "ds_read_b128 %3, %7\n\tds_read_b128 %4, %7 offset:16\n\ts_waitcnt lgkmcnt(0)"
-                         : "=&v"(ms), "=&v"(g0), "=&v"(g1), "=&v"(b0), "=&v"(b1)
-                         : "v"(ts), "v"(tg), "v"(tb)
-                         : "memory");
-            const float gmean = __uint_as_float(ms.x), grstd = __uint_as_float(ms.y);
-#pragma unroll
-            for (int k = 0; k < 4; k++) {
-                x[k] = fmaxf((x[k] - gmean) * grstd * g0[k] + b0[k], 0.f);              // expression of gn_apply_kernel
-                x[4 + k] = fmaxf((x[4 + k] - gmean) * grstd * g1[k] + b1[k], 0.f);
-            }
-        }
-        float y[8];
-#pragma unroll
-        for (int k = 0; k < 8; k++) y[k] = inside ? fminf(fmaxf(x[k] * qs, -448.f), 448.f) : 0.f;
-        unsigned o0 = 0u, o1 = 0u;
-        o0 = __builtin_amdgcn_cvt_pk_fp8_f32(y[0], y[1], o0, false);
-        o0 = __builtin_amdgcn_cvt_pk_fp8_f32(y[2], y[3], o0, true);
-        o1 = __builtin_amdgcn_cvt_pk_fp8_f32(y[4], y[5], o1, false);
-        o1 = __builtin_amdgcn_cvt_pk_fp8_f32(y[6], y[7], o1, true);
-        const u32x2 o = {o0, o1};
-        const unsigned qd = lds_base + (unsigned)(sl * kR8Slab + p * kR8Line + q * 64 + (((lc >> 1) ^ ((q >> 2) & 3)) * 16) + (lc & 1) * 8);
-        if (pp < kRRows * kRCols) asm volatile("ds_write_b64 %0, %1" ::"v"(qd), "v"(o) : "memory");
-    };
-    auto stat_load = [&](const RpTile& c, int b) {          // mean / rstd of tile c's image -> stat buffer b (plain loads by wave 0:
-        if (GNIN && tid < 64) {                             //  an uncounted extra load only makes wave 0's waits stricter)
-            const float* st = P.in_stats + ((size_t)c.si * P.N + c.img) * (kRCin / 8) * 2;
-            ((float*)(lds + kR8OffStat + b * 256))[tid] = __builtin_nontemporal_load(st + tid);
-        }
-    };
-
-    // ---- B fragment offsets inside a patch line: pixel column q = frow + kw, 16-byte chunks 2 half, 2 half + 1
-    unsigned bo[3][2];
-#pragma unroll
-    for (int kw = 0; kw < 3; kw++)
-#pragma unroll
-        for (int jj = 0; jj < 2; jj++) {
-            const int q = frow + kw;
-            bo[kw][jj] = (unsigned)(q * 64 + (((2 * half + jj) ^ ((q >> 2) & 3)) * 16));
-        }
-    auto bread = [&](i32x8 (&b)[4], int j) {                // step j = (slab, kh, kw): patch lines kh .. kh + 3
-        const int sl = j / 9, t = j % 9, kh = t / 3, kw = t % 3;
-#pragma unroll
-        for (int r = 0; r < 4; r++) {
-            const char* base = lds + sl * kR8Slab + (r + kh) * kR8Line;
-            const i32x4 lo = *(const i32x4*)(base + bo[kw][0]), hi = *(const i32x4*)(base + bo[kw][1]);
-            b[r] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
-        }
-    };
-
-    const unsigned voff = (unsigned)(wave * kR8Steps * 2048 + lane * 16);
-    i32x4 alo[kR8Ring], ahi[kR8Ring];
-#pragma unroll
-    for (int k = 0; k < kR8Ring; k++) alo[k] = ahi[k] = i32x4{0, 0, 0, 0};
-    auto barrier = [&]() {
-        __builtin_amdgcn_sched_barrier(0);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        __builtin_amdgcn_sched_barrier(0);
-    };
-
-    const bool relu = P.flags & DAFNE_CONV_RELU;
-    const float relu_lo = relu ? 0.f : -__builtin_inff();
-    const bool gn = P.flags & DAFNE_CONV_GN_STATS;
-    const bool fin = gn && (P.flags & DAFNE_CONV_GN_FINALIZE);
-    const int G8 = P.Cout / 8;
-
-    // ---- prologue: layer constants -> LDS; the first tile's patch slab by slab through the registers
-    RpTile cur = decode(pos);
-    {
-        float* gb = (float*)(lds + kR8OffGB);
-        float* lb = (float*)(lds + kR8OffBias);
-        float* lo = (float*)(lds + kR8OffOsc);
-        if (GNIN && tid < kRCin) {
-            gb[tid] = P.in_gamma[tid];
-            gb[kRCin + tid] = P.in_beta[tid];
-        }
-        for (int k = tid; k < P.Cout; k += NT) {
-            lb[k] = P.bias[k];
-            lo[k] = P.oscale[k];
-        }
-        if (GNIN && tid < 64) ((float*)(lds + kR8OffStat))[tid] = (P.in_stats + ((size_t)cur.si * P.N + cur.img) * (kRCin / 8) * 2)[tid];
-        __syncthreads();
-    }
-    patch_map(cur);
-#pragma unroll
-    for (int sl = 0; sl < 4; sl++) {
-#pragma unroll
-        for (int ii = 0; ii < 4; ii++) raw_load(sl, ii);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#pragma unroll
-        for (int ii = 0; ii < 4; ii++) convert(cur, sl, ii, 0);
-    }
-    const char* wf0 = P.w + (size_t)cur.nt * (NW * kR8Steps * 2048);
-    rp_static_for<0, kR8Ring>([&](auto J) { r8_load<decltype(J)::value>(alo, ahi, wf0, voff); });
-
-    f32x16 acc[4];
-    i32x8 bfr[2][4];
-    float gsum[4], gsq[4];
-#pragma unroll
-    for (int g = 0; g < 4; g++) gsum[g] = gsq[g] = 0.f;
-    RpTile prv = cur;
-    prv.valid = 0;
-
-    auto gn_publish = [&]() {
-        if (gn && prv.valid && tid < 32) {
-            int td = tid;
-            asm volatile("" : "+v"(td));
-            const float* redb = (const float*)(lds + kR8OffRed);
-            const float sv = redb[td * 2 + 0], qv = redb[td * 2 + 1];
-            float* o = P.gn_partial + ((size_t)prv.mt * G8 + prv.nt * 32 + td) * 2;
-            if (fin) {
-                typedef unsigned long long u64a;
-                const u64a vv = ((u64a)__float_as_uint(qv) << 32) | (u64a)__float_as_uint(sv);
-                __hip_atomic_store((u64a*)o, vv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            } else {
-                o[0] = sv;
-                o[1] = qv;
-            }
-        }
-    };
-    auto gn_ticket = [&]() {
-        if (fin && tid == 0) {
-            int last = 0;
-            if (prv.valid) {
-                const int old = __hip_atomic_fetch_add(P.gn_counters + prv.si * P.N + prv.img, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                last = old == P.seg[prv.si].tiles_per_img - 1;
-            }
-            *(int*)(lds + kR8OffRed + 256) = last;
-        }
-    };
-    auto gn_last_tile = [&]() {
-        if (fin && *(const int*)(lds + kR8OffRed + 256)) {
-            typedef unsigned long long u64a;
-            const SegDev& S = P.seg[prv.si];
-            float* scratch = (float*)(lds + kR8OffFin);
-            const int t0 = S.tile0 + prv.img * S.tiles_per_img;
-            const int g = tid & 31;
-#pragma unroll
-            for (int kk = 0; kk < 2; kk++) {
-                const int sl2 = (tid >> 5) + 16 * kk;
-                float sum = 0.f, sqs = 0.f;
-                if (g < G8)
-                    for (int tt = sl2; tt < S.tiles_per_img; tt += 32) {
-                        const u64a vv = __hip_atomic_load((const u64a*)(P.gn_partial + ((size_t)(t0 + tt) * G8 + g) * 2), __ATOMIC_RELAXED,
-                                                          __HIP_MEMORY_SCOPE_AGENT);
-                        sum += __uint_as_float((unsigned)vv);
-                        sqs += __uint_as_float((unsigned)(vv >> 32));
-                    }
-                scratch[(sl2 * 32 + g) * 2 + 0] = sum;
-                scratch[(sl2 * 32 + g) * 2 + 1] = sqs;
-            }
-            __syncthreads();
-            if (tid < 32 && tid < G8) {
-                float a = 0.f, b = 0.f;
-#pragma unroll
-                for (int kk = 0; kk < 32; kk++) {
-                    a += scratch[(kk * 32 + tid) * 2 + 0];
-                    b += scratch[(kk * 32 + tid) * 2 + 1];
-                }
-                const float cnt = (float)(S.Hout * S.Wout * 8);
-                const float mean = a / cnt;
-                float var = b / cnt - mean * mean;
-                var = var > 0.f ? var : 0.f;
-                float* o = P.gn_stats_out + (((size_t)prv.si * P.N + prv.img) * G8 + tid) * 2;
-                o[0] = mean;
-                o[1] = rsqrtf(var + P.gn_eps);
-            }
-            if (tid == 0) __hip_atomic_store(P.gn_counters + prv.si * P.N + prv.img, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __syncthreads();
-        }
-    };
-    auto gn_reduce_write = [&]() {
-        if (gn && lane == 63) {
-            float* redb = (float*)(lds + kR8OffRed);
-#pragma unroll
-            for (int g = 0; g < 4; g++) {
-                redb[(wave * 4 + g) * 2 + 0] = gsum[g];
-                redb[(wave * 4 + g) * 2 + 1] = gsq[g];
-            }
-        }
-    };
-
-    for (int k = 0; k < nmine; k++) {
-        const bool first = k == 0;
-        const RpTile nxt = decode(pos + (k + 1 < nmine ? k + 1 : k) * G);
-        const char* wf_cur = P.w + (size_t)cur.nt * (NW * kR8Steps * 2048);
-        const char* wf_nxt = P.w + (size_t)nxt.nt * (NW * kR8Steps * 2048);
-        const int sb_cur = k & 1, sb_nxt = (k + 1) & 1;
-#pragma unroll
-        for (int b = 0; b < 4; b++)
-#pragma unroll
-            for (int kk = 0; kk < 16; kk++) acc[b][kk] = 0.f;
-
-        rp_static_for<0, kR8Steps>([&](auto J) {
-            constexpr int j = decltype(J)::value;
-            constexpr int u = j % 9, sl = j / 9;
-            r8_wait_for<j>(alo, ahi, first);
-            if constexpr (u == 0) barrier();                    // slab sl - 1 is retired (step 0: the previous tile, and its slab 3)
-            // ---- the next tile's patch: slab sl - 1 converted into the place that has just been retired; the current tile's slab 3
-            // (loaded during the previous tile) behind the first barrier
-            if constexpr (j < 4) { if (!first) convert(cur, 3, j, sb_cur); }
-            if constexpr (sl >= 1 && u < 4) convert(nxt, sl - 1, u, sb_nxt);
-            if constexpr (j == 1) { patch_map(nxt); stat_load(nxt, sb_nxt); }
-            // ---- the previous tile's GroupNorm sums
-            if constexpr (j >= 4 && j < 8) {
-                if (gn) {
-                    gsum[j - 4] = rp_wave_total(gsum[j - 4]);
-                    gsq[j - 4] = rp_wave_total(gsq[j - 4]);
-                }
-            }
-            if constexpr (j == 8) gn_reduce_write();
-            if constexpr (j == 10) gn_publish();                // behind the barrier of step 9
-            if constexpr (j == 17) gn_ticket();                 // wave 0's waits since step 15 cover its partial-sum stores of step 10
-            if constexpr (j == 19) gn_last_tile();              // behind the barrier of step 18
-            // ---- matrix work: B fragments of step j + 1 are requested before the MFMAs of step j
-            if constexpr (j == 0) bread(bfr[0], 0);
-            if constexpr (j + 1 < kR8Steps) bread(bfr[(j + 1) & 1], j + 1);
-            const i32x8 a = __builtin_shufflevector(alo[j % kR8Ring], ahi[j % kR8Ring], 0, 1, 2, 3, 4, 5, 6, 7);
-#pragma unroll
-            for (int r = 0; r < 4; r++)
-                acc[r] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, bfr[j & 1][r], acc[r], 0, 0, 0, 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
-            r8_load<j + kR8Ring>(alo, ahi, j + kR8Ring < kR8Steps ? wf_cur : wf_nxt, voff);
-            if constexpr (u >= 2 && u < 6) raw_load(sl, u - 2);
-            __builtin_amdgcn_sched_barrier(0);
-        });
-        barrier();                                              // every wave is done with slab 3
-        {
-            f32x4 bia4[4], osc4[4];
-            const unsigned bad = lds_base + (unsigned)(kR8OffBias + (cur.nt * 256 + wave * 32 + 4 * half) * 4);
-            const unsigned oad = lds_base + (unsigned)(kR8OffOsc + (cur.nt * 256 + wave * 32 + 4 * half) * 4);
-            asm volatile("ds_read_b128 %0, %8\n\tds_read_b128 %1, %8 offset:32\n\tds_read_b128 %2, %8 offset:64\n\tds_read_b128 %3, %8 offset:96\n\t"
-                         "ds_read_b128 %4, %9\n\tds_read_b128 %5, %9 offset:32\n\tds_read_b128 %6, %9 offset:64\n\tds_read_b128 %7, %9 offset:96\n\t"
-                         "s_waitcnt lgkmcnt(0)"
-                         : "=&v"(bia4[0]), "=&v"(bia4[1]), "=&v"(bia4[2]), "=&v"(bia4[3]), "=&v"(osc4[0]), "=&v"(osc4[1]), "=&v"(osc4[2]), "=&v"(osc4[3])
-                         : "v"(bad), "v"(oad)
-                         : "memory");
-#pragma unroll
-            for (int g = 0; g < 4; g++) gsum[g] = gsq[g] = 0.f;
-            const int Wp = cur.W + 2;
-            const size_t rowpitch = (size_t)Wp * P.Cout * 2;
-            char* obase = P.seg[cur.si].out + ((size_t)(cur.img * (cur.H + 2) + cur.Y0 + 1) * Wp + cur.X0 + frow + 1) * P.Cout * 2
-                          + (cur.nt * 256 + wave * 32 + 8 * half) * 2;
-            char* dbase = dump + (size_t)tid * 128;
-            const bool colok = cur.valid && (cur.X0 + frow) < cur.W;
-#pragma unroll
-            for (int b = 0; b < 4; b++) {
-                const bool valid = colok && (cur.Y0 + b) < cur.H;
-                u32x2 pk[4];
-#pragma unroll
-                for (int g = 0; g < 4; g++) {
-                    // (branch-free: ReLU as a max with 0 / -inf, the GroupNorm sums added under a select -- x + 0 is exact; round 5)
-                    const float v0 = fmaxf(acc[b][4 * g] * osc4[g][0] + bia4[g][0], relu_lo), v1 = fmaxf(acc[b][4 * g + 1] * osc4[g][1] + bia4[g][1], relu_lo);
-                    const float v2 = fmaxf(acc[b][4 * g + 2] * osc4[g][2] + bia4[g][2], relu_lo), v3 = fmaxf(acc[b][4 * g + 3] * osc4[g][3] + bia4[g][3], relu_lo);
-                    gsum[g] += valid ? (v0 + v1) + (v2 + v3) : 0.f;
-                    gsq[g] += valid ? (v0 * v0 + v1 * v1) + (v2 * v2 + v3 * v3) : 0.f;
-                    pk[g].x = pack_bf16(v0, v1);
-                    pk[g].y = pack_bf16(v2, v3);
-                }
-#pragma unroll
-                for (int gp = 0; gp < 2; gp++) {
-                    u32x2 a = pk[2 * gp], c2 = pk[2 * gp + 1];
-                    const auto r0 = __builtin_amdgcn_permlane32_swap(a.x, c2.x, false, false);
-                    const auto r1 = __builtin_amdgcn_permlane32_swap(a.y, c2.y, false, false);
-                    const u32x4 v = {r0[0], r1[0], r0[1], r1[1]};
-                    char* ad = valid ? obase + b * rowpitch + gp * 32 : dbase + (b * 2 + gp) * 16;
-                    *(u32x4*)ad = v;
-                }
-            }
-        }
-        prv = cur;
-        cur = nxt;
-    }
-
-    // ---- the last tile's GroupNorm sums, straight-line
-    if (gn) {
-#pragma unroll
-        for (int g = 0; g < 4; g++) {
-            gsum[g] = rp_wave_total(gsum[g]);
-            gsq[g] = rp_wave_total(gsq[g]);
-        }
-        gn_reduce_write();
-        barrier();
-        gn_publish();
-        if (fin) {
-            if (tid < 64) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            gn_ticket();
-            barrier();
-            gn_last_tile();
-        }
-    }
-}
-
-// ---------------------------------------------------------------------------------------
 // 3x3 stride-1 convolution with <= 32 output channels and fp32 NHWC output: the prediction convolutions of
 // the head (cls_logits 15, center_pred 2, corners_pred+ctrness 9; dafne.py:318-344).  1/8 of a tower layer's
 // MFMA work on the same input bytes: these layers are bound by operand staging and barriers, not by the matrix
@@ -4093,17 +3633,6 @@ int launch_rp(const ConvDev& D, const ConvDev* D2, char* dump, hipStream_t st) {
     return dafne::check_launch("conv3x3_rp");
 }
 
-int launch_rp8(const ConvDev& D, char* dump, hipStream_t st) {
-    DAFNE_MAX_LDS_ONCE(kR8Smem, (const void*)conv3x3_rp8_kernel<false>, (const void*)conv3x3_rp8_kernel<true>);
-    int cus = 0;
-    if (int rc = dafne::device_cus(&cus)) return rc;
-    const int T = D.mtiles * D.ntiles;
-    const int rounds = (T + cus - 1) / cus;                // balanced persistent grid, as launch_rp
-    const dim3 grid((T + rounds - 1) / rounds), block(512);
-    if (D.flags & DAFNE_CONV_GN_INPUT) hipLaunchKernelGGL(conv3x3_rp8_kernel<true>, grid, block, kR8Smem, st, D, dump);
-    else hipLaunchKernelGGL(conv3x3_rp8_kernel<false>, grid, block, kR8Smem, st, D, dump);
-    return dafne::check_launch("conv3x3_rp8");
-}
 
 // the slab kernel's persistent 16-channel form takes the head's prediction layers (256 -> <= 16 channels)
 bool pred16_ok(const ConvDev& D) {
@@ -4266,19 +3795,6 @@ int dafne_conv3x3_c256_hip(const dafne_conv_params* prm, const dafne_conv_seg* s
     return launch_rp(D, nullptr, (char*)d_scratch, (hipStream_t)stream);
 }
 
-int dafne_conv3x3_c256_fp8w_hip(const dafne_conv_params* prm, const dafne_conv_seg* segs, const void* d_wfrag8, const float* d_oscale,
-                                float in_qscale, void* d_scratch, size_t scratch_bytes, void* stream) {
-    ConvDev D;
-    int rc = build(D, prm, segs, false, true);
-    if (rc) return rc;
-    if (!d_wfrag8 || !d_oscale) return dafne::fail(DAFNE_E_INVALID, "conv3x3_c256_fp8w: null weights / output scale");
-    if (!(in_qscale > 0.f)) return dafne::fail(DAFNE_E_INVALID, "conv3x3_c256_fp8w: in_qscale must be positive");
-    if (!d_scratch || scratch_bytes < (size_t)kRDumpBytes) return dafne::fail(DAFNE_E_WORKSPACE, "conv3x3_c256_fp8w: scratch %zu < %d", scratch_bytes, kRDumpBytes);
-    D.w = (const char*)d_wfrag8;
-    D.oscale = d_oscale;
-    D.in_qscale = in_qscale;
-    return launch_rp8(D, (char*)d_scratch, (hipStream_t)stream);
-}
 
 int dafne_conv3x3_c256_pair_hip(const dafne_conv_params* prm_a, const dafne_conv_seg* segs_a, const void* d_wfrag_a,
                                 const dafne_conv_params* prm_b, const dafne_conv_seg* segs_b, const void* d_wfrag_b,

@@ -243,37 +243,7 @@ def pack_conv_frag(w):
     return w.reshape(cout // 256, 8, 32, k // 16, 2, 8).permute(0, 1, 3, 4, 2, 5).contiguous().reshape(-1)   # nt, w, j, h, r, e
 
 
-def pack_conv3x3_frag8(qb):
-    """Fragment-major e4m3 weights of dafne_conv3x3_c256_fp8w_hip from pack_conv_fp8's bytes ([Cout, 2304] uint8, K order slab,
-    kh, kw, channel): [Cout/256][8 waves][36 steps][2][64 lanes][16]: rows nt*256 + wave*32 + (lane & 31), K bytes 64*step +
-    32*(lane >> 5) + 16*j .. +16."""
-    cout = qb.shape[0]
-    assert qb.dim() == 2 and qb.shape[1] == 2304 and cout % 256 == 0 and qb.dtype == torch.uint8
-    return qb.reshape(cout // 256, 8, 32, 36, 2, 2, 16).permute(0, 1, 3, 5, 4, 2, 6).contiguous().reshape(-1)   # nt, w, step, j, half, r, b
-
-
-def frag8_of(P, key):
-    """pack_conv3x3_frag8 of the e4m3 weight P[key + ".fp8"], built once and stored NEXT TO it in the packed-weights dict
-    (key + ".fp8.frag", like the bf16 ".frag" copies): it dies with the weights on invalidate() / a re-pack."""
-    fk = key + ".fp8.frag"
-    if fk not in P:
-        P[fk] = pack_conv3x3_frag8(P[key + ".fp8"][0])
-    return P[fk]
-
-
-FP8_KERNELS = ("patch", "rp8")
-
-
-def fp8_conv3x3_kernel(P):
-    """Which kernel runs the fp8 model's 3x3 layers with 256 input channels: "patch" (conv3x3_patch_fp8_kernel) or "rp8"
-    (conv3x3_rp8_kernel: persistent, fp8 resident patch).  The two round the same sums differently (2 bf16 ulps), so the choice
-    is PART OF THE MODEL (cfg.ENGINE.FP8_CONV3X3_KERNEL -> P["fp8_kernel"], fixed when the weights are packed): every plan of a
-    model -- whole batch, sub-batches of the pipelined step, TTA chunks -- uses the same one and serial == pipelined holds.
-    DAFNE_CONV_RP8=1 / 0 overrides it for the whole process (A/B runs)."""
-    v = os.environ.get("DAFNE_CONV_RP8")
-    if v is not None:
-        return "rp8" if v != "0" else "patch"
-    return P.get("fp8_kernel", "patch")
+FP8_KERNELS = ("patch",)
 
 
 _RP_SCRATCH = {}
@@ -368,7 +338,7 @@ class ConvCall:
     """One dafne_conv2d_nhwc_bf16_hip launch with its argument structs kept alive."""
 
     def __init__(self, w, b, cin, cout, k, stride, pad, flags, segs, n_images, gn_partial=None, gn_in=None, fp8=None,
-                 gn_fin=None, wfrag=None, shared_gpu=False, frag8=None):
+                 gn_fin=None, wfrag=None, shared_gpu=False):
         """gn_in: (stats [n_segs,N,Cin/8,2], gamma [Cin], beta [Cin]) of the INPUT maps when they hold the raw
         output of the previous tower convolution (flag F_GNIN: GroupNorm + ReLU applied on load).
         fp8: (oscale fp32 [Cout], in_qscale) -> `w` holds e4m3 bytes (pack_conv_fp8) and the call goes to
@@ -377,14 +347,11 @@ class ConvCall:
         tile of every image finalises the GroupNorm statistics of the OUTPUT (no dafne_groupnorm_finalize_hip launch).
         wfrag: fragment-major bf16 weights (pack_conv3x3_frag) -> the call goes to dafne_conv3x3_c256_hip (resident-patch
         kernel: 3x3 s1 p1, Cin 256, Cout % 256 == 0; its own tile geometry).
-        shared_gpu: the plan this call belongs to runs next to other plans on concurrent streams (no F_EXCL hint).
-        frag8: fragment-major e4m3 weights (frag8_of) -> an fp8 call the resident-patch kernel can take goes to
-        dafne_conv3x3_c256_fp8w_hip (the model's FP8_CONV3X3_KERNEL == "rp8")."""
+        shared_gpu: the plan this call belongs to runs next to other plans on concurrent streams (no F_EXCL hint)."""
         L = _lib.load()
         self.fp8 = fp8
         self.wfrag = wfrag
         assert fp8 is None or wfrag is None
-        self.rp8 = None             # fp8 call on the resident-patch kernel: fragment-major e4m3 weights (decided below)
         self.keep = (w, b, gn_partial, [s for s in segs], gn_in, fp8, gn_fin, wfrag)
         gi = [t.data_ptr() for t in gn_in] if gn_in is not None else [None, None, None]
         gf = (gn_fin[0].data_ptr(), gn_fin[1].data_ptr(), float(gn_fin[2])) if gn_fin is not None else (None, None, 0.0)
@@ -400,8 +367,6 @@ class ConvCall:
                                   hin, win, hout, wout)
         self.segs = arr
         self.fn = L.dafne_conv2d_nhwc_bf16_hip
-        if fp8 is not None and frag8 is not None and cin == 256 and k == 3 and L.dafne_conv3x3_c256_ok(ctypes.byref(self.prm), self.segs):
-            self.rp8 = frag8
         self.flops = 0
         self.bytes = w.numel() * w.element_size()       # algorithmic HBM bytes: every operand once
         for (_, tout, tres, hin, win, hout, wout) in segs:
@@ -416,7 +381,7 @@ class ConvCall:
         return self.fp8 is None and bool(_lib.load().dafne_conv3x3_c256_ok(ctypes.byref(self.prm), self.segs))
 
     def num_tiles(self):
-        if self.wfrag is not None or self.rp8 is not None:
+        if self.wfrag is not None:
             return _lib.load().dafne_conv3x3_c256_num_tiles(ctypes.byref(self.prm), self.segs)
         if self.fp8 is not None:
             return _lib.load().dafne_conv2d_fp8w_num_tiles(ctypes.byref(self.prm), self.segs)
@@ -434,8 +399,6 @@ class ConvCall:
 
     def kernel_name(self):
         """The HIP kernel this call dispatches to (conv.hip), for per-kernel attribution in bench.py."""
-        if self.rp8 is not None:
-            return "conv3x3_rp8"
         if self.fp8 is not None:
             return "conv3x3_patch_fp8"
         if self.wfrag is not None:
@@ -445,19 +408,12 @@ class ConvCall:
     def tiles_per_image(self):
         out = (ctypes.c_int32 * self.prm.n_segs)()
         fn = _lib.load().dafne_conv2d_fp8w_tiles_per_image if self.fp8 is not None else _lib.load().dafne_conv2d_tiles_per_image
-        if self.wfrag is not None or self.rp8 is not None:
+        if self.wfrag is not None:
             fn = _lib.load().dafne_conv3x3_c256_tiles_per_image
         _lib.check(fn(ctypes.byref(self.prm), self.segs, out), "dafne_conv2d_tiles_per_image")
         return list(out)
 
     def __call__(self, stream):
-        if self.rp8 is not None:
-            scr = rp_scratch(self.rp8.device)
-            rc = _lib.load().dafne_conv3x3_c256_fp8w_hip(ctypes.byref(self.prm), self.segs, _lib.ptr(self.rp8), _lib.ptr(self.fp8[0]),
-                                                         ctypes.c_float(self.fp8[1]), _lib.ptr(scr), scr.numel(), stream)
-            if rc:
-                _lib.check(rc, "dafne_conv3x3_c256_fp8w_hip")
-            return
         if self.fp8 is not None:
             rc = _lib.load().dafne_conv2d_nhwc_fp8w_hip(ctypes.byref(self.prm), self.segs, _lib.ptr(self.fp8[0]),
                                                         ctypes.c_float(self.fp8[1]), stream)
@@ -610,7 +566,6 @@ class DensePlan:
         self.pool = pool
 
         act_q8 = P.get("act_q8") or {}
-        rp8_on = fp8_conv3x3_kernel(P) == "rp8"
         wr_on = use_wr_kernel()
         self.wr_ws = WrWorkspace(device)
         # conv3x3_c64.hip: 65 -> 49 us per launch when it has the GPU to itself, but nothing in the timed 3-stream layout (its
@@ -655,7 +610,7 @@ class DensePlan:
                     fp8 = (q8[1] / act_q8[key], act_q8[key])       # oscale = weight scale / in_qscale
             c = ConvCall(q8[0] if fp8 else wgt, bias, cin, cout, k, stride, pad, flags,
                          [(tin.t, o.t, res.t if res is not None else None, tin.h, tin.w, ho, wo)], n, fp8=fp8,
-                         shared_gpu=self.shared_gpu, frag8=frag8_of(P, key) if (fp8 and rp8_on and cin == 256 and k == 3) else None)
+                         shared_gpu=self.shared_gpu)
             if (fp8 is None and wr_on and wr_takes(k, stride, cin, cout, WR_NOMINAL_BATCH * ho * wo) and bias is not None
                     and L.dafne_conv2d_wr_ok(ctypes.byref(c.prm), c.segs)):
                 # small-M layer (res5, FPN top): 128 px x 256 ch tiles, weights -> registers, split-K
@@ -1032,7 +987,6 @@ class HeadPlan:
         self.num_classes = num_classes
         calls = plan.calls
         sg = bool(getattr(plan, "shared_gpu", False))
-        rp8_on = fp8_conv3x3_kernel(P) == "rp8"
         fuse_gn = os.environ.get("DAFNE_FUSE_GN", "1") != "0"
         fuse_gnfin = os.environ.get("DAFNE_FUSE_GNFIN", "1") != "0"
 
@@ -1085,7 +1039,7 @@ class HeadPlan:
                     probe = ConvCall(wgt, bias, C, C, 3, 1, 1, flags & ~F_GN, seg_list(cur, outs), n, gn_in=cur_gn, wfrag=wfrag, shared_gpu=sg)
                 if use_fp8:
                     probe = ConvCall(q8[0], bias, C, C, 3, 1, 1, flags & ~F_GN, seg_list(cur, outs), n, gn_in=cur_gn,
-                                     fp8=(q8[1] / aq, aq), shared_gpu=sg, frag8=frag8_of(P, lkey) if rp8_on else None)
+                                     fp8=(q8[1] / aq, aq), shared_gpu=sg)
                 is_patch = use_fp8 or use_rp or probe.kernel_id() == 6
                 nt = probe.num_tiles()
                 partial = torch.empty(nt, C // 8, 2, dtype=torch.float32, device=device)
@@ -1110,8 +1064,7 @@ class HeadPlan:
                     # quantised on load (in_qscale 1: a normalised, rectified map sits well inside e4m3's range); the two
                     # layers that read FPN features use the calibrated scale of their input
                     c = ConvCall(q8[0], bias, C, C, 3, 1, 1, flags, seg_list(cur, outs), n, gn_partial=partial,
-                                 gn_in=cur_gn, fp8=(q8[1] / aq, aq), gn_fin=fin, shared_gpu=sg,
-                                 frag8=frag8_of(P, lkey) if rp8_on else None)
+                                 gn_in=cur_gn, fp8=(q8[1] / aq, aq), gn_fin=fin, shared_gpu=sg)
                 else:
                     c = ConvCall(wgt, bias, C, C, 3, 1, 1, flags, seg_list(cur, outs), n, gn_partial=partial, gn_in=cur_gn,
                                  gn_fin=fin, wfrag=wfrag, shared_gpu=sg)
@@ -1254,7 +1207,7 @@ def pack_head_weights(sd, device, prefix="proposal_generator.dafne_head.", fp8=F
 
 def pack_model_weights(sd, depth, device, weight_dtype="bf16", fp8_kernel="patch"):
     """weight_dtype: "bf16" or "fp8_e4m3" (cfg.ENGINE.WEIGHT_DTYPE; BASELINE config 5); fp8_kernel: cfg.ENGINE.FP8_CONV3X3_KERNEL
-    (fp8_conv3x3_kernel)."""
+    (FP8_KERNELS: "patch" only since round 6; kept in the packed weights because a kernel's rounding is part of the model)."""
     if weight_dtype not in ("bf16", "fp8_e4m3"):
         raise NotImplementedError("ENGINE.WEIGHT_DTYPE %r (bf16 or fp8_e4m3)" % (weight_dtype,))
     if fp8_kernel not in FP8_KERNELS:

@@ -17,8 +17,9 @@ from .voc_eval import voc_eval, poly_iou_pairs_device
 
 def equivalence_ap(dets, refs, thresholds=(0.5, 0.75), use_07_metric=True, iou_pairs=poly_iou_pairs_device):
     """dets, refs: per image a dict with `pred_corners` [n,8], `scores` [n], `pred_classes` [n] (numpy).  Returns
-    {"iou_0.50": {"mean": mAP, "per_class": {class id: AP}, "classes": k}, ..., "images": N, "reference_boxes": M,
-    "detections": D}."""
+    {"iou_0.50": {"mean": mAP over the classes, "weighted_mean": the same weighted by the classes' reference boxes (a class with a
+    handful of boxes moves `mean` by 1/11 AP steps per box), "per_class": {class id: AP}, "classes": k}, ..., "images": N,
+    "reference_boxes": M, "reference_boxes_per_class": {class id: m}, "detections": D}."""
     assert len(dets) == len(refs)
     names = ["img%04d" % i for i in range(len(refs))]
     gt = {}
@@ -28,7 +29,12 @@ def equivalence_ap(dets, refs, thresholds=(0.5, 0.75), use_07_metric=True, iou_p
         gt[nme] = [{"name": "c%d" % c, "difficult": 0, "bbox": [float(v) for v in b]}
                    for c, b in zip(cls, np.asarray(r["pred_corners"], dtype=np.float64).reshape(-1, 8))]
         classes.update(int(c) for c in cls)
-    out = {"images": len(refs), "reference_boxes": int(sum(len(v) for v in gt.values())),
+    per_cls_n = {}
+    for v in gt.values():
+        for o in v:
+            c = int(o["name"][1:])
+            per_cls_n[c] = per_cls_n.get(c, 0) + 1
+    out = {"images": len(refs), "reference_boxes": int(sum(len(v) for v in gt.values())), "reference_boxes_per_class": per_cls_n,
            "detections": int(sum(len(d["scores"]) for d in dets)), "metric": "VOC07 11-point AP" if use_07_metric else "VOC area AP"}
     with tempfile.TemporaryDirectory(prefix="dafne_equiv_") as tmp:
         with open(os.path.join(tmp, "images.txt"), "w") as f:
@@ -48,5 +54,8 @@ def equivalence_ap(dets, refs, thresholds=(0.5, 0.75), use_07_metric=True, iou_p
                 _, _, ap, _ = voc_eval(os.path.join(tmp, "Task1_{:s}.txt"), "{:s}", os.path.join(tmp, "images.txt"), "c%d" % c,
                                        ovthresh=thr, use_07_metric=use_07_metric, parse_gt=lambda nme: gt[nme], iou_pairs=iou_pairs)
                 per[c] = float(ap)
-            out["iou_%.2f" % thr] = {"mean": float(np.mean(list(per.values()))) if per else None, "per_class": per, "classes": len(per)}
+            wsum = float(sum(per_cls_n[c] for c in per))
+            out["iou_%.2f" % thr] = {"mean": float(np.mean(list(per.values()))) if per else None,
+                                     "weighted_mean": float(sum(per[c] * per_cls_n[c] for c in per) / wsum) if per else None,
+                                     "per_class": per, "classes": len(per)}
     return out

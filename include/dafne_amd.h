@@ -264,14 +264,6 @@ int dafne_conv3x3_c256_tiles_per_image(const dafne_conv_params* prm, const dafne
 int dafne_conv3x3_c256_pair_hip(const dafne_conv_params* prm_a, const dafne_conv_seg* segs_a, const void* d_wfrag_a,
                                 const dafne_conv_params* prm_b, const dafne_conv_seg* segs_b, const void* d_wfrag_b,
                                 void* d_scratch, size_t scratch_bytes, void* stream);
-/* fp8-weight twin on the same tiles (conv3x3_rp8_kernel; definition of the fp8 model as dafne_conv2d_nhwc_fp8w_hip: e4m3
- * weights with d_oscale[c] = weight scale / in_qscale, activations quantised to e4m3 on the way into LDS after the optional
- * GN_INPUT GroupNorm + ReLU, fp32 accumulation on v_mfma_f32_32x32x64_f8f6f4).  d_wfrag8: e4m3 bytes, fragment-major
- * [Cout/256][8 waves][36 steps][2][64 lanes][16]: rows nt*256 + wave*32 + (lane & 31), K bytes 64*step + 32*(lane >> 5) +
- * 16*j .. +16 of the packed weight [Cout][Cin/64][KH][KW][64]  (engine.pack_conv3x3_frag8).  Tile geometry, scratch, flags and
- * GroupNorm state as dafne_conv3x3_c256_hip. */
-int dafne_conv3x3_c256_fp8w_hip(const dafne_conv_params* prm, const dafne_conv_seg* segs, const void* d_wfrag8, const float* d_oscale,
-                                float in_qscale, void* d_scratch, size_t scratch_bytes, void* stream);
 size_t dafne_conv3x3_c256_scratch_bytes(void);
 int dafne_conv3x3_c256_hip(const dafne_conv_params* prm, const dafne_conv_seg* segs, const void* d_wfrag, void* d_scratch,
                            size_t scratch_bytes, void* stream);

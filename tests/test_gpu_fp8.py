@@ -24,8 +24,7 @@ def q8(x, qscale=1.0):
 
 def run_fp8(xs, w, b, in_qscale, flags=0, gn_in=None, gn_stats=False, kernel=None):
     """xs: list of [N,C,H,W] float maps (levels sharing the weights).  Returns (outputs NCHW float on the CPU, partial, call).
-    kernel: the kernel the call must land on: "conv3x3_rp8" (256 input channels only: the call gets the fragment-major weights,
-    as a model with ENGINE.FP8_CONV3X3_KERNEL "rp8" builds it) or conv3x3_patch_fp8 (default)."""
+    kernel: the kernel the call must land on (conv3x3_patch_fp8, the only fp8 kernel since round 6)."""
     from dafne_amd import engine, _lib
     d = dev()
     n, cin = xs[0].shape[:2]
@@ -38,13 +37,12 @@ def run_fp8(xs, w, b, in_qscale, flags=0, gn_in=None, gn_stats=False, kernel=Non
     oscale = (wscale / in_qscale).contiguous()
     if gn_in is not None:
         flags |= engine.F_GNIN
-    frag8 = engine.pack_conv3x3_frag8(wq) if kernel == "conv3x3_rp8" else None
-    probe = engine.ConvCall(wq, bias, cin, cout, 3, 1, 1, flags, segs, n, gn_in=gn_in, fp8=(oscale, in_qscale), frag8=frag8)
+    probe = engine.ConvCall(wq, bias, cin, cout, 3, 1, 1, flags, segs, n, gn_in=gn_in, fp8=(oscale, in_qscale))
     partial = None
     if gn_stats:
         partial = torch.zeros(4096, cout // 8, 2, dtype=torch.float32, device=d)
         probe = engine.ConvCall(wq, bias, cin, cout, 3, 1, 1, flags | engine.F_GN, segs, n, gn_partial=partial,
-                                gn_in=gn_in, fp8=(oscale, in_qscale), frag8=frag8)
+                                gn_in=gn_in, fp8=(oscale, in_qscale))
     assert probe.kernel_name() == (kernel or "conv3x3_patch_fp8")
     probe(_lib.current_stream())
     torch.cuda.synchronize()
@@ -66,19 +64,17 @@ def test_e4m3_weight_quantiser_is_exact_in_bf16():
     assert float((deq - w).abs().max() / w.abs().max()) < 2.0 ** -4
 
 
-@pytest.fixture(params=["rp8", "patch_fp8"])
-def c256_kernel(request, monkeypatch):
-    """The fp8 layers with 256 input channels run on conv3x3_patch_fp8 (ENGINE.FP8_CONV3X3_KERNEL "patch", the default) or on
-    conv3x3_rp8 ("rp8"); DAFNE_CONV_RP8=1 / 0 overrides the model's choice for the whole process."""
-    monkeypatch.setenv("DAFNE_CONV_RP8", "1" if request.param == "rp8" else "0")
+@pytest.fixture(params=["patch_fp8"])
+def c256_kernel(request):
+    """The kernel of the fp8 layers with 256 input channels: conv3x3_patch_fp8 (ENGINE.FP8_CONV3X3_KERNEL "patch").  Rounds 3-5 had a
+    second one (conv3x3_rp8: faster alone, slower in the timed layout; removed in round 6), hence the fixture."""
     return "conv3x3_" + request.param
 
 
-@pytest.fixture(params=["cfg_patch", "cfg_rp8"])
-def fp8_kernel_cfg(request, monkeypatch):
-    """The kernel choice as a model property (no environment override): cfg.ENGINE.FP8_CONV3X3_KERNEL."""
-    monkeypatch.delenv("DAFNE_CONV_RP8", raising=False)
-    return {"cfg_patch": "patch", "cfg_rp8": "rp8"}[request.param]
+@pytest.fixture(params=["cfg_patch"])
+def fp8_kernel_cfg(request):
+    """The kernel choice as a model property: cfg.ENGINE.FP8_CONV3X3_KERNEL."""
+    return {"cfg_patch": "patch"}[request.param]
 
 
 @pytest.mark.parametrize("H,W,N,cout,relu,qs", [
@@ -299,10 +295,7 @@ def test_fp8_model_uses_the_fp8_kernel_and_runs_end_to_end(c256_kernel):
     names = [c.kernel_name() for c in plan.calls if hasattr(c, "kernel_name")]
     # 26 + 3 + 12, the same set of layers at every image size; the 38 256-input ones (res4, FPN outputs, towers) on the model's
     # FP8_CONV3X3_KERNEL, the three 512-input res5 layers always on the generic fp8 patch kernel
-    if c256_kernel == "conv3x3_rp8":
-        assert names.count("conv3x3_rp8") == 38 and names.count("conv3x3_patch_fp8") == 3, names
-    else:
-        assert names.count("conv3x3_patch_fp8") == 41 and "conv3x3_rp8" not in names, names
+    assert names.count("conv3x3_patch_fp8") == 41, names
     assert "amax_probe" not in names
     assert 0 < len(out) <= cfg.MODEL.DAFNE.POST_NMS_TOPK_TEST + 8
     s = out.scores.cpu().numpy()
@@ -317,7 +310,7 @@ def test_fp8_model_pipelined_equals_serial(fp8_kernel_cfg):
     the plan that has the GPU to itself and the pipelined step's sub-batch plans use the same one (round 3 chose per plan:
     two roundings of the same sums, 2 bf16 ulps apart)."""
     cfg, m, P = _build("ucas_aod_r101_fp8.yaml", seed=13, fp8_kernel=fp8_kernel_cfg)
-    want = {"patch": "conv3x3_patch_fp8", "rp8": "conv3x3_rp8"}[fp8_kernel_cfg]
+    want = {"patch": "conv3x3_patch_fp8"}[fp8_kernel_cfg]
     g = torch.Generator().manual_seed(6)
     batches = [torch.randint(0, 256, (3, 3, 128, 160), generator=g, dtype=torch.uint8).to(dev()) for _ in range(3)]
     m.calibrate_fp8(batches[0])
@@ -326,10 +319,9 @@ def test_fp8_model_pipelined_equals_serial(fp8_kernel_cfg):
     serial = [(r.clone(), c.clone()) for r, c in serial]
     piped = [m.detect_packed(b, pipelined=True, splits=1) for b in batches]
     torch.cuda.synchronize()
-    other = {"conv3x3_patch_fp8": "conv3x3_rp8", "conv3x3_rp8": "conv3x3_patch_fp8"}[want]
     for plan in [m.plan(3, 128, 160)] + [p for ps in m._pipe[(3, 128, 160, 1)]["plans"] for p in ps]:
         names = [c.kernel_name() for c in plan.calls if hasattr(c, "kernel_name")]
-        assert names.count(want) >= 38 and (other not in names or want == "conv3x3_rp8"), (plan.shared_gpu, names)
+        assert names.count(want) >= 38, (plan.shared_gpu, names)
     for (r0, c0), (r1, c1) in zip(serial, piped):
         assert torch.equal(c0, c1)
         for i in range(3):
