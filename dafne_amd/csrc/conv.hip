@@ -1860,48 +1860,53 @@ __global__ void __launch_bounds__(512) conv3x3_patch_kernel(ConvDev P) {
 //
 // conv3x3_patch_kernel above stages weights AND pixels through LDS in half-K pieces: 36 K steps x 4 phases, a barrier
 // per phase, two wave groups that must stay exactly one phase apart -- measured 935-1000 TFLOP/s, the matrix pipe busy
-// ~50 % of the cycles the chip runs.  Here a workgroup (8 waves, one per CU) owns a 4 x 32 pixel tile and 256 output
-// channels; the (4+2) x (32+2) x 256-channel patch (four 26-KB slabs, [pixel][128 B], chunk XOR (patch column >> 1) & 7:
-// conflict-free ds_read_b128 at every tap offset, and -- the row pitch being even -- independent of the patch row, so a
-// fragment address is ONE per-lane register per tap column plus an immediate) is DMA'd once and stays; a wave owns 32 output channels and all 128 pixels, its weight fragments (fragment-major packing,
-// one coalesced 1-KiB load per k16 step, ring of 8) go straight to registers: every fragment feeds 4 MFMAs and is fetched
-// by exactly one wave, and the 144 k16 steps of a tile need no barrier for their operands (272 cycles per step measured,
-// 256 = pure MFMA issue).  K order = (64-channel slab, kh, kw, k16 step) = conv_igemm_kernel's: bit-identical outputs.
+// ~50 % of the cycles the chip runs.  Here a workgroup (8 waves, one per CU) owns an 8 x 32 pixel tile and 256 output
+// channels; the input patch sits in LDS in 64-channel slabs ([pixel][128 B], chunk XOR (patch column >> 1) & 7: conflict-free
+// ds_read_b128 at every tap offset, and -- the row pitch being even -- independent of the patch row, so a fragment address is ONE
+// per-lane register per tap column plus an immediate); a wave owns 32 output channels and all 256 pixels, its weight fragments
+// (fragment-major packing, one coalesced 1-KiB load per k16 step, ring of 8) go straight to registers: every fragment feeds
+// EIGHT MFMAs and is fetched by exactly one wave, and the 36 k16 steps of a slab need no barrier for their operands.  K order =
+// (64-channel slab, kh, kw, k16 step) = conv_igemm_kernel's: bit-identical outputs.
 //
-// A 128-pixel tile is only ~40k cycles of matrix work, and the first version (one tile per workgroup) spent another 15k
-// per tile on its prologue (patch latency), epilogue (8k: bias loads, staging, GroupNorm butterfly, stores) and store
-// drain with the matrix pipe idle -- no faster than the patch kernel.  So the kernel is PERSISTENT and software-pipelined
-// across tiles (workgroup p of G runs tiles p, p + G, ...):
-//   * the NEXT tile's patch lands while the current tile computes: slab s of the patch is dead after step 36 (s + 1) - 1, a
-//     barrier at steps 36 / 72 / 108 retires it and the next tile's slab s is DMA'd into its place in steps 40.. / 76.. /
-//     112.. (one piece per wave and step); slab 3 of a tile is requested in that tile's own steps 0..3, behind its step-0
-//     barrier (round 5: it was a burst of four behind the last step, in front of the epilogue, with an extra barrier);
-//   * GN_INPUT: a wave normalises the pieces IT loaded (GroupNorm + ReLU in place, out-of-image pixels stay zero) ~13
-//     steps after issuing them -- next tile's slabs 0..2 in steps 53.. / 89.. / 125.., its slab 3 in steps 13.. of the
-//     next tile itself (first read at step 108); the two waves of a SIMD four steps apart -- under the other waves' MFMAs; statistics of the next tile's image by
-//     one 256-B DMA piece at step 20 (double-buffered).  Round 5: the normalisation is the scale / shift form y = max(a x + b, 0)
-//     with a = rstd gamma, b = beta - mean a tabulated per tile (256 threads, step 30, published by the barrier of step 36):
-//     45 instead of 77 vector instructions and 80 instead of 88 LDS bytes per piece and lane; against the four-operation
-//     expression of the separate pass (gn_apply_kernel) a normalised bf16 operand differs by one ulp in ~1e-3 of the elements
-//     (one fused rounding instead of three), 191 instead of 196 us per tower layer at batch 8;
+// Round 6: 8 x 32 tiles instead of 4 x 32 (rounds 3-5).  The package runs these layers at its power cap, so a launch's time is its
+// energy; per step of the benchmark the 4 x 32 form pulled 26 GB of weight fragments L2 -> registers (1.18 MB per 128 pixels) at
+// 16 pJ per byte and re-read 31 % of its input as halo (6 x 34 / 4 x 32) at 132 pJ per HBM byte (scripts/l2_probe.py,
+// bench.py energy_ledger: profiles/NOTES_r06.md).  A tile of 256 pixels halves the weight bytes per flop and takes the halo to
+// 10 x 34 / 8 x 32 = 1.33.  Its whole patch would be 174 KB: the slabs go through a RING OF THREE 43-KB buffers instead -- slab g
+// (counted across tiles) lives in buffer g mod 3, is requested by DMA while slab g - 2 computes (one piece per wave and step, steps
+// 1..6 behind the barrier that retires slab g - 3), normalised in place while slab g - 1 computes (GN_INPUT), and published by the
+// barrier in front of its own first step.  The accumulators are 128 registers per wave; the B fragments of a step are read in two
+// halves of four (two register sets, the second half requested under the first half's MFMAs).
+//
+// The kernel is PERSISTENT and software-pipelined across tiles (workgroup p of G runs tiles p, p + G, ...):
+//   * slabs 0 and 1 of the NEXT tile are requested during slabs 2 and 3 of the current one (their ring buffers follow from the
+//     global slab count), slabs 2 and 3 of a tile during its own slabs 0 and 1;
+//   * GN_INPUT: a wave normalises the pieces IT loaded (GroupNorm + ReLU in place, out-of-image pixels stay zero) one slab period
+//     after issuing them, steps 8..13 (waves 0..3) / 14..19 (waves 4..7: the two waves of a SIMD six steps apart) of the period --
+//     under the other waves' MFMAs; statistics of the next tile's image by one 256-B DMA piece at step 56 (double-buffered), its
+//     scale / shift table y = max(a x + b, 0), a = rstd gamma, b = beta - mean a at step 70 (256 threads), published by the barrier
+//     of step 72, first used at step 116;
 //   * the epilogue is short and asynchronous: at the end of a tile bias / ReLU / GroupNorm sums are applied in the
-//     accumulator layout (a wave holds all 128 pixels of its 32 channels: no cross-wave reduction), the bf16 values are
+//     accumulator layout (a wave holds all 256 pixels of its 32 channels: no cross-wave reduction), the bf16 values are
 //     paired across the two half-waves with v_permlane32_swap (16 contiguous bytes per lane) and stored straight from
-//     registers -- 8 stores per lane that drain under the next tile's first steps (no LDS staging, no barrier, nothing
+//     registers -- 16 stores per lane that drain under the next tile's first steps (no LDS staging, no barrier, nothing
 //     held in registers across tiles).  The GroupNorm sums are reduced with DPP in the next tile's steps 1..8 and
-//     published by its barriers; with GN_FINALIZE the arrival ticket is taken in step 14 (no drain: the in-order vmcnt
+//     published by its barriers; with GN_FINALIZE the arrival ticket is taken in step 50 (no drain: the in-order vmcnt
 //     waits of the weight ring already cover the partial-sum stores of step 38.. of wave 0), the rare last-tile reduction
 //     runs behind the barrier of step 72;
 //   * every s_waitcnt vmcnt(n) is exact (rp_wait): stores are never predicated -- rows of out-of-image pixels go to a
 //     caller-provided dump area.
-constexpr int kRH = 4, kRW = 32, kRPx = kRH * kRW;
+constexpr int kRH = 8, kRW = 32, kRPx = kRH * kRW;
 constexpr int kRCols = kRW + 2, kRRows = kRH + 2;
-constexpr int kRPieces = (kRRows * kRCols + 7) / 8;     // 26 pieces of 8 px x 128 B per slab
-constexpr int kRSlab = kRPieces * 1024;                 // 26 624 B
+constexpr int kRPieces = (kRRows * kRCols + 7) / 8;     // 43 pieces of 8 px x 128 B per slab
+constexpr int kRSlab = kRPieces * 1024;                 // 44 032 B
+constexpr int kRBufs = 3;                               // ring of slab buffers
+constexpr int kRPP = (kRPieces + 7) / 8;                // 6 DMA pieces per wave and slab
+constexpr int kRFr = kRH;                               // B fragments (32 pixels each) per k16 step
 constexpr int kRCin = 256, kRSteps = 9 * kRCin / 16;    // 144 k16 steps
-constexpr int kRRing = 8;
+constexpr int kRRing = 6;                               // k16 steps of A fragments in flight per wave (a step is 8 MFMAs)
 constexpr int kRMaxCout = 1024;
-constexpr int kROffStat = 4 * kRSlab;                   // GN_INPUT statistics of (segment, image): 2 x [32][2] fp32
+constexpr int kROffStat = kRBufs * kRSlab;              // GN_INPUT statistics of (segment, image): 2 x [32][2] fp32
 constexpr int kROffGB = kROffStat + 512;                // per group: gamma [256], beta [256] fp32
 constexpr int kROffBias = kROffGB + 2 * 2048;           // per group: bias fp32 [Cout <= 1024]
 constexpr int kROffRed = kROffBias + 2 * kRMaxCout * 4; // [32 groups][2] fp32, finalize flag at +256
@@ -1909,36 +1914,42 @@ constexpr int kROffFin = kROffRed + 512;                // GN_FINALIZE reduction
 constexpr int kROffAB = kROffFin + 32 * 32 * 2 * 4;     // GN_INPUT: per tile parity, a[256] | b[256] fp32 of the tile's (layer, image)
 constexpr int kRSmem = kROffAB + 2 * 2048;
 static_assert(kRSmem <= 160 * 1024, "LDS budget");
-constexpr int kRDumpBytes = 64 * 1024;
+constexpr int kRDumpBytes = 128 * 1024;                 // 512 threads x 16 rows of 16 B
 
 // Vector-memory program order of a wave inside a tile (steady state; A(s + 8) of steps >= 136 are the next tile's first):
 //   step s: [wait A(s)] MFMAs | A(s + 8) | rp_post(s) more operations:
-//     0..3: one patch piece of THIS tile's slab 3 (first read at step 108; round 5 -- it was a burst of four behind step 143, in
-//     the epilogue); 20 (GN_INPUT): the statistics piece of the next tile's image; 40..43 / 76..79 / 112..115: one patch piece of
-//     the next tile's slab 0 / 1 / 2; 143: the tile's 8 row stores.
+//     steps 36 sl + 1 .. 36 sl + 6: one patch piece of the slab two ahead (sl = 0, 1: this tile's slabs 2, 3; sl = 2, 3: the next
+//     tile's slabs 0, 1); 56 (GN_INPUT): the statistics piece of the next tile's image; 143: the tile's 16 row stores.
 // rp_wait(j) = operations issued after A(j) and before the wait for it (vmcnt retires in order).  Steps 0..7 look back
-// into the previous tile; the FIRST tile of a workgroup has the prologue there instead (12 patch pieces, A(0..7), 8 dummy stores).
-constexpr int kRStatStep = 20;            // GN_INPUT: the next tile's statistics piece, early enough for the a / b table of step 30
+// into the previous tile; the FIRST tile of a workgroup has the prologue there instead (12 patch pieces, A(0..7), 16 dummy stores:
+// the same queue).
+#ifndef DAFNE_RP_BAR
+#define DAFNE_RP_BAR 12
+#endif
+constexpr int kRBar = DAFNE_RP_BAR;       // the one barrier of a slab period sits behind this step of it (see the kernel)
+constexpr int kRStatStep = 56;            // GN_INPUT: the next tile's statistics piece, early enough for the a / b table of step 70
+constexpr int kRTabStep = 70;
 constexpr int rp_post(int s, bool gnin) {
     int n = 0;
     if (gnin && s == kRStatStep) n += 1;
-    if (s < 4) n += 1;                                   // slab 3 of THIS tile's patch (round 5; it was a burst of 4 behind step 143)
-    if ((s >= 40 && s < 44) || (s >= 76 && s < 80) || (s >= 112 && s < 116)) n += 1;
-    if (s == kRSteps - 1) n += 8;
+    const int t = s % 36;
+    if (t >= kRBar + 1 && t <= kRBar + kRPP) n += 1;
+    if (s == kRSteps - 1) n += 2 * kRFr;
     return n;
 }
-// (Round 5: ONE sequence for every tile.  The first tile of a workgroup used to have its own counts for steps 0..7 -- the prologue
-// has no row stores behind A(0..7) -- and `if (first) wait(kF) else wait(kN)` on the ring register made the compiler put a COPY of
-// the register in front of the steady-state wait: the MFMAs of steps 0..7 of every later tile could read a fragment that had not
-// landed.  The prologue now issues 8 dummy dword stores to the dump area behind A(0..7): same queue, same counts, no branch.)
+// (ONE sequence for every tile -- round 5: a first-tile special case `if (first) wait(kF) else wait(kN)` on the ring register made
+// the compiler put a COPY of the register in front of the steady-state wait.  The prologue issues 16 dummy dword stores to the dump
+// area behind A(0..7): same queue, same counts, no branch.)
 constexpr int rp_wait(int j, bool gnin) {
     int n = rp_post((j - kRRing + kRSteps) % kRSteps, gnin);
     for (int s = j - kRRing + 1; s < j; s++) n += 1 + rp_post((s + kRSteps) % kRSteps, gnin);
     return n;
 }
-static_assert(rp_wait(0, false) == 15 && rp_wait(4, false) == 19 && rp_wait(7, false) == 19 && rp_wait(8, false) == 11 && rp_wait(12, false) == 7 &&
-              rp_wait(48, false) == 11 && rp_wait(48, true) == 11 && rp_wait(45, true) == 11 &&
-              rp_wait(52, false) == 7 && rp_wait(143, true) == 7 && rp_wait(kRStatStep + 8, true) == 8, "vmcnt bookkeeping");
+static_assert(kRRing != 6 || kRBar != 12 || (rp_wait(0, false) == 21 && rp_wait(2, false) == 21 && rp_wait(5, false) == 21 && rp_wait(6, false) == 5 &&
+              rp_wait(13, false) == 5 && rp_wait(14, false) == 6 && rp_wait(19, false) == 11 && rp_wait(20, false) == 10 && rp_wait(24, false) == 6 &&
+              rp_wait(25, false) == 5 && rp_wait(52, false) == 8 && rp_wait(kRStatStep + 6, true) == 6 && rp_wait(kRStatStep + 6, false) == 5 &&
+              rp_wait(143, true) == 5), "vmcnt bookkeeping");
+static_assert(kRBar >= 2 * kRPP && 36 - kRBar - 1 >= kRRing + 1, "a period's requests are covered by the wave's own waits before its normalisation starts");
 
 template <int J>
 __device__ __forceinline__ void rp_load(bf16x8 (&ar)[kRRing], const char* wf_cur, const char* wf_nxt, unsigned voff) {
@@ -1977,13 +1988,20 @@ __device__ __forceinline__ float rp_wave_total(float v) {
     return v;
 }
 
-// the four B fragments of k16 step J (patch rows kh .. kh + 3 at tap column kw, chunk kc of slab sl): inline asm, completion
+// four of the eight B fragments of k16 step J: patch rows kh + 4 HF .. kh + 4 HF + 3 at tap column kw, chunk kc of the slab whose
+// ring buffer starts at LDS address `sbase` (runtime: a slab's buffer follows from the global slab count); inline asm, completion
 // is awaited by the caller (lgkmcnt)
-template <int J>
-__device__ __forceinline__ void rp_bread(bf16x8 (&b)[4], const unsigned (&pb)[3], unsigned lds_base) {
-    constexpr int sl = J / 36, t = J % 36, kh = t / 12, kw = (t >> 2) % 3, kc = t & 3;
-    const unsigned ad = lds_base + ((pb[kw] ^ (unsigned)(kc << 5)) + (unsigned)(sl * kRSlab));
-    constexpr int o0 = (kh + 0) * kRCols * 128, o1 = (kh + 1) * kRCols * 128, o2 = (kh + 2) * kRCols * 128, o3 = (kh + 3) * kRCols * 128;
+template <int J, int HF>
+__device__ __forceinline__ void rp_bread(bf16x8 (&b)[4], const unsigned (&pb)[3], unsigned sbase) {
+    constexpr int t = J % 36, kh = t / 12, kw = (t >> 2) % 3, kc = t & 3;
+    // (the XOR is computed here, at every request: left to the compiler the twelve (kw, kc) combinations become twelve registers
+    // held across the whole unrolled tile loop)
+    unsigned pq = pb[kw];
+    asm volatile("" : "+v"(pq));
+    const unsigned ad = sbase + (pq ^ (unsigned)(kc << 5));
+    constexpr int r0 = kh + 4 * HF;
+    constexpr int o0 = (r0 + 0) * kRCols * 128, o1 = (r0 + 1) * kRCols * 128, o2 = (r0 + 2) * kRCols * 128, o3 = (r0 + 3) * kRCols * 128;
+    static_assert(o3 <= 65535, "ds_read immediate");
     asm volatile("ds_read_b128 %0, %4 offset:%5\n\tds_read_b128 %1, %4 offset:%6\n\tds_read_b128 %2, %4 offset:%7\n\tds_read_b128 %3, %4 offset:%8"
                  : "=&v"(b[0]), "=&v"(b[1]), "=&v"(b[2]), "=&v"(b[3])
                  : "v"(ad), "n"(o0), "n"(o1), "n"(o2), "n"(o3)
@@ -2002,7 +2020,15 @@ __global__ void __launch_bounds__(512, 2) conv3x3_rp_kernel(ConvDev PA, ConvDev 
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int frow = lane & 31, half = lane >> 5;
-    const int lane_ = lane, frow_ = frow, half_ = half;
+    // the lane id, recomputed where the tile loop needs it (two instructions; all 64 lanes are active everywhere in this kernel): a
+    // per-lane value held across the unrolled tile loop is one register too many (it spilled, and its reload drains vmcnt)
+    // (volatile asm: the builtin form is loop-invariant for the compiler, which hoists it -- and whatever is derived from it --
+    // out of the tile loop again)
+    auto lane_now = []() {
+        int l;
+        asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
+        return l;
+    };
     const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) char*)lds;
 
     // up to two GROUPS of tiles in one launch (two layers of identical shape and flags with their own tensors, weights and
@@ -2042,34 +2068,32 @@ __global__ void __launch_bounds__(512, 2) conv3x3_rp_kernel(ConvDev PA, ConvDev 
     };
 
     // ---- patch DMA map: piece pc = 8 consecutive patch pixels (patch pixel pp = p * 34 + q <-> haloed input pixel
-    // (Y0 + p, X0 + q)); wave w moves pieces w, w + 8, w + 16 and w + 24 of every slab -- the six waves without a fourth
-    // piece re-load THEIR OWN third piece (same wave, in order: it lands before the wave touches the piece)
-    int ppc[4];
+    // (Y0 + p, X0 + q)); wave w moves pieces w, w + 8, .., w + 40 of every slab -- the five waves without a sixth
+    // piece re-load THEIR OWN fifth piece (same wave, in order: it lands before the wave touches the piece)
+    int ppc[kRPP];
 #pragma unroll
-    for (int ii = 0; ii < 4; ii++) {
+    for (int ii = 0; ii < kRPP; ii++) {
         int pc = wave + NW * ii;
         if (pc >= kRPieces) pc -= NW;
         ppc[ii] = pc;
     }
-    unsigned pofs[4];                                      // of the tile whose patch is being fetched
-    const char* pin = nullptr;
-    auto patch_map = [&](const RpTile& c) {
-        int lane = lane_;
-        asm volatile("" : "+v"(lane));       // per-lane parts recomputed per tile (hoisted they spill; a reload drains vmcnt)
+    // piece ii of channel slab sl of tile c's patch into ring buffer `buf`.  The per-lane source offset is computed at every issue
+    // (about ten vector instructions; six offsets per tile held in registers across the tile loop spill): the piece's first patch
+    // pixel is wave-uniform (scalar division by the row pitch), a lane adds its 0..7
+    auto patch_piece = [&](const RpTile& c, int sl, int buf, int ii) {
+        int lane = lane_now();
+        asm volatile("" : "+v"(lane));
         const int Hp = c.H + 2, Wp = c.W + 2;
         const unsigned max_pix = (unsigned)(P.N * Hp * Wp - 1);
-#pragma unroll
-        for (int ii = 0; ii < 4; ii++) {
-            const int pp = ppc[ii] * 8 + (lane >> 3);
-            const int p = pp / kRCols, q = pp - p * kRCols;
-            unsigned g = (unsigned)((c.img * Hp + c.Y0 + p) * Wp + c.X0 + q);
-            g = g < max_pix ? g : max_pix;                   // ragged tiles reach past the image (and the buffer)
-            pofs[ii] = g * (unsigned)(kRCin * 2) + (unsigned)(((lane & 7) ^ ((q >> 1) & 7)) * 16);
-        }
-        pin = PG(c.grp).seg[c.si].in;
-    };
-    auto patch_piece = [&](int sl, int ii) {
-        __builtin_amdgcn_global_load_lds((gvoid*)(pin + pofs[ii] + sl * 128), (lvoid*)(lds + sl * kRSlab + ppc[ii] * 1024), 16, 0, 0);
+        const int S = ppc[ii] * 8, pS = S / kRCols, qS = S - pS * kRCols;      // scalar
+        int q = qS + (lane >> 3);
+        const int wrap = q >= kRCols ? 1 : 0;
+        q -= wrap * kRCols;
+        const int p = pS + wrap;
+        unsigned g = (unsigned)((c.img * Hp + c.Y0 + p) * Wp + c.X0 + q);
+        g = g < max_pix ? g : max_pix;                       // ragged tiles reach past the image (and the buffer)
+        const unsigned ofs = g * (unsigned)(kRCin * 2) + (unsigned)(((lane & 7) ^ ((q >> 1) & 7)) * 16);
+        __builtin_amdgcn_global_load_lds((gvoid*)(PG(c.grp).seg[c.si].in + ofs + sl * 128), (lvoid*)(lds + buf * kRSlab + ppc[ii] * 1024), 16, 0, 0);
     };
     // GroupNorm + ReLU of one landed patch piece of tile c, in place (inline-asm LDS ops: a plain LDS access would make the
     // compiler drain vmcnt).  A lane handles LOGICAL chunk lane&7 (8 channels = one group) of pixel lane>>3 of the piece.
@@ -2078,9 +2102,9 @@ __global__ void __launch_bounds__(512, 2) conv3x3_rp_kernel(ConvDev PA, ConvDev 
     // (scalar division by the row pitch) plus the lane's 0..7; the LDS address is lane * 16 XOR the column swizzle; packed fp32
     // math, ReLU as a packed 16-bit integer max on the rounded pairs (max(round(y), 0) = round(max(y, 0)): rounding is monotonic
     // and keeps the sign bit), out-of-image pixels masked to zero.
-    auto gn_piece = [&](const RpTile& c, int sl, int ii, int statbuf) {
-        if (ii == 3 && wave + 3 * NW >= kRPieces) return;                 // duplicate of this wave's piece ii = 2
-        int lane = lane_;
+    auto gn_piece = [&](const RpTile& c, int sl, int buf, int ii, int statbuf) {
+        if (ii == kRPP - 1 && wave + (kRPP - 1) * NW >= kRPieces) return; // duplicate of this wave's previous piece
+        int lane = lane_now();
         asm volatile("" : "+v"(lane));       // recompute the per-lane parts at every call: hoisted out of the tile loop they spill
         const int pc = ppc[ii];                                           // wave-uniform
         const int S = pc * 8, pS = S / kRCols, qS = S - pS * kRCols;      // scalar
@@ -2090,7 +2114,7 @@ __global__ void __launch_bounds__(512, 2) conv3x3_rp_kernel(ConvDev PA, ConvDev 
         const int p = pS + wrap;
         const bool inside = (unsigned)(c.Y0 + p - 1) < (unsigned)c.H && (unsigned)(c.X0 + q - 1) < (unsigned)c.W && p < kRRows;
         const unsigned msk = inside ? 0xffffffffu : 0u;
-        const unsigned ad = (((unsigned)lane << 4) ^ (((unsigned)q << 3) & 0x70u)) + (lds_base + (unsigned)(sl * kRSlab + pc * 1024));
+        const unsigned ad = (((unsigned)lane << 4) ^ (((unsigned)q << 3) & 0x70u)) + (lds_base + (unsigned)(buf * kRSlab + pc * 1024));
         const unsigned ta = (((unsigned)lane << 5) & 0xe0u) + (lds_base + (unsigned)(kROffAB + statbuf * 2048 + sl * kBK * 4));
         typedef __attribute__((ext_vector_type(2))) short s16x2;
         auto cvt = [&](unsigned w, f32x2 a, f32x2 b) -> unsigned {       // two channels: bf16 pair -> a x + b -> ReLU -> bf16 pair
@@ -2118,8 +2142,8 @@ __global__ void __launch_bounds__(512, 2) conv3x3_rp_kernel(ConvDev PA, ConvDev 
     // the a / b table of tile c's (layer, image) -> AB buffer b, by the first 256 threads (one channel each) from the landed
     // statistics piece and the layer's gamma / beta; inline-asm LDS operations (a plain access would make the compiler drain vmcnt)
     auto ab_table = [&](const RpTile& c, int b) {
-        if (tid < kRCin) {
-            int td = tid;
+        if (wave < kRCin / 64) {
+            int td = wave * 64 + lane_now();
             asm volatile("" : "+v"(td));
             const unsigned tsd = lds_base + (unsigned)(kROffStat + b * 256) + (unsigned)(td >> 3) * 8u;
             const unsigned tgd = lds_base + (unsigned)(kROffGB + c.grp * (2 * kRCin * 4)) + (unsigned)td * 4u;
@@ -2167,7 +2191,7 @@ __global__ void __launch_bounds__(512, 2) conv3x3_rp_kernel(ConvDev PA, ConvDev 
     const bool gn = P.flags & DAFNE_CONV_GN_STATS;
     const bool fin = gn && (P.flags & DAFNE_CONV_GN_FINALIZE);     // wave-uniform
     const int G8 = P.Cout / 8;
-    const int gnlate = wave >> 2;                                  // GN_INPUT: waves 4..7 convert their pieces four steps later
+    const int gnlate = wave >> 2;                                  // GN_INPUT: waves 4..7 convert their pieces six steps later
 
     // ---- prologue: layer constants -> LDS (plain loads: nothing asynchronous is in flight yet), first tile's patch
     RpTile cur = decode(pos);
@@ -2189,33 +2213,36 @@ __global__ void __launch_bounds__(512, 2) conv3x3_rp_kernel(ConvDev PA, ConvDev 
             __syncthreads();
         }
     }
-    patch_map(cur);
 #pragma unroll
-    for (int sl = 0; sl < 3; sl++)            // slab 3 follows in steps 0..3 of the tile, like every tile's
+    for (int sl = 0; sl < 2; sl++)            // slabs 2, 3 follow during slabs 0, 1 of the tile, like every tile's
 #pragma unroll
-        for (int ii = 0; ii < 4; ii++) patch_piece(sl, ii);
+        for (int ii = 0; ii < kRPP; ii++) patch_piece(cur, sl, sl, ii);
     {
         const char* wf0 = PG(cur.grp).w + (size_t)cur.nt * (NW * kRSteps * 1024);
         rp_static_for<0, kRRing>([&](auto J) { rp_load<decltype(J)::value>(ar, wf0, wf0, voff); });
     }
-    // 8 dummy dword stores (the wave's 256 B of the dump area each): the queue behind A(0..7) now looks like a steady-state tile's
-    // -- A(136..143), then the previous tile's 8 row stores -- so steps 0..7 of the first tile wait with the same counts
+    // 16 dummy dword stores (into the wave's part of the dump area): the queue behind A(0..7) now looks like a steady-state tile's
+    // -- A(136..143), then the previous tile's 16 row stores -- so steps 0..7 of the first tile wait with the same counts
     {
-        char* dd = dump + (size_t)tid * 128;
+        char* dd = dump + (size_t)tid * 256;
 #pragma unroll
-        for (int k = 0; k < 8; k++) asm volatile("global_store_dword %0, %1, off offset:%2" :: "v"(dd), "v"(0), "n"(k * 4) : "memory");
+        for (int k = 0; k < 2 * kRFr; k++) asm volatile("global_store_dword %0, %1, off offset:%2" :: "v"(dd), "v"(0), "n"(k * 4) : "memory");
     }
+    asm volatile("s_waitcnt vmcnt(%0)" :: "n"(kRRing + 2 * kRFr) : "memory");         // this wave's 12 patch pieces have landed (the A loads + 16 stores are younger)
     if (GNIN) {
-        asm volatile("s_waitcnt vmcnt(16)" ::: "memory");     // this wave's 12 patch pieces have landed (8 A loads + 8 stores are younger)
+        // slab 0 only: slab 1 is normalised in the first slab period of the loop, like every tile's
 #pragma unroll
-        for (int sl = 0; sl < 3; sl++)
-#pragma unroll
-            for (int ii = 0; ii < 4; ii++) gn_piece(cur, sl, ii, 0);
+        for (int ii = 0; ii < kRPP; ii++) gn_piece(cur, 0, 0, ii, 0);
     }
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();             // slab 0 of the first tile is published (later slabs: the barrier of step 12 of every period)
+    __builtin_amdgcn_sched_barrier(0);
 
-    f32x16 acc[4];
-    bf16x8 bfr[2][4];
-    float gsum[4], gsq[4];                    // GroupNorm sums of the previous tile (this wave's 4 groups), reduced in steps 1..8
+    f32x16 acc[kRFr];
+    bf16x8 bfr[2][4];                         // [half of the step's eight fragments][4]
+    int gs0 = 0;                              // ring buffer of the current tile's slab 0 (global slab count mod 3)
+    float gsum[4], gsq[4];                    // GroupNorm sums of a tile (this wave's 4 groups): live inside its epilogue only
 #pragma unroll
     for (int g = 0; g < 4; g++) gsum[g] = gsq[g] = 0.f;
     RpTile prv = cur;
@@ -2229,8 +2256,8 @@ __global__ void __launch_bounds__(512, 2) conv3x3_rp_kernel(ConvDev PA, ConvDev 
 #endif
     // the GroupNorm partial sums of the previous tile: behind a barrier that follows the redb writes of step 9
     auto gn_publish = [&]() {
-        if (gn && prv.valid && tid < 32) {
-            int td = tid;
+        if (gn && prv.valid && wave == 0 && lane_now() < 32) {
+            int td = lane_now();
             asm volatile("" : "+v"(td));              // (a hoisted tid * 8 spills: its reload would drain vmcnt)
             const float* redb = (const float*)(lds + kROffRed);
             const float sv = redb[td * 2 + 0], qv = redb[td * 2 + 1];
@@ -2246,7 +2273,7 @@ __global__ void __launch_bounds__(512, 2) conv3x3_rp_kernel(ConvDev PA, ConvDev 
         }
     };
     auto gn_ticket = [&]() {
-        if (fin && tid == 0) {
+        if (fin && wave == 0 && lane_now() == 0) {
             int last = 0;
             if (prv.valid) {
                 const int old = __hip_atomic_fetch_add(PG(prv.grp).gn_counters + prv.si * P.N + prv.img, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -2264,6 +2291,8 @@ __global__ void __launch_bounds__(512, 2) conv3x3_rp_kernel(ConvDev PA, ConvDev 
             const SegDev& S = Q.seg[prv.si];
             float* scratch = (float*)(lds + kROffFin);
             const int t0 = S.tile0 + prv.img * S.tiles_per_img;
+            int tid = wave * 64 + lane_now();              // (recomputed: hoisted per-thread values spill)
+            asm volatile("" : "+v"(tid));
             const int g = tid & 31;
 #pragma unroll
             for (int kk = 0; kk < 2; kk++) {
@@ -2311,7 +2340,6 @@ __global__ void __launch_bounds__(512, 2) conv3x3_rp_kernel(ConvDev PA, ConvDev 
     };
 
     for (int k = 0; k < nmine; k++) {
-        const bool first = k == 0;
         RP_STAMP(0);
 #ifdef DAFNE_RP_TIMING
         const unsigned long long rp_rt0 = __builtin_amdgcn_s_memrealtime();
@@ -2321,76 +2349,96 @@ __global__ void __launch_bounds__(512, 2) conv3x3_rp_kernel(ConvDev PA, ConvDev 
         const char* wf_nxt = PG(nxt.grp).w + (size_t)nxt.nt * (NW * kRSteps * 1024);
         const int sb_cur = k & 1, sb_nxt = (k + 1) & 1;
 #pragma unroll
-        for (int b = 0; b < 4; b++)
+        for (int b = 0; b < kRFr; b++)
 #pragma unroll
             for (int kk = 0; kk < 16; kk++) acc[b][kk] = 0.f;
+        // ring buffers of this tile's four slab periods: computing (gs0 + sl) % 3; the DMA of period sl fills (gs0 + sl + 2) % 3
+        // (the buffer the period's opening barrier has just retired); the normalisation of period sl works on (gs0 + sl + 1) % 3
+        int bufc[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) bufc[q] = (gs0 + q) % kRBufs;
+        unsigned sbase[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) sbase[q] = lds_base + (unsigned)(bufc[q] * kRSlab);
 
         rp_static_for<0, kRSteps>([&](auto J) {
             constexpr int j = decltype(J)::value;
-            constexpr int sl = j / 36, t = j % 36, kh = t / 12, kw = (t >> 2) % 3, kc = t & 3;
+            constexpr int sl = j / 36, t = j % 36;
             rp_wait_for<j, GNIN>(ar);
-            if constexpr (j == 0 || j == 36 || j == 72 || j == 108) {
-                barrier();
-                if constexpr (j == 0) RP_STAMP(1);
-                if constexpr (j == 36) RP_STAMP(2);
-                if constexpr (j == 72) RP_STAMP(3);
-                if constexpr (j == 108) RP_STAMP(4);
-            }
-            // ---- GN_INPUT: pieces this wave loaded ~13 steps ago
-            // (waves w and w + 4 share a SIMD: the second half of the workgroup converts four steps later, so that one of the
-            // two always has MFMAs for the matrix pipe)
+            // ---- GN_INPUT, steps 0..11 of a period: the pieces this wave requested in the PREVIOUS period (slab sl + 1 of this tile; in
+            // period 3: slab 0 of the next tile), one per step; waves w and w + 4 share a SIMD: the second half of the workgroup converts
+            // six steps later, so that one of the two always has MFMAs for the matrix pipe
             if constexpr (GNIN) {
-                if constexpr (j >= 13 && j < 21) { if (((j - 13) >> 2) == gnlate) gn_piece(cur, 3, (j - 13) & 3, sb_cur); }
-                if constexpr (j >= 53 && j < 61) { if (((j - 53) >> 2) == gnlate) gn_piece(nxt, 0, (j - 53) & 3, sb_nxt); }
-                if constexpr (j >= 89 && j < 97) { if (((j - 89) >> 2) == gnlate) gn_piece(nxt, 1, (j - 89) & 3, sb_nxt); }
-                if constexpr (j >= 125 && j < 133) { if (((j - 125) >> 2) == gnlate) gn_piece(nxt, 2, (j - 125) & 3, sb_nxt); }
-            }
-            if constexpr (j == 37) patch_map(nxt);
-            // the next tile's a / b table: its statistics piece (step 20) is covered by this wave's wait of step 29; published by
-            // the barrier of step 36, first read at step 53
-            if constexpr (GNIN && j == 30) ab_table(nxt, sb_nxt);
-            // ---- the previous tile's GroupNorm sums
-            if constexpr (j >= 1 && j < 9) {
-                if (gn) {
-                    constexpr int g = (j - 1) >> 1;
-                    if constexpr (((j - 1) & 1) == 0) gsum[g] = rp_wave_total(gsum[g]);
-                    else gsq[g] = rp_wave_total(gsq[g]);
+                if constexpr (t < 2 * kRPP) {
+                    if ((t / kRPP) == gnlate) {
+                        if constexpr (sl < 3) gn_piece(cur, sl + 1, (gs0 + sl + 1) % kRBufs, t % kRPP, sb_cur);
+                        else gn_piece(nxt, 0, (gs0 + 4) % kRBufs, t % kRPP, sb_nxt);
+                    }
                 }
             }
-            if constexpr (j == 9) gn_reduce_write();
-            if constexpr (j == 38) gn_publish();               // behind the barrier of step 36: the sums of all 32 groups
-            if constexpr (j == 50) gn_ticket();                // wave 0's waits since step 47 cover its partial-sum stores of step 38
-            if constexpr (j == 73) gn_last_tile();             // behind the barrier of step 72
-            // ---- this tile's matrix work.  The B fragments of step j + 1 are requested before the MFMAs of step j (two register
-            // sets; hipcc serialised read -> wait -> MFMA four times per step on one set); the counted lgkmcnt leaves exactly
-            // those four reads in flight (other LDS / scalar-memory operations in flight only make the wait stricter)
-            if constexpr (j == 0) rp_bread<0>(bfr[0], pb, lds_base);
+            static_assert(2 * kRPP <= kRBar, "the normalisation of a period ends in front of its barrier");
+            if constexpr (t == kRBar) {
+                // THE barrier of a slab period.  It publishes the NEXT period's slab -- every wave's pieces of it have landed (a wave's
+                // waits cover its own, requested 30 steps ago) and, GN_INPUT, are normalised -- and retires the PREVIOUS period's (every
+                // wave is past its last read of it), whose buffer the requests of steps 13..18 refill.  No barrier at a tile's first
+                // step: a wave that is through its epilogue starts the next tile while its SIMD mate is still storing rows
+                // (round 6, first 8 x 32 form: a barrier at step 0 cost 6 k of 92 k cycles per tile).
+                barrier();
+                if constexpr (j == kRBar) RP_STAMP(1);
+                if constexpr (j == 36 + kRBar) RP_STAMP(2);
+                if constexpr (j == 72 + kRBar) RP_STAMP(3);
+                if constexpr (j == 108 + kRBar) RP_STAMP(4);
+            }
+            // the next tile's a / b table: its statistics piece (step 56) is covered by this wave's wait of step 63; published by
+            // the barrier of step 84, first read at step 108
+            if constexpr (GNIN && j == kRTabStep) ab_table(nxt, sb_nxt);
+            // ---- the previous tile's GroupNorm sums (reduced over the wave and parked in LDS by its epilogue)
+            if constexpr (j == kRBar + 2) gn_publish();        // behind the barrier of step 12: the sums of all 32 groups
+            if constexpr (j == kRBar + 14) gn_ticket();        // wave 0's waits since step 20 cover its partial-sum stores of step 14
+            if constexpr (j == 36 + kRBar + 1) gn_last_tile(); // behind the barrier of step 48
+            // ---- this tile's matrix work: eight B fragments per step in two halves of four (two register sets).  The second half is
+            // requested before the first half's MFMAs, the next step's first half before the second half's; the counted lgkmcnt
+            // leaves exactly the four younger reads in flight (other LDS / scalar-memory operations in flight only make the wait
+            // stricter).  Requests cross slab boundaries (the next slab was published at step 12 of this period) but not the tile's end:
+            // the epilogue sits there.
+            if constexpr (j == 0) rp_bread<j, 0>(bfr[0], pb, sbase[0]);
+            rp_bread<j, 1>(bfr[1], pb, sbase[sl]);
+            asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(bfr[0][0]), "+v"(bfr[0][1]), "+v"(bfr[0][2]), "+v"(bfr[0][3]) :: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int r = 0; r < 4; r++) acc[r] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ar[j % kRRing], bfr[0][r], acc[r], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
             if constexpr (j + 1 < kRSteps) {
-                rp_bread<j + 1>(bfr[(j + 1) & 1], pb, lds_base);
-                asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(bfr[j & 1][0]), "+v"(bfr[j & 1][1]), "+v"(bfr[j & 1][2]), "+v"(bfr[j & 1][3]) :: "memory");
+                rp_bread<j + 1, 0>(bfr[0], pb, sbase[(j + 1) / 36]);
+                asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(bfr[1][0]), "+v"(bfr[1][1]), "+v"(bfr[1][2]), "+v"(bfr[1][3]) :: "memory");
             } else {
-                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(bfr[j & 1][0]), "+v"(bfr[j & 1][1]), "+v"(bfr[j & 1][2]), "+v"(bfr[j & 1][3]) :: "memory");
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(bfr[1][0]), "+v"(bfr[1][1]), "+v"(bfr[1][2]), "+v"(bfr[1][3]) :: "memory");
             }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int r = 0; r < 4; r++) acc[r] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ar[j % kRRing], bfr[j & 1][r], acc[r], 0, 0, 0);
+            for (int r = 0; r < 4; r++) acc[4 + r] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ar[j % kRRing], bfr[1][r], acc[4 + r], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
             rp_load<j + kRRing>(ar, wf_cur, wf_nxt, voff);
             // ---- counted vector-memory operations behind the weight load (rp_post)
             if constexpr (GNIN && j == kRStatStep) stat_piece(nxt, sb_nxt);
-            if constexpr (j < 4) patch_piece(3, j);              // this tile's slab 3 (pofs / pin are this tile's until step 37)
-            if constexpr (j >= 40 && j < 44) patch_piece(0, j - 40);
-            if constexpr (j >= 76 && j < 80) patch_piece(1, j - 76);
-            if constexpr (j >= 112 && j < 116) patch_piece(2, j - 112);
+            // the slab two periods ahead, one piece per step: this tile's slabs 2, 3 in periods 0, 1, the next tile's slabs 0, 1 in
+            // periods 2, 3
+            if constexpr (t >= kRBar + 1 && t <= kRBar + kRPP) {
+                if constexpr (sl < 2) patch_piece(cur, sl + 2, (gs0 + sl + 2) % kRBufs, t - kRBar - 1);
+                else patch_piece(nxt, sl - 2, (gs0 + sl + 2) % kRBufs, t - kRBar - 1);
+            }
             __builtin_amdgcn_sched_barrier(0);
         });
+        gs0 = (gs0 + 4) % kRBufs;
         RP_STAMP(5);
-        // ---- end of tile: this tile's epilogue.  (Round 5: no barrier and no patch pieces here -- slab 3 of the next tile's patch is
-        // requested in that tile's steps 0..3, behind its step-0 barrier, which also retires this tile's slab 3; a wave that is done
-        // with its 144 steps goes straight into its epilogue while its SIMD mate still has the matrix pipe.)
+        // ---- end of tile: this tile's epilogue.  No barrier and no patch pieces here: a wave that is done with its 144 steps goes
+        // straight into its epilogue while its SIMD mate still has the matrix pipe.
         RP_STAMP(6);
         {
             f32x4 bia4[4];
+            int le = lane_now();                  // per-lane parts recomputed per tile (hoisted out of the tile loop they spill)
+            asm volatile("" : "+v"(le));
+            const int frow = le & 31, half = le >> 5;
             const unsigned bad = lds_base + (unsigned)(kROffBias + (cur.grp * kRMaxCout + cur.nt * 256 + wave * 32 + 4 * half) * 4);
             asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:32\n\tds_read_b128 %2, %4 offset:64\n\tds_read_b128 %3, %4 offset:96\n\t"
                          "s_waitcnt lgkmcnt(0)"
@@ -2404,14 +2452,16 @@ __global__ void __launch_bounds__(512, 2) conv3x3_rp_kernel(ConvDev PA, ConvDev 
             const size_t rowpitch = (size_t)Wp * P.Cout * 2;
             char* obase = PG(cur.grp).seg[cur.si].out + ((size_t)(cur.img * (cur.H + 2) + cur.Y0 + 1) * Wp + cur.X0 + frow + 1) * P.Cout * 2
                           + (cur.nt * 256 + wave * 32 + 8 * half) * 2;
-            char* dbase = dump + (size_t)tid * 128;
+            // rows of out-of-image pixels: every such store of a lane goes to the same 48 bytes of the dump area (never read; one
+            // address instead of sixteen -- the compiler hoists loop-invariant addresses out of the tile loop and spills them)
+            char* const dbase = dump + (size_t)(wave * 64 + le) * 256;
             const bool colok = cur.valid && (cur.X0 + frow) < cur.W;
             // round 5: branch-free (the runtime flags were exec-mask branches around every group: 414 vector + 215 scalar
             // instructions per tile): ReLU as a max with 0 or -inf, the GroupNorm sums always formed and ADDED under a select
             // (x + 0 is exact: the sums of a plain / out-of-image row are unchanged bit for bit)
             const float lo = relu ? 0.f : -__builtin_inff();
 #pragma unroll
-            for (int b = 0; b < 4; b++) {
+            for (int b = 0; b < kRFr; b++) {
                 const bool valid = colok && (cur.Y0 + b) < cur.H;
                 u32x2 pk[4];
 #pragma unroll
@@ -2431,9 +2481,26 @@ __global__ void __launch_bounds__(512, 2) conv3x3_rp_kernel(ConvDev PA, ConvDev 
                     const auto r0 = __builtin_amdgcn_permlane32_swap(a.x, c2.x, false, false);
                     const auto r1 = __builtin_amdgcn_permlane32_swap(a.y, c2.y, false, false);
                     const u32x4 v = {r0[0], r1[0], r0[1], r1[1]};
-                    char* ad = valid ? obase + b * rowpitch + gp * 32 : dbase + (b * 2 + gp) * 16;
-                    *(u32x4*)ad = v;
+                    // (a plain store: v_permlane32_swap -> vector-memory read of its result is a hazard the compiler pads with wait states
+                    // only when it can see the store -- the first 8 x 32 form issued it from inline asm right behind the swaps and
+                    // lost dwords of the quad-3 lanes)
+                    char* const ad = valid ? obase : dbase;
+#ifdef DAFNE_RP_NOSTORE                          // timing ablation (wrong results): what do the row stores cost?
+                    if (gp == 1 || (b & 3) != 0) { asm volatile("" :: "v"(v)); continue; }
+#endif
+                    *(u32x4*)(ad + gp * 32) = v;
                 }
+                obase += rowpitch;
+            }
+            // the tile's GroupNorm sums: over the wave (DPP, fixed tree), lane 63 parks them in LDS; published behind the barrier of the
+            // next tile's step 36 (round 6: rounds 3-5 carried the eight partial sums in registers into the next tile's steps 1..9)
+            if (gn) {
+#pragma unroll
+                for (int g = 0; g < 4; g++) {
+                    gsum[g] = rp_wave_total(gsum[g]);
+                    gsq[g] = rp_wave_total(gsq[g]);
+                }
+                gn_reduce_write();
             }
         }
         prv = cur;
@@ -2449,18 +2516,12 @@ __global__ void __launch_bounds__(512, 2) conv3x3_rp_kernel(ConvDev PA, ConvDev 
 #endif
     }
 
-    // ---- the last tile's GroupNorm sums, straight-line
+    // ---- the last tile's GroupNorm sums (in LDS since its epilogue), straight-line
     if (gn) {
-#pragma unroll
-        for (int g = 0; g < 4; g++) {
-            gsum[g] = rp_wave_total(gsum[g]);
-            gsq[g] = rp_wave_total(gsq[g]);
-        }
-        gn_reduce_write();
         barrier();
         gn_publish();
         if (fin) {
-            if (tid < 64) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // wave 0's partial-sum stores are complete
+            if (wave == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // wave 0's partial-sum stores are complete
             gn_ticket();
             barrier();
             gn_last_tile();

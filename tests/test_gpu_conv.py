@@ -875,7 +875,7 @@ def _rp_call(wp, bp, cout, flags, segs, N, d, **kw):
 
 
 @pytest.mark.parametrize("cout,sizes,N,relu", [
-    (256, [(64, 64)], 8, True),                                   # res4-like: exact 4 x 32 tiles
+    (256, [(64, 64)], 8, True),                                   # res4-like: exact 8 x 32 tiles
     # (the generic entry point must stay on conv_igemm here: < 200 patch-kernel tiles per nominal batch of 8)
     (256, [(64, 64), (32, 32), (16, 16), (8, 8), (4, 4)], 2, False),          # five levels in one launch
     (512, [(25, 47), (5, 70)], 3, True),                          # two channel tiles; ragged rows and columns, 3 tile columns
@@ -883,7 +883,7 @@ def _rp_call(wp, bp, cout, flags, segs, N, d, **kw):
 ])
 def test_resident_patch_kernel_equals_generic_conv(cout, sizes, N, relu):
     """dafne_conv3x3_c256_hip (conv3x3_rp_kernel: whole 256-channel patch resident in LDS, weights streamed L2 -> registers,
-    4 x 32 tiles) against dafne_conv2d_nhwc_bf16_hip on the same operands: same K order and epilogue expressions ->
+    8 x 32 tiles) against dafne_conv2d_nhwc_bf16_hip on the same operands: same K order and epilogue expressions ->
     bit-identical outputs on every level, halo untouched; and against torch within bf16 rounding."""
     from dafne_amd import engine, _lib
     d = dev()
@@ -900,7 +900,7 @@ def test_resident_patch_kernel_equals_generic_conv(cout, sizes, N, relu):
     engine.ConvCall(wp, bp, 256, cout, 3, 1, 1, fl, [(i.t, o.t, None, i.h, i.w, i.h, i.w) for i, o in zip(ins, out_g)], N)(st)
     c = _rp_call(wp, bp, cout, fl, [(i.t, o.t, None, i.h, i.w, i.h, i.w) for i, o in zip(ins, out_r)], N, d)
     assert c.rp_ok() and c.kernel_name() == "conv3x3_rp"
-    assert c.num_tiles() == sum(N * ((h + 3) // 4) * ((wd + 31) // 32) for h, wd in sizes)
+    assert c.num_tiles() == sum(N * ((h + 7) // 8) * ((wd + 31) // 32) for h, wd in sizes)
     c(st)
     c(st)
     torch.cuda.synchronize()
