@@ -269,8 +269,10 @@ __global__ void __launch_bounds__(512, 2) conv_bneck_kernel(BneckDev P) {
         u32x4(&rr)[8] = rs;                     // (a non-dependent use: a generic lambda captures the array only through one)
         const unsigned vo = qcx[k & 1];
         const char* xb = P.res + row_pix(k >> 1) * (size_t)(kCB * 2);
-        // nt: X is read once per block (the Y rows, not-nt, are the next block's X)
-        asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3 nt" : "+v"(rr[k]) : "v"(vo), "s"(xb), "n"(c * 512) : "memory");
+        // default cache policy.  (Rounds 4-5 marked the shortcut DMA non-temporal: +0.45 %.  Here a 128-byte line of X is read by TWO
+        // waves, 64 bytes each, at different moments: with `nt` the second one fetched it from HBM again -- 108.6 against 101.1 MB
+        // fetched per block, 70.6 against 67.7 us, round 6)
+        asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" : "+v"(rr[k]) : "v"(vo), "s"(xb), "n"(c * 512) : "memory");
     };
     // a 16-byte row store with the lanes of out-of-image pixels switched off (all 64 lanes are active around it: the kernel has no
     // divergent control flow); the instruction is issued -- and counted by vmcnt -- whatever the mask

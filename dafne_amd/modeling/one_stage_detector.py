@@ -257,7 +257,7 @@ class OneStageDetector(nn.Module):
 
     # ------------------------------------------------------------ fused path
     def detect_packed(self, images_u8, valid_hw=None, out_hw=None, layout_hwc=False, do_postprocess=True,
-                      pipelined=False, splits=1, stream_offset=0, graphs=None, defer=False, even=False):
+                      pipelined=False, splits=1, stream_offset=0, graphs=None, defer=False, even=False, post_per_split=False):
         """images_u8: device uint8 [N,3,H,W] (or [N,H,W,3] with layout_hwc) BGR.
         valid_hw: optional per-image (h, w) true sizes; out_hw: optional per-image
         requested output (height, width).  Returns (rows [N,k_cap,18], counts [N])
@@ -279,8 +279,12 @@ class OneStageDetector(nn.Module):
         the persistent tower kernel leaves CUs idle (232 of 256 workgroups) that the post-process kernels fill, while beside
         the backbone's chip-wide launches they cost 3.7 % of the step (scratch/no_post.py, defer_post.py: +1.4 .. +4 %).
         Returns the PREVIOUS call's (rows, counts) -- None on the first call; flush_deferred() enqueues and returns the last.
-        even=True: sub-batches of EQUAL size (a lone step with a host wait behind it -- forward() -- ends when its longest
-        stream does; the unequal sizes of subbatch_bounds pay only in a loop whose steps overlap)."""
+        even=True: sub-batches of EQUAL size (a lone step with a host wait behind it ends when its longest stream does; the unequal
+        sizes of subbatch_bounds pay only in a loop whose steps overlap -- or with post_per_split).
+        post_per_split=True (immediate form only; forward()'s, round 6): decode / rotated NMS / rescale run per SUB-BATCH on the side
+        stream, smallest sub-batch first, each as soon as its own convolutions are done -- with unequal sub-batches the post-process
+        of the short one runs under the long one's convolutions and only the long one's own share trails the step.  Per-image
+        results are those of the whole-batch post-process (every image is decoded and suppressed on its own)."""
         if not images_u8.is_cuda or images_u8.dtype != torch.uint8:
             raise RuntimeError("detect_packed needs a uint8 CUDA tensor (the MI355X engine has no CPU path)")
         if self.cfg.ENGINE.WEIGHT_DTYPE == "fp8_e4m3" and self._act_q8 is None:
@@ -352,6 +356,8 @@ class OneStageDetector(nn.Module):
                 self.side_stream = _shared_stream(images_u8.device, "side", 0)
                 self._pipe = {}
             key = (n, hn, wn, splits, "even") if (even and splits > 1) else (n, hn, wn, splits)
+            if post_per_split and not defer and splits > 1:
+                key = key + ("pps",)
 
             def build_pipe():
                 nc = self.proposal_generator.dafne_head.num_classes
@@ -375,7 +381,8 @@ class OneStageDetector(nn.Module):
                 # 4 splits: 714 -> 960 img/s); the high-priority pool gives each its own queue.  With the
                 # post-process stream in the mix 3 splits measured best (scratch/split_sweep.sh)
                 return {"i": 0, "cs": [_shared_stream(images_u8.device, "compute", k) for k in range(splits)], "ho": hos,
-                        "plans": plan_sets, "bounds": bounds, "cand": [None] * nsets, "done": [None] * nsets, "runs": [0] * nsets}
+                        "plans": plan_sets, "bounds": bounds, "cand": [None] * nsets, "done": [None] * nsets, "runs": [0] * nsets,
+                        "cand_split": [[None] * splits for _ in range(nsets)]}
             if key not in self._pipe:
                 self._lru_get(self._pipe, key, build_pipe)
                 # plan building enqueued buffer fills, weight packing and uploads on the caller's stream: finished before any
@@ -468,6 +475,27 @@ class OneStageDetector(nn.Module):
                 return self._run_deferred(prev, tower_evs) if prev is not None else None
             for k in range(splits):
                 mark("end", k, cs[k])
+            if post_per_split and splits > 1:
+                evs = []
+                for k in range(splits):
+                    ev = torch.cuda.Event()
+                    ev.record(cs[k])
+                    evs.append(ev)
+                with torch.cuda.stream(self.side_stream):
+                    parts = [None] * splits
+                    for k in sorted(range(splits), key=lambda q: (bounds[q + 1] - bounds[q], q)):      # the shortest sub-batch ends first
+                        lo, hi = bounds[k], bounds[k + 1]
+                        self.side_stream.wait_event(evs[k])
+                        cand = outs.decode_packed(head_levels(plans[k].head, strides), out=st["cand_split"][slot][k])
+                        st["cand_split"][slot][k] = cand
+                        parts[k] = outs.select_packed(cand, sizes=sizes[lo:hi], scale_corners=do_postprocess)
+                    res = (torch.cat([r for r, _ in parts]), torch.cat([c for _, c in parts]))
+                    done = torch.cuda.Event()
+                    done.record(self.side_stream)
+                st["done"][slot] = done
+                for t in res:
+                    t.record_stream(main)
+                return res
             with torch.cuda.stream(self.side_stream):
                 for k in range(splits):
                     ev = torch.cuda.Event()
@@ -597,7 +625,7 @@ class OneStageDetector(nn.Module):
         if self.training:
             raise NotImplementedError("training is outside the scope of the MI355X inference engine")
         batch, valid, out_hw = self._pack_inputs(batched_inputs)
-        splits = min(2, max(1, int(self.cfg.ENGINE.PIPELINE_SPLITS)))
+        splits = min(int(os.environ.get("DAFNE_FWD_SPLITS", "2")), max(1, int(self.cfg.ENGINE.PIPELINE_SPLITS)))
         if len(batched_inputs) >= 2 and splits >= 2:
             # the call detectron2's loop makes (tools/plain_train_net.py:316-336: outputs = model(inputs)) runs on sub-batch
             # streams as well, immediate post-process.  TWO sub-batches of EQUAL size: the host waits behind every call, so a
@@ -605,8 +633,12 @@ class OneStageDetector(nn.Module):
             # scratch/fwd_sync_probe.py) -- the unequal three-way split of the streamed loop pays only where steps overlap.
             # Result-neutral: an image gets the same bits in any batch composition (DESIGN section 5,
             # test_an_image_gets_the_same_detections_in_any_batch)
+            # (round 6: the post-process per sub-batch, the short sub-batch's under the long one's convolutions -- detect_packed(
+            # post_per_split=True), DAFNE_FWD_PPS=1 -- measured 7.05-7.16 ms per call of 8 against 6.94 for this form (4+4, one
+            # whole-batch post-process): two decode / NMS passes cost more than the overlap returns; scripts/fwd_sync_probe.py)
+            pps = os.environ.get("DAFNE_FWD_PPS", "0") == "1"
             rows, counts = self.detect_packed(batch, valid_hw=valid, out_hw=out_hw, do_postprocess=do_postprocess,
-                                              pipelined=True, splits=splits, even=True)
+                                              pipelined=True, splits=splits, even=not pps, post_per_split=pps)
             # the rows are produced on the side stream and the host needs them now: a HOST wait on that stream.  (A device-side
             # wait_stream of the caller's stream, followed by the read-back's own wait, cost 0.85 ms per call once all the
             # shared streams are bound: 7.70 against 6.84 ms per call of 8, scratch/fwd_phase_probe.py)
