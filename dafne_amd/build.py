@@ -68,5 +68,52 @@ def build(force=False, verbose=False):
     return OUT
 
 
+# The static ISA guards (scripts/check_async_loads.py, scripts/check_packed_fp32.py) as a BUILD step: `python -m dafne_amd.build --check`
+# compiles every unit once more to a listing (hipcc -S, same flags) and fails on a flagged instruction.  ASYNC_CHECKED: the units whose
+# hand-scheduled kernels are fully unrolled per tile, which is what the checker's in-order queue walks (program-text order); the
+# persistent kernels with RUNTIME loops (conv_b2b_mid / _narrow, conv_blk_mid / _narrow, conv_wr) re-use ring registers across a back
+# edge the model does not follow -- their waits are covered by the bit-identity tests under load (tests/test_gpu_reproducible.py).
+ASYNC_CHECKED = {"conv.hip": ["conv3x3_rp_kernel"], "conv_bneck.hip": ["conv_bneck_kernel"], "conv_b2b.hip": ["conv_b2b_kernel"],
+                 "conv3x3_c64.hip": ["conv3x3_c64_kernel"]}
+NO_MATRIX_UNITS = ("decode.hip", "poly_nms.hip", "resize.hip", "dense_ops.hip")
+
+
+def check(verbose=True):
+    """-> list of (unit, kernel or None, text) violations of the two static rules; empty when the build is clean."""
+    import tempfile
+    sys.path.insert(0, os.path.join(HERE, "..", "scripts"))
+    import check_async_loads as cal
+    import check_packed_fp32 as cpf
+    bad = []
+    srcs = sorted(f for f in os.listdir(CSRC) if f.endswith(".hip"))
+    with tempfile.TemporaryDirectory() as td:
+        procs = []
+        for s in srcs:
+            out = os.path.join(td, s + ".s")
+            flags = [f for f in COMMON if f != "-fPIC"] + PER_FILE.get(s, [])
+            procs.append((s, out, subprocess.Popen([HIPCC] + flags + ["-S", "--cuda-device-only", "-o", out, os.path.join(CSRC, s)],
+                                                   stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
+        for s, out, p in procs:
+            log, _ = p.communicate()
+            if p.returncode != 0:
+                raise RuntimeError("hipcc -S failed on %s:\n%s" % (s, log.decode()))
+            lines = open(out).read().split("\n")
+            for n, k, t in (cpf.check_none(lines) if s in NO_MATRIX_UNITS else cpf.check(lines)):
+                bad.append((s, k, "packed fp32: " + t))
+            for name, body in cal.kernels(lines):
+                if any(k in name for k in ASYNC_CHECKED.get(s, [])):
+                    for i, l, why in cal.check(body):
+                        bad.append((s, name, "async load: %s (%s)" % (l, why)))
+            if verbose:
+                print("checked %-22s %s" % (s, "async + packed" if s in ASYNC_CHECKED else "packed"))
+    return bad
+
+
 if __name__ == "__main__":
     print(build(force="--force" in sys.argv, verbose=True))
+    if "--check" in sys.argv:
+        v = check()
+        for s, k, t in v[:40]:
+            print("VIOLATION %s [%s] %s" % (s, k, t))
+        print("%d violations" % len(v))
+        sys.exit(1 if v else 0)

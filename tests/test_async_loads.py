@@ -18,7 +18,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 
 
-@pytest.mark.parametrize("src,kernels", [("conv.hip", ["conv3x3_rp_kernel"]), ("conv_bneck.hip", ["conv_bneck_kernel"])])
+@pytest.mark.parametrize("src,kernels", [("conv.hip", ["conv3x3_rp_kernel"]), ("conv_bneck.hip", ["conv_bneck_kernel"]),
+                                         ("conv_b2b.hip", ["conv_b2b_kernel"]), ("conv3x3_c64.hip", ["conv3x3_c64_kernel"])])
 def test_no_instruction_touches_an_in_flight_load_destination(tmp_path, src, kernels):
     if not os.path.exists(HIPCC):
         pytest.skip("hipcc not installed")
@@ -36,7 +37,7 @@ def test_no_instruction_touches_an_in_flight_load_destination(tmp_path, src, ker
         seen += 1
         viol = chk.check(body)
         assert not viol, (name, viol[:6])
-    assert seen >= 2, seen           # both instantiations of every listed kernel were found
+    assert seen >= (2 if src in ("conv.hip", "conv_bneck.hip") else 1), seen           # every instantiation of the listed kernels was found
 
 
 def test_the_checker_sees_a_copy_in_front_of_the_wait():
