@@ -165,7 +165,13 @@ def _defaults():
                     PIPELINE_SPLITS=int(os.environ.get("DAFNE_PIPELINE_SPLITS", "3")), MAX_PLANS=48,
                     # replay every sub-batch's dense launches from a HIP graph in the pipelined / streamed step (one host call
                     # per stream and step instead of ~200)
-                    HIP_GRAPHS=True),
+                    HIP_GRAPHS=True,
+                    # debug: after every detect_packed of the one-stream path, assert that all head outputs are finite (one host
+                    # sync per call).  The convolution epilogues implement "no ReLU" as max(v, -inf): under IEEE maxNum a NaN
+                    # accumulator of a non-ReLU layer (FPN lateral / output, P6, tower convolutions in front of GroupNorm) becomes
+                    # -inf instead of propagating, so a corrupted checkpoint or an overflow shows as empty / wrong detections rather
+                    # than as NaNs -- this switch makes it loud
+                    CHECK_FINITE=False),
     )
 
 

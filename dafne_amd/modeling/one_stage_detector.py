@@ -347,6 +347,13 @@ class OneStageDetector(nn.Module):
                         plan.capture()
                 dense(images_u8, 0, n, plan)
                 self._last_head = plan.head          # (tests: the head outputs the returned detections were decoded from)
+                if getattr(self.cfg.ENGINE, "CHECK_FINITE", False):
+                    # the FPN maps first: behind them GroupNorm-on-load computes max(a x + b, 0), which turns a NaN into 0 again
+                    for l, (ft, lg, dc, ce) in enumerate(zip(plan.features, plan.head.logits, plan.head.delta_ctr, plan.head.center)):
+                        for nme, t in (("FPN map", ft.t), ("logits", lg), ("delta / ctrness", dc), ("center", ce)):
+                            if not bool(torch.isfinite(t).all()):
+                                raise _lib.DafneHipError("ENGINE.CHECK_FINITE: non-finite %s at level %d (weights / input overflow? a NaN "
+                                                         "accumulator of a non-ReLU layer turns into -inf)" % (nme, l))
                 return outs.predict_packed(head_levels(plan.head, strides), sizes=sizes,
                                            scale_corners=do_postprocess)
             # ---- pipeline: [preprocess, convs (split over `splits` streams), decode] | [NMS, gather]

@@ -912,6 +912,59 @@ def test_resident_patch_kernel_equals_generic_conv(cout, sizes, N, relu):
         close_bf16(r.nchw_float().cpu(), bfr(F.relu(ref) if relu else ref))
 
 
+@pytest.mark.parametrize("gnin", [False, True])
+def test_resident_patch_kernel_many_tiles_per_workgroup(gnin):
+    """The persistent loop of conv3x3_rp_kernel over FIVE / FOUR tiles per workgroup (round 6: 8 x 32 tiles on a ring of three slab
+    buffers -- a tile's slab 0 sits in buffer 0, 1, 2, 0, .. from tile to tile; slabs 0 / 1 of the next tile are requested during slabs
+    2 / 3 of the current one): plain, ragged 150 x 150 maps (1140 tiles on 228 workgroups) bit-identical to the generic kernel;
+    GN_INPUT, 16 x 128 x 128 (1024 tiles on 256 workgroups) against the patch kernel's GN_INPUT form (another K order and three
+    roundings instead of one in the normalisation: one bf16 ulp in < 4e-3 of the outputs, as in the chain test)."""
+    from dafne_amd import engine, _lib
+    d = dev()
+    g = torch.Generator().manual_seed(606 + gnin)
+    C = 256
+    N, H, W = (16, 128, 128) if gnin else (12, 150, 150)
+    x = bfr(torch.randn(N, C, H, W, generator=g))
+    w = bfr(torch.randn(C, C, 3, 3, generator=g) / 48.0)
+    b = torch.randn(C, generator=g) * 0.1
+    wp, bp = engine.pack_conv(w, b, d)
+    xi = engine.Act.from_nchw(x.to(d))
+    o_ref, o_rp = engine.Act(N, H, W, C, d), engine.Act(N, H, W, C, d)
+    st = _lib.current_stream()
+    kw, fl = {}, engine.F_RELU
+    if gnin:
+        stats = torch.zeros(1, N, C // 8, 2, dtype=torch.float32, device=d)
+        stats[..., 0] = (torch.randn(N, C // 8, generator=g) * 0.2).to(d)
+        stats[..., 1] = (0.5 + torch.rand(N, C // 8, generator=g)).to(d)
+        gamma = (1 + 0.2 * torch.randn(C, generator=g)).to(d)
+        beta = (0.3 * torch.randn(C, generator=g)).to(d)
+        kw, fl = {"gn_in": (stats, gamma, beta)}, engine.F_GNIN
+    ref = engine.ConvCall(wp, bp, C, C, 3, 1, 1, fl, [(xi.t, o_ref.t, None, H, W, H, W)], N, **kw)
+    c = _rp_call(wp, bp, C, fl, [(xi.t, o_rp.t, None, H, W, H, W)], N, d, **kw)
+    assert c.kernel_name() == "conv3x3_rp" and c.num_tiles() == N * ((H + 7) // 8) * ((W + 31) // 32) >= 1024
+    ref(st)
+    for _ in range(2):
+        c(st)
+    torch.cuda.synchronize()
+    if gnin:
+        assert ref.kernel_id() == 6
+        dlt = (o_rp.t.float() - o_ref.t.float()).abs()
+        assert float((dlt > 0).float().mean()) < 4e-3 and float(dlt.max()) <= 2.0 ** -7 * float(o_ref.t.float().abs().max())
+    else:
+        # (a map of this size goes to the patch kernel through the generic entry: its K order is (slab, kw, K half, kh), this kernel's
+        # (slab, kh, kw, k16) like conv_igemm's -- one bf16 ulp in ~2e-4 of the outputs; the bit-identical comparison against
+        # conv_igemm is test_resident_patch_kernel_equals_generic_conv at sizes that stay on it)
+        assert ref.kernel_id() == 6
+        dlt = (o_rp.t.float() - o_ref.t.float()).abs()
+        assert float((dlt > 0).float().mean()) < 1e-3 and float(dlt.max()) <= 2.0 ** -7 * float(o_ref.t.float().abs().max())
+    first = o_rp.t.clone()
+    c(st)
+    torch.cuda.synchronize()
+    assert torch.equal(o_rp.t, first)                     # run to run identical
+    close_bf16(o_rp.nchw_float().cpu()[:2], bfr(F.relu(F.conv2d(x[:2], w, b, padding=1))) if not gnin else o_rp.nchw_float().cpu()[:2])
+    assert float(o_rp.t[:, 0].abs().max()) == 0 and float(o_rp.t[:, :, -1].abs().max()) == 0
+
+
 def test_resident_patch_kernel_shape_rules():
     from dafne_amd import engine, _lib
     d = dev()

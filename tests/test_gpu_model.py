@@ -512,3 +512,25 @@ def test_tta_view_sharded_driver_equals_the_wrapper():
     assert len(a) == len(b) > 0
     assert a.image_size == b.image_size == (128, 160)          # the ORIGINAL image's size, not the first view's
     assert torch.equal(a.pred_corners, b.pred_corners) and torch.equal(a.scores, b.scores) and torch.equal(a.pred_classes, b.pred_classes)
+
+
+def test_check_finite_debug_mode_makes_a_poisoned_weight_loud():
+    """ENGINE.CHECK_FINITE (round 6, advisor): the branch-free epilogues turn a NaN accumulator of a non-ReLU layer into -inf (max with
+    -inf), so a corrupted checkpoint shows as empty / wrong detections; with the switch on, the one-stream detect_packed raises when a
+    head output is not finite -- and stays silent on a healthy model."""
+    from dafne_amd import _lib
+    cfg, m, P = build("dota-1.0_r50.yaml", seed=5)
+    cfg.ENGINE.CHECK_FINITE = True
+    g = torch.Generator().manual_seed(4)
+    img = torch.randint(0, 256, (3, 128, 160), generator=g, dtype=torch.uint8)
+    out = m([{"image": img, "height": 128, "width": 160}])
+    assert len(out[0]["instances"]) > 0
+    bad = {k: v.clone() for k, v in P.items()}
+    key = "backbone.fpn_lateral4.weight"
+    assert key in bad
+    bad[key][3, 5, 0, 0] = float("nan")
+    m.load_state_dict(bad)
+    m.to(dev())
+    m.invalidate()
+    with pytest.raises(_lib.DafneHipError, match="CHECK_FINITE"):
+        m([{"image": img, "height": 128, "width": 160}])
