@@ -41,6 +41,7 @@
 //     Every output element is the same sum in the same order as before: bit-identical to the separate launches.
 // Ragged tiles (H % 4 or W % 32 != 0): loads are clamped into the buffer; the stores of out-of-image pixels are issued with
 // those lanes' EXEC bits off (the instruction count -- and with it the vmcnt bookkeeping -- is the same for every tile).
+#include <cstdlib>
 #include <type_traits>
 
 #include "common.h"
@@ -56,31 +57,41 @@ typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
 typedef __attribute__((address_space(1))) void gvoid;
 typedef __attribute__((address_space(3))) void lvoid;
 
-constexpr int kTH = 4, kTW = 32, kPx = kTH * kTW;      // output tile
-constexpr int kPC = kTW + 2, kPR = kTH + 2;            // input patch
-constexpr int kPPieces = (kPR * kPC + 7) / 8;          // 26 DMA pieces of 8 px x 128 B per slab
-constexpr int kPSlab = kPPieces * 1024;                // 26 624 B
-constexpr int kSlab = kPx * 128;                       // one 64-channel slab of a 128-px tile: 16 KB
-constexpr int kBuf = 4 * kSlab;                        // 256 channels: 64 KB
-// LDS map.  The patch is dead when T is written.
-constexpr int kOffY = 0;                               // phase B: the Y chunk (K operand of conv1')
-constexpr int kOffT = kBuf;                            // T tile
-constexpr int kOffPatch = 3 * kSlab;                   // phase A only: [4 slabs][208 px][128 B]
-constexpr int kOffBias = kOffPatch + 4 * kPSlab;       // fp32 [256 conv2 | 1024 conv3 | 256 conv1 | 2 x 256 spare]
-constexpr int kSmemTotal = kOffBias + 8 * 1024;
-static_assert(kOffPatch + 4 * kPSlab >= kOffT + kBuf && kSmemTotal <= 160 * 1024, "LDS budget");
+// Tile geometry, a template parameter of the kernel (round 6): TH x 32 output pixels, TH = 4 (128 pixels: a weight fragment feeds four
+// MFMAs) or TH = 2 (64 pixels, two MFMAs per fragment) for launches with few tiles -- a res4 block of ONE image is 32 tiles of 4 x 32 on
+// 256 CUs; every CU streams the block's 2.2 MB of weights whatever its tile, so the half tile costs twice the L2 -> CU traffic per pixel
+// and is chosen only where the CUs would otherwise be idle (dafne_bottleneck_body_hip).  The weight layout does not depend on it.
+constexpr int kTW = 32, kPC = kTW + 2;
+template <int TH>
+struct BN {
+    static constexpr int kTH = TH, kPx = TH * kTW;             // output tile
+    static constexpr int kPR = TH + 2;                         // input patch rows
+    static constexpr int kPPieces = (kPR * kPC + 7) / 8;       // DMA pieces of 8 px x 128 B per slab: 26 (TH 4) / 17 (TH 2)
+    static constexpr int kPP = (kPPieces + 7) / 8;             // pieces per wave and slab: 4 / 3
+    static constexpr int kPSlab = kPPieces * 1024;
+    static constexpr int kSlab = kPx * 128;                    // one 64-channel slab of the tile: 16 / 8 KB
+    static constexpr int kBuf = 4 * kSlab;                     // 256 channels
+    // LDS map.  The patch is dead when T is written.
+    static constexpr int kOffY = 0;                            // phase B: the Y chunk (K operand of conv1')
+    static constexpr int kOffT = kBuf;                         // T tile
+    static constexpr int kOffPatch = 3 * kSlab;                // phase A only: [4 slabs][patch px][128 B]
+    static constexpr int kOffBias = kOffPatch + 4 * kPSlab;    // fp32 [256 conv2 | 1024 conv3 | 256 conv1 | 2 x 256 spare]
+    static constexpr int kSmemTotal = kOffBias + 8 * 1024;
+    static_assert(kOffPatch + 4 * kPSlab >= kOffT + kBuf && kSmemTotal <= 160 * 1024, "LDS budget");
+    static constexpr int kPF = kPx / 32;                       // pixel fragments per wave
+    static constexpr int kRL = kPx / 16;                       // quad-layout row instructions per wave and 256-channel chunk (16 px each)
+    static constexpr int kTrickle = 3 * kPP;                   // patch slabs 1..3: one piece per wave and step 0 .. kTrickle - 1
+};
 constexpr int kCM = 256, kCB = 1024, kChunks = kCB / 256;
 constexpr int kNW = 8, kNT = 512;
-constexpr int kPF = kPx / 32;                          // pixel fragments per wave
 constexpr int kStepsA = 9 * (kCM / 16);                // 144 k16 steps of the 3x3
 constexpr int kStepsB = 2 * kChunks * 16;              // 128 k16 steps of conv3 + conv1'
 constexpr int kSteps = kStepsA + kStepsB;
 constexpr int kRing = 8;                               // k16 steps of A fragments in flight per wave
 constexpr int kWABytes = kNW * kStepsA * 1024;         // phase A weights: [8 waves][144 steps][64 lanes][8]
 constexpr int kPhaseBytes = kNW * 16 * 1024;           // one GEMM of phase B: [8 waves][16 steps][64 lanes][8]
-constexpr int kTrickle = 12;                           // patch slabs 1..3: 12 pieces per wave, one per step 0..11
-constexpr int kRes0 = 60, kResStride = 4;              // the first shortcut chunk: 8 register loads per lane at steps 60, 64, .., 88
-constexpr int kDumpBytes = kPx * kCB * 2;              // scratch the ABI asks for (rounds 3-5: rows of out-of-image pixels; now timing stamps only)
+constexpr int kRes0 = 60, kResStride = 4;              // the first shortcut chunk: one register load per lane at steps 60, 64, ..
+constexpr int kDumpBytes = 128 * kCB * 2;              // scratch the ABI asks for (rounds 3-5: rows of out-of-image pixels; now timing stamps only)
 
 struct BneckDev {
     const char* in;      // bf16 [N, H+2, W+2, 256]   U
@@ -120,28 +131,32 @@ __device__ __forceinline__ unsigned pack_bf16(float a, float b) {
 // bn_wait(j) = number of those instructions issued after A(j) and before the wait for it: vmcnt retires in order, so
 // `s_waitcnt vmcnt(bn_wait(j))` is exactly "A(j) and everything older has landed".  The shortcut loads of chunk c sit in front
 // of A(144 + 32 c - 8): the first step of G2b(c - 1) already waits for them, a whole G1 ahead of their use in E(c).
+template <int TH>
 constexpr int bn_post(int s) {
+    constexpr int kRL = BN<TH>::kRL;
     if (s < kStepsA)
-        return (s < kTrickle ? 1 : 0) + ((s >= kRes0 && s < kRes0 + 8 * kResStride && (s - kRes0) % kResStride == 0) ? 1 : 0);
+        return (s < BN<TH>::kTrickle ? 1 : 0) + ((s >= kRes0 && s < kRes0 + kRL * kResStride && (s - kRes0) % kResStride == 0) ? 1 : 0);
     const int j = s - kStepsA, i = j & 31, c = j >> 5;
-    return i == 15 ? 8 + (c + 1 < kChunks ? 8 : 0) : 0;
+    return i == 15 ? kRL + (c + 1 < kChunks ? kRL : 0) : 0;
 }
+template <int TH>
 constexpr int bn_wait(int j) {
     int n = 0;
     if (j < kRing) {
         n += kRing - 1 - j;                                    // A(j+1 .. 7)
-        for (int s = 0; s < j; s++) n += 1 + bn_post(s);
+        for (int s = 0; s < j; s++) n += 1 + bn_post<TH>(s);
     } else {
-        n += bn_post(j - kRing);                               // the operations right behind A(j) at the end of step j - 8
-        for (int s = j - kRing + 1; s < j; s++) n += (s + kRing < kSteps ? 1 : 0) + bn_post(s);
+        n += bn_post<TH>(j - kRing);                           // the operations right behind A(j) at the end of step j - 8
+        for (int s = j - kRing + 1; s < j; s++) n += (s + kRing < kSteps ? 1 : 0) + bn_post<TH>(s);
     }
     return n;
 }
-// spot checks (hand-counted): steady state 7; the trickle adds one per step; the 16 operations of an epilogue
-static_assert(bn_wait(0) == 7 && bn_wait(1) == 8 && bn_wait(7) == 14 && bn_wait(8) == 15 && bn_wait(12) == 15 && bn_wait(13) == 14 &&
-              bn_wait(20) == 7 && bn_wait(61) == 8 && bn_wait(68) == 9 && bn_wait(100) == 7 && bn_wait(kStepsA + 7) == 7 &&
-              bn_wait(kStepsA + 15) == 7 && bn_wait(kStepsA + 16) == 23 && bn_wait(kStepsA + 23) == 23 && bn_wait(kStepsA + 24) == 7 &&
-              bn_wait(kStepsA + 96 + 16) == 15 && bn_wait(kStepsA + 96 + 24) == 7 && bn_wait(kStepsA + 127) == 0,
+// spot checks (hand-counted, 4 x 32 tiles): steady state 7; the trickle adds one per step; the 16 operations of an epilogue
+static_assert(bn_wait<4>(0) == 7 && bn_wait<4>(1) == 8 && bn_wait<4>(7) == 14 && bn_wait<4>(8) == 15 && bn_wait<4>(12) == 15 && bn_wait<4>(13) == 14 &&
+              bn_wait<4>(20) == 7 && bn_wait<4>(61) == 8 && bn_wait<4>(68) == 9 && bn_wait<4>(100) == 7 && bn_wait<4>(kStepsA + 7) == 7 &&
+              bn_wait<4>(kStepsA + 15) == 7 && bn_wait<4>(kStepsA + 16) == 23 && bn_wait<4>(kStepsA + 23) == 23 && bn_wait<4>(kStepsA + 24) == 7 &&
+              bn_wait<4>(kStepsA + 96 + 16) == 15 && bn_wait<4>(kStepsA + 96 + 24) == 7 && bn_wait<4>(kStepsA + 127) == 0 &&
+              bn_wait<2>(9) == 15 && bn_wait<2>(10) == 14 && bn_wait<2>(kStepsA + 16) == 15 && bn_wait<2>(kStepsA + 96 + 16) == 11,
               "vmcnt bookkeeping");
 
 template <int I, int N, class F>
@@ -167,40 +182,71 @@ __device__ __forceinline__ void bn_load(bf16x8 (&ar)[kRing], const char* wf, uns
         asm volatile("global_load_dwordx4 %0, %1, %2" : "+v"(ar[J % kRing]) : "v"(voffB), "s"(sb) : "memory");
     }
 }
-// the four B fragments of phase-A step J (patch rows kh .. kh + 3 at tap column kw, chunk kc of slab sl): inline asm,
-// completion is awaited by the caller (lgkmcnt)
-template <int J>
-__device__ __forceinline__ void bn_bread(bf16x8 (&b)[kPF], const unsigned (&pb)[3], unsigned lds_base) {
+// the PF B fragments of phase-A step J (patch rows kh .. kh + PF - 1 at tap column kw, chunk kc of slab sl; PSLAB = the slab's bytes):
+// inline asm, completion is awaited by the caller (lgkmcnt)
+template <int J, int PF, int PSLAB>
+__device__ __forceinline__ void bn_bread(bf16x8 (&b)[PF], const unsigned (&pb)[3], unsigned lds_base) {
     constexpr int sl = J / 36, t = J % 36, kh = t / 12, kw = (t >> 2) % 3, kc = t & 3;
-    const unsigned ad = lds_base + ((pb[kw] ^ (unsigned)(kc << 5)) + (unsigned)(sl * kPSlab));
+    const unsigned ad = lds_base + ((pb[kw] ^ (unsigned)(kc << 5)) + (unsigned)(sl * PSLAB));
     constexpr int o0 = (kh + 0) * kPC * 128, o1 = (kh + 1) * kPC * 128, o2 = (kh + 2) * kPC * 128, o3 = (kh + 3) * kPC * 128;
-    asm volatile("ds_read_b128 %0, %4 offset:%5\n\tds_read_b128 %1, %4 offset:%6\n\tds_read_b128 %2, %4 offset:%7\n\tds_read_b128 %3, %4 offset:%8"
-                 : "=&v"(b[0]), "=&v"(b[1]), "=&v"(b[2]), "=&v"(b[3])
-                 : "v"(ad), "n"(o0), "n"(o1), "n"(o2), "n"(o3)
-                 : "memory");
+    if constexpr (PF == 4) {
+        asm volatile("ds_read_b128 %0, %4 offset:%5\n\tds_read_b128 %1, %4 offset:%6\n\tds_read_b128 %2, %4 offset:%7\n\tds_read_b128 %3, %4 offset:%8"
+                     : "=&v"(b[0]), "=&v"(b[1]), "=&v"(b[2]), "=&v"(b[3])
+                     : "v"(ad), "n"(o0), "n"(o1), "n"(o2), "n"(o3)
+                     : "memory");
+    } else {
+        static_assert(PF == 2, "2 or 4 pixel fragments");
+        asm volatile("ds_read_b128 %0, %2 offset:%3\n\tds_read_b128 %1, %2 offset:%4"
+                     : "=&v"(b[0]), "=&v"(b[1])
+                     : "v"(ad), "n"(o0), "n"(o1)
+                     : "memory");
+    }
 }
 
-// phase B: the four B fragments (pixel fragments 4096 B apart) of k16 step ST of slab Q of the buffer at byte offset BUF
-template <int BUF, int Q, int ST>
-__device__ __forceinline__ void bn_bread_b(bf16x8 (&b)[kPF], const unsigned (&bs)[4], unsigned lds_base) {
+// phase B: the PF B fragments (pixel fragments 4096 B apart) of k16 step ST of the slab at byte offset OFF of the buffer at BUF
+template <int BUF, int OFF, int ST, int PF>
+__device__ __forceinline__ void bn_bread_b(bf16x8 (&b)[PF], const unsigned (&bs)[4], unsigned lds_base) {
     const unsigned ad = lds_base + (unsigned)BUF + bs[ST];
-    constexpr int o = Q * kSlab;
-    asm volatile("ds_read_b128 %0, %4 offset:%5\n\tds_read_b128 %1, %4 offset:%6\n\tds_read_b128 %2, %4 offset:%7\n\tds_read_b128 %3, %4 offset:%8"
-                 : "=&v"(b[0]), "=&v"(b[1]), "=&v"(b[2]), "=&v"(b[3])
-                 : "v"(ad), "n"(o), "n"(o + 4096), "n"(o + 8192), "n"(o + 12288)
-                 : "memory");
+    constexpr int o = OFF;
+    if constexpr (PF == 4) {
+        asm volatile("ds_read_b128 %0, %4 offset:%5\n\tds_read_b128 %1, %4 offset:%6\n\tds_read_b128 %2, %4 offset:%7\n\tds_read_b128 %3, %4 offset:%8"
+                     : "=&v"(b[0]), "=&v"(b[1]), "=&v"(b[2]), "=&v"(b[3])
+                     : "v"(ad), "n"(o), "n"(o + 4096), "n"(o + 8192), "n"(o + 12288)
+                     : "memory");
+    } else {
+        asm volatile("ds_read_b128 %0, %2 offset:%3\n\tds_read_b128 %1, %2 offset:%4"
+                     : "=&v"(b[0]), "=&v"(b[1])
+                     : "v"(ad), "n"(o), "n"(o + 4096)
+                     : "memory");
+    }
+}
+// the caller's wait for the fragments of the current step: all but the PF youngest LDS operations
+template <int PF, bool LAST>
+__device__ __forceinline__ void bn_bwait(bf16x8 (&b)[PF]) {
+    if constexpr (PF == 4) {
+        if constexpr (LAST) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]) :: "memory");
+        else asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]) :: "memory");
+    } else {
+        if constexpr (LAST) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(b[0]), "+v"(b[1]) :: "memory");
+        else asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(b[0]), "+v"(b[1]) :: "memory");
+    }
 }
 
-template <int J>
+template <int J, int TH>
 __device__ __forceinline__ void bn_wait_for(bf16x8 (&ar)[kRing]) {
-    constexpr int kWaitN = bn_wait(J);
+    constexpr int kWaitN = bn_wait<TH>(J);
     asm volatile("s_waitcnt vmcnt(%1)" : "+v"(ar[J % kRing]) : "n"(kWaitN) : "memory");
 }
 
 // HEAD = false (the stage's last block: no next conv1): GEMM2 and the Z rows are skipped; the weight stream still
 // walks the (zero) conv1' fragments -- the vmcnt bookkeeping is one schedule for both forms.
-template <bool HEAD>
+template <bool HEAD, int TH>
 __global__ void __launch_bounds__(512, 2) conv_bneck_kernel(BneckDev P) {
+    typedef BN<TH> Geo;
+    constexpr int kTH = Geo::kTH, kPx = Geo::kPx, kPPieces = Geo::kPPieces, kPP = Geo::kPP, kPSlab = Geo::kPSlab, kSlab = Geo::kSlab;
+    constexpr int kOffY = Geo::kOffY, kOffT = Geo::kOffT, kOffPatch = Geo::kOffPatch, kOffBias = Geo::kOffBias;
+    constexpr int kPF = Geo::kPF, kRL = Geo::kRL, kTrickle = Geo::kTrickle;
+    static_assert(kPx == kTH * kTW, "tile");
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -216,12 +262,12 @@ __global__ void __launch_bounds__(512, 2) conv_bneck_kernel(BneckDev P) {
     const int Wp = P.W + 2;
 
     // ---- patch DMA map: piece pc = 8 consecutive patch pixels (patch pixel pp = p * 34 + q <-> input pixel
-    // (row0 - 1 + p, col0 - 1 + q)); wave w moves pieces w, w + 8, w + 16 and min(w + 24, 25) of every slab (the six waves
-    // without a fourth piece re-load piece 25: every wave issues the same number of DMAs)
-    size_t pofs[4];
-    unsigned pdst[4];
+    // (row0 - 1 + p, col0 - 1 + q)); wave w moves pieces w, w + 8, .. (kPP of every slab; a wave without a last piece re-loads the
+    // slab's last one: every wave issues the same number of DMAs)
+    size_t pofs[kPP];
+    unsigned pdst[kPP];
 #pragma unroll
-    for (int ii = 0; ii < 4; ii++) {
+    for (int ii = 0; ii < kPP; ii++) {
         int pc = wave + kNW * ii;
         pc = pc < kPPieces ? pc : kPPieces - 1;
         const int pp = pc * 8 + (lane >> 3);
@@ -261,12 +307,12 @@ __global__ void __launch_bounds__(512, 2) conv_bneck_kernel(BneckDev P) {
     auto row_mask = [&](int k) -> unsigned long long { return row0 + (k >> 1) < P.H ? colm[k & 1] : 0ull; };
     // shortcut values of the chunk ahead in quad layout: rs[k], loaded by inline asm ("+v": one register set for the whole kernel),
     // valid behind the weight waits that cover them (see bn_post)
-    u32x4 rs[8];
+    u32x4 rs[kRL];
 #pragma unroll
-    for (int k = 0; k < 8; k++) rs[k] = u32x4{};
+    for (int k = 0; k < kRL; k++) rs[k] = u32x4{};
     auto res_load = [&](auto C, auto K) {
         constexpr int c = decltype(C)::value, k = decltype(K)::value;
-        u32x4(&rr)[8] = rs;                     // (a non-dependent use: a generic lambda captures the array only through one)
+        u32x4(&rr)[kRL] = rs;                   // (a non-dependent use: a generic lambda captures the array only through one)
         const unsigned vo = qcx[k & 1];
         const char* xb = P.res + row_pix(k >> 1) * (size_t)(kCB * 2);
         // default cache policy.  (Rounds 4-5 marked the shortcut DMA non-temporal: +0.45 %.  Here a 128-byte line of X is read by TWO
@@ -306,7 +352,7 @@ __global__ void __launch_bounds__(512, 2) conv_bneck_kernel(BneckDev P) {
 #pragma unroll
     for (int k = 0; k < kRing; k++) ar[k] = bf16x8{};
     auto load_step = [&](auto J) { bn_load<decltype(J)::value>(ar, P.wf, voffA, voffB); };
-    auto wait_step = [&](auto J) { bn_wait_for<decltype(J)::value>(ar); };
+    auto wait_step = [&](auto J) { bn_wait_for<decltype(J)::value, TH>(ar); };
 
     f32x16 acc1[kPF], acc2[kPF];
 
@@ -357,7 +403,7 @@ __global__ void __launch_bounds__(512, 2) conv_bneck_kernel(BneckDev P) {
     // the wave's 8 KB of the buffer -> HBM rows in quad layout (LDS operations of one wave execute in order: the pieces this wave
     // wrote a moment ago are read back without a barrier), four instructions per LDS round trip
     auto rows_out = [&](char* base, size_t pix_bytes, const unsigned (&qc)[2], auto OFF) {
-        static_for<0, 2>([&](auto G) {
+        static_for<0, kRL / 4>([&](auto G) {
             constexpr int g = decltype(G)::value;
             const unsigned qa = ql;
             u32x4 v[4];
@@ -388,7 +434,7 @@ __global__ void __launch_bounds__(512, 2) conv_bneck_kernel(BneckDev P) {
         __builtin_amdgcn_global_load_lds((gvoid*)(bsrc + lane * 4), (lvoid*)(lds + kOffBias + wave * 1024), 16, 0, 0);
     }
 #pragma unroll
-    for (int ii = 0; ii < 4; ii++) patch_piece(0, ii);
+    for (int ii = 0; ii < kPP; ii++) patch_piece(0, ii);
     static_for<0, kRing>(load_step);
 
     // ================================================================ phase A: T = relu(conv2(U) + bias2)
@@ -404,20 +450,20 @@ __global__ void __launch_bounds__(512, 2) conv_bneck_kernel(BneckDev P) {
         if constexpr (j == 35) barrier();            // slabs 1..3: every wave passed a wait covering its last piece at step 20
         // the B fragments of step j + 1 are requested before the MFMAs of step j (two register sets; the counted lgkmcnt leaves
         // exactly those four reads in flight)
-        if constexpr (j == 0) bn_bread<0>(bfr[0], pb, lds_base);
+        if constexpr (j == 0) bn_bread<0, kPF, kPSlab>(bfr[0], pb, lds_base);
         if constexpr (j + 1 < kStepsA) {
-            bn_bread<j + 1>(bfr[(j + 1) & 1], pb, lds_base);
-            asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(bfr[j & 1][0]), "+v"(bfr[j & 1][1]), "+v"(bfr[j & 1][2]), "+v"(bfr[j & 1][3]) :: "memory");
+            bn_bread<j + 1, kPF, kPSlab>(bfr[(j + 1) & 1], pb, lds_base);
+            bn_bwait<kPF, false>(bfr[j & 1]);
         } else {
-            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(bfr[j & 1][0]), "+v"(bfr[j & 1][1]), "+v"(bfr[j & 1][2]), "+v"(bfr[j & 1][3]) :: "memory");
+            bn_bwait<kPF, true>(bfr[j & 1]);
         }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int r = 0; r < kPF; r++) acc1[r] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ar[j % kRing], bfr[j & 1][r], acc1[r], 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
         load_step(std::integral_constant<int, j + kRing>{});
-        if constexpr (j < kTrickle) patch_piece(1 + j / 4, j & 3);
-        if constexpr (j >= kRes0 && j < kRes0 + 8 * kResStride && (j - kRes0) % kResStride == 0) {
+        if constexpr (j < kTrickle) patch_piece(1 + j / kPP, j % kPP);
+        if constexpr (j >= kRes0 && j < kRes0 + kRL * kResStride && (j - kRes0) % kResStride == 0) {
             res_load(std::integral_constant<int, 0>{}, std::integral_constant<int, (j - kRes0) / kResStride>{});
         }
     });
@@ -453,11 +499,12 @@ __global__ void __launch_bounds__(512, 2) conv_bneck_kernel(BneckDev P) {
         // ago (see the top of the file).  The values have landed: they are older than A(j0 - 8), which the first step of G2b(c - 1)
         // waited for (chunk 0's: requested in phase A, older than A(96)).  The pin makes the LDS writes depend on an instruction
         // behind those waits.
-        asm volatile("" : "+v"(rs[0]), "+v"(rs[1]), "+v"(rs[2]), "+v"(rs[3]), "+v"(rs[4]), "+v"(rs[5]), "+v"(rs[6]), "+v"(rs[7]) :: "memory");
-        static_for<0, 8>([&](auto K) {
+        if constexpr (kRL == 8) asm volatile("" : "+v"(rs[0]), "+v"(rs[1]), "+v"(rs[2]), "+v"(rs[3]), "+v"(rs[4]), "+v"(rs[5]), "+v"(rs[6]), "+v"(rs[7]) :: "memory");
+        else asm volatile("" : "+v"(rs[0]), "+v"(rs[1]), "+v"(rs[2]), "+v"(rs[3]) :: "memory");
+        static_for<0, kRL>([&](auto K) {
             constexpr int k = decltype(K)::value;
             const unsigned qa = ql;                 // (non-dependent uses: a generic lambda captures the two only through them)
-            const u32x4(&rr)[8] = rs;
+            const u32x4(&rr)[kRL] = rs;
             asm volatile("ds_write_b128 %0, %1 offset:%2" :: "v"(qa), "v"(rr[k]), "n"(k * 2048) : "memory");
         });
         // ---- G1(c): acc1 = W3[c] . T  (K = 256 over the four slabs of the T tile)
@@ -469,12 +516,12 @@ __global__ void __launch_bounds__(512, 2) conv_bneck_kernel(BneckDev P) {
             constexpr int i = decltype(I)::value;
             constexpr int j = j0 + i;
             wait_step(std::integral_constant<int, j>{});
-            if constexpr (i == 0) bn_bread_b<kOffT, 0, 0>(bfr[j & 1], bs, lds_base);
+            if constexpr (i == 0) bn_bread_b<kOffT, 0, 0, kPF>(bfr[j & 1], bs, lds_base);
             if constexpr (i + 1 < 16) {
-                bn_bread_b<kOffT, ((i + 1) >> 2), ((i + 1) & 3)>(bfr[(j + 1) & 1], bs, lds_base);
-                asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(bfr[j & 1][0]), "+v"(bfr[j & 1][1]), "+v"(bfr[j & 1][2]), "+v"(bfr[j & 1][3]) :: "memory");
+                bn_bread_b<kOffT, ((i + 1) >> 2) * kSlab, ((i + 1) & 3), kPF>(bfr[(j + 1) & 1], bs, lds_base);
+                bn_bwait<kPF, false>(bfr[j & 1]);
             } else {
-                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(bfr[j & 1][0]), "+v"(bfr[j & 1][1]), "+v"(bfr[j & 1][2]), "+v"(bfr[j & 1][3]) :: "memory");
+                bn_bwait<kPF, true>(bfr[j & 1]);
             }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -488,10 +535,10 @@ __global__ void __launch_bounds__(512, 2) conv_bneck_kernel(BneckDev P) {
         // wave's 32 channels of Y chunk c: residual pieces from its 8 KB of the Y buffer, y = relu((acc1 + bias3) + x) written over
         // them (the K operand of conv1'), then the 8 KB read back in quad layout and stored
         {
-            if constexpr (c + 1 < kChunks) static_for<0, 8>([&](auto K) { res_load(std::integral_constant<int, c + 1>{}, K); });
+            if constexpr (c + 1 < kChunks) static_for<0, kRL>([&](auto K) { res_load(std::integral_constant<int, c + 1>{}, K); });
             f32x4 bv[4];
             bias16(256 + c * 256, bv);
-            static_for<0, 2>([&](auto BP) {
+            static_for<0, kPF / 2>([&](auto BP) {
                 constexpr int b0 = 2 * decltype(BP)::value;
                 const unsigned e0 = ey[0], e1 = ey[1];
                 u32x4 r[4];
@@ -521,12 +568,12 @@ __global__ void __launch_bounds__(512, 2) conv_bneck_kernel(BneckDev P) {
                 constexpr int q = 2 * hh + (i >> 2), st = i & 3;
                 wait_step(std::integral_constant<int, j>{});
                 if constexpr (HEAD) {
-                    if constexpr (i == 0) bn_bread_b<kOffY, q, st>(bfr[j & 1], bs, lds_base);
+                    if constexpr (i == 0) bn_bread_b<kOffY, q * kSlab, st, kPF>(bfr[j & 1], bs, lds_base);
                     if constexpr (i + 1 < 8) {
-                        bn_bread_b<kOffY, 2 * hh + ((i + 1) >> 2), ((i + 1) & 3)>(bfr[(j + 1) & 1], bs, lds_base);
-                        asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(bfr[j & 1][0]), "+v"(bfr[j & 1][1]), "+v"(bfr[j & 1][2]), "+v"(bfr[j & 1][3]) :: "memory");
+                        bn_bread_b<kOffY, (2 * hh + ((i + 1) >> 2)) * kSlab, ((i + 1) & 3), kPF>(bfr[(j + 1) & 1], bs, lds_base);
+                        bn_bwait<kPF, false>(bfr[j & 1]);
                     } else {
-                        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(bfr[j & 1][0]), "+v"(bfr[j & 1][1]), "+v"(bfr[j & 1][2]), "+v"(bfr[j & 1][3]) :: "memory");
+                        bn_bwait<kPF, true>(bfr[j & 1]);
                     }
                     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -588,15 +635,32 @@ int dafne_bottleneck_body_hip(const void* d_in, const void* d_res, const void* d
     D.out = (char*)d_out; D.next = (char*)d_next; D.dump = (char*)d_scratch;
     D.N = n_images; D.H = H; D.W = W;
     D.tiles_x = (W + kTW - 1) / kTW;
-    D.tiles_per_img = D.tiles_x * ((H + kTH - 1) / kTH);
+    // 4 x 32 tiles; 2 x 32 where the launch would leave more than three quarters of the CUs without a tile (one image of a 64 x 64 map:
+    // 32 tiles on 256 CUs -> 64 half tiles; same results bit for bit, twice the weight traffic per pixel).  DAFNE_BNECK_TH = 2 / 4
+    // forces a geometry (tests, A/B runs).
+    int cus = 0;
+    if (int rc = dafne::device_cus(&cus)) return rc;
+    const long long tiles4 = (long long)D.tiles_x * ((H + 3) / 4) * n_images;
+    int th = tiles4 * 4 <= cus ? 2 : 4;
+    if (const char* e = getenv("DAFNE_BNECK_TH")) {
+        const int f = atoi(e);
+        if (f == 2 || f == 4) th = f;
+    }
+    D.tiles_per_img = D.tiles_x * ((H + th - 1) / th);
     const long long tiles = (long long)D.tiles_per_img * n_images;
     const long long pix = (long long)n_images * (H + 2) * (W + 2);
     if (tiles > (1ll << 24) || pix * (kCB * 2) > 0xffffffffll) return dafne::fail(DAFNE_E_UNSUPPORTED, "bottleneck_body: too large");
     D.tiles = (int)tiles;
     D.max_pix = (unsigned)(pix - 1);
-    DAFNE_MAX_LDS_ONCE(kSmemTotal, (const void*)conv_bneck_kernel<true>, (const void*)conv_bneck_kernel<false>);
-    if (head) hipLaunchKernelGGL(conv_bneck_kernel<true>, dim3(D.tiles), dim3(kNT), kSmemTotal, (hipStream_t)stream, D);
-    else hipLaunchKernelGGL(conv_bneck_kernel<false>, dim3(D.tiles), dim3(kNT), kSmemTotal, (hipStream_t)stream, D);
+    if (th == 4) {
+        DAFNE_MAX_LDS_ONCE(BN<4>::kSmemTotal, (const void*)conv_bneck_kernel<true, 4>, (const void*)conv_bneck_kernel<false, 4>);
+        if (head) hipLaunchKernelGGL((conv_bneck_kernel<true, 4>), dim3(D.tiles), dim3(kNT), BN<4>::kSmemTotal, (hipStream_t)stream, D);
+        else hipLaunchKernelGGL((conv_bneck_kernel<false, 4>), dim3(D.tiles), dim3(kNT), BN<4>::kSmemTotal, (hipStream_t)stream, D);
+    } else {
+        DAFNE_MAX_LDS_ONCE(BN<2>::kSmemTotal, (const void*)conv_bneck_kernel<true, 2>, (const void*)conv_bneck_kernel<false, 2>);
+        if (head) hipLaunchKernelGGL((conv_bneck_kernel<true, 2>), dim3(D.tiles), dim3(kNT), BN<2>::kSmemTotal, (hipStream_t)stream, D);
+        else hipLaunchKernelGGL((conv_bneck_kernel<false, 2>), dim3(D.tiles), dim3(kNT), BN<2>::kSmemTotal, (hipStream_t)stream, D);
+    }
     return dafne::check_launch("conv_bneck");
 }
 

@@ -791,13 +791,19 @@ def test_bottleneck_tail_head_fused_equals_two_convs(N, H, W):
     assert float((got - z_ref).abs().max()) < 0.02 * float(z_ref.abs().max())
 
 
-@pytest.mark.parametrize("N,H,W", [(1, 8, 32), (8, 64, 64), (3, 13, 21), (2, 30, 44), (1, 1, 1), (1, 5, 70)])
-def test_bottleneck_body_fused_equals_three_convs(N, H, W):
+@pytest.mark.parametrize("th", [4, 2, 0])
+@pytest.mark.parametrize("N,H,W", [(1, 8, 32), (8, 64, 64), (3, 13, 21), (2, 30, 44), (1, 1, 1), (1, 5, 70), (1, 64, 64)])
+def test_bottleneck_body_fused_equals_three_convs(N, H, W, th, monkeypatch):
     """dafne_bottleneck_body_hip (conv2 3x3 + ReLU, conv3 + residual + ReLU, the next block's conv1 + ReLU in one kernel;
     the 3x3's output never reaches HBM) against the three launches of the generic path: bit for bit on both outputs --
-    the headline shape (8 x 64 x 64, 256 exact tiles) and ragged sizes (partial 4 x 32 tiles in both directions, more
+    the headline shape (8 x 64 x 64, 256 exact tiles) and ragged sizes (partial tiles in both directions, more
     than one tile column, a single pixel) --, the zero halo untouched, nothing written outside the two outputs; and
-    against torch within bf16 rounding."""
+    against torch within bf16 rounding.  Both tile geometries (round 6: 4 x 32, and 2 x 32 for launches with few tiles) on every
+    shape, and the library's own choice (th = 0)."""
+    if th:
+        monkeypatch.setenv("DAFNE_BNECK_TH", str(th))
+    else:
+        monkeypatch.delenv("DAFNE_BNECK_TH", raising=False)
     from dafne_amd import engine, _lib
     L = _lib.load()
     d = dev()
