@@ -635,13 +635,14 @@ int dafne_bottleneck_body_hip(const void* d_in, const void* d_res, const void* d
     D.out = (char*)d_out; D.next = (char*)d_next; D.dump = (char*)d_scratch;
     D.N = n_images; D.H = H; D.W = W;
     D.tiles_x = (W + kTW - 1) / kTW;
-    // 4 x 32 tiles; 2 x 32 where the launch would leave more than three quarters of the CUs without a tile (one image of a 64 x 64 map:
-    // 32 tiles on 256 CUs -> 64 half tiles; same results bit for bit, twice the weight traffic per pixel).  DAFNE_BNECK_TH = 2 / 4
-    // forces a geometry (tests, A/B runs).
+    // 4 x 32 tiles; 2 x 32 where the launch would leave seven eighths of the CUs without a tile (one image of a 64 x 64 map: 32 tiles
+    // on 256 CUs -> 64 half tiles: 46 -> 28 us per block; same results bit for bit, twice the weight traffic per pixel -- a two-image
+    // sub-batch of the timed layout on half tiles cost 0.8 % of the step, so the bound is an eighth, not a quarter).  DAFNE_BNECK_TH =
+    // 2 / 4 forces a geometry (tests, A/B runs).
     int cus = 0;
     if (int rc = dafne::device_cus(&cus)) return rc;
     const long long tiles4 = (long long)D.tiles_x * ((H + 3) / 4) * n_images;
-    int th = tiles4 * 4 <= cus ? 2 : 4;
+    int th = tiles4 * 8 <= cus ? 2 : 4;
     if (const char* e = getenv("DAFNE_BNECK_TH")) {
         const int f = atoi(e);
         if (f == 2 || f == 4) th = f;
