@@ -375,14 +375,17 @@ int dafne_bottleneck_tail_head_hip(const void* d_in, const void* d_res, const vo
  *   T = relu(conv2(d_in) + bias2)  (3x3, 256 -> 256, pad 1; d_in = the block's conv1 output),
  *   d_out = relu(conv3(T) + bias3 + d_res)  (1x1, 256 -> 1024),  d_next = relu(conv1'(d_out) + bias1)  (1x1, 1024 -> 256).
  * T never reaches HBM.  Tensors as for dafne_bottleneck_tail_head_hip (bf16 NHWC, 1-pixel halo, interior written); any
- * H, W (4 x 32 pixel tiles; rows of out-of-image tile pixels are written to d_scratch, which needs
- * dafne_bottleneck_body_scratch_bytes() bytes and holds nothing afterwards).  d_wfrag: conv2 fragment-major, bf16
- * [8 waves][144 k16 steps][64 lanes][8] (rows wave*32 + (lane & 31); K columns 16*step + 8*(lane >> 5) .. +8 of
- * dafne_conv2d_nhwc_bf16_hip's packed weight: 64-channel slab, kh, kw, channel), followed by
- * dafne_bottleneck_tail_head_hip's d_wfrag  (engine.pack_bneck).  Bit-identical to dafne_conv2d_nhwc_bf16_hip(conv2, RELU)
- * followed by dafne_bottleneck_tail_head_hip.  d_next == NULL (the stage's last block: no next conv1): only d_out is
- * produced (d_bias1 may be NULL; the conv1' section of d_wfrag is still read: pack zeros), bit-identical to
- * dafne_conv2d_nhwc_bf16_hip(conv2, RELU) followed by (conv3, RELU|RESIDUAL).
+ * H, W (4 x 32 pixel tiles -- 2 x 32 where a launch would leave seven eighths of the CUs without a tile; stores of out-of-image
+ * tile pixels are masked; d_scratch needs dafne_bottleneck_body_scratch_bytes() bytes and holds nothing afterwards).
+ * d_wfrag (ABI 140): conv2 fragment-major, bf16 [8 waves][144 k16 steps][64 lanes][8] (row wave*32 + perm[lane & 31]; K columns
+ * 16*step + 8*(lane >> 5) .. +8 of dafne_conv2d_nhwc_bf16_hip's packed weight: 64-channel slab, kh, kw, channel), followed by
+ * [8 GEMMs][8 waves][16 k16 steps][64 lanes][8]: GEMM 2c = conv3 rows c*256 + wave*32 + perm[lane & 31] over K = 256, GEMM 2c+1 =
+ * conv1' rows wave*32 + perm[lane & 31] over K-chunk c.  perm[8g + 4h + i] = 16 (g >> 1) + 8h + 4 (g & 1) + i  (g = 0..3, h = 0..1,
+ * i = 0..3): the rows of every 32-block in the order that makes a lane's 16 accumulator registers two runs of 8 consecutive
+ * channels (engine.pack_bneck; NOT dafne_bottleneck_tail_head_hip's layout any more).  Bit-identical to
+ * dafne_conv2d_nhwc_bf16_hip(conv2, RELU) followed by dafne_bottleneck_tail_head_hip.  d_next == NULL (the stage's last block: no
+ * next conv1): only d_out is produced (d_bias1 may be NULL; the conv1' section of d_wfrag is still read: pack zeros),
+ * bit-identical to dafne_conv2d_nhwc_bf16_hip(conv2, RELU) followed by (conv3, RELU|RESIDUAL).
  */
 size_t dafne_bottleneck_body_scratch_bytes(void);
 int dafne_bottleneck_body_hip(const void* d_in, const void* d_res, const void* d_wfrag, const float* d_bias2,
