@@ -163,6 +163,9 @@ def _defaults():
                     # evaluation.inference.inference_on_dataset): the layout bench.py times.  Round 5: three sub-batches of UNEQUAL
                     # size (one_stage_detector.subbatch_bounds: 8 images = 3 + 2 + 3), so that the streams drift out of phase
                     PIPELINE_SPLITS=int(os.environ.get("DAFNE_PIPELINE_SPLITS", "3")), MAX_PLANS=48,
+                    # ... and together at most this many bytes of device memory (one-stream plans + sub-batch pipelines; 0 = no byte
+                    # bound).  96 GB: a third of the MI355X's 288 GB for launch plans, the rest for the caller
+                    MAX_PLAN_BYTES=96 << 30,
                     # replay every sub-batch's dense launches from a HIP graph in the pipelined / streamed step (one host call
                     # per stream and step instead of ~200)
                     HIP_GRAPHS=True,

@@ -95,6 +95,7 @@ class OneStageDetector(nn.Module):
         self._packed = None
         self._plans = {}
         self._graphs = {}
+        self.__dict__.pop("_plan_lru", None)      # (its entries reference the caches they describe)
         self._act_q8 = None         # fp8 model: calibrated activation scales {weight key: in_qscale} (calibrate_fp8)
         self.side_stream = None
         self._consts = {}
@@ -113,6 +114,7 @@ class OneStageDetector(nn.Module):
         self._packed = None
         self._plans = {}
         self._graphs = {}
+        self.__dict__.pop("_plan_lru", None)      # (its entries reference the caches they describe)
         self._act_q8 = None
         self._pending = None
         self.__dict__.pop("_deferred", None)
@@ -156,6 +158,7 @@ class OneStageDetector(nn.Module):
         self._packed["act_q8"] = dict(self._act_q8)
         self._plans = {}
         self._graphs = {}
+        self.__dict__.pop("_plan_lru", None)      # (its entries reference the caches they describe)
         if hasattr(self, "_pipe"):
             self._pipe = {}
 
@@ -215,6 +218,7 @@ class OneStageDetector(nn.Module):
         self._packed["act_q8"] = dict(self._act_q8)
         self._plans = {}
         self._graphs = {}
+        self.__dict__.pop("_plan_lru", None)      # (its entries reference the caches they describe)
         if hasattr(self, "_pipe"):
             self._pipe = {}
         return dict(self._act_q8)
@@ -233,17 +237,39 @@ class OneStageDetector(nn.Module):
 
     def _lru_get(self, cache, key, build):
         """cache[key], built on first use; the caches of launch plans (buffers of a whole network at one batch shape: 0.3-5 GB
-        each) keep the cfg.ENGINE.MAX_PLANS most recently used shapes.  Before one is dropped the device is synchronised: its
-        launches may still be queued, and its buffers go back to the allocator."""
+        each) keep the cfg.ENGINE.MAX_PLANS most recently used shapes EACH and, together (the one-stream plans and the sub-batch
+        pipelines share one budget; advisor, round 5), at most cfg.ENGINE.MAX_PLAN_BYTES of device memory as the allocator counts it
+        around the build -- on datasets where nearly every batch has its own (H, W) the entry count alone let the caches grow to
+        whatever 48 + 48 shapes happen to weigh.  Before an entry is dropped the device is synchronised: its launches may still be
+        queued, and its buffers go back to the allocator."""
+        import collections
+        lru = self.__dict__.setdefault("_plan_lru", collections.OrderedDict())      # (id(cache), key) -> [cache, bytes], oldest first
+        tag = (id(cache), key)
         if key in cache:
             cache[key] = cache.pop(key)              # dicts keep insertion order: most recently used last
+            if tag in lru:
+                lru.move_to_end(tag)
             return cache[key]
         cap = max(2, int(getattr(self.cfg.ENGINE, "MAX_PLANS", 48)))
         if len(cache) >= cap:
             torch.cuda.synchronize(self.device)
             while len(cache) >= cap:
-                cache.pop(next(iter(cache)))
+                old = next(iter(cache))
+                cache.pop(old)
+                lru.pop((id(cache), old), None)
+        on_gpu = self.device.type == "cuda"
+        self._weights()                              # (packed once per model, outside a plan's account)
+        m0 = torch.cuda.memory_allocated(self.device) if on_gpu else 0
         cache[key] = build()
+        lru[tag] = [cache, max(0, (torch.cuda.memory_allocated(self.device) if on_gpu else 0) - m0)]
+        cap_bytes = int(getattr(self.cfg.ENGINE, "MAX_PLAN_BYTES", 0) or 0)
+        if cap_bytes > 0 and sum(v[1] for v in lru.values()) > cap_bytes and len(lru) > 1:
+            torch.cuda.synchronize(self.device)
+            for old in list(lru):
+                if old == tag or sum(v[1] for v in lru.values()) <= cap_bytes:
+                    break
+                c, _ = lru.pop(old)
+                c.pop(old[1], None)
         return cache[key]
 
     def plan(self, n, h, w, slot=0, graph=False):

@@ -534,3 +534,30 @@ def test_check_finite_debug_mode_makes_a_poisoned_weight_loud():
     m.invalidate()
     with pytest.raises(_lib.DafneHipError, match="CHECK_FINITE"):
         m([{"image": img, "height": 128, "width": 160}])
+
+
+def test_plan_caches_share_a_byte_budget():
+    """cfg.ENGINE.MAX_PLAN_BYTES (round 6, advisor): the one-stream plans and the sub-batch pipelines together hold at most that many
+    bytes of device memory (as the allocator counts it around a build); the least recently used entry of EITHER cache goes first, the
+    entry just built never; a dropped shape is rebuilt with the same detections."""
+    cfg, m, P = build("dota-1.0_r50.yaml", seed=31)
+    g = torch.Generator().manual_seed(9)
+    shapes = [(96, 128), (128, 128), (128, 160), (160, 160)]
+    imgs = [torch.randint(0, 256, (2, 3, h, w), generator=g, dtype=torch.uint8).to(dev()) for h, w in shapes]
+    r0, c0 = m.detect_packed(imgs[0])
+    torch.cuda.synchronize()
+    first = (r0.clone(), c0.clone())
+    one = sum(v[1] for v in m._plan_lru.values())
+    assert one > 0 and len(m._plan_lru) == 1
+    cfg.ENGINE.MAX_PLAN_BYTES = int(2.5 * one)            # room for about two plans of this size
+    for im in imgs[1:]:
+        m.detect_packed(im)
+        m.detect_packed(im, pipelined=True, splits=2)
+        torch.cuda.synchronize()
+        tot = sum(v[1] for v in m._plan_lru.values())
+        assert tot <= cfg.ENGINE.MAX_PLAN_BYTES or len(m._plan_lru) == 1, (tot, len(m._plan_lru))
+        assert len(m._plan_lru) == len(m._plans) + len(m._pipe)
+    assert (2, 96, 128, 0) not in m._plans
+    r, c = m.detect_packed(imgs[0])
+    torch.cuda.synchronize()
+    assert torch.equal(c, first[1]) and all(torch.equal(r[i, :int(c[i])], first[0][i, :int(c[i])]) for i in range(2))
