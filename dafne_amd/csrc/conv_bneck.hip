@@ -81,13 +81,15 @@ struct BN {
     static constexpr int kPF = kPx / 32;                       // pixel fragments per wave
     static constexpr int kRL = kPx / 16;                       // quad-layout row instructions per wave and 256-channel chunk (16 px each)
     static constexpr int kTrickle = 3 * kPP;                   // patch slabs 1..3: one piece per wave and step 0 .. kTrickle - 1
+    // k16 steps of A fragments in flight per wave (32 registers).  (Round 6: 16 for the half tile -- it has the registers -- changed
+    // nothing: 27.7 us per block alone, 0.894 against 0.908 ms for the 22 blocks of one image in the plan.)
+    static constexpr int kRing = 8;
 };
 constexpr int kCM = 256, kCB = 1024, kChunks = kCB / 256;
 constexpr int kNW = 8, kNT = 512;
 constexpr int kStepsA = 9 * (kCM / 16);                // 144 k16 steps of the 3x3
 constexpr int kStepsB = 2 * kChunks * 16;              // 128 k16 steps of conv3 + conv1'
 constexpr int kSteps = kStepsA + kStepsB;
-constexpr int kRing = 8;                               // k16 steps of A fragments in flight per wave
 constexpr int kWABytes = kNW * kStepsA * 1024;         // phase A weights: [8 waves][144 steps][64 lanes][8]
 constexpr int kPhaseBytes = kNW * 16 * 1024;           // one GEMM of phase B: [8 waves][16 steps][64 lanes][8]
 constexpr int kRes0 = 60, kResStride = 4;              // the first shortcut chunk: one register load per lane at steps 60, 64, ..
@@ -142,6 +144,7 @@ constexpr int bn_post(int s) {
 template <int TH>
 constexpr int bn_wait(int j) {
     int n = 0;
+    constexpr int kRing = BN<TH>::kRing;
     if (j < kRing) {
         n += kRing - 1 - j;                                    // A(j+1 .. 7)
         for (int s = 0; s < j; s++) n += 1 + bn_post<TH>(s);
@@ -169,7 +172,7 @@ __device__ __forceinline__ void static_for(F&& f) {
 
 // A fragment of k16 step J: one coalesced 1-KiB load per wave, L2 -> registers.  Inline asm: the compiler would sink visible
 // loads to their uses and wait for each; readiness is tracked by hand (bn_wait).
-template <int J>
+template <int J, int kRing>
 __device__ __forceinline__ void bn_load(bf16x8 (&ar)[kRing], const char* wf, unsigned voffA, unsigned voffB) {
     if constexpr (J < kStepsA) {
         const char* sb = wf + (size_t)J * 1024;
@@ -233,8 +236,9 @@ __device__ __forceinline__ void bn_bwait(bf16x8 (&b)[PF]) {
 }
 
 template <int J, int TH>
-__device__ __forceinline__ void bn_wait_for(bf16x8 (&ar)[kRing]) {
-    constexpr int kWaitN = bn_wait<TH>(J);
+__device__ __forceinline__ void bn_wait_for(bf16x8 (&ar)[BN<TH>::kRing]) {
+    constexpr int kWaitN = bn_wait<TH>(J), kRing = BN<TH>::kRing;
+    static_assert(kWaitN < 64, "vmcnt is a 6-bit counter");
     asm volatile("s_waitcnt vmcnt(%1)" : "+v"(ar[J % kRing]) : "n"(kWaitN) : "memory");
 }
 
@@ -245,7 +249,7 @@ __global__ void __launch_bounds__(512, 2) conv_bneck_kernel(BneckDev P) {
     typedef BN<TH> Geo;
     constexpr int kTH = Geo::kTH, kPx = Geo::kPx, kPPieces = Geo::kPPieces, kPP = Geo::kPP, kPSlab = Geo::kPSlab, kSlab = Geo::kSlab;
     constexpr int kOffY = Geo::kOffY, kOffT = Geo::kOffT, kOffPatch = Geo::kOffPatch, kOffBias = Geo::kOffBias;
-    constexpr int kPF = Geo::kPF, kRL = Geo::kRL, kTrickle = Geo::kTrickle;
+    constexpr int kPF = Geo::kPF, kRL = Geo::kRL, kTrickle = Geo::kTrickle, kRing = Geo::kRing;
     static_assert(kPx == kTH * kTW, "tile");
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const int tid = threadIdx.x;
@@ -351,7 +355,7 @@ __global__ void __launch_bounds__(512, 2) conv_bneck_kernel(BneckDev P) {
     bf16x8 ar[kRing];
 #pragma unroll
     for (int k = 0; k < kRing; k++) ar[k] = bf16x8{};
-    auto load_step = [&](auto J) { bn_load<decltype(J)::value>(ar, P.wf, voffA, voffB); };
+    auto load_step = [&](auto J) { bn_load<decltype(J)::value, kRing>(ar, P.wf, voffA, voffB); };
     auto wait_step = [&](auto J) { bn_wait_for<decltype(J)::value, TH>(ar); };
 
     f32x16 acc1[kPF], acc2[kPF];
