@@ -216,8 +216,6 @@ def pack_bneck(w2, w3, w1):
     assert tuple(w2.shape) == (256, 2304) and w2.dtype == BF16
     assert tuple(w3.shape) == (1024, 256) and tuple(w1.shape) == (256, 1024) and w3.dtype == BF16 and w1.dtype == BF16
     perm = _bneck_row_perm(w2.device)
-    if os.environ.get("DAFNE_BNECK_OLDPACK") == "1":        # A/B against a round-5 library (scratch/ab_bench.sh); removed with it
-        perm = torch.arange(32, device=w2.device)
     a0 = w2.reshape(8, 32, 144, 2, 8)[:, perm].permute(0, 2, 3, 1, 4)                       # w, j, h, r, e
     a1 = w3.reshape(4, 8, 32, 16, 2, 8)[:, :, perm].permute(0, 1, 3, 4, 2, 5)               # c, w, t, h, r, e
     a2 = w1.reshape(8, 32, 4, 16, 2, 8)[:, perm].permute(2, 0, 3, 4, 1, 5)                  # c, w, t, h, r, e
