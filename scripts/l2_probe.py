@@ -51,3 +51,20 @@ for blocks in (256, 512):
     fl = blocks * 8 * iters * 4 * 32768.0
     print("MFMA only blocks %d: %.3f ms  %.0f TFLOP/s  %.0f W %4.0f MHz -> %.3f pJ/flop total, %.3f above idle" % (
         blocks, ms, fl / ms / 1e9, wv, mhz, wv * ms * 1e-3 / fl * 1e12, (wv - idle) * ms * 1e-3 / fl * 1e12))
+tab = torch.randn(2, 8, 64, 8, device=d)
+tab[1] = torch.relu(tab[0])
+tab = tab.bfloat16().contiguous()
+def loop_tab(kind, iters, blocks, secs=3.0):
+    global w
+    keep, w = w, tab
+    try:
+        return loop(kind, 0, iters, blocks, secs)
+    finally:
+        w = keep
+for kind, name in ((7, "32x32x16, one constant pair (asm)"), (3, "32x32x16, 8 rotating operand pairs"), (4, "32x32x16, rotating, B behind a ReLU"),
+                   (5, "16x16x32, one constant pair"), (6, "16x16x32, 8 rotating operand pairs")):
+    iters = 8192
+    ms, wv, mhz = loop_tab(kind, iters, 256)
+    fl = 256 * 8 * iters * 4 * 32768.0
+    print("MFMA %-36s: %.3f ms  %.0f TFLOP/s  %.0f W %4.0f MHz -> %.3f pJ/flop total, %.3f above idle" % (
+        name, ms, fl / ms / 1e9, wv, mhz, wv * ms * 1e-3 / fl * 1e12, (wv - idle) * ms * 1e-3 / fl * 1e12))
