@@ -2239,7 +2239,16 @@ __global__ void __launch_bounds__(512, 2) conv3x3_rp_kernel(ConvDev PA, ConvDev 
     __builtin_amdgcn_s_barrier();             // slab 0 of the first tile is published (later slabs: the barrier of step 12 of every period)
     __builtin_amdgcn_sched_barrier(0);
 
+#ifdef ABL_RP_M16      // timing ablation (wrong results): the same flops, operand reads and LDS traffic through v_mfma_f32_16x16x32_bf16
+    typedef __attribute__((ext_vector_type(4))) float f32x4_;
+    f32x4_ acc[kRFr][4];
+#define RP_ACC(b, i) acc[b][(i) >> 2][(i) & 3]
+#define RP_MFMA(C, A, B, B2) (C[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A, B, C[0], 0, 0, 0), C[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(B2, A, C[1], 0, 0, 0))
+#else
     f32x16 acc[kRFr];
+#define RP_ACC(b, i) acc[b][i]
+#define RP_MFMA(C, A, B, B2) C = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A, B, C, 0, 0, 0)
+#endif
     bf16x8 bfr[2][4];                         // [half of the step's eight fragments][4]
     int gs0 = 0;                              // ring buffer of the current tile's slab 0 (global slab count mod 3)
     float gsum[4], gsq[4];                    // GroupNorm sums of a tile (this wave's 4 groups): live inside its epilogue only
@@ -2351,7 +2360,7 @@ __global__ void __launch_bounds__(512, 2) conv3x3_rp_kernel(ConvDev PA, ConvDev 
 #pragma unroll
         for (int b = 0; b < kRFr; b++)
 #pragma unroll
-            for (int kk = 0; kk < 16; kk++) acc[b][kk] = 0.f;
+            for (int kk = 0; kk < 16; kk++) RP_ACC(b, kk) = 0.f;
         // ring buffers of this tile's four slab periods: computing (gs0 + sl) % 3; the DMA of period sl fills (gs0 + sl + 2) % 3
         // (the buffer the period's opening barrier has just retired); the normalisation of period sl works on (gs0 + sl + 1) % 3
         int bufc[4];
@@ -2406,7 +2415,7 @@ __global__ void __launch_bounds__(512, 2) conv3x3_rp_kernel(ConvDev PA, ConvDev 
             asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(bfr[0][0]), "+v"(bfr[0][1]), "+v"(bfr[0][2]), "+v"(bfr[0][3]) :: "memory");
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int r = 0; r < 4; r++) acc[r] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ar[j % kRRing], bfr[0][r], acc[r], 0, 0, 0);
+            for (int r = 0; r < 4; r++) RP_MFMA(acc[r], ar[j % kRRing], bfr[0][r], bfr[0][(r + 1) & 3]);
             __builtin_amdgcn_sched_barrier(0);
             if constexpr (j + 1 < kRSteps) {
                 rp_bread<j + 1, 0>(bfr[0], pb, sbase[(j + 1) / 36]);
@@ -2416,7 +2425,7 @@ __global__ void __launch_bounds__(512, 2) conv3x3_rp_kernel(ConvDev PA, ConvDev 
             }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int r = 0; r < 4; r++) acc[4 + r] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ar[j % kRRing], bfr[1][r], acc[4 + r], 0, 0, 0);
+            for (int r = 0; r < 4; r++) RP_MFMA(acc[4 + r], ar[j % kRRing], bfr[1][r], bfr[1][(r + 1) & 3]);
             __builtin_amdgcn_sched_barrier(0);
             rp_load<j + kRRing>(ar, wf_cur, wf_nxt, voff);
             // ---- counted vector-memory operations behind the weight load (rp_post)
@@ -2466,8 +2475,8 @@ __global__ void __launch_bounds__(512, 2) conv3x3_rp_kernel(ConvDev PA, ConvDev 
                 u32x2 pk[4];
 #pragma unroll
                 for (int g = 0; g < 4; g++) {
-                    const float v0 = fmaxf(acc[b][4 * g] + bia4[g][0], lo), v1 = fmaxf(acc[b][4 * g + 1] + bia4[g][1], lo);
-                    const float v2 = fmaxf(acc[b][4 * g + 2] + bia4[g][2], lo), v3 = fmaxf(acc[b][4 * g + 3] + bia4[g][3], lo);
+                    const float v0 = fmaxf(RP_ACC(b, 4 * g) + bia4[g][0], lo), v1 = fmaxf(RP_ACC(b, 4 * g + 1) + bia4[g][1], lo);
+                    const float v2 = fmaxf(RP_ACC(b, 4 * g + 2) + bia4[g][2], lo), v3 = fmaxf(RP_ACC(b, 4 * g + 3) + bia4[g][3], lo);
                     const float s4 = (v0 + v1) + (v2 + v3), q4 = (v0 * v0 + v1 * v1) + (v2 * v2 + v3 * v3);
                     gsum[g] += valid ? s4 : 0.f;
                     gsq[g] += valid ? q4 : 0.f;
