@@ -586,9 +586,14 @@ __global__ void __launch_bounds__(512, 2) conv_bneck_kernel(BneckDev P) {
                 __builtin_amdgcn_sched_barrier(0);
                 load_step(std::integral_constant<int, j + kRing>{});
             });
-            // (the last barrier of waves 4..7 would have no partner: waves 0..3 are through)
-            if constexpr (c + 1 < kChunks || hh == 0) barrier();
-            else if (!late) barrier();
+            // Every wave, also behind G2b(3).  For waves 4..7 that last barrier has no partner among waves 0..3, which are one
+            // segment ahead: through their Z rows and gone, or about to be -- s_barrier waits for the surviving waves of a
+            // workgroup only.  It is what keeps a late wave's Z pieces (written into slabs 2 / 3 of the Y buffer right below) off
+            // the Y chunk its three mates may still be reading in THEIR G2b(3).  (Round 6's first form left it out "for want of a
+            // partner": beside memory-bound kernels on other streams the half-tile geometry then produced wrong Z channels 128..255
+            // in a third of its launches -- the waves of a half drift apart by whole steps when the weight ring runs dry --,
+            // tests/test_gpu_reproducible.py::test_bottleneck_beside_memory_traffic.)
+            barrier();
             if constexpr (c == 0) BN_STAMP();
         });
     });
