@@ -1966,6 +1966,44 @@ __device__ __forceinline__ void rp_wait_for(bf16x8 (&ar)[kRRing]) {
     constexpr int kN = rp_wait(J, GNIN);
     asm volatile("s_waitcnt vmcnt(%1)" : "+v"(ar[J % kRRing]) : "n"(kN) : "memory");
 }
+// ---- the 16x16x32 form (round 6; conv3x3_rp_kernel<GNIN, true>, flag DAFNE_CONV_FRAG16): the same tile, slabs, ring and schedule with
+// v_mfma_f32_16x16x32_bf16 -- 6-8 % fewer joules per flop on this package (half the accumulator traffic; profiles/NOTES_r06.md).
+// A k32 group = the k16 steps 2m, 2m + 1 of the same (slab, kh, kw).  Fragment F(2m + cb) = output channels 16 cb .. 16 cb + 15 of the
+// wave x the 32 k of group m (lane: channel lane & 15, k 8 (lane >> 4) .. + 8); a B fragment = 16 pixels x those 32 k (lane: pixel
+// lane & 15, the same k).  Step 2m + h multiplies BOTH fragments of its group with tile rows 4h .. 4h + 3 (8 B fragments: row, column
+// half), so a fragment lives for two steps: it is requested FIVE steps ahead into the slot of the fragment that died one step ago
+// (F(j + 5) at the end of step j into slot (j + 5) % 6), and the even step of a pair waits for the pair's younger fragment.
+constexpr int kRDist16 = kRRing - 1;
+constexpr int rp_wait16(int j, bool gnin) {            // even j: operations issued after F(j + 1) (end of step j + 1 - kRDist16) and before this wait
+    int n = rp_post((j + 1 - kRDist16 + kRSteps) % kRSteps, gnin);
+    for (int s = j + 2 - kRDist16; s < j; s++) n += 1 + rp_post((s + kRSteps) % kRSteps, gnin);
+    return n;
+}
+static_assert(kRRing != 6 || kRBar != 12 || (rp_wait16(0, false) == 19 && rp_wait16(2, false) == 19 && rp_wait16(4, false) == 3 && rp_wait16(14, false) == 4 &&
+              rp_wait16(20, false) == 6), "vmcnt bookkeeping (16x16x32 form)");
+template <int J, bool GNIN>
+__device__ __forceinline__ void rp_wait16_for(bf16x8 (&ar)[kRRing]) {
+    static_assert((J & 1) == 0, "the even step of a pair waits");
+    constexpr int kN = rp_wait16(J, GNIN);
+    asm volatile("s_waitcnt vmcnt(%2)" : "+v"(ar[J % kRRing]), "+v"(ar[(J + 1) % kRRing]) : "n"(kN) : "memory");
+}
+// four of the eight B fragments of step J in the 16x16x32 form: tile rows 4 (J & 1) + 2 HF, + 1 (patch rows + kh) at tap column kw, both
+// column halves (16 pixels = 2048 B apart: the swizzle of column q + 16 is that of q), the 32 channels 32 kc2 .. of the slab
+template <int J, int HF>
+__device__ __forceinline__ void rp_bread16(bf16x8 (&b)[4], const unsigned (&pb)[3], unsigned sbase) {
+    constexpr int t = J % 36, kh = t / 12, kw = (t >> 2) % 3, kc2 = (t >> 1) & 1;
+    unsigned pq = pb[kw];
+    asm volatile("" : "+v"(pq));
+    const unsigned ad = sbase + (pq ^ (unsigned)(kc2 << 6));
+    constexpr int r0 = kh + 4 * (J & 1) + 2 * HF;
+    constexpr int o0 = r0 * kRCols * 128, o1 = o0 + 2048, o2 = (r0 + 1) * kRCols * 128, o3 = o2 + 2048;
+    static_assert(o3 <= 65535, "ds_read immediate");
+    asm volatile("ds_read_b128 %0, %4 offset:%5\n\tds_read_b128 %1, %4 offset:%6\n\tds_read_b128 %2, %4 offset:%7\n\tds_read_b128 %3, %4 offset:%8"
+                 : "=&v"(b[0]), "=&v"(b[1]), "=&v"(b[2]), "=&v"(b[3])
+                 : "v"(ad), "n"(o0), "n"(o1), "n"(o2), "n"(o3)
+                 : "memory");
+}
+
 template <int I, int N, class F>
 __device__ __forceinline__ void rp_static_for(F&& f) {
     if constexpr (I < N) {
@@ -1985,6 +2023,18 @@ __device__ __forceinline__ float rp_wave_total(float v) {
     v += dpp(v, std::integral_constant<int, 0x140>{}, std::integral_constant<int, 0xF>{});     // row_mirror: every lane = its row's sum
     v += dpp(v, std::integral_constant<int, 0x142>{}, std::integral_constant<int, 0xA>{});     // row_bcast15 into rows 1, 3
     v += dpp(v, std::integral_constant<int, 0x143>{}, std::integral_constant<int, 0xC>{});     // row_bcast31 into rows 2, 3
+    return v;
+}
+// the same tree without its last step: the sums of lanes 0..31 / 32..63, valid in lanes 31 / 63
+__device__ __forceinline__ float rp_half_total(float v) {
+    auto dpp = [](float x, auto CTRL, auto RM) {
+        return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), decltype(CTRL)::value, decltype(RM)::value, 0xF, false));
+    };
+    v += dpp(v, std::integral_constant<int, 0xB1>{}, std::integral_constant<int, 0xF>{});
+    v += dpp(v, std::integral_constant<int, 0x4E>{}, std::integral_constant<int, 0xF>{});
+    v += dpp(v, std::integral_constant<int, 0x141>{}, std::integral_constant<int, 0xF>{});
+    v += dpp(v, std::integral_constant<int, 0x140>{}, std::integral_constant<int, 0xF>{});
+    v += dpp(v, std::integral_constant<int, 0x142>{}, std::integral_constant<int, 0xA>{});
     return v;
 }
 
@@ -2012,7 +2062,7 @@ struct RpTile {
     int nt, mt, si, img, Y0, X0, H, W, valid, grp;
 };
 
-template <bool GNIN>
+template <bool GNIN, bool M16>
 __global__ void __launch_bounds__(512, 2) conv3x3_rp_kernel(ConvDev PA, ConvDev PB, int n_groups, char* dump) {
     constexpr int NT = 512, NW = 8;
     extern __shared__ __attribute__((aligned(16))) char lds[];
@@ -2168,12 +2218,15 @@ __global__ void __launch_bounds__(512, 2) conv3x3_rp_kernel(ConvDev PA, ConvDev 
     // ---- B fragment offsets: patch row p (0..5) at tap column kw (0..2): pixel p * 34 + q, q = kw + frow; k16 step kc reads
     // the 16-byte chunk (2 kc + half) ^ sw, sw = (q >> 1) & 7, i.e. (pb[kw] ^ (kc << 5)) + p * 34 * 128 with
     // pb[kw] = q * 128 | ((half ^ (sw & 1)) << 4) | ((sw >> 1) << 5)
+    // (16x16x32 form: q = kw + (lane & 15); the 32-channel group kc2 reads chunk (4 kc2 + (lane >> 4)) ^ sw, i.e. (pb[kw] ^ (kc2 << 6)) +
+    // p * 34 * 128 with pb[kw] = q * 128 | (((lane >> 4) ^ (sw & 3)) << 4) | ((sw >> 2) << 6); the right column half is 2048 B further)
     unsigned pb[3];
 #pragma unroll
     for (int kw = 0; kw < 3; kw++) {
-        const int q = kw + frow;
+        const int q = kw + (M16 ? (lane & 15) : frow);
         const int sw = (q >> 1) & 7;
-        pb[kw] = (unsigned)(q * 128 + ((half ^ (sw & 1)) << 4) + ((sw >> 1) << 5));
+        pb[kw] = M16 ? (unsigned)(q * 128 + (((lane >> 4) ^ (sw & 3)) << 4) + ((sw >> 2) << 6))
+                     : (unsigned)(q * 128 + ((half ^ (sw & 1)) << 4) + ((sw >> 1) << 5));
     }
 
     const unsigned voff = (unsigned)(wave * kRSteps * 1024 + lane * 16);
@@ -2219,7 +2272,7 @@ __global__ void __launch_bounds__(512, 2) conv3x3_rp_kernel(ConvDev PA, ConvDev 
         for (int ii = 0; ii < kRPP; ii++) patch_piece(cur, sl, sl, ii);
     {
         const char* wf0 = PG(cur.grp).w + (size_t)cur.nt * (NW * kRSteps * 1024);
-        rp_static_for<0, kRRing>([&](auto J) { rp_load<decltype(J)::value>(ar, wf0, wf0, voff); });
+        rp_static_for<0, (M16 ? kRDist16 : kRRing)>([&](auto J) { rp_load<decltype(J)::value>(ar, wf0, wf0, voff); });
     }
     // 16 dummy dword stores (into the wave's part of the dump area): the queue behind A(0..7) now looks like a steady-state tile's
     // -- A(136..143), then the previous tile's 16 row stores -- so steps 0..7 of the first tile wait with the same counts
@@ -2228,7 +2281,7 @@ __global__ void __launch_bounds__(512, 2) conv3x3_rp_kernel(ConvDev PA, ConvDev 
 #pragma unroll
         for (int k = 0; k < 2 * kRFr; k++) asm volatile("global_store_dword %0, %1, off offset:%2" :: "v"(dd), "v"(0), "n"(k * 4) : "memory");
     }
-    asm volatile("s_waitcnt vmcnt(%0)" :: "n"(kRRing + 2 * kRFr) : "memory");         // this wave's 12 patch pieces have landed (the A loads + 16 stores are younger)
+    asm volatile("s_waitcnt vmcnt(%0)" :: "n"((M16 ? kRDist16 : kRRing) + 2 * kRFr) : "memory");         // this wave's 12 patch pieces have landed (the A loads + 16 stores are younger)
     if (GNIN) {
         // slab 0 only: slab 1 is normalised in the first slab period of the loop, like every tile's
 #pragma unroll
@@ -2239,19 +2292,14 @@ __global__ void __launch_bounds__(512, 2) conv3x3_rp_kernel(ConvDev PA, ConvDev 
     __builtin_amdgcn_s_barrier();             // slab 0 of the first tile is published (later slabs: the barrier of step 12 of every period)
     __builtin_amdgcn_sched_barrier(0);
 
-#ifdef ABL_RP_M16      // timing ablation (wrong results): the same flops, operand reads and LDS traffic through v_mfma_f32_16x16x32_bf16
-    typedef __attribute__((ext_vector_type(4))) float f32x4_;
-    f32x4_ acc[kRFr][4];
-#define RP_ACC(b, i) acc[b][(i) >> 2][(i) & 3]
-#define RP_MFMA(C, A, B, B2) (C[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A, B, C[0], 0, 0, 0), C[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(B2, A, C[1], 0, 0, 0))
-#else
-    f32x16 acc[kRFr];
-#define RP_ACC(b, i) acc[b][i]
-#define RP_MFMA(C, A, B, B2) C = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A, B, C, 0, 0, 0)
-#endif
+    // 128 accumulator registers either way: 8 fragments of 32 pixels x 32 channels, or 32 of 16 pixels x 16 channels -- (tile row b,
+    // column half, channel half cb) at index (b * 2 + side) * 2 + cb
+    f32x16 acc[M16 ? 1 : kRFr];
+    f32x4 acc16[M16 ? 4 * kRFr : 1];
     bf16x8 bfr[2][4];                         // [half of the step's eight fragments][4]
     int gs0 = 0;                              // ring buffer of the current tile's slab 0 (global slab count mod 3)
     float gsum[4], gsq[4];                    // GroupNorm sums of a tile (this wave's 4 groups): live inside its epilogue only
+                                              // (16x16x32 form: a lane's 4 channels of fragment cb lie in group 2 cb + (lane >> 5): two sums)
 #pragma unroll
     for (int g = 0; g < 4; g++) gsum[g] = gsq[g] = 0.f;
     RpTile prv = cur;
@@ -2357,10 +2405,15 @@ __global__ void __launch_bounds__(512, 2) conv3x3_rp_kernel(ConvDev PA, ConvDev 
         const char* wf_cur = PG(cur.grp).w + (size_t)cur.nt * (NW * kRSteps * 1024);
         const char* wf_nxt = PG(nxt.grp).w + (size_t)nxt.nt * (NW * kRSteps * 1024);
         const int sb_cur = k & 1, sb_nxt = (k + 1) & 1;
+        if constexpr (M16) {
 #pragma unroll
-        for (int b = 0; b < kRFr; b++)
+            for (int b = 0; b < 4 * kRFr; b++) acc16[b] = f32x4{0.f, 0.f, 0.f, 0.f};
+        } else {
 #pragma unroll
-            for (int kk = 0; kk < 16; kk++) RP_ACC(b, kk) = 0.f;
+            for (int b = 0; b < kRFr; b++)
+#pragma unroll
+                for (int kk = 0; kk < 16; kk++) acc[b][kk] = 0.f;
+        }
         // ring buffers of this tile's four slab periods: computing (gs0 + sl) % 3; the DMA of period sl fills (gs0 + sl + 2) % 3
         // (the buffer the period's opening barrier has just retired); the normalisation of period sl works on (gs0 + sl + 1) % 3
         int bufc[4];
@@ -2373,7 +2426,8 @@ __global__ void __launch_bounds__(512, 2) conv3x3_rp_kernel(ConvDev PA, ConvDev 
         rp_static_for<0, kRSteps>([&](auto J) {
             constexpr int j = decltype(J)::value;
             constexpr int sl = j / 36, t = j % 36;
-            rp_wait_for<j, GNIN>(ar);
+            if constexpr (!M16) rp_wait_for<j, GNIN>(ar);
+            else if constexpr ((j & 1) == 0) rp_wait16_for<j, GNIN>(ar);
             // ---- GN_INPUT, steps 0..11 of a period: the pieces this wave requested in the PREVIOUS period (slab sl + 1 of this tile; in
             // period 3: slab 0 of the next tile), one per step; waves w and w + 4 share a SIMD: the second half of the workgroup converts
             // six steps later, so that one of the two always has MFMAs for the matrix pipe
@@ -2410,24 +2464,54 @@ __global__ void __launch_bounds__(512, 2) conv3x3_rp_kernel(ConvDev PA, ConvDev 
             // leaves exactly the four younger reads in flight (other LDS / scalar-memory operations in flight only make the wait
             // stricter).  Requests cross slab boundaries (the next slab was published at step 12 of this period) but not the tile's end:
             // the epilogue sits there.
-            if constexpr (j == 0) rp_bread<j, 0>(bfr[0], pb, sbase[0]);
-            rp_bread<j, 1>(bfr[1], pb, sbase[sl]);
-            asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(bfr[0][0]), "+v"(bfr[0][1]), "+v"(bfr[0][2]), "+v"(bfr[0][3]) :: "memory");
-            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (!M16) {
+                if constexpr (j == 0) rp_bread<j, 0>(bfr[0], pb, sbase[0]);
+                rp_bread<j, 1>(bfr[1], pb, sbase[sl]);
+                asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(bfr[0][0]), "+v"(bfr[0][1]), "+v"(bfr[0][2]), "+v"(bfr[0][3]) :: "memory");
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int r = 0; r < 4; r++) RP_MFMA(acc[r], ar[j % kRRing], bfr[0][r], bfr[0][(r + 1) & 3]);
-            __builtin_amdgcn_sched_barrier(0);
-            if constexpr (j + 1 < kRSteps) {
-                rp_bread<j + 1, 0>(bfr[0], pb, sbase[(j + 1) / 36]);
-                asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(bfr[1][0]), "+v"(bfr[1][1]), "+v"(bfr[1][2]), "+v"(bfr[1][3]) :: "memory");
+                for (int r = 0; r < 4; r++) acc[r] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ar[j % kRRing], bfr[0][r], acc[r], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                if constexpr (j + 1 < kRSteps) {
+                    rp_bread<j + 1, 0>(bfr[0], pb, sbase[(j + 1) / 36]);
+                    asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(bfr[1][0]), "+v"(bfr[1][1]), "+v"(bfr[1][2]), "+v"(bfr[1][3]) :: "memory");
+                } else {
+                    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(bfr[1][0]), "+v"(bfr[1][1]), "+v"(bfr[1][2]), "+v"(bfr[1][3]) :: "memory");
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int r = 0; r < 4; r++) acc[4 + r] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ar[j % kRRing], bfr[1][r], acc[4 + r], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                rp_load<j + kRRing>(ar, wf_cur, wf_nxt, voff);
             } else {
-                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(bfr[1][0]), "+v"(bfr[1][1]), "+v"(bfr[1][2]), "+v"(bfr[1][3]) :: "memory");
-            }
-            __builtin_amdgcn_sched_barrier(0);
+                // 16x16x32 form: the same two halves of four B fragments -- (row 4h, left | right), (row 4h + 1, ..) then rows 4h + 2, + 3,
+                // h = j & 1 -- each against both channel halves of the wave: 16 instructions of half the size
+                constexpr int jb = j & ~1, h8 = (j & 1) * 16;
+                if constexpr (j == 0) rp_bread16<j, 0>(bfr[0], pb, sbase[0]);
+                rp_bread16<j, 1>(bfr[1], pb, sbase[sl]);
+                asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(bfr[0][0]), "+v"(bfr[0][1]), "+v"(bfr[0][2]), "+v"(bfr[0][3]) :: "memory");
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int r = 0; r < 4; r++) RP_MFMA(acc[4 + r], ar[j % kRRing], bfr[1][r], bfr[1][(r + 1) & 3]);
-            __builtin_amdgcn_sched_barrier(0);
-            rp_load<j + kRRing>(ar, wf_cur, wf_nxt, voff);
+                for (int r = 0; r < 4; r++)
+#pragma unroll
+                    for (int cb = 0; cb < 2; cb++)
+                        acc16[h8 + 2 * r + cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ar[(jb + cb) % kRRing], bfr[0][r], acc16[h8 + 2 * r + cb], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                if constexpr (j + 1 < kRSteps) {
+                    rp_bread16<j + 1, 0>(bfr[0], pb, sbase[(j + 1) / 36]);
+                    asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(bfr[1][0]), "+v"(bfr[1][1]), "+v"(bfr[1][2]), "+v"(bfr[1][3]) :: "memory");
+                } else {
+                    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(bfr[1][0]), "+v"(bfr[1][1]), "+v"(bfr[1][2]), "+v"(bfr[1][3]) :: "memory");
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int r = 0; r < 4; r++)
+#pragma unroll
+                    for (int cb = 0; cb < 2; cb++)
+                        acc16[h8 + 8 + 2 * r + cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ar[(jb + cb) % kRRing], bfr[1][r], acc16[h8 + 8 + 2 * r + cb], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                rp_load<j + kRDist16>(ar, wf_cur, wf_nxt, voff);
+            }
             // ---- counted vector-memory operations behind the weight load (rp_post)
             if constexpr (GNIN && j == kRStatStep) stat_piece(nxt, sb_nxt);
             // the slab two periods ahead, one piece per step: this tile's slabs 2, 3 in periods 0, 1, the next tile's slabs 0, 1 in
@@ -2443,6 +2527,70 @@ __global__ void __launch_bounds__(512, 2) conv3x3_rp_kernel(ConvDev PA, ConvDev 
         // ---- end of tile: this tile's epilogue.  No barrier and no patch pieces here: a wave that is done with its 144 steps goes
         // straight into its epilogue while its SIMD mate still has the matrix pipe.
         RP_STAMP(6);
+        if constexpr (M16) {
+            // 16x16x32 form: a lane holds, of fragment (tile row b, column half, channel half cb), pixel column 16 side + (lane & 15) and
+            // the 4 channels 16 cb + 4 (lane >> 4) ..: v_permlane16_swap pairs the two channel halves across neighbouring rows of 16
+            // lanes -- q = lane >> 4 even: its own channels 4q .. 4q + 3 and row q + 1's 4q + 4 .. of cb 0; q odd: the same of cb 1 --
+            // 16 contiguous bytes per lane at channel 16 (q & 1) + 8 (q >> 1), one store per fragment pair, 16 per tile as before
+            f32x4 bia[2];
+            int le = lane_now();
+            asm volatile("" : "+v"(le));
+            const int col = le & 15, q4 = le >> 4;
+            const unsigned bad = lds_base + (unsigned)(kROffBias + (cur.grp * kRMaxCout + cur.nt * 256 + wave * 32 + 4 * q4) * 4);
+            asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:64\n\ts_waitcnt lgkmcnt(0)" : "=&v"(bia[0]), "=&v"(bia[1]) : "v"(bad) : "memory");
+#pragma unroll
+            for (int g = 0; g < 4; g++) gsum[g] = gsq[g] = 0.f;
+            const int Wp = cur.W + 2;
+            const size_t rowpitch = (size_t)Wp * P.Cout * 2;
+            char* obase = PG(cur.grp).seg[cur.si].out + ((size_t)(cur.img * (cur.H + 2) + cur.Y0 + 1) * Wp + cur.X0 + col + 1) * P.Cout * 2
+                          + (cur.nt * 256 + wave * 32 + 16 * (q4 & 1) + 8 * (q4 >> 1)) * 2;
+            char* const dbase = dump + (size_t)(wave * 64 + le) * 256;
+            const bool colok0 = cur.valid && (cur.X0 + col) < cur.W, colok1 = cur.valid && (cur.X0 + col + 16) < cur.W;
+            const float lo = relu ? 0.f : -__builtin_inff();
+            const size_t sidepitch = (size_t)16 * P.Cout * 2;
+#pragma unroll
+            for (int b = 0; b < kRFr; b++) {
+                const bool rowok = (cur.Y0 + b) < cur.H;
+#pragma unroll
+                for (int side = 0; side < 2; side++) {
+                    const bool valid = rowok && (side ? colok1 : colok0);
+                    u32x2 pk[2];
+#pragma unroll
+                    for (int cb = 0; cb < 2; cb++) {
+                        const f32x4 a4 = acc16[(b * 2 + side) * 2 + cb];
+                        const float v0 = fmaxf(a4[0] + bia[cb][0], lo), v1 = fmaxf(a4[1] + bia[cb][1], lo);
+                        const float v2 = fmaxf(a4[2] + bia[cb][2], lo), v3 = fmaxf(a4[3] + bia[cb][3], lo);
+                        const float s4 = (v0 + v1) + (v2 + v3), qq = (v0 * v0 + v1 * v1) + (v2 * v2 + v3 * v3);
+                        gsum[cb] += valid ? s4 : 0.f;
+                        gsq[cb] += valid ? qq : 0.f;
+                        pk[cb].x = pack_bf16(v0, v1);
+                        pk[cb].y = pack_bf16(v2, v3);
+                    }
+                    const auto r0 = __builtin_amdgcn_permlane16_swap(pk[0].x, pk[1].x, false, false);
+                    const auto r1 = __builtin_amdgcn_permlane16_swap(pk[0].y, pk[1].y, false, false);
+                    const u32x4 v = {r0[0], r1[0], r0[1], r1[1]};
+                    char* const ad = valid ? obase + side * sidepitch : dbase;        // (a plain store: see the swap -> store hazard below)
+                    *(u32x4*)ad = v;
+                }
+                obase += rowpitch;
+            }
+            if (gn) {
+                // group 2 cb + (lane >> 5) of the wave: over the 32 lanes of a half wave (DPP, fixed tree), lanes 31 / 63 park the sums
+#pragma unroll
+                for (int cb = 0; cb < 2; cb++) {
+                    gsum[cb] = rp_half_total(gsum[cb]);
+                    gsq[cb] = rp_half_total(gsq[cb]);
+                }
+                if ((lane & 31) == 31) {
+                    float* redb = (float*)(lds + kROffRed);
+#pragma unroll
+                    for (int cb = 0; cb < 2; cb++) {
+                        redb[(wave * 4 + 2 * cb + (lane >> 5)) * 2 + 0] = gsum[cb];
+                        redb[(wave * 4 + 2 * cb + (lane >> 5)) * 2 + 1] = gsq[cb];
+                    }
+                }
+            }
+        } else
         {
             f32x4 bia4[4];
             int le = lane_now();                  // per-lane parts recomputed per tile (hoisted out of the tile loop they spill)
@@ -2475,8 +2623,8 @@ __global__ void __launch_bounds__(512, 2) conv3x3_rp_kernel(ConvDev PA, ConvDev 
                 u32x2 pk[4];
 #pragma unroll
                 for (int g = 0; g < 4; g++) {
-                    const float v0 = fmaxf(RP_ACC(b, 4 * g) + bia4[g][0], lo), v1 = fmaxf(RP_ACC(b, 4 * g + 1) + bia4[g][1], lo);
-                    const float v2 = fmaxf(RP_ACC(b, 4 * g + 2) + bia4[g][2], lo), v3 = fmaxf(RP_ACC(b, 4 * g + 3) + bia4[g][3], lo);
+                    const float v0 = fmaxf(acc[b][4 * g] + bia4[g][0], lo), v1 = fmaxf(acc[b][4 * g + 1] + bia4[g][1], lo);
+                    const float v2 = fmaxf(acc[b][4 * g + 2] + bia4[g][2], lo), v3 = fmaxf(acc[b][4 * g + 3] + bia4[g][3], lo);
                     const float s4 = (v0 + v1) + (v2 + v3), q4 = (v0 * v0 + v1 * v1) + (v2 * v2 + v3 * v3);
                     gsum[g] += valid ? s4 : 0.f;
                     gsq[g] += valid ? q4 : 0.f;
@@ -2525,6 +2673,12 @@ __global__ void __launch_bounds__(512, 2) conv3x3_rp_kernel(ConvDev PA, ConvDev 
 #endif
     }
 
+    // the fragment loads past the last tile (nobody reads them) are still in flight INTO ar[]: dead registers for the compiler, which
+    // hands them to the temporaries below (the 16x16x32 form did: scripts/check_async_loads.py) -- the operands keep them allocated
+    // until the queue is empty
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int k = 0; k < kRRing; k++) asm volatile("" : "+v"(ar[k]) :: "memory");
     // ---- the last tile's GroupNorm sums (in LDS since its epilogue), straight-line
     if (gn) {
         barrier();
@@ -3529,7 +3683,7 @@ int build(ConvDev& D, const dafne_conv_params* p, const dafne_conv_seg* segs, bo
     if (p->n_segs < 1 || p->n_segs > kMaxSegs || p->n_images < 1) return dafne::fail(DAFNE_E_INVALID, "conv: bad segment/image count");
     {
         const unsigned known = DAFNE_CONV_RELU | DAFNE_CONV_RESIDUAL | DAFNE_CONV_UPSAMPLE_ADD | DAFNE_CONV_OUT_F32 | DAFNE_CONV_GN_STATS |
-                               DAFNE_CONV_GN_INPUT | DAFNE_CONV_GN_FINALIZE | DAFNE_CONV_EXCLUSIVE;
+                               DAFNE_CONV_GN_INPUT | DAFNE_CONV_GN_FINALIZE | DAFNE_CONV_EXCLUSIVE | (rp ? DAFNE_CONV_FRAG16 : 0u);
         if (p->flags & ~known) return dafne::fail(DAFNE_E_INVALID, "conv: unknown flag bits 0x%x", p->flags & ~known);
     }
     const bool stem = p->Cin == 4 && p->KH == 7 && p->KW == 7 && p->stride == 2;
@@ -3684,7 +3838,8 @@ int launch_patch_fp8(const ConvDev& D, hipStream_t st) {
 }
 
 int launch_rp(const ConvDev& D, const ConvDev* D2, char* dump, hipStream_t st) {
-    DAFNE_MAX_LDS_ONCE(kRSmem, (const void*)conv3x3_rp_kernel<false>, (const void*)conv3x3_rp_kernel<true>);
+    DAFNE_MAX_LDS_ONCE(kRSmem, (const void*)conv3x3_rp_kernel<false, false>, (const void*)conv3x3_rp_kernel<true, false>,
+                       (const void*)conv3x3_rp_kernel<false, true>, (const void*)conv3x3_rp_kernel<true, true>);
     int cus = 0;                                           // persistent: at most one workgroup per CU, tiles dealt round-robin
     if (int rc = dafne::device_cus(&cus)) return rc;
     const int T = D.mtiles * D.ntiles + (D2 ? D2->mtiles * D2->ntiles : 0);
@@ -3698,8 +3853,11 @@ int launch_rp(const ConvDev& D, const ConvDev* D2, char* dump, hipStream_t st) {
     const int rounds = (T + lim - 1) / lim;
     const int G = (T + rounds - 1) / rounds;
     const dim3 grid(G), block(512);
-    if (D.flags & DAFNE_CONV_GN_INPUT) hipLaunchKernelGGL(conv3x3_rp_kernel<true>, grid, block, kRSmem, st, D, E, ng, dump);
-    else hipLaunchKernelGGL(conv3x3_rp_kernel<false>, grid, block, kRSmem, st, D, E, ng, dump);
+    const bool gnin = D.flags & DAFNE_CONV_GN_INPUT, m16 = D.flags & DAFNE_CONV_FRAG16;
+    if (gnin && m16) hipLaunchKernelGGL((conv3x3_rp_kernel<true, true>), grid, block, kRSmem, st, D, E, ng, dump);
+    else if (gnin) hipLaunchKernelGGL((conv3x3_rp_kernel<true, false>), grid, block, kRSmem, st, D, E, ng, dump);
+    else if (m16) hipLaunchKernelGGL((conv3x3_rp_kernel<false, true>), grid, block, kRSmem, st, D, E, ng, dump);
+    else hipLaunchKernelGGL((conv3x3_rp_kernel<false, false>), grid, block, kRSmem, st, D, E, ng, dump);
     return dafne::check_launch("conv3x3_rp");
 }
 

@@ -21,6 +21,7 @@ BF16 = torch.bfloat16
 STAGE_BLOCKS = {50: (3, 4, 6, 3), 101: (3, 4, 23, 3)}
 
 F_RELU, F_RES, F_UP, F_F32, F_GN, F_GNIN, F_GNFIN, F_EXCL = 1, 2, 4, 8, 16, 32, 64, 128
+F_FRAG16 = 256      # dafne_conv3x3_c256_hip only: the weights are pack_conv3x3_frag16's, the launch runs the 16x16x32 form
 
 
 # ------------------------------------------------------------------ activations
@@ -232,6 +233,26 @@ def pack_conv3x3_frag(w):
     return w.reshape(cout // 256, 8, 32, 144, 2, 8).permute(0, 1, 3, 4, 2, 5).contiguous().reshape(-1)   # nt, w, j, h, r, e
 
 
+def pack_conv3x3_frag16(w):
+    """The same weights in the fragment order of the kernel's 16x16x32 form (flag F_FRAG16, include/dafne_amd.h): bf16
+    [Cout/256][8 waves][144 fragments][64 lanes][8], fragment 2m + cb = rows nt*256 + wave*32 + 16*cb + (lane & 15), K columns
+    32*m + 8*(lane >> 4) .. +8."""
+    cout = w.shape[0]
+    assert w.dim() == 2 and w.shape[1] == 2304 and cout % 256 == 0 and w.dtype == BF16
+    return w.reshape(cout // 256, 8, 2, 16, 72, 4, 8).permute(0, 1, 4, 2, 5, 3, 6).contiguous().reshape(-1)   # nt, w, m, cb, q, r, e
+
+
+def rp_frag16():
+    """The resident-patch kernel's matrix instruction: v_mfma_f32_16x16x32_bf16 (default; 6-8 % fewer joules per flop on this package)
+    or, DAFNE_RP_MFMA16=0, v_mfma_f32_32x32x16_bf16 (bit-identical to the generic kernels; A/B runs and the parity tests of that form)."""
+    return os.environ.get("DAFNE_RP_MFMA16", "1") != "0"
+
+
+def pack_rp(w):
+    """(fragment-major weights, flag bits) of a resident-patch call in the form rp_frag16() selects."""
+    return (pack_conv3x3_frag16(w), F_FRAG16) if rp_frag16() else (pack_conv3x3_frag(w), 0)
+
+
 def pack_conv_frag(w):
     """Fragment-major weights of dafne_conv2d_wr_hip from a packed weight ([Cout, K] bf16 in pack_conv's K order, Cout % 256 ==
     0, K % 64 == 0): bf16 [Cout/256][8 waves][K/16 steps][64 lanes][8]: rows nt*256 + wave*32 + (lane & 31), K columns
@@ -336,20 +357,23 @@ class ConvCall:
     """One dafne_conv2d_nhwc_bf16_hip launch with its argument structs kept alive."""
 
     def __init__(self, w, b, cin, cout, k, stride, pad, flags, segs, n_images, gn_partial=None, gn_in=None, fp8=None,
-                 gn_fin=None, wfrag=None, shared_gpu=False):
+                 gn_fin=None, wfrag=None, shared_gpu=False, frag16=False):
         """gn_in: (stats [n_segs,N,Cin/8,2], gamma [Cin], beta [Cin]) of the INPUT maps when they hold the raw
         output of the previous tower convolution (flag F_GNIN: GroupNorm + ReLU applied on load).
         fp8: (oscale fp32 [Cout], in_qscale) -> `w` holds e4m3 bytes (pack_conv_fp8) and the call goes to
         dafne_conv2d_nhwc_fp8w_hip (fp8 MFMA, activations quantised on load).
         gn_fin: (stats out [n_segs,N,Cout/8,2] fp32, counters [n_segs,N] int32 zeros, eps) with flag F_GNFIN: the last
         tile of every image finalises the GroupNorm statistics of the OUTPUT (no dafne_groupnorm_finalize_hip launch).
-        wfrag: fragment-major bf16 weights (pack_conv3x3_frag) -> the call goes to dafne_conv3x3_c256_hip (resident-patch
+        wfrag: fragment-major bf16 weights (pack_conv3x3_frag; frag16: pack_conv3x3_frag16, flag F_FRAG16) -> the call goes to dafne_conv3x3_c256_hip (resident-patch
         kernel: 3x3 s1 p1, Cin 256, Cout % 256 == 0; its own tile geometry).
         shared_gpu: the plan this call belongs to runs next to other plans on concurrent streams (no F_EXCL hint)."""
         L = _lib.load()
         self.fp8 = fp8
         self.wfrag = wfrag
         assert fp8 is None or wfrag is None
+        assert not frag16 or wfrag is not None
+        if frag16:
+            flags |= F_FRAG16
         self.keep = (w, b, gn_partial, [s for s in segs], gn_in, fp8, gn_fin, wfrag)
         gi = [t.data_ptr() for t in gn_in] if gn_in is not None else [None, None, None]
         gf = (gn_fin[0].data_ptr(), gn_fin[1].data_ptr(), float(gn_fin[2])) if gn_fin is not None else (None, None, 0.0)
@@ -620,10 +644,12 @@ class DensePlan:
                 return o
             if fp8 is None and k == 3 and cin == 256 and use_rp_kernel() and c.kernel_id() == 6 and c.rp_ok():
                 # 256-channel 3x3 layers the patch kernel would take (FPN outputs): resident-patch kernel
-                if key + ".frag" not in P:
-                    P[key + ".frag"] = pack_conv3x3_frag(wgt)
+                f16 = rp_frag16()
+                fkey = key + (".frag16" if f16 else ".frag")
+                if fkey not in P:
+                    P[fkey] = pack_rp(wgt)[0]
                 c = ConvCall(wgt, bias, cin, cout, k, stride, pad, flags,
-                             [(tin.t, o.t, None, tin.h, tin.w, ho, wo)], n, wfrag=P[key + ".frag"], shared_gpu=self.shared_gpu)
+                             [(tin.t, o.t, None, tin.h, tin.w, ho, wo)], n, wfrag=P[fkey], shared_gpu=self.shared_gpu, frag16=f16)
             self.calls.append(c)
             self.flops += c.flops
             return o
@@ -1030,11 +1056,14 @@ class HeadPlan:
                 rp_small = os.environ.get("DAFNE_RP_LAYER0", "0") == "1"
                 use_rp = rp_on and not use_fp8 and probe.rp_ok() and (cur_gn is not None or probe.kernel_id() == 6 or rp_small)
                 wfrag = None
+                f16 = use_rp and rp_frag16()
                 if use_rp:
-                    if lkey + ".frag" not in P:
-                        P[lkey + ".frag"] = pack_conv3x3_frag(wgt)
-                    wfrag = P[lkey + ".frag"]
-                    probe = ConvCall(wgt, bias, C, C, 3, 1, 1, flags & ~F_GN, seg_list(cur, outs), n, gn_in=cur_gn, wfrag=wfrag, shared_gpu=sg)
+                    fkey = lkey + (".frag16" if f16 else ".frag")
+                    if fkey not in P:
+                        P[fkey] = pack_rp(wgt)[0]
+                    wfrag = P[fkey]
+                    probe = ConvCall(wgt, bias, C, C, 3, 1, 1, flags & ~F_GN, seg_list(cur, outs), n, gn_in=cur_gn, wfrag=wfrag, shared_gpu=sg,
+                                     frag16=f16)
                 if use_fp8:
                     probe = ConvCall(q8[0], bias, C, C, 3, 1, 1, flags & ~F_GN, seg_list(cur, outs), n, gn_in=cur_gn,
                                      fp8=(q8[1] / aq, aq), shared_gpu=sg)
@@ -1065,7 +1094,7 @@ class HeadPlan:
                                  gn_in=cur_gn, fp8=(q8[1] / aq, aq), gn_fin=fin, shared_gpu=sg)
                 else:
                     c = ConvCall(wgt, bias, C, C, 3, 1, 1, flags, seg_list(cur, outs), n, gn_partial=partial, gn_in=cur_gn,
-                                 gn_fin=fin, wfrag=wfrag, shared_gpu=sg)
+                                 gn_fin=fin, wfrag=wfrag, shared_gpu=sg, frag16=f16)
                 c.tower_tag = (name, i)
                 calls.append(c)
                 plan.flops += c.flops

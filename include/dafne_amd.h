@@ -207,6 +207,10 @@ int dafne_gather_detections_hip(const float* d_corners, const float* d_scores, c
                                     * LDS of their CU for a 4-stage operand ring (K loop without a drain per step); launches of
                                     * plans that share the GPU with other streams keep the small footprint */
 
+#define DAFNE_CONV_FRAG16 256u     /* dafne_conv3x3_c256_hip / _pair_hip only: d_wfrag is in the 16x16x32 fragment order (below) and the
+                                    * launch runs on v_mfma_f32_16x16x32_bf16 (cheaper per flop on this package); fp32 sums in another
+                                    * order than the 32x32x16 form: <= 1 bf16 ulp apart on an output, run-to-run identical */
+
 typedef struct dafne_conv_seg {
     const void* d_in;   /* bf16 [N, Hin+2, Win+2, Cin]; stem: [N, Hin, Win, 4] pre-padded */
     void* d_out;        /* bf16 [N, Hout+2, Wout+2, Cout] or fp32 [N,Hout,Wout,Cout]      */
@@ -249,6 +253,10 @@ int dafne_conv2d_nhwc_bf16_hip(const dafne_conv_params* prm, const dafne_conv_se
  * a finalised mean / rstd may differ from the other kernel's in the last bit).  prm->d_weight is ignored; d_wfrag: bf16
  * [Cout/256][8 waves][144 k16 steps][64 lanes][8] = rows nt*256 + wave*32 + (lane & 31), K columns 16*step +
  * 8*(lane >> 5) .. +8 of the packed weight [Cout][Cin/64][KH][KW][64]  (engine.pack_conv3x3_frag).
+ * With DAFNE_CONV_FRAG16 in prm->flags (round 6): d_wfrag: bf16 [Cout/256][8 waves][144 fragments][64 lanes][8], fragment 2m + cb =
+ * rows nt*256 + wave*32 + 16*cb + (lane & 15), K columns 32*m + 8*(lane >> 4) .. +8  (engine.pack_conv3x3_frag16); the launch runs the
+ * 16x16x32 form of the kernel: the same tiles, statistics layout and definition, fp32 sums of an output in another order (<= 1 bf16
+ * ulp from the 32x32x16 form; not bit-identical to dafne_conv2d_nhwc_bf16_hip).
  * The kernel is persistent (one workgroup per CU walks the tiles) and never predicates a store: rows of out-of-image
  * tile pixels go to d_scratch (>= dafne_conv3x3_c256_scratch_bytes(); holds nothing afterwards; may be shared by calls).
  * Shapes: Cin == 256, Cout % 256 == 0, Cout <= 1024, bias, bf16 output, no residual / top-down add; else

@@ -12,7 +12,8 @@ g = torch.Generator().manual_seed(0)
 w = torch.randn(C, C, 3, 3, generator=g) / (C * 9) ** 0.5
 b = torch.randn(C, generator=g) * 0.1
 wp, bp = engine.pack_conv(w, b, d)
-wf = engine.pack_conv3x3_frag(wp)
+wf, _f16 = engine.pack_rp(wp)       # DAFNE_RP_MFMA16=0: the 32x32x16 form
+f16 = bool(_f16)
 gamma = torch.ones(C, device=d); beta = torch.zeros(C, device=d)
 NI = 3          # cycled instances (no MALL reuse between launches)
 sets = []
@@ -26,9 +27,9 @@ for k in range(NI):
     partial = torch.zeros(8192, C // 8, 2, device=d)
     fl = engine.F_GN | engine.F_GNIN
     calls = [engine.ConvCall(wp, bp, C, C, 3, 1, 1, fl, segs, B, gn_partial=partial, gn_in=(stats, gamma, beta)),
-             engine.ConvCall(wp, bp, C, C, 3, 1, 1, fl, segs, B, gn_partial=partial, gn_in=(stats, gamma, beta), wfrag=wf),
+             engine.ConvCall(wp, bp, C, C, 3, 1, 1, fl, segs, B, gn_partial=partial, gn_in=(stats, gamma, beta), wfrag=wf, frag16=f16),
              engine.ConvCall(wp, bp, C, C, 3, 1, 1, engine.F_GN, segs, B, gn_partial=partial),
-             engine.ConvCall(wp, bp, C, C, 3, 1, 1, engine.F_GN, segs, B, gn_partial=partial, wfrag=wf)]
+             engine.ConvCall(wp, bp, C, C, 3, 1, 1, engine.F_GN, segs, B, gn_partial=partial, wfrag=wf, frag16=f16)]
     sets.append(calls)
 st = _lib.current_stream()
 flops = sets[0][0].flops

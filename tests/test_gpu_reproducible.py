@@ -33,11 +33,26 @@ class _MatrixLoad:
                     self.a[k] @ self.b[k]
 
 
-def _stress(fn, same, rounds, per_round, dev):
-    """fn() on a side stream `per_round` times per burst of matrix load; -> launches whose result differs from the idle one."""
+class _MemoryLoad:
+    """256-MB device copies on two high-priority streams (round 6): HBM and the fabric stay busy, the CUs mostly free -- the waves of a
+    workgroup on another stream then wait for their operands at different moments and drift apart, which the matrix load does not do."""
+
+    def __init__(self, dev):
+        self.cs = [torch.cuda.Stream(device=dev, priority=-1) for _ in range(2)]
+        self.big = [torch.empty(64 << 20, dtype=torch.float32, device=dev) for _ in range(4)]
+
+    def kick(self, n=3):
+        for k in range(2):
+            with torch.cuda.stream(self.cs[k]):
+                for _ in range(n):
+                    self.big[2 * k].copy_(self.big[2 * k + 1])
+
+
+def _stress(fn, same, rounds, per_round, dev, load_cls=None):
+    """fn() on a side stream `per_round` times per burst of matrix (or `load_cls`) load; -> launches whose result differs from the idle one."""
     ref = fn()
     torch.cuda.synchronize()
-    load = _MatrixLoad(dev)
+    load = (load_cls or _MatrixLoad)(dev)
     side = torch.cuda.Stream(device=dev)
     bad, n, pend = 0, 0, []
     for it in range(rounds):
@@ -107,9 +122,9 @@ def test_tower_convolution_beside_matrix_kernels():
     x = engine.Act.from_nchw(torch.relu(torch.randn(N, 256, H, W, generator=g)).to(dev))
     wgt = torch.randn(256, 256, 3, 3, generator=g) / 48.0
     wp, bp = engine.pack_conv(wgt, torch.randn(256, generator=g) * 0.1, dev)
-    wfrag = engine.pack_conv3x3_frag(wp)
+    wfrag, f16 = engine.pack_rp(wp)            # the form the plans use (16x16x32 by default)
     out = engine.Act(N, H, W, 256, dev)
-    call = engine.ConvCall(wp, bp, 256, 256, 3, 1, 1, engine.F_RELU, [(x.t, out.t, None, H, W, H, W)], N, wfrag=wfrag)
+    call = engine.ConvCall(wp, bp, 256, 256, 3, 1, 1, engine.F_RELU, [(x.t, out.t, None, H, W, H, W)], N, wfrag=wfrag, frag16=bool(f16))
     assert call.kernel_name() == "conv3x3_rp"
 
     def run():
@@ -148,3 +163,102 @@ def test_whole_dense_path_beside_matrix_kernels():
         return all(torch.equal(x, y) for x, y in zip(a, b))
     bad, n = _stress(run, same, 120, 1, dev)
     assert n == 120 and bad == 0, "%d of %d passes of the dense path differ from the idle result" % (bad, n)
+
+
+@pytest.mark.parametrize("th", [2, 4])
+def test_bottleneck_beside_memory_traffic(th, monkeypatch):
+    """conv_bneck beside MEMORY-bound work on two other streams (round 6).  The matrix load above keeps the CUs busy but not HBM; with
+    256-MB device copies running, the waves of a workgroup wait for their weight fragments at different moments and drift apart by whole
+    steps.  The first ping-pong form of the kernel had no barrier between the late half's last GEMM segment and its Z epilogue -- a wave
+    wrote its Z pieces into the LDS slab its mates were still reading: wrong Z channels 128..255 in 545 of 1200 launches of the half-tile
+    geometry (found as run-to-run different TTA detections, tests/test_gpu_model.py); 0 since.  Both geometries, bits of the idle GPU."""
+    monkeypatch.setenv("DAFNE_BNECK_TH", str(th))
+    from dafne_amd import engine, _lib
+    dev = torch.device("cuda", 0)
+    L = _lib.load()
+    g = torch.Generator().manual_seed(17)
+    bfr = lambda t: t.to(torch.bfloat16).float()
+    N, H, W = 3, 30, 30
+    w2p, b2p = engine.pack_conv(bfr(torch.randn(256, 256, 3, 3, generator=g) / 48.0), torch.randn(256, generator=g) * 0.2, dev)
+    w3p, b3p = engine.pack_conv(bfr(torch.randn(1024, 256, 1, 1, generator=g) / 16.0), torch.randn(1024, generator=g) * 0.2, dev)
+    w1p, b1p = engine.pack_conv(bfr(torch.randn(256, 1024, 1, 1, generator=g) / 32.0), torch.randn(256, generator=g) * 0.2, dev)
+    wf = engine.pack_bneck(w2p, w3p, w1p)
+    u = engine.Act.from_nchw(bfr(torch.randn(N, 256, H, W, generator=g)).to(dev))
+    x = engine.Act.from_nchw(bfr(torch.randn(N, 1024, H, W, generator=g)).to(dev))
+    y, z = engine.Act(N, H, W, 1024, dev), engine.Act(N, H, W, 256, dev)
+    nscr = L.dafne_bottleneck_body_scratch_bytes()
+    scr = torch.empty(nscr, dtype=torch.uint8, device=dev)
+    ms = torch.cuda.Stream(device=dev, priority=-1)
+    side = [torch.cuda.Stream(device=dev, priority=-1) for _ in range(2)]
+    big = [torch.empty(64 << 20, dtype=torch.float32, device=dev) for _ in range(4)]
+
+    def run():
+        _lib.check(L.dafne_bottleneck_body_hip(_lib.ptr(u.t), _lib.ptr(x.t), _lib.ptr(wf), _lib.ptr(b2p), _lib.ptr(b3p), _lib.ptr(b1p), N, H, W,
+                                               _lib.ptr(y.t), _lib.ptr(z.t), _lib.ptr(scr), nscr, ctypes.c_void_p(ms.cuda_stream)), "bneck")
+        with torch.cuda.stream(ms):
+            return y.t.clone(), z.t.clone()
+    torch.cuda.synchronize()
+    ref = run()
+    torch.cuda.synchronize()
+    bad = n = 0
+    for _ in range(100):
+        for k, s in enumerate(side):
+            with torch.cuda.stream(s):
+                for _ in range(3):
+                    big[2 * k].copy_(big[2 * k + 1])
+        pend = [run() for _ in range(4)]
+        torch.cuda.synchronize()
+        for yy, zz in pend:
+            n += 1
+            bad += 0 if (torch.equal(yy, ref[0]) and torch.equal(zz, ref[1])) else 1
+    assert n == 400 and bad == 0, "%d of %d launches of conv_bneck (tile height %d) differ from the idle result" % (bad, n, th)
+
+
+def test_whole_dense_path_beside_memory_traffic():
+    """The dense part of an R101 plan (every convolution kernel of the library) beside device copies on two other streams: FPN maps and
+    head outputs bit for bit those of the idle GPU.  (The matrix-load form of this test passed while conv_bneck had the race above.)"""
+    import bench
+    dev = torch.device("cuda", 0)
+    cfg, model, sd = bench.build_model(101, dev, seed=3)
+    g = torch.Generator().manual_seed(9)
+    for n, h, w in ((3, 480, 480), (2, 256, 320)):          # (res4 on half tiles: 45 workgroups; on 4 x 32 tiles)
+        batch = torch.randint(0, 256, (n, 3, h, w), generator=g, dtype=torch.uint8).to(dev)
+        model.detect_packed(batch)
+        torch.cuda.synchronize()
+        plan = model.plan(n, h, w)
+        hp = plan.head
+
+        def run():
+            model.detect_packed(batch)
+            outs = [a.t.clone() for a in plan.features]
+            for l in range(5):
+                outs += [hp.logits[l].clone(), hp.delta_ctr[l].clone(), hp.center[l].clone()]
+            return outs
+
+        def same(a, b):
+            return all(torch.equal(x, y) for x, y in zip(a, b))
+        bad, cnt = _stress(run, same, 80, 1, dev, load_cls=_MemoryLoad)
+        assert cnt == 80 and bad == 0, "%d of %d passes of the dense path (%d x %d x %d) differ from the idle result" % (bad, cnt, n, h, w)
+
+
+def test_tower_convolution_beside_memory_traffic():
+    """conv3x3_rp (the form the plans use) with GroupNorm statistics on ragged levels, several tiles per workgroup, beside device copies."""
+    from dafne_amd import engine, _lib
+    dev = torch.device("cuda", 0)
+    g = torch.Generator().manual_seed(12)
+    N, H, W = 6, 150, 150
+    x = engine.Act.from_nchw(torch.relu(torch.randn(N, 256, H, W, generator=g)).to(dev))
+    wp, bp = engine.pack_conv(torch.randn(256, 256, 3, 3, generator=g) / 48.0, torch.randn(256, generator=g) * 0.1, dev)
+    wfrag, f16 = engine.pack_rp(wp)
+    out = engine.Act(N, H, W, 256, dev)
+    probe = engine.ConvCall(wp, bp, 256, 256, 3, 1, 1, engine.F_RELU, [(x.t, out.t, None, H, W, H, W)], N, wfrag=wfrag, frag16=bool(f16))
+    partial = torch.zeros(probe.num_tiles(), 32, 2, dtype=torch.float32, device=dev)
+    call = engine.ConvCall(wp, bp, 256, 256, 3, 1, 1, engine.F_RELU | engine.F_GN, [(x.t, out.t, None, H, W, H, W)], N, gn_partial=partial,
+                           wfrag=wfrag, frag16=bool(f16))
+    assert call.kernel_name() == "conv3x3_rp" and call.num_tiles() > 512
+
+    def run():
+        call(_lib.current_stream())
+        return out.t.clone(), partial.clone()
+    bad, n = _stress(run, lambda a, b: torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]), 100, 3, dev, load_cls=_MemoryLoad)
+    assert bad == 0, "%d of %d launches of conv3x3_rp differ from the idle result" % (bad, n)

@@ -100,3 +100,22 @@ def test_instances_host_twin_is_dropped_by_any_edit():
     a = make(); a.remove("scores")
     assert not a.to("cpu").has("scores")
     a = make(); assert not a.to("cpu", non_blocking=True).has("marker")     # any other .to() form copies
+
+
+def test_fragment_orders_of_the_resident_patch_kernel():
+    """engine.pack_conv3x3_frag / pack_conv3x3_frag16 against the element maps include/dafne_amd.h states for dafne_conv3x3_c256_hip
+    (32x32x16 form: fragment = k16 step, row lane & 31, K 16 step + 8 (lane >> 5); 16x16x32 form, flag DAFNE_CONV_FRAG16: fragment
+    2m + cb, row 16 cb + (lane & 15), K 32 m + 8 (lane >> 4))."""
+    import torch
+    from dafne_amd import engine
+    cout, K = 512, 2304
+    w = (torch.arange(cout * K, dtype=torch.float32) % 30011).reshape(cout, K).to(torch.bfloat16)     # (distinct enough: every check is exact)
+    f32 = engine.pack_conv3x3_frag(w).reshape(cout // 256, 8, 144, 64, 8)
+    f16 = engine.pack_conv3x3_frag16(w).reshape(cout // 256, 8, 144, 64, 8)
+    g = torch.Generator().manual_seed(5)
+    for _ in range(200):
+        nt, wv, j, lane, e = (int(torch.randint(0, n, (1,), generator=g)) for n in (cout // 256, 8, 144, 64, 8))
+        assert f32[nt, wv, j, lane, e] == w[nt * 256 + wv * 32 + (lane & 31), 16 * j + 8 * (lane >> 5) + e]
+        m, cb = j >> 1, j & 1
+        assert f16[nt, wv, j, lane, e] == w[nt * 256 + wv * 32 + 16 * cb + (lane & 15), 32 * m + 8 * (lane >> 4) + e]
+    assert engine.F_FRAG16 == 256
