@@ -14,6 +14,7 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "scripts"))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 
 NO_MATRIX_UNITS = ("decode.hip", "poly_nms.hip", "resize.hip", "dense_ops.hip")
@@ -30,13 +31,10 @@ def test_packed_fp32_rule_per_translation_unit(tmp_path):
     import check_packed_fp32 as chk
     srcs = sorted(f for f in os.listdir(B.CSRC) if f.endswith(".hip"))
 
+    import _listings
+
     def listing(s):
-        out = str(tmp_path / (s + ".s"))
-        flags = [f for f in B.COMMON if f not in ("-fPIC",)] + B.PER_FILE.get(s, [])
-        r = subprocess.run([B.HIPCC] + flags + ["-S", "--cuda-device-only", "-o", out, os.path.join(B.CSRC, s)],
-                           capture_output=True, text=True, timeout=1500)
-        assert r.returncode == 0, (s, r.stderr[-1500:])
-        lines = open(out).read().split("\n")
+        lines = _listings.listing(s)
         has_mfma = any("v_mfma_" in l for l in lines)
         return s, has_mfma, chk.check(lines), chk.check_none(lines), chk.forms(lines)
     with ThreadPoolExecutor(max_workers=6) as ex:
